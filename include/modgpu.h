@@ -1,0 +1,229 @@
+/* include/modgpu.h — C ABI of libmodgpu.so: modimizer's seqhash + modset hot path on MI355X (gfx950).
+ *
+ * Two layers, both plain C (pointers and sizes only, no C++/torch types):
+ *
+ *  (1) the reference's own seqhash.h / modset.h API with identical signatures and struct layouts,
+ *      so modmap/modutils-style callers link against this library unchanged
+ *      (reference seqhash.h:36-60, modset.h:30-42; struct layouts seqhash.h:15-34, modset.h:17-28);
+ *
+ *  (2) batch entry points that carry the GPU path: whole batches of reads are scanned, the
+ *      modimizers compacted in (read,pos) order, and inserted into / looked up in a device-resident
+ *      modset table.  These replace the per-read loops of the reference callers
+ *      (modutils.c:19-31, modmap.c:106-118, modmap.c:197-206).
+ *
+ * Error behaviour follows the reference: invalid parameters and capacity overflow print
+ * "FATAL ERROR: ..." and exit(-1) (utils.c:19-30) in layer (1); layer (2) functions return a
+ * non-zero MgStatus and leave a message retrievable with mgLastError().  There is no CPU fallback:
+ * every batch entry point fails with MG_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef MODGPU_H
+#define MODGPU_H
+
+#include <stdio.h>
+#include <stdint.h>
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint8_t  U8;
+typedef uint16_t U16;
+typedef uint32_t U32;
+typedef uint64_t U64;
+
+/* ------------------------------------------------------------------------------------------
+ * Layer 1: reference-compatible types (layouts are ABI: reference callers touch the fields).
+ * ------------------------------------------------------------------------------------------ */
+
+/* seqhash.h:15-23 — 80 bytes, written raw into .mod files (seqhash.c:41-44) */
+typedef struct {
+  int seed ;
+  int k ;
+  int w ;
+  U64 mask ;
+  int shift1, shift2 ;
+  U64 factor1, factor2 ;
+  U64 patternRC[4] ;
+} Seqhash ;
+
+/* seqhash.h:25-34.  hashBuf and fBuf are free()-able heap blocks and the iterator itself is a
+ * free()-able block, because the reference's destroy is header-inlined into callers
+ * (seqhash.h:54-55).  This library keeps the precomputed modimizers of the read behind hashBuf. */
+typedef struct {
+  Seqhash *sh ;
+  char *s, *sEnd ;
+  U64 h, hRC ;
+  U64 *hashBuf ;
+  bool *fBuf ;
+  int base ;
+  int iStart, iMin ;
+  bool isDone ;
+} SeqhashRCiterator ;
+
+/* modset.h:17-28 — transparent: callers read/write index/value/depth/info/max directly */
+typedef struct {
+  Seqhash *hasher ;
+  int tableBits ;
+  U32 size ;
+  U64 tableSize ;
+  U64 tableMask ;
+  U32 *index ;
+  U64 *value ;
+  U16 *depth ;
+  U8  *info ;
+  U32 max ;
+} Modset ;
+
+/* seqhash.h:36-60 */
+Seqhash *seqhashCreate (int k, int w, int seed) ;                         /* seqhash.c:20-37 */
+void seqhashWrite (Seqhash *sh, FILE *f) ;                                /* seqhash.c:41-44 */
+Seqhash *seqhashRead (FILE *f) ;                                          /* seqhash.c:46-53 */
+void seqhashReport (Seqhash *sh, FILE *f) ;                               /* seqhash.c:55-56 */
+SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len) ;        /* seqhash.c:154-177 */
+bool modRCnext (SeqhashRCiterator *si, U64 *kmer, int *pos, bool *isF) ;  /* seqhash.c:179-196 */
+SeqhashRCiterator *minimizerRCiterator (Seqhash *sh, char *s, int len) ;  /* seqhash.c:83-108 */
+bool minimizerRCnext (SeqhashRCiterator *si, U64 *u, int *pos, bool *isF) ; /* seqhash.c:110-152 */
+char *seqString (U64 kmer, int len) ;                                     /* seqhash.c:198-206 */
+/* header-inline in the reference (seqhash.h:37,54-60); exported here as real symbols too */
+void mgSeqhashDestroy (Seqhash *sh) ;
+void mgSeqhashRCiteratorDestroy (SeqhashRCiterator *si) ;
+static inline U64 seqhash (Seqhash *sh, U64 k) { return ((k * sh->factor1) >> sh->shift1) ; }
+
+/* modset.h:30-42 */
+Modset *modsetCreate (Seqhash *sh, int bits, U32 size) ;                  /* modset.c:15-31 */
+void modsetDestroy (Modset *ms) ;                                         /* modset.c:33-34 */
+void modsetWrite (Modset *ms, FILE *f) ;                                  /* modset.c:79-88 */
+Modset *modsetRead (FILE *f) ;                                            /* modset.c:90-104 */
+U32 modsetIndexFind (Modset *ms, U64 kmer, int isAdd) ;                   /* modset.c:45-62 */
+void modsetSummary (Modset *ms, FILE *f) ;                                /* modset.c:130-153 */
+bool modsetPack (Modset *ms) ;                                            /* modset.c:36-43 */
+void modsetDepthPrune (Modset *ms, int min, int max) ;                    /* modset.c:64-77 */
+bool modsetMerge (Modset *ms1, Modset *ms2) ;                             /* modset.c:106-128 */
+
+/* ------------------------------------------------------------------------------------------
+ * Layer 2: batch / device entry points (the GPU hot path).
+ * ------------------------------------------------------------------------------------------ */
+
+typedef enum {
+  MG_OK = 0,
+  MG_ERR_NO_DEVICE = 1,     /* no usable HIP device / runtime: there is no CPU fallback */
+  MG_ERR_HIP = 2,           /* a HIP call failed; see mgLastError() */
+  MG_ERR_ARG = 3,           /* invalid argument */
+  MG_ERR_CAPACITY = 4,      /* output or modset capacity exceeded */
+  MG_ERR_NOMEM = 5
+} MgStatus ;
+
+const char *mgLastError (void) ;
+int  mgDeviceCount (void) ;                 /* 0 when no device; never initialises a context */
+MgStatus mgSetDevice (int device) ;         /* device used by subsequent calls of this thread */
+const char *mgVersion (void) ;
+
+/* Device memory helpers so a host language needs no other HIP binding. */
+MgStatus mgDeviceAlloc (void **dptr, size_t bytes) ;
+MgStatus mgDeviceFree (void *dptr) ;
+MgStatus mgMemcpyH2D (void *dst, const void *src, size_t bytes, void *stream) ;
+MgStatus mgMemcpyD2H (void *dst, const void *src, size_t bytes, void *stream) ;
+MgStatus mgMemsetD (void *dst, int byte, size_t bytes, void *stream) ;
+MgStatus mgStreamSynchronize (void *stream) ;
+
+/* 2-bit packed read layout in HBM: base i of the concatenated batch lives in bits
+ * [30-2*(i%16), 32-2*(i%16)) of 32-bit word i/16 (first base in the most significant bits, so a
+ * k-mer read left to right is a contiguous big-endian bit field).  Buffers are
+ * mgPackedWords(n) words long: ceil(n/16) plus MG_PACK_PAD zero words of read-ahead slack.
+ * Input bytes are bases 0..3 (seqio.c:643-652 after the N->0 patch of modmap.c:97); only the low
+ * two bits of each byte are used. */
+#define MG_PACK_PAD 8
+size_t   mgPackedWords (U64 nBases) ;
+void     mgPackHost (const char *bases, U64 nBases, U32 *words) ;
+MgStatus mgPackDevice (const U8 *dBases, U64 nBases, U32 *dWords, void *stream) ;
+MgStatus mgUnpackDevice (const U32 *dWords, U64 nBases, U8 *dBases, void *stream) ;
+
+/* Scan (seqhash.c:154-196 over a whole batch).
+ * dPacked: the batch, reads concatenated without padding; dReadOffsets[nReads+1]: start of each
+ * read in bases (offsets[0] = 0, offsets[nReads] = totalBases).
+ * Outputs, in (read, pos) order, one entry per modimizer:
+ *   dKmer[i]  canonical k-mer (seqhash.c:183)
+ *   dPosF[i]  pos within its read in bits 0..30 (seqhash.c:184), isForward in bit 31
+ *   dReadId[i] read ordinal (may be NULL)
+ * dCount: device U64[2] -> {number of modimizers found, 1 if capacity was exceeded}.  When the
+ * capacity is exceeded the first `capacity` entries are still correct and count is the true total.
+ * dWork: mgScanWorkBytes(totalBases, nReads) bytes of device scratch. */
+#define MG_POS_MASK 0x7fffffffu
+#define MG_FWD_BIT  0x80000000u
+size_t   mgScanWorkBytes (U64 totalBases, U32 nReads) ;
+MgStatus seqhashScanBatchDevice (const Seqhash *sh, const U32 *dPacked, U64 totalBases,
+                                 const U64 *dReadOffsets, U32 nReads,
+                                 U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
+                                 U64 *dCount, void *dWork, void *stream) ;
+
+/* Host-buffer convenience form of the above: bases[] as the reference's iterator takes them
+ * (one byte per base, values 0..3), readOffsets[nReads+1].  Outputs are malloc()ed arrays the
+ * caller frees; *survStart[nReads+1] gives each read's slice of the outputs. Returns the number of
+ * modimizers, or -1 on error. */
+int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
+                          U64 **kmer, int **pos, bool **isF, int64_t **survStart) ;
+
+/* Device modset (modset.c:45-62 as a batch).  The device table is created on first use from the
+ * host arrays of `ms` and lives until modsetDestroy / mgModsetDeviceRelease.
+ *
+ * modsetAddBatchDevice: for i in order, what `index = modsetIndexFind (ms, kmer[i], true) ;
+ * ++depth[index]` (modutils.c:25-26) would do: new k-mers receive indices max+1, max+2, ... in
+ * order of first occurrence, ms->max is updated before return, depth increments accumulate on the
+ * device until modsetSyncToHost.  dIndexOut (optional) receives the index of every kmer[i].
+ * withDepth = 0 gives the modmap.c:109 form (insert without touching depth).
+ *
+ * modsetFindBatchDevice: `modsetIndexFind (ms, kmer[i], false)` — 0 for absent k-mers.
+ *
+ * n must be < 2^31 per call. */
+MgStatus modsetAddBatchDevice (Modset *ms, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth, void *stream) ;
+MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, U32 *dIndexOut, void *stream) ;
+
+/* Bring the host arrays of ms up to date with the device: value[] for new entries, saturating
+ * depth[] += device counts (modutils.c:26), and (when wantIndex) the open-addressed index[] table
+ * rebuilt exactly as the reference's sequence of inserts would have left it (modset.c:51-57). */
+MgStatus modsetSyncToHost (Modset *ms, int wantIndex) ;
+/* Drop the device table (host arrays untouched; pending device depth counts are synced first). */
+MgStatus mgModsetDeviceRelease (Modset *ms) ;
+/* Tell the library the caller changed ms->value/max/depth on the host behind its back. */
+void     mgModsetHostChanged (Modset *ms) ;
+
+/* modutils.c:53-63 on the device: dHist[65536] (U64) += histogram of depth[1..max], where depth is
+ * the host depth at last sync plus pending device counts, saturated at 65535. */
+MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist65536, void *stream) ;
+
+/* One-call forms used by the drivers and the benchmark: scan a device-resident packed batch and
+ * feed the modimizers straight into the modset.
+ *   mgAddReadsDevice   = addSequence (modutils.c:19-31) over every read of the batch;
+ *   mgQueryReadsDevice = the lookup loop of queryProcess (modmap.c:197-206): seeds (index,pos)
+ *                        per read incl. misses.
+ * nHash receives the number of modimizers.  Scratch is taken from an internal per-modset arena
+ * that grows on demand. */
+MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                           const U64 *dReadOffsets, U32 nReads, U64 *nHash, void *stream) ;
+MgStatus mgQueryReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                             const U64 *dReadOffsets, U32 nReads,
+                             U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
+                             U64 *nSeeds, void *stream) ;
+
+/* Host-side batch mirrors of the reference callers' loops. */
+/* modutils.c:19-31 over nReads reads; returns total hashes, -1 on error. ms->max updated. */
+int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads) ;
+/* modutils.c:53-63 */
+void    mgDepthHistogram (Modset *ms, FILE *f) ;
+
+/* Deterministic synthetic reads generated directly in HBM (not from the reference):
+ *   mgSynthGenome: nBases iid-uniform bases, base g = splitmix64(seed ^ g*0x9E3779B97F4A7C15) >> 62
+ *   mgSynthReads : read r = genome[start[r], start[r]+len[r]) reverse-complemented when
+ *                  strand[r] != 0, each base substituted with probability errRate (a counter-based
+ *                  hash of (seed, global base ordinal) decides), written 2-bit packed. */
+MgStatus mgSynthGenome (U32 *dPacked, U64 nBases, U64 seed, void *stream) ;
+MgStatus mgSynthReads (const U32 *dGenomePacked, U64 genomeBases,
+                       const U64 *dReadStart, const U64 *dReadOffsets, const U8 *dStrand, U32 nReads,
+                       U64 totalBases, double errRate, U64 seed, U32 *dPackedOut, void *stream) ;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODGPU_H */

@@ -1,0 +1,280 @@
+"""modimizer_amd — MI355X-native seqhash + modset hot path (libmodgpu.so) behind the reference's API.
+
+This module is a thin ctypes binding over the C ABI declared in include/modgpu.h; all work happens
+in the HIP library.  There is no CPU fallback: if the library or a HIP device is missing the batch
+entry points raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmodgpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+U64P = C.POINTER(C.c_uint64)
+U32P = C.POINTER(C.c_uint32)
+
+MG_POS_MASK = 0x7FFFFFFF
+MG_FWD_BIT = 0x80000000
+
+
+class Seqhash(C.Structure):            # include/modgpu.h (reference seqhash.h:15-23)
+    _fields_ = [("seed", C.c_int), ("k", C.c_int), ("w", C.c_int), ("mask", C.c_uint64),
+                ("shift1", C.c_int), ("shift2", C.c_int), ("factor1", C.c_uint64),
+                ("factor2", C.c_uint64), ("patternRC", C.c_uint64 * 4)]
+
+
+class SeqhashRCiterator(C.Structure):  # reference seqhash.h:25-34
+    _fields_ = [("sh", C.POINTER(Seqhash)), ("s", C.c_void_p), ("sEnd", C.c_void_p),
+                ("h", C.c_uint64), ("hRC", C.c_uint64), ("hashBuf", C.c_void_p), ("fBuf", C.c_void_p),
+                ("base", C.c_int), ("iStart", C.c_int), ("iMin", C.c_int), ("isDone", C.c_bool)]
+
+
+class Modset(C.Structure):             # reference modset.h:17-28
+    _fields_ = [("hasher", C.POINTER(Seqhash)), ("tableBits", C.c_int), ("size", C.c_uint32),
+                ("tableSize", C.c_uint64), ("tableMask", C.c_uint64), ("index", U32P),
+                ("value", U64P), ("depth", C.POINTER(C.c_uint16)), ("info", C.POINTER(C.c_uint8)),
+                ("max", C.c_uint32)]
+
+
+# every symbol include/modgpu.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "seqhashCreate", "seqhashWrite", "seqhashRead", "seqhashReport", "modRCiterator", "modRCnext",
+    "minimizerRCiterator", "minimizerRCnext", "seqString", "mgSeqhashDestroy", "mgSeqhashRCiteratorDestroy",
+    "modsetCreate", "modsetDestroy", "modsetWrite", "modsetRead", "modsetIndexFind", "modsetSummary",
+    "modsetPack", "modsetDepthPrune", "modsetMerge",
+    "mgLastError", "mgDeviceCount", "mgSetDevice", "mgVersion", "mgDeviceAlloc", "mgDeviceFree",
+    "mgMemcpyH2D", "mgMemcpyD2H", "mgMemsetD", "mgStreamSynchronize",
+    "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice",
+    "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch",
+    "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgModsetDeviceRelease",
+    "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
+    "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
+]
+
+
+def build(force=False):
+    """Compile libmodgpu.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".c", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "modgpu.h"))
+    stale = force or not os.path.exists(LIB_PATH) or \
+        any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        cmd = ["make", "-C", CSRC, "-j4", "-s"] + (["-B"] if force else [])
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libmodgpu.so (building it first if the sources are newer). Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if os.environ.get("MODGPU_NO_TORCH", "0") != "1":
+        # torch bundles its own libamdhip64.so.7; load it first so both sides share ONE HIP runtime
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int64
+    SH, MS, IT = C.POINTER(Seqhash), C.POINTER(Modset), C.POINTER(SeqhashRCiterator)
+
+    def sig(name, res, *args):
+        f = getattr(L, name); f.restype = res; f.argtypes = list(args)
+    sig("seqhashCreate", SH, i32, i32, i32)
+    sig("seqhashWrite", None, SH, vp); sig("seqhashRead", SH, vp); sig("seqhashReport", None, SH, vp)
+    sig("modRCiterator", IT, SH, vp, i32)
+    sig("modRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
+    sig("minimizerRCiterator", IT, SH, vp, i32)
+    sig("minimizerRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
+    sig("seqString", C.c_char_p, u64, i32)
+    sig("mgSeqhashDestroy", None, SH); sig("mgSeqhashRCiteratorDestroy", None, IT)
+    sig("modsetCreate", MS, SH, i32, u32); sig("modsetDestroy", None, MS)
+    sig("modsetWrite", None, MS, vp); sig("modsetRead", MS, vp)
+    sig("modsetIndexFind", u32, MS, u64, i32); sig("modsetSummary", None, MS, vp)
+    sig("modsetPack", C.c_bool, MS); sig("modsetDepthPrune", None, MS, i32, i32)
+    sig("modsetMerge", C.c_bool, MS, MS)
+    sig("mgLastError", C.c_char_p); sig("mgDeviceCount", i32); sig("mgSetDevice", i32, i32)
+    sig("mgVersion", C.c_char_p)
+    sig("mgDeviceAlloc", i32, C.POINTER(vp), C.c_size_t); sig("mgDeviceFree", i32, vp)
+    sig("mgMemcpyH2D", i32, vp, vp, C.c_size_t, vp); sig("mgMemcpyD2H", i32, vp, vp, C.c_size_t, vp)
+    sig("mgMemsetD", i32, vp, i32, C.c_size_t, vp); sig("mgStreamSynchronize", i32, vp)
+    sig("mgPackedWords", C.c_size_t, u64); sig("mgPackHost", None, vp, u64, vp)
+    sig("mgPackDevice", i32, vp, u64, vp, vp); sig("mgUnpackDevice", i32, vp, u64, vp, vp)
+    sig("mgScanWorkBytes", C.c_size_t, u64, u32)
+    sig("seqhashScanBatchDevice", i32, SH, vp, u64, vp, u32, vp, vp, vp, u64, vp, vp, vp)
+    sig("seqhashScanBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
+    sig("modsetAddBatchDevice", i32, MS, vp, u64, vp, i32, vp)
+    sig("modsetFindBatchDevice", i32, MS, vp, u64, vp, vp)
+    sig("modsetSyncToHost", i32, MS, i32); sig("mgModsetDeviceRelease", i32, MS)
+    sig("mgModsetHostChanged", None, MS)
+    sig("modsetDepthHistogramDevice", i32, MS, vp, vp)
+    sig("mgAddReadsDevice", i32, MS, vp, u64, vp, u32, U64P, vp)
+    sig("mgQueryReadsDevice", i32, MS, vp, u64, vp, u32, vp, vp, vp, u64, U64P, vp)
+    sig("mgAddSequenceBatch", i64, MS, vp, vp, i32); sig("mgDepthHistogram", None, MS, vp)
+    sig("mgSynthGenome", i32, vp, u64, u64, vp)
+    sig("mgSynthReads", i32, vp, u64, vp, vp, vp, u32, u64, C.c_double, u64, vp, vp)
+    _lib = L
+    return L
+
+
+class ModgpuError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        raise ModgpuError("libmodgpu status %d: %s" % (status, lib().mgLastError().decode()))
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+class CFile:
+    """FILE* for the reference-style functions that print to a FILE (modsetSummary etc.)."""
+
+    def __init__(self, path, mode="w"):
+        self.f = _libc.fopen(path.encode(), mode.encode())
+        if not self.f:
+            raise OSError("cannot open " + path)
+
+    def __enter__(self):
+        return C.c_void_p(self.f)
+
+    def __exit__(self, *a):
+        _libc.fclose(self.f)
+
+
+# ------------------------------------------------------------------------------------------------
+# Host-side mirror of the reference interface (same names / argument meaning).
+
+def seqhashCreate(k, w, seed=17):
+    """reference seqhash.c:20-37.  Invalid k/w make the C library die() exactly like the reference;
+    here they raise ValueError first so a Python caller survives."""
+    if k < 1 or k >= 32:
+        raise ValueError("seqhash k %d must be between 1 and 32" % k)
+    if w < 1:
+        raise ValueError("seqhash w %d must be positive" % w)
+    return lib().seqhashCreate(k, w, seed)
+
+
+def modsetCreate(sh, bits, size=0):
+    """reference modset.c:15-31"""
+    if bits < 20 or bits > 34:
+        raise ValueError("table bits %d must be between 20 and 34" % bits)
+    if size >= (1 << bits) >> 2:
+        raise ValueError("Modset size %u is too big for %d bits" % (size, bits))
+    return lib().modsetCreate(sh, bits, size)
+
+
+def iterate(sh, bases, minimizer=False):
+    """Drive modRCiterator/modRCnext (or the minimizer pair) over one read, as the reference's
+    callers do (modutils.c:22-29).  bases: uint8 array of 0..3."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    mk, nx = (L.minimizerRCiterator, L.minimizerRCnext) if minimizer else (L.modRCiterator, L.modRCnext)
+    it = mk(sh, bases.ctypes.data, len(bases))
+    u = C.c_uint64(); p = C.c_int(); f = C.c_bool()
+    ks, ps, fs = [], [], []
+    while nx(it, C.byref(u), C.byref(p), C.byref(f)):
+        ks.append(u.value); ps.append(p.value); fs.append(int(f.value))
+    L.mgSeqhashRCiteratorDestroy(it)
+    return np.array(ks, np.uint64), np.array(ps, np.int32), np.array(fs, np.uint8)
+
+
+def scan_batch(sh, bases, offsets):
+    """seqhashScanBatch: all modimizers of a batch of reads in (read,pos) order.
+    Returns (kmer u64[], pos i32[], isF u8[], survStart i64[nReads+1])."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_reads = len(offsets) - 1
+    pk, pp, pf, ps = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = L.seqhashScanBatch(sh, bases.ctypes.data, offsets.ctypes.data, n_reads,
+                           C.byref(pk), C.byref(pp), C.byref(pf), C.byref(ps))
+    if n < 0:
+        raise ModgpuError("seqhashScanBatch failed: " + L.mgLastError().decode())
+
+    def take(ptr, ctype, count, dtype):
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (max(count, 1),))[:count].astype(dtype, copy=True)
+        _libc.free(ptr)
+        return a
+    kmer = take(pk, C.c_uint64, n, np.uint64)
+    pos = take(pp, C.c_int, n, np.int32)
+    isf = take(pf, C.c_bool, n, np.uint8)
+    st = take(ps, C.c_int64, n_reads + 1, np.int64)
+    return kmer, pos, isf, st
+
+
+class DeviceBuffer:
+    """A raw device allocation owned through the C ABI (no torch needed)."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        check(lib().mgDeviceAlloc(C.byref(self.ptr), self.nbytes))
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(max(arr.nbytes, 16))
+        if arr.nbytes:
+            check(lib().mgMemcpyH2D(b.ptr, arr.ctypes.data, arr.nbytes, None))
+            check(lib().mgStreamSynchronize(None))
+        return b
+
+    def to_numpy(self, dtype, count):
+        out = np.empty(count, dtype)
+        if out.nbytes:
+            check(lib().mgMemcpyD2H(out.ctypes.data, self.ptr, out.nbytes, None))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().mgDeviceFree(self.ptr); self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pack_host(bases):
+    """mgPackHost: bytes 0..3 -> 2-bit packed uint32 words (first base in the top bits)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    words = np.zeros(lib().mgPackedWords(len(bases)), np.uint32)
+    lib().mgPackHost(bases.ctypes.data, len(bases), words.ctypes.data)
+    return words
+
+
+def modset_arrays(ms):
+    """Host view (copies) of value/depth/info for entries 0..max of a Modset*."""
+    m = ms.contents
+    n = m.max + 1
+    return (np.ctypeslib.as_array(m.value, (n,)).copy(),
+            np.ctypeslib.as_array(m.depth, (n,)).copy(),
+            np.ctypeslib.as_array(m.info, (n,)).copy())
+
+
+def add_sequence_batch(ms, bases, offsets):
+    """mgAddSequenceBatch: modutils.c:19-31 over a batch of reads (GPU). Returns total hashes."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = lib().mgAddSequenceBatch(ms, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1)
+    if n < 0:
+        raise ModgpuError("mgAddSequenceBatch failed: " + lib().mgLastError().decode())
+    return n

@@ -1,0 +1,633 @@
+/* mg_api.hip — host glue behind the C ABI of include/modgpu.h (layer 2, the batch/device path):
+ * device bookkeeping, the per-Modset device table registry, and the composite entry points.
+ * The reference-compatible scalar API (layer 1) lives in mg_host.c and calls the mgHook* functions
+ * defined here to keep the host arrays and the device table coherent.
+ */
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <unordered_map>
+#include "mg_common.h"
+#include "mg_internal.h"
+
+/* ---------------------------------------------------------------------------------------- */
+/* errors / device                                                                            */
+
+static thread_local char gErr[512] = "";
+
+void mgSetError (const char *fmt, ...)
+{ va_list ap; va_start (ap, fmt); vsnprintf (gErr, sizeof (gErr), fmt, ap); va_end (ap); }
+
+extern "C" const char *mgLastError (void) { return gErr; }
+extern "C" const char *mgVersion (void) { return "modgpu 0.1 (gfx950)"; }
+
+MgStatus mgHipFail (hipError_t e, const char *what)
+{ mgSetError ("HIP error %d (%s) in %s", (int) e, hipGetErrorString (e), what); return MG_ERR_HIP; }
+
+extern "C" int mgDeviceCount (void)
+{ int n = 0; if (hipGetDeviceCount (&n) != hipSuccess) { (void) hipGetLastError (); return 0; } return n; }
+
+MgStatus mgEnsureDevice (void)
+{
+  static int known = -1;
+  if (known < 0) known = mgDeviceCount ();
+  if (known <= 0)
+    { mgSetError ("no HIP device available: libmodgpu has no CPU fallback for the batch path");
+      return MG_ERR_NO_DEVICE;
+    }
+  return MG_OK;
+}
+
+extern "C" MgStatus mgSetDevice (int device)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; MG_HIP (hipSetDevice (device)); return MG_OK; }
+
+extern "C" MgStatus mgDeviceAlloc (void **dptr, size_t bytes)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; MG_HIP (hipMalloc (dptr, bytes ? bytes : 16)); return MG_OK; }
+extern "C" MgStatus mgDeviceFree (void *dptr) { if (dptr) MG_HIP (hipFree (dptr)); return MG_OK; }
+extern "C" MgStatus mgMemcpyH2D (void *dst, const void *src, size_t bytes, void *stream)
+{ if (bytes) MG_HIP (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t) stream)); return MG_OK; }
+extern "C" MgStatus mgMemcpyD2H (void *dst, const void *src, size_t bytes, void *stream)
+{ if (bytes) MG_HIP (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream));
+  MG_HIP (hipStreamSynchronize ((hipStream_t) stream)); return MG_OK; }
+extern "C" MgStatus mgMemsetD (void *dst, int byte, size_t bytes, void *stream)
+{ if (bytes) MG_HIP (hipMemsetAsync (dst, byte, bytes, (hipStream_t) stream)); return MG_OK; }
+extern "C" MgStatus mgStreamSynchronize (void *stream)
+{ MG_HIP (hipStreamSynchronize ((hipStream_t) stream)); return MG_OK; }
+
+/* ---------------------------------------------------------------------------------------- */
+/* hash parameters                                                                            */
+
+MgHashParams mgMakeParams (const Seqhash *sh)
+{
+  MgHashParams p;
+  p.factor1 = sh->factor1; p.mask = sh->mask; p.k = sh->k; p.shift1 = sh->shift1;
+  p.d = (U32) sh->w;
+  p.dShift = __builtin_ctz (p.d);
+  U64 odd = (U64) (p.d >> p.dShift);
+  U64 x = odd;                                   /* Newton: inverse of an odd number mod 2^64 */
+  for (int i = 0 ; i < 6 ; ++i) x *= 2 - odd * x;
+  p.dOddInv = x;
+  p.dOddLim = ~(U64) 0 / odd;
+  return p;
+}
+
+static MgStatus mgCheckHasher (const Seqhash *sh)
+{
+  if (!sh || sh->k < 1 || sh->k >= 32 || sh->w < 1 || sh->shift1 != 64 - 2 * sh->k)
+    { mgSetError ("invalid Seqhash (k %d w %d)", sh ? sh->k : -1, sh ? sh->w : -1); return MG_ERR_ARG; }
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* packing                                                                                    */
+
+extern "C" size_t mgPackedWords (U64 nBases) { return (size_t) ((nBases + 15) / 16) + MG_PACK_PAD; }
+
+extern "C" void mgPackHost (const char *bases, U64 nBases, U32 *words)
+{
+  U64 nw = (nBases + 15) / 16;
+  for (U64 i = 0 ; i < nw ; ++i)
+    { U32 w = 0;
+      U64 b0 = i * 16;
+      int m = (nBases - b0 >= 16) ? 16 : (int) (nBases - b0);
+      for (int j = 0 ; j < m ; ++j) w |= (U32) (bases[b0 + j] & 3) << (30 - 2 * j);
+      words[i] = w;
+    }
+  for (int j = 0 ; j < MG_PACK_PAD ; ++j) words[nw + j] = 0;
+}
+
+extern "C" MgStatus mgPackDevice (const U8 *dBases, U64 nBases, U32 *dWords, void *stream)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; return mgLaunchPack (dBases, nBases, dWords, (hipStream_t) stream); }
+extern "C" MgStatus mgUnpackDevice (const U32 *dWords, U64 nBases, U8 *dBases, void *stream)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; return mgLaunchUnpack (dWords, nBases, dBases, (hipStream_t) stream); }
+
+/* ---------------------------------------------------------------------------------------- */
+/* scan                                                                                       */
+
+extern "C" MgStatus seqhashScanBatchDevice (const Seqhash *sh, const U32 *dPacked, U64 totalBases,
+                                            const U64 *dReadOffsets, U32 nReads,
+                                            U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
+                                            U64 *dCount, void *dWork, void *stream)
+{
+  MgStatus s = mgEnsureDevice (); if (s) return s;
+  if ((s = mgCheckHasher (sh))) return s;
+  if (!dCount || (totalBases && (!dPacked || !dReadOffsets || !dWork)))
+    { mgSetError ("seqhashScanBatchDevice: null argument"); return MG_ERR_ARG; }
+  return mgLaunchScan (mgMakeParams (sh), dPacked, totalBases, dReadOffsets, nReads,
+                       dKmer, dPosF, dReadId, capacity, dCount, dWork, (hipStream_t) stream);
+}
+
+/* grow-only device scratch */
+struct MgArena {
+  char *base = 0; size_t bytes = 0; size_t used = 0;
+  MgStatus reserve (size_t need)
+  { if (need <= bytes) return MG_OK;
+    if (base) MG_HIP (hipFree (base));
+    base = 0; bytes = 0;
+    size_t want = need + need / 8 + (1 << 20);
+    MG_HIP (hipMalloc ((void **) &base, want));
+    bytes = want;
+    return MG_OK;
+  }
+  void reset () { used = 0; }
+  void *take (size_t n) { size_t a = (used + 255) & ~(size_t) 255; used = a + n; return base + a; }
+  void release () { if (base) (void) hipFree (base); base = 0; bytes = used = 0; }
+};
+static inline size_t al256 (size_t n) { return (n + 255) & ~(size_t) 255; }
+
+static U64 mgSurvivorGuess (const Seqhash *sh, U64 totalBases)
+{
+  U64 g = totalBases / (U64) sh->w;
+  g += g / 4 + (1 << 16);
+  return g < totalBases ? g : totalBases;
+}
+
+extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
+                                     U64 **kmerOut, int **posOut, bool **isFOut, int64_t **survStartOut)
+{
+  if (mgEnsureDevice () || mgCheckHasher (sh)) return -1;
+  if (nReads < 0 || (nReads && (!readOffsets || readOffsets[0] != 0)))
+    { mgSetError ("seqhashScanBatch: bad read offsets"); return -1; }
+  U64 total = nReads ? (U64) readOffsets[nReads] : 0;
+  size_t nw = mgPackedWords (total);
+  U32 *hPacked = (U32 *) malloc (nw * sizeof (U32));
+  mgPackHost (bases, total, hPacked);
+  U64 cap = mgSurvivorGuess (sh, total);
+  MgArena ar;
+  int64_t result = -1;
+  U64 *hK = 0; U32 *hP = 0, *hR = 0;
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { size_t need = al256 (nw * 4) + al256 (((size_t) nReads + 1) * 8) + al256 (cap * 8) + 2 * al256 (cap * 4)
+                    + al256 (mgScanWorkBytes (total, (U32) nReads)) + 4096;
+      if (ar.reserve (need)) break;
+      ar.reset ();
+      U32 *dP = (U32 *) ar.take (nw * 4);
+      U64 *dOff = (U64 *) ar.take (((size_t) nReads + 1) * 8);
+      U64 *dK = (U64 *) ar.take (cap * 8);
+      U32 *dPos = (U32 *) ar.take (cap * 4);
+      U32 *dRid = (U32 *) ar.take (cap * 4);
+      void *dWork = ar.take (mgScanWorkBytes (total, (U32) nReads));
+      U64 *dCount = (U64 *) ar.take (16);
+      if (hipMemcpy (dP, hPacked, nw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+      if (nReads && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+      if (seqhashScanBatchDevice (sh, dP, total, dOff, (U32) nReads, dK, dPos, dRid, cap, dCount, dWork, 0)) break;
+      U64 cnt[2];
+      if (hipMemcpy (cnt, dCount, 16, hipMemcpyDeviceToHost) != hipSuccess) break;
+      if (cnt[1] || cnt[0] > cap) { cap = cnt[0]; continue; }
+      U64 n = cnt[0];
+      hK = (U64 *) malloc ((n + 1) * 8); hP = (U32 *) malloc ((n + 1) * 4); hR = (U32 *) malloc ((n + 1) * 4);
+      if (n)
+        { if (hipMemcpy (hK, dK, n * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+          if (hipMemcpy (hP, dPos, n * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+          if (hipMemcpy (hR, dRid, n * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        }
+      result = (int64_t) n;
+      break;
+    }
+  ar.release ();
+  free (hPacked);
+  if (result < 0)
+    { if (!gErr[0]) mgSetError ("seqhashScanBatch: device failure");
+      free (hK); free (hP); free (hR); return -1;
+    }
+  int64_t n = result;
+  if (posOut) { int *p = (int *) malloc ((n + 1) * sizeof (int)); for (int64_t i = 0 ; i < n ; ++i) p[i] = (int) (hP[i] & MG_POS_MASK); *posOut = p; }
+  if (isFOut) { bool *f = (bool *) malloc ((n + 1) * sizeof (bool)); for (int64_t i = 0 ; i < n ; ++i) f[i] = (hP[i] & MG_FWD_BIT) != 0; *isFOut = f; }
+  if (survStartOut)
+    { int64_t *st = (int64_t *) malloc (((size_t) nReads + 1) * sizeof (int64_t));
+      int64_t i = 0;
+      for (int r = 0 ; r <= nReads ; ++r) { while (i < n && (int64_t) hR[i] < r) ++i; st[r] = i; }
+      *survStartOut = st;
+    }
+  if (kmerOut) *kmerOut = hK; else free (hK);
+  free (hP); free (hR);
+  return n;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* per-Modset device state                                                                    */
+
+struct MgDev {
+  MgTable t;
+  MgArena arena;
+  U32 hostIndexMax;        /* entries 1..hostIndexMax are present in the host index[] table */
+  bool built;
+};
+
+static std::mutex gRegLock;
+static std::unordered_map<const Modset *, MgDev *> gReg;
+extern "C" { volatile int mgLiveDeviceModsets = 0; }
+
+static MgDev *mgDevLookup (const Modset *ms)
+{ std::lock_guard<std::mutex> g (gRegLock); auto it = gReg.find (ms); return it == gReg.end () ? 0 : it->second; }
+
+static void mgDevFree (MgDev *d)
+{
+  if (!d) return;
+  if (d->built)
+    { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.slotOfIndex);
+      (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters);
+    }
+  d->arena.release ();
+  delete d;
+}
+
+static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
+{
+  MgTable &t = d->t;
+  if (ms->tableBits < 20 || ms->tableBits > 32)
+    { mgSetError ("device modset supports table bits 20..32 (got %d)", ms->tableBits); return MG_ERR_ARG; }
+  memset (&t, 0, sizeof (t));
+  t.nSlots = (U64) 1 << (ms->tableBits - 1);          /* >= 2 * size: load factor <= 0.5 */
+  t.slotMask = t.nSlots - 1;
+  t.size = ms->size;
+  U64 cap = (ms->tableSize >> 2);                      /* device arrays cover the largest legal size */
+  MG_HIP (hipMalloc ((void **) &t.slots, t.nSlots * sizeof (MgSlot)));
+  MG_HIP (hipMalloc ((void **) &t.value, cap * sizeof (U64)));
+  MG_HIP (hipMalloc ((void **) &t.slotOfIndex, cap * sizeof (U32)));
+  MG_HIP (hipMalloc ((void **) &t.baseDepth, cap * sizeof (U16)));
+  MG_HIP (hipMalloc ((void **) &t.counters, 64));
+  d->built = true;
+  MG_HIP (hipMemsetAsync (t.slots, 0, t.nSlots * sizeof (MgSlot), st));
+  MG_HIP (hipMemsetAsync (t.baseDepth, 0, cap * sizeof (U16), st));
+  MG_HIP (hipMemsetAsync (t.counters, 0, 64, st));
+  t.max = 0; t.syncedMax = 0;
+  if (ms->max)
+    { MG_HIP (hipMemcpyAsync (t.value, ms->value, ((size_t) ms->max + 1) * sizeof (U64), hipMemcpyHostToDevice, st));
+      MG_HIP (hipMemcpyAsync (t.baseDepth, ms->depth, ((size_t) ms->max + 1) * sizeof (U16), hipMemcpyHostToDevice, st));
+      MgStatus s = mgTableLoadHost (&t, t.value, 1, ms->max, st); if (s) return s;
+      MG_HIP (hipStreamSynchronize (st));
+      t.max = t.syncedMax = ms->max;
+    }
+  d->hostIndexMax = ms->max;
+  return MG_OK;
+}
+
+/* get (and bring up to date) the device state of ms */
+static MgStatus mgDevGet (Modset *ms, MgDev **out, hipStream_t st)
+{
+  MgStatus s = mgEnsureDevice (); if (s) return s;
+  if (!ms || !ms->hasher) { mgSetError ("null Modset"); return MG_ERR_ARG; }
+  if ((s = mgCheckHasher (ms->hasher))) return s;
+  MgDev *d = mgDevLookup (ms);
+  if (!d)
+    { d = new MgDev (); d->built = false; d->hostIndexMax = 0;
+      if ((s = mgDevBuild (ms, d, st))) { mgDevFree (d); return s; }
+      std::lock_guard<std::mutex> g (gRegLock); gReg[ms] = d; mgLiveDeviceModsets = (int) gReg.size ();
+    }
+  else if (ms->max > d->t.max)
+    { /* the host appended entries through the scalar API (modsetIndexFind isAdd): mirror them */
+      U32 first = d->t.max + 1, last = ms->max;
+      if (last >= (ms->tableSize >> 2)) { mgSetError ("modset max %u beyond table capacity", last); return MG_ERR_CAPACITY; }
+      MG_HIP (hipMemcpyAsync (d->t.value + first, ms->value + first, (size_t) (last - first + 1) * sizeof (U64), hipMemcpyHostToDevice, st));
+      MG_HIP (hipMemcpyAsync (d->t.baseDepth + first, ms->depth + first, (size_t) (last - first + 1) * sizeof (U16), hipMemcpyHostToDevice, st));
+      if ((s = mgTableLoadHost (&d->t, d->t.value, first, last, st))) return s;
+      MG_HIP (hipStreamSynchronize (st));
+      d->t.max = d->t.syncedMax = last;
+      if (d->hostIndexMax == first - 1) d->hostIndexMax = last;
+    }
+  d->t.size = ms->size;
+  *out = d;
+  return MG_OK;
+}
+
+extern "C" MgStatus mgModsetDeviceRelease (Modset *ms)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d) return MG_OK;
+  MgStatus s = modsetSyncToHost (ms, 1);
+  { std::lock_guard<std::mutex> g (gRegLock); gReg.erase (ms); mgLiveDeviceModsets = (int) gReg.size (); }
+  mgDevFree (d);
+  return s;
+}
+
+extern "C" void mgModsetHostChanged (Modset *ms)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d) return;
+  { std::lock_guard<std::mutex> g (gRegLock); gReg.erase (ms); mgLiveDeviceModsets = (int) gReg.size (); }
+  mgDevFree (d);
+}
+
+/* hooks for mg_host.c */
+extern "C" void mgHookDestroy (Modset *ms) { mgModsetHostChanged (ms); }
+extern "C" void mgHookHostRewrote (Modset *ms) { mgModsetHostChanged (ms); }
+extern "C" void mgHookNeedHostAll (Modset *ms, int wantIndex)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d) return;
+  if (modsetSyncToHost (ms, wantIndex) != MG_OK)
+    { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }
+}
+extern "C" void mgHookNeedHost (Modset *ms, int wantIndex)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d) return;
+  if (d->t.syncedMax == d->t.max && (!wantIndex || d->hostIndexMax >= d->t.max)) return;
+  mgHookNeedHostAll (ms, wantIndex);
+}
+extern "C" int mgHookHasDevice (Modset *ms) { return mgDevLookup (ms) != 0; }
+
+/* ---------------------------------------------------------------------------------------- */
+/* batch insert / find                                                                        */
+
+#define MG_ADD_CHUNK ((U64) 1 << 30)
+
+static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
+                            U32 *dSlotId, void *dDesc, hipStream_t st)
+{
+  MgTable &t = d->t;
+  MgStatus s;
+  MG_HIP (hipMemsetAsync (t.counters, 0, 16, st));
+  if ((s = mgTableInsert (&t, dKmer, n, dSlotId, withDepth, st))) return s;
+  if ((s = mgTableAssign (&t, dKmer, n, dSlotId, dDesc, st))) return s;
+  if (dIndexOut && (s = mgTableGather (&t, dSlotId, n, dIndexOut, st))) return s;
+  U64 c[2];
+  MG_HIP (hipMemcpyAsync (c, t.counters, 16, hipMemcpyDeviceToHost, st));
+  MG_HIP (hipStreamSynchronize (st));
+  U64 newMax = (U64) t.max + c[0];
+  if (c[1] || newMax >= t.size)
+    { /* modset.c:58 */
+      mgSetError ("hashTableSize %u is too small for %llu", t.size, (unsigned long long) newMax);
+      return MG_ERR_CAPACITY;
+    }
+  t.max = (U32) newMax;
+  ms->max = t.max;
+  return MG_OK;
+}
+
+/* arenaLive: dKmer itself lives in d->arena (mgAddReadsDevice), so the arena must not be reset
+ * or reallocated; the caller reserved room for the temporaries taken here. */
+static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
+                            bool arenaLive, hipStream_t st)
+{
+  if (!n) return MG_OK;
+  U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
+  size_t need = al256 (chunk * 4) + al256 (mgAssignDescBytes (chunk)) + 4096;
+  MgStatus s = MG_OK;
+  if (!arenaLive)
+    { if ((s = d->arena.reserve (need))) return s;
+      d->arena.reset ();
+    }
+  else if (d->arena.bytes - d->arena.used < need)
+    { mgSetError ("internal: arena too small for insert temporaries"); return MG_ERR_NOMEM; }
+  U32 *dSlotId = (U32 *) d->arena.take (chunk * 4);
+  void *dDesc = d->arena.take (mgAssignDescBytes (chunk));
+  for (U64 off = 0 ; off < n && !s ; off += chunk)
+    { U64 m = n - off < chunk ? n - off : chunk;
+      s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, dSlotId, dDesc, st);
+    }
+  return s;
+}
+
+extern "C" MgStatus modsetAddBatchDevice (Modset *ms, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  return mgAddBatch (ms, d, dKmer, n, dIndexOut, withDepth, false, st);
+}
+
+extern "C" MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, U32 *dIndexOut, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  return mgTableFind (&d->t, dKmer, n, dIndexOut, st);
+}
+
+extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d) return MG_OK;
+  MgTable &t = d->t;
+  hipStream_t st = 0;
+  MG_HIP (hipDeviceSynchronize ());
+  if (t.max > t.syncedMax)
+    { U32 first = t.syncedMax + 1;
+      MG_HIP (hipMemcpy (ms->value + first, t.value + first, (size_t) (t.max - first + 1) * sizeof (U64), hipMemcpyDeviceToHost));
+      t.syncedMax = t.max;
+    }
+  ms->max = t.max;
+  if (t.max)
+    { /* depth[i] = min (65535, depth[i] + pending)   (modutils.c:26 applied `pending` times) */
+      U16 *dDelta; MG_HIP (hipMalloc ((void **) &dDelta, (size_t) t.max * sizeof (U16)));
+      MgStatus s = mgTableExportDepth (&t, dDelta, 1, t.max, st);
+      U16 *h = (U16 *) malloc ((size_t) t.max * sizeof (U16));
+      hipError_t e = s ? hipSuccess : hipMemcpy (h, dDelta, (size_t) t.max * sizeof (U16), hipMemcpyDeviceToHost);
+      (void) hipFree (dDelta);
+      if (s) { free (h); return s; }
+      if (e != hipSuccess) { free (h); return mgHipFail (e, "depth D2H"); }
+      for (U32 i = 1 ; i <= t.max ; ++i)
+        { U32 v = (U32) ms->depth[i] + h[i - 1]; ms->depth[i] = (U16) (v > 0xffffu ? 0xffffu : v); }
+      free (h);
+    }
+  if (wantIndex && d->hostIndexMax < t.max)
+    { U32 *dIndex; MG_HIP (hipMalloc ((void **) &dIndex, ms->tableSize * sizeof (U32)));
+      MgStatus s = mgTableReplayIndex (&t, mgMakeParams (ms->hasher), ms->tableBits, dIndex, st);
+      hipError_t e = s ? hipSuccess : hipMemcpy (ms->index, dIndex, ms->tableSize * sizeof (U32), hipMemcpyDeviceToHost);
+      (void) hipFree (dIndex);
+      if (s) return s;
+      if (e != hipSuccess) return mgHipFail (e, "index D2H");
+      d->hostIndexMax = t.max;
+    }
+  return MG_OK;
+}
+
+extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  return mgTableHistogram (&d->t, dHist, st);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* composite: scan a device-resident batch straight into the modset                           */
+
+struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; };
+
+/* scan into arena buffers, growing once if the survivor guess was too small */
+static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked, U64 totalBases,
+                                 const U64 *dReadOffsets, U32 nReads, bool wantPos, size_t extraPerSurvivor,
+                                 MgScanBufs *b, U64 *nOut, hipStream_t st)
+{
+  U64 cap = mgSurvivorGuess (sh, totalBases);
+  MgHashParams p = mgMakeParams (sh);
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
+      size_t need = al256 (cap * perS) + 4 * 4096 + al256 (mgScanWorkBytes (totalBases, nReads))
+                    + al256 (mgAssignDescBytes (cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK)) + 8 * 256;
+      MgStatus s = d->arena.reserve (need); if (s) return s;
+      d->arena.reset ();
+      b->cap = cap;
+      b->kmer = (U64 *) d->arena.take (cap * 8);
+      b->posF = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
+      b->rid = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
+      b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads));
+      b->count = (U64 *) d->arena.take (16);
+      if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st))) return s;
+      U64 c[2];
+      MG_HIP (hipMemcpyAsync (c, b->count, 16, hipMemcpyDeviceToHost, st));
+      MG_HIP (hipStreamSynchronize (st));
+      if (!c[1] && c[0] <= cap) { *nOut = c[0]; return MG_OK; }
+      cap = c[0];
+    }
+  mgSetError ("scan capacity could not be established");
+  return MG_ERR_CAPACITY;
+}
+
+extern "C" MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                                      const U64 *dReadOffsets, U32 nReads, U64 *nHash, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  if (nHash) *nHash = 0;
+  if (!totalBases || !nReads) return MG_OK;
+  MgScanBufs b; U64 n = 0;
+  /* posF is not needed by addSequence (modutils.c:24 passes 0 for isF and ignores pos) but the
+     scan kernel writes it unconditionally; slotId shares the arena (4 B per survivor). */
+  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, 4, &b, &n, st))) return s;
+  if (nHash) *nHash = n;
+  return mgAddBatch (ms, d, b.kmer, n, 0, 1, true, st);
+}
+
+extern "C" MgStatus mgQueryReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                                        const U64 *dReadOffsets, U32 nReads,
+                                        U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
+                                        U64 *nSeeds, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  if (nSeeds) *nSeeds = 0;
+  if (!totalBases || !nReads) return MG_OK;
+  MgScanBufs b; U64 n = 0;
+  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, 0, &b, &n, st))) return s;
+  if (nSeeds) *nSeeds = n;
+  if (n > capacity) { mgSetError ("mgQueryReadsDevice: %llu seeds exceed capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
+  if ((s = mgTableFind (&d->t, b.kmer, n, dSeedIndex, st))) return s;
+  if (dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));
+  if (dSeedRead) MG_HIP (hipMemcpyAsync (dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st));
+  MG_HIP (hipStreamSynchronize (st));
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* host-buffer mirrors of the reference callers' loops                                        */
+
+extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads)
+{
+  if (mgEnsureDevice ()) return -1;
+  if (nReads <= 0) return 0;
+  U64 total = (U64) readOffsets[nReads];
+  size_t nw = mgPackedWords (total);
+  U32 *hPacked = (U32 *) malloc (nw * sizeof (U32));
+  mgPackHost (bases, total, hPacked);
+  U32 *dP = 0; U64 *dOff = 0;
+  int64_t res = -1;
+  if (hipMalloc ((void **) &dP, nw * 4) == hipSuccess && hipMalloc ((void **) &dOff, ((size_t) nReads + 1) * 8) == hipSuccess
+      && hipMemcpy (dP, hPacked, nw * 4, hipMemcpyHostToDevice) == hipSuccess
+      && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess)
+    { U64 nHash = 0;
+      if (mgAddReadsDevice (ms, dP, total, dOff, (U32) nReads, &nHash, 0) == MG_OK) res = (int64_t) nHash;
+    }
+  else mgSetError ("mgAddSequenceBatch: device allocation or copy failed");
+  if (dP) (void) hipFree (dP);
+  if (dOff) (void) hipFree (dOff);
+  free (hPacked);
+  return res;
+}
+
+extern "C" void mgDepthHistogram (Modset *ms, FILE *f)
+{
+  U64 *hist = (U64 *) calloc (65536, sizeof (U64));
+  MgDev *d = mgDevLookup (ms);
+  bool done = false;
+  if (d)
+    { U64 *dHist = 0;
+      if (hipMalloc ((void **) &dHist, 65536 * 8) == hipSuccess)
+        { if (hipMemset (dHist, 0, 65536 * 8) == hipSuccess && modsetDepthHistogramDevice (ms, dHist, 0) == MG_OK
+              && hipMemcpy (hist, dHist, 65536 * 8, hipMemcpyDeviceToHost) == hipSuccess) done = true;
+          (void) hipFree (dHist);
+        }
+      if (!done) { fprintf (stderr, "FATAL ERROR: depth histogram on device failed: %s\n", mgLastError ()); exit (-1); }
+    }
+  else
+    for (U32 i = 1 ; i <= ms->max ; ++i) ++hist[ms->depth[i]];      /* host-only modset: nothing on the device */
+  for (U32 b = 0 ; b < 65536 ; ++b)
+    if (hist[b]) fprintf (f, "DP\t%u\t%u\n", b, (U32) hist[b]);       /* modutils.c:61 */
+  free (hist);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* per-read iterator facade: one GPU scan per modRCiterator call, replayed by modRCnext       */
+
+struct MgIterScratch {
+  U32 *dPacked = 0; U64 *dOff = 0; U64 *dKmer = 0; U32 *dPosF = 0; void *dWork = 0; U64 *dCount = 0;
+  size_t wordsCap = 0, survCap = 0, workCap = 0;
+  U32 *hPacked = 0; size_t hWordsCap = 0;
+};
+static thread_local MgIterScratch gIt;
+
+extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut)
+{
+  /* returns 0 on success; *rec is a malloc()ed block {n kmers (U64), n posF (U32)} */
+  *rec = 0; *nOut = 0;
+  if (mgEnsureDevice ()) return -1;
+  if (len < sh->k) return 0;
+  U64 total = (U64) len;
+  size_t nw = mgPackedWords (total);
+  MgIterScratch &g = gIt;
+  if (nw > g.hWordsCap) { free (g.hPacked); g.hPacked = (U32 *) malloc (2 * nw * 4); g.hWordsCap = 2 * nw; }
+  mgPackHost (s, total, g.hPacked);
+  if (!g.dOff) { if (hipMalloc ((void **) &g.dOff, 16) != hipSuccess || hipMalloc ((void **) &g.dCount, 16) != hipSuccess) return -1; }
+  if (nw > g.wordsCap)
+    { if (g.dPacked) (void) hipFree (g.dPacked);
+      if (hipMalloc ((void **) &g.dPacked, 2 * nw * 4) != hipSuccess) return -1;
+      g.wordsCap = 2 * nw;
+    }
+  size_t wb = mgScanWorkBytes (total, 1);
+  if (wb > g.workCap)
+    { if (g.dWork) (void) hipFree (g.dWork);
+      if (hipMalloc (&g.dWork, 2 * wb) != hipSuccess) return -1;
+      g.workCap = 2 * wb;
+    }
+  U64 cap = mgSurvivorGuess (sh, total);
+  MgHashParams p = mgMakeParams (sh);
+  U64 off[2] = { 0, total };
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { if (cap > g.survCap)
+        { if (g.dKmer) (void) hipFree (g.dKmer);
+          if (g.dPosF) (void) hipFree (g.dPosF);
+          if (hipMalloc ((void **) &g.dKmer, 2 * cap * 8) != hipSuccess || hipMalloc ((void **) &g.dPosF, 2 * cap * 4) != hipSuccess) return -1;
+          g.survCap = 2 * cap;
+        }
+      if (hipMemcpyAsync (g.dPacked, g.hPacked, nw * 4, hipMemcpyHostToDevice, 0) != hipSuccess) return -1;
+      if (hipMemcpyAsync (g.dOff, off, 16, hipMemcpyHostToDevice, 0) != hipSuccess) return -1;
+      if (mgLaunchScan (p, g.dPacked, total, g.dOff, 1, g.dKmer, g.dPosF, 0, g.survCap, g.dCount, g.dWork, 0)) return -1;
+      U64 c[2];
+      if (hipMemcpy (c, g.dCount, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      if (c[1] || c[0] > g.survCap) { cap = c[0]; continue; }
+      U64 n = c[0];
+      U64 *blk = (U64 *) malloc ((size_t) n * 12 + 16);
+      if (n)
+        { if (hipMemcpy (blk, g.dKmer, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { free (blk); return -1; }
+          if (hipMemcpy (blk + n, g.dPosF, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { free (blk); return -1; }
+        }
+      *rec = blk; *nOut = n;
+      return 0;
+    }
+  return -1;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* synthetic data                                                                             */
+
+extern "C" MgStatus mgSynthGenome (U32 *dPacked, U64 nBases, U64 seed, void *stream)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; return mgLaunchSynthGenome (dPacked, nBases, seed, (hipStream_t) stream); }
+
+extern "C" MgStatus mgSynthReads (const U32 *dGenomePacked, U64 genomeBases,
+                                  const U64 *dReadStart, const U64 *dReadOffsets, const U8 *dStrand, U32 nReads,
+                                  U64 totalBases, double errRate, U64 seed, U32 *dPackedOut, void *stream)
+{ MgStatus s = mgEnsureDevice (); if (s) return s;
+  return mgLaunchSynthReads (dGenomePacked, genomeBases, dReadStart, dReadOffsets, dStrand, nReads, totalBases,
+                             errRate, seed, dPackedOut, (hipStream_t) stream);
+}

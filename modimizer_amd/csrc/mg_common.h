@@ -1,0 +1,133 @@
+/* mg_common.h — shared declarations for the HIP side of libmodgpu (gfx950 only). */
+#ifndef MG_COMMON_H
+#define MG_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "modgpu.h"
+
+#define MG_WAVE 64
+
+/* scan tiling: one workgroup walks tiles of the concatenated batch */
+#define MG_SCAN_THREADS   256
+#define MG_POS_PER_THREAD 64
+#define MG_TILE_BASES     (MG_SCAN_THREADS * MG_POS_PER_THREAD)   /* 16384 k-mer starts per tile */
+#define MG_TILE_WORDS     (MG_TILE_BASES / 16)                    /* 1024 packed words = 4 KiB  */
+
+/* Hash parameters in the form the kernels use. */
+struct MgHashParams {
+  U64 factor1;
+  U64 mask;        /* 2^(2k) - 1 */
+  int k;
+  int shift1;      /* 64 - 2k */
+  U32 d;           /* the modulus sh->w */
+  int dShift;      /* d = dOdd << dShift */
+  U64 dOddInv;     /* inverse of dOdd mod 2^64 */
+  U64 dOddLim;     /* floor((2^64-1) / dOdd) */
+};
+
+void mgSetError (const char *fmt, ...);
+MgStatus mgHipFail (hipError_t e, const char *what);
+MgStatus mgEnsureDevice (void);
+MgHashParams mgMakeParams (const Seqhash *sh);
+
+#define MG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mgHipFail (e_, #call); } while (0)
+
+#ifdef __HIPCC__
+/* Exact "x % d == 0" without a division (d = dOdd * 2^dShift):
+ * low dShift bits zero, and (x >> dShift) * dOdd^-1 mod 2^64 <= floor((2^64-1)/dOdd). */
+__device__ __forceinline__ bool mgDivisible (U64 x, const MgHashParams &p)
+{
+  if (x & (((U64) 1 << p.dShift) - 1)) return false;
+  return ((x >> p.dShift) * p.dOddInv) <= p.dOddLim;
+}
+
+/* reverse complement of a k-mer held in the low 2k bits */
+__device__ __forceinline__ U64 mgRevComp (U64 f, int shift1)
+{
+  U64 x = __brevll (f);
+  x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+  return (~x) >> shift1;
+}
+
+/* 64-bit tile descriptor for the ordered single-pass compaction (decoupled look-back):
+ * bits 63..62 status, bits 61..0 value.  Published and polled with agent-scope relaxed atomics
+ * (one naturally aligned 8-byte granule carries both data and tag, so no separate flag). */
+#define MG_DESC_INVALID   0ull
+#define MG_DESC_AGGREGATE 1ull
+#define MG_DESC_PREFIX    2ull
+__device__ __forceinline__ void mgDescStore (U64 *d, U64 status, U64 v)
+{ __hip_atomic_store (d, (status << 62) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ U64 mgDescLoad (const U64 *d)
+{ return __hip_atomic_load (d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* Exclusive prefix of `count` over all earlier tiles; publishes this tile's aggregate/prefix.
+ * Called by every lane of wave 0 of the workgroup (count is tile-uniform); returns the same value
+ * in every lane.  Tiles are handed out by an atomic ticket, so every predecessor has started. */
+__device__ __forceinline__ U64 mgLookback (U64 *desc, U64 tile, U64 count)
+{
+  const int lane = threadIdx.x & 63;
+  if (tile == 0)
+    { if (lane == 0) mgDescStore (&desc[0], MG_DESC_PREFIX, count);
+      return 0;
+    }
+  if (lane == 0) mgDescStore (&desc[tile], MG_DESC_AGGREGATE, count);
+  U64 sum = 0;
+  int64_t top = (int64_t) tile - 1;
+  for (;;)
+    { int64_t j = top - lane;
+      U64 v = (MG_DESC_PREFIX << 62);            /* lanes before tile 0 act as a zero prefix */
+      if (j >= 0)
+        { do { v = mgDescLoad (&desc[j]); } while ((v >> 62) == MG_DESC_INVALID); }
+      unsigned long long isPrefix = __ballot ((v >> 62) == MG_DESC_PREFIX);
+      U64 val = v & 0x3fffffffffffffffull;
+      int first = isPrefix ? __ffsll ((long long) isPrefix) - 1 : 63;   /* nearest predecessor with a prefix */
+      U64 contrib = (lane <= first) ? val : 0;
+      for (int off = 32 ; off ; off >>= 1) contrib += __shfl_xor (contrib, off);
+      sum += contrib;
+      if (isPrefix) break;
+      top -= 64;
+    }
+  if (lane == 0) mgDescStore (&desc[tile], MG_DESC_PREFIX, sum + count);
+  return sum;
+}
+#endif /* __HIPCC__ */
+
+/* launchers implemented in the .hip files */
+MgStatus mgLaunchPack (const U8 *dBases, U64 nBases, U32 *dWords, hipStream_t st);
+MgStatus mgLaunchUnpack (const U32 *dWords, U64 nBases, U8 *dBases, hipStream_t st);
+MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
+                       const U64 *dReadOffsets, U32 nReads,
+                       U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
+                       U64 *dCount, void *dWork, hipStream_t st);
+
+/* device modset table */
+struct MgSlot { U64 key; U32 ordIdx; U32 cnt; };   /* 16 bytes; key = kmer+1, 0 = empty */
+struct MgTable {
+  MgSlot *slots; U64 nSlots; U64 slotMask;
+  U64 *value;          /* [size] device mirror of ms->value for device-assigned entries */
+  U32 *slotOfIndex;    /* [size] */
+  U16 *baseDepth;      /* [size] host depth at last sync */
+  U32 size;            /* capacity in entries (ms->size) */
+  U32 max;             /* entries known to the device table */
+  U32 syncedMax;       /* entries whose value[] the host already has */
+  U64 *scratch; size_t scratchBytes;     /* arena for per-call temporaries */
+  U64 *counters;       /* device U64[8] */
+  int device;
+};
+MgStatus mgTableInsert (MgTable *t, const U64 *dKmer, U64 n, U32 *dSlotId, int withDepth, hipStream_t st);
+MgStatus mgTableAssign (MgTable *t, const U64 *dKmer, U64 n, const U32 *dSlotId, void *dDesc, hipStream_t st);
+MgStatus mgTableGather (MgTable *t, const U32 *dSlotId, U64 n, U32 *dIndexOut, hipStream_t st);
+MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
+MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);
+MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipStream_t st);
+MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st);
+MgStatus mgTableReplayIndex (MgTable *t, const MgHashParams &p, int tableBits, U32 *dIndex, hipStream_t st);
+size_t   mgAssignDescBytes (U64 n);
+
+MgStatus mgLaunchSynthGenome (U32 *dPacked, U64 nBases, U64 seed, hipStream_t st);
+MgStatus mgLaunchSynthReads (const U32 *dGenome, U64 genomeBases, const U64 *dReadStart,
+                             const U64 *dReadOffsets, const U8 *dStrand, U32 nReads, U64 totalBases,
+                             double errRate, U64 seed, U32 *dOut, hipStream_t st);
+
+#endif

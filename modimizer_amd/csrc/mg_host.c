@@ -1,0 +1,370 @@
+/* mg_host.c — layer 1 of libmodgpu: the reference's seqhash.h / modset.h API in plain C.
+ *
+ * Same signatures, struct layouts, messages and exit behaviour as the reference
+ * (seqhash.c, modset.c, utils.c:19-30), so modmap/modutils-style callers link unchanged.
+ * What differs is where the work happens:
+ *   - modRCiterator runs ONE GPU scan over the read (mg_scan.hip) and modRCnext replays it;
+ *   - the Modset host arrays are a mirror: batch inserts/lookups run on the device table
+ *     (mg_table.hip) and the mgHook* calls below bring the host arrays up to date before any
+ *     function here reads them.
+ * Scalar modsetIndexFind works on the host arrays, as the transparent struct demands (callers
+ * index ms->value/depth/info themselves: modutils.c:26, modmap.c:126-129).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include "modgpu.h"
+#include "mg_internal.h"
+
+/* utils.c:19-30 */
+static void die (const char *format, ...)
+{
+  va_list args;
+  va_start (args, format);
+  fprintf (stderr, "FATAL ERROR: ");
+  vfprintf (stderr, format, args);
+  fprintf (stderr, "\n");
+  va_end (args);
+  exit (-1);
+}
+
+static void *xalloc (size_t n, int zero)
+{
+  void *p = zero ? calloc (n ? n : 1, 1) : malloc (n ? n : 1);
+  if (!p) die ("memory allocation failure requesting %llu bytes", (unsigned long long) n);
+  return p;
+}
+
+/* ------------------------------ seqhash ------------------------------ */
+
+Seqhash *seqhashCreate (int k, int w, int seed)
+{
+  Seqhash *sh = (Seqhash *) xalloc (sizeof (Seqhash), 1);
+  if (k < 1 || k >= 32) die ("seqhash k %d must be between 1 and 32\n", k);
+  if (w < 1) die ("seqhash w %d must be positive\n", w);
+  sh->k = k; sh->w = w; sh->seed = seed;
+  sh->mask = ((U64) 1 << (2 * k)) - 1;
+  sh->shift1 = 64 - 2 * k;
+  sh->shift2 = 2 * k;
+  /* glibc random() stream after srandom(seed); the high word is drawn first (seqhash.c:30-33) */
+  srandom ((unsigned) seed);
+  U64 hi = (U64) random (), lo = (U64) random ();
+  sh->factor1 = (hi << 32) | lo | 1;
+  hi = (U64) random (); lo = (U64) random ();
+  sh->factor2 = (hi << 32) | lo | 1;
+  for (int b = 0 ; b < 4 ; ++b) sh->patternRC[b] = (U64) (3 - b) << (2 * (k - 1));
+  return sh;
+}
+
+void mgSeqhashDestroy (Seqhash *sh) { free (sh); }
+
+void seqhashWrite (Seqhash *sh, FILE *f)
+{
+  if (fwrite ("SQHSHv2", 8, 1, f) != 1) die ("failed to write seqhash header");
+  if (fwrite (sh, sizeof (Seqhash), 1, f) != 1) die ("failed to write seqhash");
+}
+
+Seqhash *seqhashRead (FILE *f)
+{
+  Seqhash *sh = (Seqhash *) xalloc (sizeof (Seqhash), 0);
+  char name[8];
+  if (fread (name, 8, 1, f) != 1) die ("failed to read seqhash header");
+  if (memcmp (name, "SQHSHv2", 8)) die ("seqhash read mismatch");
+  if (fread (sh, sizeof (Seqhash), 1, f) != 1) die ("failed to read seqhash");
+  return sh;
+}
+
+void seqhashReport (Seqhash *sh, FILE *f)
+{ fprintf (f, "SH k %d  w/m %d  s %d\n", sh->k, sh->w, sh->seed); }
+
+char *seqString (U64 kmer, int len)
+{
+  static char buf[33];
+  if (len > 32) len = 32;
+  if (len < 0) len = 0;
+  buf[len] = 0;
+  for (int i = len ; i-- ; kmer >>= 2) buf[i] = "acgt"[kmer & 3];
+  return buf;
+}
+
+/* Iterator facade.  Layout kept from seqhash.h:25-34; hashBuf is the free()-able block that
+ * carries the replay records: [0] = n, then n k-mers, then n packed (pos | isF<<31) words.
+ * iMin is the replay cursor. */
+static SeqhashRCiterator *iterAlloc (Seqhash *sh, char *s, int len)
+{
+  SeqhashRCiterator *si = (SeqhashRCiterator *) xalloc (sizeof (SeqhashRCiterator), 1);
+  si->sh = sh; si->s = s; si->sEnd = s + len;
+  si->fBuf = (bool *) xalloc ((size_t) sh->w * sizeof (bool), 1);
+  return si;
+}
+
+SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len)
+{
+  SeqhashRCiterator *si = iterAlloc (sh, s, len);
+  U64 *rec = 0, n = 0;
+  if (mgIterScan (sh, s, len, &rec, &n)) die ("modRCiterator: GPU scan failed: %s", mgLastError ());
+  U64 *blk = (U64 *) xalloc ((size_t) (n + 1) * 8 + (size_t) n * 4 + 8, 0);
+  blk[0] = n;
+  if (n)
+    { memcpy (blk + 1, rec, (size_t) n * 8);
+      memcpy (blk + 1 + n, rec + n, (size_t) n * 4);
+    }
+  free (rec);
+  si->hashBuf = blk;
+  si->iMin = 0;
+  si->isDone = (n == 0);
+  return si;
+}
+
+bool modRCnext (SeqhashRCiterator *si, U64 *kmer, int *pos, bool *isF)
+{
+  if (si->isDone) return false;
+  U64 n = si->hashBuf[0];
+  const U64 *km = si->hashBuf + 1;
+  const U32 *pf = (const U32 *) (km + n);
+  U64 i = (U64) (unsigned) si->iMin;
+  if (kmer) *kmer = km[i];
+  if (pos) *pos = (int) (pf[i] & MG_POS_MASK);
+  if (isF) *isF = (pf[i] & MG_FWD_BIT) != 0;
+  si->h = km[i];
+  if (++i >= n) si->isDone = true;
+  si->iMin = (int) i;
+  return true;
+}
+
+void mgSeqhashRCiteratorDestroy (SeqhashRCiterator *si)
+{ free (si->hashBuf); free (si->fBuf); free (si); }
+
+/* minimizerRCiterator / minimizerRCnext (seqhash.c:83-152): no program in the reference calls
+ * them, so they are not on the accelerated path; kept on the host for API completeness.  The
+ * stream of canonical hashes is produced one k-mer at a time and the "window of w hashes that
+ * restarts right after each reported minimum" logic of the reference is followed exactly,
+ * including that the very first hash is never stored in the ring (seqhash.c:101). */
+static U64 stepHash (SeqhashRCiterator *si, bool *fwd)
+{
+  Seqhash *sh = si->sh;
+  if (si->s >= si->sEnd) return ~(U64) 0;
+  int b = *si->s & 3;
+  si->h = ((si->h << 2) & sh->mask) | (U64) b;
+  si->hRC = (si->hRC >> 2) | sh->patternRC[b];
+  U64 a = seqhash (sh, si->h), c = seqhash (sh, si->hRC);
+  *fwd = a < c;
+  return a < c ? a : c;
+}
+
+SeqhashRCiterator *minimizerRCiterator (Seqhash *sh, char *s, int len)
+{
+  SeqhashRCiterator *si = iterAlloc (sh, s, len);
+  si->hashBuf = (U64 *) xalloc ((size_t) sh->w * sizeof (U64), 1);
+  if (len < sh->k) { si->isDone = true; return si; }
+  for (int i = 0 ; i < sh->k ; ++i, ++si->s)
+    { int b = *si->s & 3;
+      si->h = (si->h << 2) | (U64) b;
+      si->hRC = (si->hRC >> 2) | sh->patternRC[b];
+    }
+  U64 a = seqhash (sh, si->h), c = seqhash (sh, si->hRC);
+  si->fBuf[0] = a < c;
+  U64 best = a < c ? a : c;                /* slot 0 itself stays 0, as in the reference */
+  si->iMin = 0;
+  for (int i = 1 ; i < sh->w ; ++i, ++si->s)
+    { si->hashBuf[i] = stepHash (si, &si->fBuf[i]);
+      if (si->hashBuf[i] < best) { best = si->hashBuf[i]; si->iMin = i; }
+    }
+  return si;
+}
+
+bool minimizerRCnext (SeqhashRCiterator *si, U64 *u, int *pos, bool *isF)
+{
+  if (si->isDone) return false;
+  const int w = si->sh->w;
+  U64 out = si->hashBuf[si->iMin];
+  if (u) *u = out;
+  if (pos) *pos = si->base + si->iMin + (si->iMin < si->iStart ? w : 0);
+  if (isF) *isF = si->fBuf[si->iMin];
+  if (si->s >= si->sEnd) { si->isDone = true; return true; }
+
+  /* refill ring slots iStart..iMin (cyclically) with the next hashes */
+  int i = si->iStart;
+  for (;;)
+    { si->hashBuf[i] = stepHash (si, &si->fBuf[i]); ++si->s;
+      if (i == si->iMin) break;
+      if (++i == w) { i = 0; si->base += w; }
+    }
+  si->iStart = si->iMin + 1;
+  if (si->iStart == w) { si->iStart = 0; si->base += w; }
+
+  U64 bound; int pick;
+  if (si->hashBuf[si->iMin] != ~(U64) 0) { bound = ~(U64) 0; pick = si->iMin; }   /* full new window */
+  else { bound = out; pick = -1; }
+  for (i = 0 ; i < w ; ++i) if (si->hashBuf[i] < bound) { bound = si->hashBuf[i]; pick = i; }
+  si->iMin = pick;
+  if (pick < 0) si->isDone = true;
+  return true;
+}
+
+/* ------------------------------ modset ------------------------------ */
+
+Modset *modsetCreate (Seqhash *sh, int bits, U32 size)
+{
+  if (bits < 20 || bits > 34) die ("table bits %d must be between 20 and 34", bits);
+  Modset *ms = (Modset *) xalloc (sizeof (Modset), 1);
+  ms->hasher = sh;
+  ms->tableBits = bits;
+  ms->tableSize = (U64) 1 << bits;
+  ms->tableMask = ms->tableSize - 1;
+  ms->index = (U32 *) xalloc (ms->tableSize * sizeof (U32), 1);
+  if (size >= (ms->tableSize >> 2)) die ("Modset size %u is too big for %d bits", size, bits);
+  ms->size = size ? size : (U32) ((ms->tableSize >> 2) - 1);
+  ms->value = (U64 *) xalloc ((size_t) ms->size * sizeof (U64), 0);
+  ms->depth = (U16 *) xalloc ((size_t) ms->size * sizeof (U16), 1);
+  ms->info = (U8 *) xalloc ((size_t) ms->size, 1);
+  return ms;
+}
+
+void modsetDestroy (Modset *ms)
+{
+  if (mgLiveDeviceModsets) mgHookDestroy (ms);
+  free (ms->index); free (ms->value); free (ms->depth); free (ms->info); free (ms);
+}
+
+static void regrow (Modset *ms, U32 newSize)
+{
+  U32 keep = ms->size < newSize ? ms->size : newSize;
+  U64 *v = (U64 *) xalloc ((size_t) newSize * sizeof (U64), 0);
+  U16 *d = (U16 *) xalloc ((size_t) newSize * sizeof (U16), 1);
+  U8 *f = (U8 *) xalloc ((size_t) newSize, 1);
+  memcpy (v, ms->value, (size_t) keep * sizeof (U64));
+  memcpy (d, ms->depth, (size_t) keep * sizeof (U16));
+  memcpy (f, ms->info, (size_t) keep);
+  free (ms->value); free (ms->depth); free (ms->info);
+  ms->value = v; ms->depth = d; ms->info = f; ms->size = newSize;
+}
+
+bool modsetPack (Modset *ms)
+{
+  if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 0);
+  if (ms->size == ms->max + 1) return false;
+  regrow (ms, ms->max + 1);
+  return true;
+}
+
+/* host-array form of the probe loop; assumes index[] and value[] are current */
+static U32 hostFind (Modset *ms, U64 kmer, int isAdd)
+{
+  U64 hash = seqhash (ms->hasher, kmer);
+  U64 at = hash & ms->tableMask;
+  U64 hop = 0;
+  U32 ix = ms->index[at];
+  while (ix && ms->value[ix] != kmer)
+    { if (!hop) hop = ((hash >> ms->tableBits) & ms->tableMask) | 1;
+      at = (at + hop) & ms->tableMask;
+      ix = ms->index[at];
+    }
+  if (!ix && isAdd)
+    { ix = ms->index[at] = ++ms->max;
+      if (ms->max >= ms->size) die ("hashTableSize %u is too small for %u", ms->size, ms->max);
+      ms->value[ix] = kmer;
+    }
+  return ix;
+}
+
+U32 modsetIndexFind (Modset *ms, U64 kmer, int isAdd)
+{
+  if (mgLiveDeviceModsets) mgHookNeedHost (ms, 1);
+  return hostFind (ms, kmer, isAdd);
+}
+
+void modsetDepthPrune (Modset *ms, int min, int max)
+{
+  if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 0);
+  U32 n = ms->max;
+  ms->max = 0;
+  memset (ms->index, 0, ms->tableSize * sizeof (U32));
+  for (U32 i = 1 ; i <= n ; ++i)
+    if (ms->depth[i] >= min && (!max || ms->depth[i] < max))
+      { hostFind (ms, ms->value[i], 1);
+        ms->info[ms->max] = ms->info[i];
+        ms->depth[ms->max] = ms->depth[i];
+      }
+  fprintf (stderr, "  pruned Modset from %d to %d with min %d <= depth < max %d\n", n, ms->max, min, max);
+  if (mgLiveDeviceModsets) mgHookHostRewrote (ms);
+}
+
+void modsetWrite (Modset *ms, FILE *f)
+{
+  if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 1);
+  U32 n = ms->max + 1;
+  if (fwrite ("MSHSTv2", 8, 1, f) != 1) die ("failed to write modset header");
+  if (fwrite (&ms->tableBits, sizeof (int), 1, f) != 1) die ("failed to write bits");
+  if (fwrite (&n, sizeof (U32), 1, f) != 1) die ("failed to write size");
+  seqhashWrite (ms->hasher, f);
+  if (fwrite (ms->index, sizeof (U32), ms->tableSize, f) != ms->tableSize) die ("fail write index");
+  if (fwrite (ms->value, sizeof (U64), n, f) != n) die ("failed to write value");
+  if (fwrite (ms->depth, sizeof (U16), n, f) != n) die ("failed to write depth");
+  if (fwrite (ms->info, sizeof (U8), n, f) != n) die ("failed to write info");
+}
+
+Modset *modsetRead (FILE *f)
+{
+  char name[8];
+  int bits; U32 n;
+  if (fread (name, 8, 1, f) != 1) die ("failed to read modset header");
+  if (memcmp (name, "MSHSTv2", 8)) { name[7] = 0; die ("bad modset header %s != MSHSTv2", name); }
+  if (fread (&bits, sizeof (int), 1, f) != 1) die ("failed to read bits");
+  if (fread (&n, sizeof (U32), 1, f) != 1) die ("failed to read size");
+  Seqhash *sh = seqhashRead (f);
+  Modset *ms = modsetCreate (sh, bits, n);
+  if (fread (ms->index, sizeof (U32), ms->tableSize, f) != ms->tableSize) die ("failed read index");
+  if (fread (ms->value, sizeof (U64), n, f) != n) die ("failed to read value");
+  if (fread (ms->depth, sizeof (U16), n, f) != n) die ("failed to read depth");
+  if (fread (ms->info, sizeof (U8), n, f) != n) die ("failed to read info");
+  ms->max = n - 1;
+  return ms;
+}
+
+bool modsetMerge (Modset *ms1, Modset *ms2)
+{
+  Seqhash *a = ms1->hasher, *b = ms2->hasher;
+  if (a->w != b->w || a->k != b->k || a->factor1 != b->factor1) return false;
+  if (mgLiveDeviceModsets) { mgHookNeedHostAll (ms1, 1); mgHookNeedHostAll (ms2, 0); }
+  U64 want = (U64) ms1->max + ms2->max + 1;
+  if (want >= (ms1->tableSize >> 2)) want = (ms1->tableSize >> 2) - 1;
+  regrow (ms1, (U32) want);
+  for (U32 i = 1 ; i <= ms2->max ; ++i)
+    { U32 j = hostFind (ms1, ms2->value[i], 1);
+      U32 d = (U32) ms1->depth[j] + ms2->depth[i];
+      ms1->depth[j] = (U16) (d > 0xffff ? 0xffff : d);
+      int c = (ms1->info[j] & 3) + (ms2->info[i] & 3);
+      if (c > 3) c = 3;
+      ms1->info[j] = (U8) ((ms1->info[j] & 3) | c);
+    }
+  if (mgLiveDeviceModsets) mgHookHostRewrote (ms1);
+  return true;
+}
+
+void modsetSummary (Modset *ms, FILE *f)
+{
+  if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 0);
+  seqhashReport (ms->hasher, f);
+  fprintf (f, "MS table bits %d size %llu number of entries %u",
+           ms->tableBits, (unsigned long long) ms->tableSize, ms->max);
+  if (!ms->max) { fputc ('\n', f); return; }
+  U32 *h = (U32 *) xalloc (65536 * sizeof (U32), 1);
+  U32 copy[4] = { 0, 0, 0, 0 }, bins = 0;
+  for (U32 i = 1 ; i <= ms->max ; ++i)
+    { U32 d = ms->depth[i];
+      ++h[d]; if (d + 1 > bins) bins = d + 1;
+      ++copy[ms->info[i] & 3];
+    }
+  U64 sum = 0, tot = 0;
+  for (U32 i = 0 ; i < bins ; ++i) { sum += h[i]; tot += (U32) (i * h[i]); }   /* 32-bit products, modset.c:144 */
+  int64_t half = (int64_t) (tot / 2);
+  U32 n50 = 0;
+  for ( ; n50 < bins ; ++n50) { half -= (U32) (n50 * h[n50]); if (half < 0) break; }
+  fprintf (f, " total count %llu\nMS average depth %.1f N50 depth %u",
+           (unsigned long long) tot, tot / (double) sum, n50);
+  if (copy[0] < ms->max)
+    fprintf (f, " copy0 %u copy1 %u copy2 %u copyM %u", copy[0], copy[1], copy[2], copy[3]);
+  fputc ('\n', f);
+  free (h);
+}

@@ -1,0 +1,20 @@
+/* mg_internal.h — private glue between mg_host.c (reference-compatible scalar API, plain C)
+ * and mg_api.hip (device state).  Not part of the public ABI. */
+#ifndef MG_INTERNAL_H
+#define MG_INTERNAL_H
+#include "modgpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+extern volatile int mgLiveDeviceModsets;          /* >0 when any Modset has a device table */
+void mgHookDestroy (Modset *ms);                   /* modset is going away */
+void mgHookHostRewrote (Modset *ms);               /* host arrays were rebuilt: drop the device table */
+void mgHookNeedHost (Modset *ms, int wantIndex);   /* make value[] (and index[]) current; cheap when they are */
+void mgHookNeedHostAll (Modset *ms, int wantIndex);/* also fold pending device depth counts into depth[] */
+int  mgHookHasDevice (Modset *ms);
+/* one GPU scan of one read for the iterator facade: *rec = malloc()ed {U64 kmer[n]; U32 posF[n]} */
+int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
+#ifdef __cplusplus
+}
+#endif
+#endif
