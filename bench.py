@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — Gbp/s hashed+sketched (k=21, d=64) on MI355X, with HBM-roofline and CPU baseline.
+
+One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM:
+clear the modset (what modsetCreate's calloc is to the reference), scan every read for modimizers
+(seqhash.c:154-196) and insert them with depth counting (modset.c:45-62 + modutils.c:19-31).
+With N > 1 each rank owns its own contiguous block of reads (weak scaling) and builds its own
+modset; the 65536-bin depth histograms are summed with an RCCL all-reduce (BASELINE.json config 4).
+
+Workload at N=1: BASELINE.json configs[1] — 10 Gbp ONT-like reads (log-normal lengths, N50 20 kb,
+5 % substitutions, 30x of a 333 Mbp genome), k=21 d=64 seed 17, table bits 30.
+Environment overrides (for quick runs): MODGPU_BENCH_GBP, MODGPU_BENCH_BITS, MODGPU_CPU_SAMPLE_MBP.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]   (N>1 via torch.distributed.run)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    import modimizer_amd as mg
+    from modimizer_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    L = mg.lib()
+    mg.check(L.mgSetDevice(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    k, d, seed, bits = 21, 64, 17, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
+    gbp = float(os.environ.get("MODGPU_BENCH_GBP", "10"))
+    total = int(gbp * 1e9)
+    genome_bases = max(int(total / 30), 1_000_000)
+    err = 0.05
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- synthetic reads, generated in HBM -------------------------------------------------
+    t_gen = time.time()
+    starts, offsets, strands = synth.ont_read_plan(total, genome_bases, seed=1000 + rank)
+    n_reads = len(starts)
+    genome = torch.empty(L.mgPackedWords(genome_bases), dtype=torch.int32, device=dev)
+    mg.check(L.mgSynthGenome(genome.data_ptr(), genome_bases, 12345, stream))
+    d_starts = torch.from_numpy(starts.view(np.int64)).to(dev)
+    d_offsets = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_strands = torch.from_numpy(strands).to(dev)
+    reads = torch.empty(L.mgPackedWords(total), dtype=torch.int32, device=dev)
+    mg.check(L.mgSynthReads(genome.data_ptr(), genome_bases, d_starts.data_ptr(), d_offsets.data_ptr(),
+                            d_strands.data_ptr(), n_reads, total, err, 777 + rank, reads.data_ptr(), stream))
+    torch.cuda.synchronize()
+    del genome
+    t_gen = time.time() - t_gen
+
+    sh = mg.seqhashCreate(k, d, seed)
+    ms = mg.modsetCreate(sh, bits)
+    hist = torch.zeros(65536, dtype=torch.int64, device=dev)
+    n_hash = C.c_uint64(0)
+
+    def step():
+        mg.check(L.mgModsetClear(ms, stream))
+        mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads,
+                                    C.byref(n_hash), stream))
+        if world > 1:
+            hist.zero_()
+            mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), stream))
+            dist.all_reduce(hist)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    L.mgProfileEnable(1)
+    L.mgProfileReset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- per-kernel HIP-event timings -> roofline of the dominant kernel --------------------
+    kern = {}
+    for i in range(L.mgProfileKernels()):
+        name = C.c_char_p(); ms_tot = C.c_double(); n = C.c_uint64()
+        mg.check(L.mgProfileGet(i, C.byref(name), C.byref(ms_tot), C.byref(n)))
+        if n.value:
+            kern[name.value.decode()] = (ms_tot.value, n.value)
+    L.mgProfileEnable(0)
+    S = n_hash.value
+    entries = ms.contents.max
+    n_slots = 1 << (bits - 1)
+    alg_bytes = {                                   # algorithmic bytes per launch
+        "mgScanKernel": (0.25 + 12.0 / d) * total,  # 2-bit read + (kmer 8 + pos 4) per modimizer
+        "mgTableInsertKernel": 16.0 * S,            # one 16-byte slot (key 8 + index 4 + depth 4) per modimizer
+        "mgTableAssignKernel": 8.0 * S + 12.0 * entries,
+        "memset": 16.0 * n_slots,
+    }
+    dom = max(kern.items(), key=lambda kv: kv[1][0])[0] if kern else None
+    roofline = None
+    if dom:
+        avg_ms = kern[dom][0] / kern[dom][1]
+        ach = alg_bytes.get(dom, 0.0) / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(HERE, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("%g" % gbp)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes.get(dom),
+                    "kernels_ms_per_step": {kname: round(v[0] / args.steps, 4) for kname, v in sorted(kern.items())}}
+
+    value = world * total * args.steps / dt / 1e9
+    out = {
+        "metric": "Gbp/s hashed+sketched (k=21,d=64)", "value": round(value, 3), "unit": "Gbp/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%g Gbp per GPU synthetic ONT-like reads (log-normal N50 20 kb, 5%% subs, 30x of a %d Mbp genome), "
+                               "k=21 d=64 seed=17, seqhash scan + modset build (table bits %d)%s"
+                               % (gbp, genome_bases // 1_000_000, bits,
+                                  ", per-GPU build + RCCL all-reduce of the depth histogram" if world > 1 else ""),
+                   "reads_per_gpu": n_reads, "bases_per_gpu": total, "modimizers_per_gpu": S,
+                   "modset_entries": entries, "k": k, "d": d, "table_bits": bits,
+                   "parallelism": "reads sharded x%d, modset per GPU" % world},
+        "roofline": roofline,
+        "setup_s": round(t_gen, 2),
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): the compiled reference on a bounded sample ---------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream):
+    """The reference's own C path (oracle/_ref/ref_bench, built from the unmodified sources) timed
+    single-threaded — its real execution model — on the first reads of the same workload."""
+    sample_mbp = float(os.environ.get("MODGPU_CPU_SAMPLE_MBP", "400"))
+    want = int(sample_mbp * 1e6)
+    n = int(np.searchsorted(offsets, want, side="right")) - 1
+    n = max(1, min(n, len(offsets) - 1))
+    nb = int(offsets[n])
+    d_bytes = torch.empty(nb, dtype=torch.uint8, device=dev)
+    mg.check(L.mgUnpackDevice(reads.data_ptr(), nb, d_bytes.data_ptr(), stream))
+    torch.cuda.synchronize()
+    h_bytes = d_bytes.cpu().numpy()
+    del d_bytes
+    off = offsets[:n + 1].astype(np.int64)
+    sample_desc = "first %d reads (%.0f Mbp) of the same workload, single thread, table bits 28" % (n, nb / 1e6)
+    ref_bench = os.path.join(HERE, "oracle", "_ref", "ref_bench")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(shm, "modgpu_cpu_sample_%d.bin" % os.getpid())
+    try:
+        if os.path.exists(ref_bench):
+            with open(path, "wb") as f:
+                np.array([n, nb], np.uint64).tofile(f); off.tofile(f); h_bytes.tofile(f)
+            try:
+                r = subprocess.run([ref_bench, path, str(k), str(d), str(seed), "28"],
+                                   capture_output=True, text=True, timeout=900)
+                if r.returncode == 0:
+                    j = json.loads(r.stdout.strip().splitlines()[-1])
+                    return {"value": round(j["sketch_mbps"] / 1e3, 5), "unit": "Gbp/s", "cores": 1,
+                            "kind": "reference", "sample": sample_desc,
+                            "scan_only_gbps": round(j["scan_mbps"] / 1e3, 5),
+                            "host_cores_online": os.cpu_count()}
+            except Exception:
+                pass
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    # fall back to this repo's C restatement of the same path
+    from oracle import pyoracle as po
+    oh = po.Hasher(k, d, seed)
+    oms = po.Modset(oh, 28)
+    t0 = time.perf_counter()
+    po.lib().orcScanMany(C.byref(oh.c), h_bytes.ctypes.data, off.ctypes.data, n, oms.p)
+    dt = time.perf_counter() - t0
+    return {"value": round(nb / dt / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
+            "sample": sample_desc, "host_cores_online": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

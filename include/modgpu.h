@@ -188,6 +188,9 @@ MgStatus modsetSyncToHost (Modset *ms, int wantIndex) ;
 MgStatus mgModsetDeviceRelease (Modset *ms) ;
 /* Tell the library the caller changed ms->value/max/depth on the host behind its back. */
 void     mgModsetHostChanged (Modset *ms) ;
+/* Forget every entry: the state modsetCreate (modset.c:15-31) returns, without reallocating.
+ * Clears the device table (if any), ms->max, and the host index[]/depth[]/info[] of used entries. */
+MgStatus mgModsetClear (Modset *ms, void *stream) ;
 
 /* modutils.c:53-63 on the device: dHist[65536] (U64) += histogram of depth[1..max], where depth is
  * the host depth at last sync plus pending device counts, saturated at 65535. */
@@ -207,11 +210,47 @@ MgStatus mgQueryReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
                              U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
                              U64 *nSeeds, void *stream) ;
 
+/* mgInsertReadsDevice = the insert loop of referenceFastaRead (modmap.c:106-118, isAdd true): every
+ * modimizer is inserted WITHOUT touching depth and its (index,pos,read) returned. */
+MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                              const U64 *dReadOffsets, U32 nReads,
+                              U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
+                              U64 *nSeeds, void *stream) ;
+
 /* Host-side batch mirrors of the reference callers' loops. */
 /* modutils.c:19-31 over nReads reads; returns total hashes, -1 on error. ms->max updated. */
 int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads) ;
 /* modutils.c:53-63 */
 void    mgDepthHistogram (Modset *ms, FILE *f) ;
+/* modutils.c:33-51 on reads already in memory: adds every read, prints the "added ..." line */
+int     mgAddSequences (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads, FILE *out) ;
+/* modutils.c:194-198 ("-wt") */
+void    mgModsetWriteText (Modset *ms, FILE *f) ;
+
+/* modmap.c's Reference (modmap.c:35-47) and its three operations, on sequences already in memory
+ * (bases 0..3 one byte each, offsets[n+1], names[n]).  The per-k-mer loops run on the GPU
+ * (mgInsertReadsDevice / mgQueryReadsDevice); the CSR pack (modmap.c:74-91) and the seed chaining
+ * (modmap.c:213-276) are the reference's serial host logic and stay on the host. */
+typedef struct {
+  Modset *ms ;
+  U32 size ;                   /* capacity of index/offset/id */
+  U32 max ;                    /* occurrences stored */
+  U32 *index, *offset, *id ;   /* per occurrence: modset index, position in its sequence, sequence id */
+  U32 *depth ;                 /* occurrences per modset index */
+  U32 *rev, *loc ;             /* CSR inverse: occurrences grouped by modset index */
+  int nSeq ;
+  char **names ;               /* sequence names (the reference keeps them in a DICT) */
+  U32 *len ;
+} MgReference ;
+MgReference *mgReferenceCreate (Modset *ms, U32 size) ;                               /* modmap.c:49-64 */
+void mgReferenceDestroy (MgReference *ref) ;                                          /* modmap.c:66-72 */
+/* modmap.c:93-134: scan + insert/lookup every sequence, classify copy number, pack; prints the two
+ * report lines to out.  Returns 0 on success. */
+int  mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,
+                      const char **names, bool isAdd, FILE *out) ;
+/* modmap.c:188-281: "Q" line and "M" lines for every read. */
+int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
+                     const char **names, FILE *out) ;
 
 /* Deterministic synthetic reads generated directly in HBM (not from the reference):
  *   mgSynthGenome: nBases iid-uniform bases, base g = splitmix64(seed ^ g*0x9E3779B97F4A7C15) >> 62
@@ -222,6 +261,15 @@ MgStatus mgSynthGenome (U32 *dPacked, U64 nBases, U64 seed, void *stream) ;
 MgStatus mgSynthReads (const U32 *dGenomePacked, U64 genomeBases,
                        const U64 *dReadStart, const U64 *dReadOffsets, const U8 *dStrand, U32 nReads,
                        U64 totalBases, double errRate, U64 seed, U32 *dPackedOut, void *stream) ;
+
+/* Per-kernel timing with HIP events on the launch stream (for bench.py's roofline object).
+ * While enabled, every kernel launch of the library is bracketed by an event pair; mgProfileGet
+ * returns, per kernel id in [0, mgProfileKernels()), its name, summed duration and launch count
+ * since the last mgProfileReset (it synchronises the device to read the events). */
+void     mgProfileEnable (int on) ;
+void     mgProfileReset (void) ;
+int      mgProfileKernels (void) ;
+MgStatus mgProfileGet (int id, const char **name, double *totalMs, U64 *launches) ;
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,9 @@ EXPORTS = [
     "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgModsetDeviceRelease",
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
+    "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
+    "mgReferenceRead", "mgQueryProcess",
+    "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
@@ -123,6 +126,14 @@ def lib():
     sig("mgAddSequenceBatch", i64, MS, vp, vp, i32); sig("mgDepthHistogram", None, MS, vp)
     sig("mgSynthGenome", i32, vp, u64, u64, vp)
     sig("mgSynthReads", i32, vp, u64, vp, vp, vp, u32, u64, C.c_double, u64, vp, vp)
+    sig("mgInsertReadsDevice", i32, MS, vp, u64, vp, u32, vp, vp, vp, u64, U64P, vp)
+    sig("mgAddSequences", i32, MS, vp, vp, i32, vp); sig("mgModsetWriteText", None, MS, vp)
+    sig("mgReferenceCreate", vp, MS, u32); sig("mgReferenceDestroy", None, vp)
+    sig("mgReferenceRead", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), C.c_bool, vp)
+    sig("mgQueryProcess", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), vp)
+    sig("mgModsetClear", i32, MS, vp)
+    sig("mgProfileEnable", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)
+    sig("mgProfileGet", i32, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), U64P)
     _lib = L
     return L
 

@@ -56,6 +56,72 @@ extern "C" MgStatus mgStreamSynchronize (void *stream)
 { MG_HIP (hipStreamSynchronize ((hipStream_t) stream)); return MG_OK; }
 
 /* ---------------------------------------------------------------------------------------- */
+/* per-kernel event timing (bench.py's roofline object)                                       */
+
+static const char *gKernelNames[MG_K_COUNT] = {
+  "mgPackKernel", "mgUnpackKernel", "mgTileFirstReadKernel", "mgScanKernel", "mgTableInsertKernel",
+  "mgTableAssignKernel", "mgTableGatherKernel", "mgTableFindKernel", "mgTableLoadKernel",
+  "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
+  "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset" };
+#define MG_PROF_POOL 8192
+struct MgProfRec { int id; hipEvent_t a, b; };
+static struct {
+  bool on = false;
+  MgProfRec rec[MG_PROF_POOL]; int used = 0, made = 0;
+  double ms[MG_K_COUNT] = { 0 }; U64 n[MG_K_COUNT] = { 0 };
+  int open = -1;
+} gProf;
+
+static void mgProfDrain (void)
+{
+  if (!gProf.used) return;
+  (void) hipDeviceSynchronize ();
+  for (int i = 0 ; i < gProf.used ; ++i)
+    { float t = 0;
+      if (hipEventElapsedTime (&t, gProf.rec[i].a, gProf.rec[i].b) == hipSuccess)
+        { gProf.ms[gProf.rec[i].id] += t; ++gProf.n[gProf.rec[i].id]; }
+    }
+  gProf.used = 0;
+}
+
+void mgProfBegin (int id, hipStream_t st)
+{
+  if (!gProf.on) return;
+  if (gProf.used == MG_PROF_POOL) mgProfDrain ();
+  MgProfRec &r = gProf.rec[gProf.used];
+  if (gProf.used >= gProf.made)
+    { if (hipEventCreate (&r.a) != hipSuccess || hipEventCreate (&r.b) != hipSuccess) { gProf.on = false; return; }
+      gProf.made = gProf.used + 1;
+    }
+  r.id = id;
+  (void) hipEventRecord (r.a, st);
+  gProf.open = gProf.used;
+}
+
+void mgProfEnd (int id, hipStream_t st)
+{
+  if (!gProf.on || gProf.open < 0) return;
+  (void) id;
+  (void) hipEventRecord (gProf.rec[gProf.open].b, st);
+  gProf.used = gProf.open + 1;
+  gProf.open = -1;
+}
+
+extern "C" void mgProfileEnable (int on) { if (!on) mgProfDrain (); gProf.on = on != 0; }
+extern "C" void mgProfileReset (void)
+{ mgProfDrain (); for (int i = 0 ; i < MG_K_COUNT ; ++i) { gProf.ms[i] = 0; gProf.n[i] = 0; } }
+extern "C" int mgProfileKernels (void) { return MG_K_COUNT; }
+extern "C" MgStatus mgProfileGet (int id, const char **name, double *totalMs, U64 *launches)
+{
+  if (id < 0 || id >= MG_K_COUNT) { mgSetError ("bad kernel id"); return MG_ERR_ARG; }
+  mgProfDrain ();
+  if (name) *name = gKernelNames[id];
+  if (totalMs) *totalMs = gProf.ms[id];
+  if (launches) *launches = gProf.n[id];
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
 /* hash parameters                                                                            */
 
 MgHashParams mgMakeParams (const Seqhash *sh)
@@ -310,6 +376,32 @@ extern "C" void mgModsetHostChanged (Modset *ms)
   mgDevFree (d);
 }
 
+extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgDev *d = mgDevLookup (ms);
+  /* Host arrays only hold what the host was given: with a device table, entries beyond
+     syncedMax exist on the device alone and index[] is populated up to hostIndexMax. */
+  U32 hostIndexed = d ? d->hostIndexMax : ms->max;
+  U32 hostUsed = d ? d->t.syncedMax : ms->max;
+  if (d)
+    { MgTable &t = d->t;
+      mgProfBegin (MG_K_MEMSET, st);
+      MG_HIP (hipMemsetAsync (t.slots, 0, t.nSlots * sizeof (MgSlot), st));
+      mgProfEnd (MG_K_MEMSET, st);
+      if (t.syncedMax) MG_HIP (hipMemsetAsync (t.baseDepth, 0, ((size_t) t.syncedMax + 1) * sizeof (U16), st));
+      t.max = t.syncedMax = 0;
+      d->hostIndexMax = 0;
+    }
+  if (hostIndexed) memset (ms->index, 0, ms->tableSize * sizeof (U32));
+  if (hostUsed)
+    { memset (ms->depth, 0, ((size_t) hostUsed + 1) * sizeof (U16));
+      memset (ms->info, 0, (size_t) hostUsed + 1);
+    }
+  ms->max = 0;
+  return MG_OK;
+}
+
 /* hooks for mg_host.c */
 extern "C" void mgHookDestroy (Modset *ms) { mgModsetHostChanged (ms); }
 extern "C" void mgHookHostRewrote (Modset *ms) { mgModsetHostChanged (ms); }
@@ -490,25 +582,40 @@ extern "C" MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalB
   return mgAddBatch (ms, d, b.kmer, n, 0, 1, true, st);
 }
 
-extern "C" MgStatus mgQueryReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
-                                        const U64 *dReadOffsets, U32 nReads,
-                                        U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
-                                        U64 *nSeeds, void *stream)
+/* mode 0: lookup only (modmap.c:202); mode 1: insert without depth (modmap.c:109) */
+static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 totalBases,
+                             const U64 *dReadOffsets, U32 nReads,
+                             U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
+                             U64 *nSeeds, hipStream_t st)
 {
-  hipStream_t st = (hipStream_t) stream;
   MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
   if (nSeeds) *nSeeds = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
-  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, 0, &b, &n, st))) return s;
+  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st))) return s;
   if (nSeeds) *nSeeds = n;
-  if (n > capacity) { mgSetError ("mgQueryReadsDevice: %llu seeds exceed capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
-  if ((s = mgTableFind (&d->t, b.kmer, n, dSeedIndex, st))) return s;
+  if (n > capacity)
+    { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
+  if (mode == 0) s = mgTableFind (&d->t, b.kmer, n, dSeedIndex, st);
+  else s = mgAddBatch (ms, d, b.kmer, n, dSeedIndex, 0, true, st);
+  if (s) return s;
   if (dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));
   if (dSeedRead) MG_HIP (hipMemcpyAsync (dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st));
   MG_HIP (hipStreamSynchronize (st));
   return MG_OK;
 }
+
+extern "C" MgStatus mgQueryReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                                        const U64 *dReadOffsets, U32 nReads,
+                                        U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
+                                        U64 *nSeeds, void *stream)
+{ return mgSeedReads (ms, 0, dPacked, totalBases, dReadOffsets, nReads, dSeedIndex, dSeedPosF, dSeedRead, capacity, nSeeds, (hipStream_t) stream); }
+
+extern "C" MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
+                                         const U64 *dReadOffsets, U32 nReads,
+                                         U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
+                                         U64 *nSeeds, void *stream)
+{ return mgSeedReads (ms, 1, dPacked, totalBases, dReadOffsets, nReads, dSeedIndex, dSeedPosF, dSeedRead, capacity, nSeeds, (hipStream_t) stream); }
 
 /* ---------------------------------------------------------------------------------------- */
 /* host-buffer mirrors of the reference callers' loops                                        */

@@ -1,0 +1,252 @@
+/* mg_callers.c — C counterparts of the reference's hot-path callers, on top of the batch ABI:
+ *   modutils: addSequenceFile's loop + report (modutils.c:33-51), "-wt" dump (modutils.c:194-198)
+ *   modmap  : Reference build (modmap.c:49-134) and queryProcess (modmap.c:188-281)
+ * Inputs are sequences already in memory (the FASTA front end, seqio.c, is out of scope).  Every
+ * per-k-mer loop of the reference is one GPU batch call here; what remains on the host is the
+ * reference's own serial bookkeeping, restated with its quirks because its printed output is the
+ * parity target.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "modgpu.h"
+
+static void fatal (const char *what)
+{ fprintf (stderr, "FATAL ERROR: %s: %s\n", what, mgLastError ()); exit (-1); }
+
+/* ---- packed batch on the device (host bytes -> 2-bit words -> HBM) ---- */
+typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } DevBatch;
+
+static void batchUpload (DevBatch *b, const char *bases, const int64_t *offsets, int nReads)
+{
+  b->nReads = (U32) nReads;
+  b->total = nReads ? (U64) offsets[nReads] : 0;
+  size_t nw = mgPackedWords (b->total);
+  U32 *h = (U32 *) malloc (nw * sizeof (U32));
+  mgPackHost (bases, b->total, h);
+  if (mgDeviceAlloc (&b->dPacked, nw * 4) || mgDeviceAlloc (&b->dOff, ((size_t) nReads + 1) * 8)) fatal ("device alloc");
+  if (mgMemcpyH2D (b->dPacked, h, nw * 4, 0) || mgMemcpyH2D (b->dOff, offsets, ((size_t) nReads + 1) * 8, 0)
+      || mgStreamSynchronize (0)) fatal ("H2D");
+  free (h);
+}
+
+static void batchFree (DevBatch *b) { mgDeviceFree (b->dPacked); mgDeviceFree (b->dOff); }
+
+/* ---------------------------------- modutils ---------------------------------- */
+
+int mgAddSequences (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads, FILE *out)
+{
+  int64_t nHash = mgAddSequenceBatch (ms, bases, readOffsets, nReads);
+  if (nHash < 0) return -1;
+  U64 totLen = nReads ? (U64) readOffsets[nReads] : 0;
+  fprintf (out, "added %llu sequences total length %llu total hashes %llu, new max %u\n",
+           (unsigned long long) nReads, (unsigned long long) totLen, (unsigned long long) nHash, ms->max);
+  return 0;
+}
+
+void mgModsetWriteText (Modset *ms, FILE *f)
+{
+  if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");
+  Seqhash *sh = ms->hasher;
+  fprintf (f, "modset bits %d size %d k %d w %d seed %d\n", ms->tableBits, ms->max + 1, sh->k, sh->w, sh->seed);
+  for (U32 i = 1 ; i <= ms->max ; ++i)
+    fprintf (f, "%d\t%s\t%d\t%d\n", (int) i, seqString (ms->value[i], sh->k), ms->depth[i], ms->info[i]);
+}
+
+/* ---------------------------------- modmap ---------------------------------- */
+
+MgReference *mgReferenceCreate (Modset *ms, U32 size)
+{
+  if (!ms || !ms->size) { fprintf (stderr, "FATAL ERROR: modset must be initialised before reference\n"); exit (-1); }
+  if (!size) { fprintf (stderr, "FATAL ERROR: refCreate must have size > 0\n"); exit (-1); }
+  MgReference *ref = (MgReference *) calloc (1, sizeof (MgReference));
+  ref->ms = ms;
+  ref->size = size;
+  ref->depth = (U32 *) calloc (ms->size, sizeof (U32));
+  ref->index = (U32 *) malloc ((size_t) size * sizeof (U32));
+  ref->offset = (U32 *) malloc ((size_t) size * sizeof (U32));
+  ref->id = (U32 *) malloc ((size_t) size * sizeof (U32));
+  return ref;
+}
+
+void mgReferenceDestroy (MgReference *ref)
+{
+  if (!ref) return;
+  free (ref->depth); free (ref->loc); free (ref->rev);
+  free (ref->index); free (ref->offset); free (ref->id);
+  for (int i = 0 ; i < ref->nSeq ; ++i) free (ref->names[i]);
+  free (ref->names); free (ref->len); free (ref);
+}
+
+/* modmap.c:74-91 */
+static void referencePack (MgReference *ref)
+{
+  Modset *ms = ref->ms;
+  U32 n = ref->max ? ref->max : 1, m = ms->max + 1;
+  ref->depth = (U32 *) realloc (ref->depth, (size_t) (m > ms->size ? m : ms->size) * sizeof (U32));
+  ref->index = (U32 *) realloc (ref->index, (size_t) n * sizeof (U32));
+  ref->offset = (U32 *) realloc (ref->offset, (size_t) n * sizeof (U32));
+  ref->id = (U32 *) realloc (ref->id, (size_t) n * sizeof (U32));
+  ref->size = ref->max;
+  ref->rev = (U32 *) malloc ((size_t) n * sizeof (U32));
+  ref->loc = (U32 *) malloc ((size_t) m * sizeof (U32));
+  ref->loc[0] = 0;
+  for (U32 i = 1 ; i < m ; ++i) ref->loc[i] = ref->loc[i - 1] + ref->depth[i - 1];
+  memset (ref->depth, 0, (size_t) m * sizeof (U32));
+  for (U32 i = 0 ; i < ref->max ; ++i)
+    { U32 ix = ref->index[i];
+      ref->rev[ref->loc[ix] + ref->depth[ix]++] = i;
+    }
+}
+
+int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,
+                     const char **names, bool isAdd, FILE *out)
+{
+  Modset *ms = ref->ms;
+  /* names: the reference die()s on a duplicate name (modmap.c:102) */
+  ref->names = (char **) realloc (ref->names, (size_t) (ref->nSeq + nSeq) * sizeof (char *));
+  ref->len = (U32 *) realloc (ref->len, (size_t) (ref->nSeq + nSeq) * sizeof (U32));
+  for (int i = 0 ; i < nSeq ; ++i)
+    { for (int j = 0 ; j < ref->nSeq + i ; ++j)
+        if (!strcmp (ref->names[j], names[i]))
+          { fprintf (stderr, "FATAL ERROR: duplicate ref sequence name %s\n", names[i]); exit (-1); }
+      ref->names[ref->nSeq + i] = strdup (names[i]);
+      ref->len[ref->nSeq + i] = (U32) (offsets[i + 1] - offsets[i]);
+    }
+  U64 totLen = nSeq ? (U64) offsets[nSeq] : 0;
+
+  DevBatch b; batchUpload (&b, bases, offsets, nSeq);
+  U64 cap = b.total ? b.total : 1, n = 0;
+  if (cap > ((U64) ref->size)) cap = ref->size;       /* more seeds than this cannot be stored anyway */
+  void *dIx = 0, *dPos = 0, *dRid = 0;
+  U64 guess = b.total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b.total) guess = b.total;
+  if (guess < 1) guess = 1;
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { if (mgDeviceAlloc (&dIx, guess * 4) || mgDeviceAlloc (&dPos, guess * 4) || mgDeviceAlloc (&dRid, guess * 4)) fatal ("device alloc");
+      MgStatus s = isAdd ? mgInsertReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0)
+                         : mgQueryReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
+      if (s == MG_OK) break;
+      if (s == MG_ERR_CAPACITY && n > guess && attempt == 0)
+        { mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); guess = n; continue; }
+      if (s == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }   /* modset.c:58 */
+      fatal ("reference scan");
+    }
+  U32 *hIx = (U32 *) malloc ((size_t) (n + 1) * 4), *hPos = (U32 *) malloc ((size_t) (n + 1) * 4), *hRid = (U32 *) malloc ((size_t) (n + 1) * 4);
+  if (n && (mgMemcpyD2H (hIx, dIx, n * 4, 0) || mgMemcpyD2H (hPos, dPos, n * 4, 0) || mgMemcpyD2H (hRid, dRid, n * 4, 0))) fatal ("D2H");
+  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); batchFree (&b);
+
+  U32 idBase = (U32) ref->nSeq;
+  for (U64 i = 0 ; i < n ; ++i)
+    { U32 ix = hIx[i];
+      if (!ix) continue;                                            /* modmap.c:110 */
+      if (ref->max + 1 >= ref->size) { fprintf (stderr, "FATAL ERROR: reference size overflow\n"); exit (-1); }
+      ref->index[ref->max] = ix;
+      ++ref->depth[ix];
+      ref->offset[ref->max] = hPos[i] & MG_POS_MASK;
+      ref->id[ref->max] = idBase + hRid[i];
+      ++ref->max;
+    }
+  free (hIx); free (hPos); free (hRid);
+  ref->nSeq += nSeq;
+
+  fprintf (out, "  %d hashes from %d reference sequences, total length %lld\n", ref->max, ref->nSeq, (long long) totLen);
+  if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");       /* info[] is classified on the host arrays */
+  U32 n1 = 0, n2 = 0, nM = 0;
+  for (U32 i = 1 ; i <= ms->max ; ++i)                             /* modmap.c:125-129 */
+    { U32 dp = ref->depth[i];
+      if (dp == 1) { ms->info[i] = (U8) ((ms->info[i] & 0xfc) | 1); ++n1; }
+      else if (dp == 2) { ms->info[i] = (U8) ((ms->info[i] & 0xfc) | 2); ++n2; }
+      else { ms->info[i] |= 3; ++nM; }
+    }
+  fprintf (out, "  %d copy 1, %d copy 2, %d multiple\n", n1, n2, nM);
+  if (isAdd) modsetPack (ms);
+  referencePack (ref);
+  return 0;
+}
+
+/* one end-of-block test, modmap.c:232-241 (repeated at :245-254 without the "no block" clause) */
+static bool blockEnds (const MgReference *ref, U32 loc, U32 loc0, U32 locN, U32 i0, U32 iN, bool withUnset)
+{
+  if (withUnset && !loc0) return true;
+  if (ref->id[loc] != ref->id[loc0]) return true;
+  bool end = false;
+  if (loc0 < locN)
+    { if (loc < locN) end = true;
+      int dd = (int) (locN - loc0 - iN + i0); if (dd > 50 || dd < -50) end = true;
+    }
+  else if (loc0 > locN)
+    { if (loc > locN) end = true;
+      int dd = (int) (loc0 - locN - iN + i0); if (dd > 50 || dd < -50) end = true;
+    }
+  return end;
+}
+
+static void printM (const MgReference *ref, FILE *out, const char *name, const U32 *seedPos,
+                    U32 i0, U32 iN, U32 loc0, U32 locN, int n1, int n2, int copy1)
+{
+  fprintf (out, "M\t%s\t%d\t%d\t%d\t%s\t%d\t%d\t%d %d\t%.2f\t%.2f\n",
+           name, (int) seedPos[i0], (int) seedPos[iN], (int) (seedPos[iN] - seedPos[i0]),
+           ref->names[ref->id[loc0]], (int) ref->offset[loc0], (int) ref->offset[locN],
+           n1, n2, (n1 + n2) / (double) ((locN > loc0) ? (locN - loc0) : (loc0 - locN)),
+           n1 / (double) copy1);
+}
+
+int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
+                    const char **names, FILE *out)
+{
+  Modset *ms = ref->ms;
+  DevBatch b; batchUpload (&b, bases, offsets, nReads);
+  U64 n = 0, guess = b.total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b.total) guess = b.total;
+  if (guess < 1) guess = 1;
+  void *dIx = 0, *dPos = 0, *dRid = 0;
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { if (mgDeviceAlloc (&dIx, guess * 4) || mgDeviceAlloc (&dPos, guess * 4) || mgDeviceAlloc (&dRid, guess * 4)) fatal ("device alloc");
+      MgStatus s = mgQueryReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
+      if (s == MG_OK) break;
+      if (s == MG_ERR_CAPACITY && attempt == 0)
+        { mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); guess = n; continue; }
+      fatal ("query scan");
+    }
+  U32 *six = (U32 *) malloc ((size_t) (n + 1) * 4), *spos = (U32 *) malloc ((size_t) (n + 1) * 4), *srid = (U32 *) malloc ((size_t) (n + 1) * 4);
+  if (n && (mgMemcpyD2H (six, dIx, n * 4, 0) || mgMemcpyD2H (spos, dPos, n * 4, 0) || mgMemcpyD2H (srid, dRid, n * 4, 0))) fatal ("D2H");
+  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); batchFree (&b);
+  for (U64 i = 0 ; i < n ; ++i) spos[i] &= MG_POS_MASK;
+
+  U64 at = 0;
+  for (int r = 0 ; r < nReads ; ++r)
+    { U64 first = at;
+      while (at < n && srid[at] == (U32) r) ++at;
+      U32 ns = (U32) (at - first);
+      const U32 *ix = six + first, *ps = spos + first;
+      int missed = 0, copy[4] = { 0, 0, 0, 0 };
+      for (U32 i = 0 ; i < ns ; ++i)
+        if (ix[i]) ++copy[ms->info[ix[i]] & 3]; else ++missed;
+      fprintf (out, "Q\t%s\t%llu\t%d miss, %d copy1, %d copy2, %d multi, %.2f hit\n",
+               names[r], (unsigned long long) (offsets[r + 1] - offsets[r]), missed, copy[1], copy[2], copy[3],
+               ((int) ns - missed) / (double) ((int) ns));
+      /* chaining, modmap.c:213-276: occurrence number 0 doubles as "no block open"; a block is
+         printed when it ends only with more than two copy-1 seeds, and the block left open at the
+         end of the read only with more than two copy-2 seeds */
+      U32 loc0 = 0, locN = 0, i0 = 0, iN = 0;
+      int n1 = 0, n2 = 0;
+      for (U32 i = 0 ; i < ns ; ++i)
+        { U32 x = ix[i];
+          if (!x || (ms->info[x] & 3) == 3) continue;
+          U32 loc = ref->rev[ref->loc[x]];
+          bool is1 = (ms->info[x] & 3) == 1;
+          bool end = blockEnds (ref, loc, loc0, locN, i0, iN, true);
+          if (end && loc0 && !is1)
+            { loc = ref->rev[ref->loc[x] + 1];
+              end = blockEnds (ref, loc, loc0, locN, i0, iN, false);
+            }
+          if (end)
+            { if (n1 > 2) printM (ref, out, names[r], ps, i0, iN, loc0, locN, n1, n2, copy[1]);
+              n1 = n2 = 0; loc0 = loc; i0 = i;
+            }
+          if (is1) ++n1; else ++n2;
+          locN = loc; iN = i;
+        }
+      if (n2 > 2) printM (ref, out, names[r], ps, i0, iN, loc0, locN, n1, n2, copy[1]);
+    }
+  free (six); free (spos); free (srid);
+  return 0;
+}

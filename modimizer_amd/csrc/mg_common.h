@@ -31,6 +31,15 @@ MgStatus mgHipFail (hipError_t e, const char *what);
 MgStatus mgEnsureDevice (void);
 MgHashParams mgMakeParams (const Seqhash *sh);
 
+enum MgKernelId {
+  MG_K_PACK = 0, MG_K_UNPACK, MG_K_TILE_FIRST_READ, MG_K_SCAN, MG_K_TABLE_INSERT, MG_K_TABLE_ASSIGN,
+  MG_K_TABLE_GATHER, MG_K_TABLE_FIND, MG_K_TABLE_LOAD, MG_K_TABLE_EXPORT, MG_K_TABLE_HIST,
+  MG_K_INDEX_REPLAY, MG_K_INDEX_FINISH, MG_K_SYNTH_GENOME, MG_K_SYNTH_READS, MG_K_MEMSET, MG_K_COUNT
+};
+void mgProfBegin (int id, hipStream_t st);
+void mgProfEnd (int id, hipStream_t st);
+#define MG_LAUNCH(id, st, ...) do { mgProfBegin (id, st); hipLaunchKernelGGL (__VA_ARGS__); mgProfEnd (id, st); } while (0)
+
 #define MG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mgHipFail (e_, #call); } while (0)
 
 #ifdef __HIPCC__

@@ -59,7 +59,7 @@ MgStatus mgLaunchPack (const U8 *dBases, U64 nBases, U32 *dWords, hipStream_t st
   U64 nWords = (U64) mgPackedWords (nBases);
   if (!nWords) return MG_OK;
   U64 blocks = (nWords + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL (mgPackKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st, dBases, nBases, dWords, nWords);
+  MG_LAUNCH (MG_K_PACK, st, mgPackKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st, dBases, nBases, dWords, nWords);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -68,7 +68,7 @@ MgStatus mgLaunchUnpack (const U32 *dWords, U64 nBases, U8 *dBases, hipStream_t 
 {
   if (!nBases) return MG_OK;
   U64 blocks = (nBases + 255) / 256; if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL (mgUnpackKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st, dWords, nBases, dBases);
+  MG_LAUNCH (MG_K_UNPACK, st, mgUnpackKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st, dWords, nBases, dBases);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -298,7 +298,7 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
   U64 *desc = (U64 *) (wb + 256);
   U32 *tfr = (U32 *) (wb + 256 + nTiles * 8);
   MG_HIP (hipMemsetAsync (wb, 0, 256 + nTiles * 8, st));
-  hipLaunchKernelGGL (mgTileFirstReadKernel, dim3 ((unsigned) ((nTiles + 1 + 255) / 256)), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_TILE_FIRST_READ, st, mgTileFirstReadKernel, dim3 ((unsigned) ((nTiles + 1 + 255) / 256)), dim3 (256), 0, st,
                       dReadOffsets, nReads, nTiles, tfr);
   MG_HIP (hipGetLastError ());
 
@@ -309,9 +309,9 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
   a.outKmer = dKmer; a.outPosF = dPosF; a.outRead = dReadId; a.capacity = capacity; a.dCount = dCount;
   unsigned grid = (unsigned) (nTiles < 2048 ? nTiles : 2048);
   if (p.dOddInv == 1 && p.dOddLim == ~0ull)
-    hipLaunchKernelGGL (mgScanKernel<true>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<true>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
   else
-    hipLaunchKernelGGL (mgScanKernel<false>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<false>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }

@@ -71,7 +71,7 @@ MgStatus mgLaunchSynthGenome (U32 *dPacked, U64 nBases, U64 seed, hipStream_t st
 {
   U64 nWords = (U64) mgPackedWords (nBases);
   U64 blocks = (nWords + 255) / 256; if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL (mgSynthGenomeKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st, dPacked, nBases, nWords, seed);
+  MG_LAUNCH (MG_K_SYNTH_GENOME, st, mgSynthGenomeKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st, dPacked, nBases, nWords, seed);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -84,7 +84,7 @@ MgStatus mgLaunchSynthReads (const U32 *dGenome, U64 genomeBases, const U64 *dRe
   U64 nWords = (U64) mgPackedWords (totalBases);
   U64 thresh = errRate <= 0 ? 0 : (errRate >= 1 ? ~0ull : (U64) (errRate * 18446744073709551616.0));
   U64 blocks = (nWords + 255) / 256; if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL (mgSynthReadsKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_SYNTH_READS, st, mgSynthReadsKernel, dim3 ((unsigned) blocks), dim3 (256), 0, st,
                       dGenome, genomeBases, dReadStart, dReadOffsets, dStrand, nReads, totalBases, nWords, thresh, seed, dOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;

@@ -266,7 +266,7 @@ size_t mgAssignDescBytes (U64 n)
 MgStatus mgTableInsert (MgTable *t, const U64 *dKmer, U64 n, U32 *dSlotId, int withDepth, hipStream_t st)
 {
   if (!n) return MG_OK;
-  hipLaunchKernelGGL (mgTableInsertKernel, dim3 (mgGrid (n)), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_TABLE_INSERT, st, mgTableInsertKernel, dim3 (mgGrid (n)), dim3 (256), 0, st,
                       t->slots, t->slotMask, dKmer, n, dSlotId, withDepth, t->counters);
   MG_HIP (hipGetLastError ());
   return MG_OK;
@@ -280,7 +280,7 @@ MgStatus mgTableAssign (MgTable *t, const U64 *dKmer, U64 n, const U32 *dSlotId,
   U32 *ticket = (U32 *) dDesc;
   U64 *desc = (U64 *) ((char *) dDesc + 256);
   unsigned grid = (unsigned) (nTiles < 2048 ? nTiles : 2048);
-  hipLaunchKernelGGL (mgTableAssignKernel, dim3 (grid), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgTableAssignKernel, dim3 (grid), dim3 (256), 0, st,
                       t->slots, dKmer, dSlotId, n, nTiles, desc, ticket,
                       t->value, t->slotOfIndex, t->max, t->size, t->counters);
   MG_HIP (hipGetLastError ());
@@ -290,7 +290,7 @@ MgStatus mgTableAssign (MgTable *t, const U64 *dKmer, U64 n, const U32 *dSlotId,
 MgStatus mgTableGather (MgTable *t, const U32 *dSlotId, U64 n, U32 *dIndexOut, hipStream_t st)
 {
   if (!n) return MG_OK;
-  hipLaunchKernelGGL (mgTableGatherKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, dSlotId, n, dIndexOut);
+  MG_LAUNCH (MG_K_TABLE_GATHER, st, mgTableGatherKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, dSlotId, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -298,7 +298,7 @@ MgStatus mgTableGather (MgTable *t, const U32 *dSlotId, U64 n, U32 *dIndexOut, h
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st)
 {
   if (!n) return MG_OK;
-  hipLaunchKernelGGL (mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, t->slotMask, dKmer, n, dIndexOut);
+  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, t->slotMask, dKmer, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -306,7 +306,7 @@ MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipSt
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st)
 {
   if (last < first) return MG_OK;
-  hipLaunchKernelGGL (mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
                       t->slots, t->slotMask, dValue, first, last, t->slotOfIndex, t->counters);
   MG_HIP (hipGetLastError ());
   return MG_OK;
@@ -315,7 +315,7 @@ MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hi
 MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipStream_t st)
 {
   if (last < first) return MG_OK;
-  hipLaunchKernelGGL (mgTableExportDepthKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
                       t->slots, t->slotOfIndex, t->baseDepth, dDelta, first, last);
   MG_HIP (hipGetLastError ());
   return MG_OK;
@@ -324,7 +324,7 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipSt
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st)
 {
   if (!t->max) return MG_OK;
-  hipLaunchKernelGGL (mgTableHistKernel, dim3 (mgGrid (t->max, 256, 1024)), dim3 (256), 0, st,
+  MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->max, 256, 1024)), dim3 (256), 0, st,
                       t->slots, t->slotOfIndex, t->baseDepth, t->max, (unsigned long long *) dHist);
   MG_HIP (hipGetLastError ());
   return MG_OK;
@@ -335,11 +335,11 @@ MgStatus mgTableReplayIndex (MgTable *t, const MgHashParams &p, int tableBits, U
   U64 n = (U64) 1 << tableBits;
   MG_HIP (hipMemsetAsync (dIndex, 0xff, n * sizeof (U32), st));
   if (t->max)
-    { hipLaunchKernelGGL (mgReplayIndexKernel, dim3 (mgGrid (t->max)), dim3 (256), 0, st,
+    { MG_LAUNCH (MG_K_INDEX_REPLAY, st, mgReplayIndexKernel, dim3 (mgGrid (t->max)), dim3 (256), 0, st,
                           t->value, t->max, p.factor1, p.shift1, tableBits, dIndex);
       MG_HIP (hipGetLastError ());
     }
-  hipLaunchKernelGGL (mgIndexFinishKernel, dim3 (mgGrid (n, 256, 8192)), dim3 (256), 0, st, dIndex, n);
+  MG_LAUNCH (MG_K_INDEX_FINISH, st, mgIndexFinishKernel, dim3 (mgGrid (n, 256, 8192)), dim3 (256), 0, st, dIndex, n);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }

@@ -1,0 +1,27 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, reads sharded in contiguous blocks,
+one modset per rank, and a single collective — the sum of the 65536-bin depth histograms
+(BASELINE.json config 4).  torch.distributed is used only as the RCCL (backend "nccl") / gloo
+transport; there is no data-path collective besides this one."""
+import numpy as np
+
+
+def shard_bounds(n_reads, world, rank):
+    """contiguous block of reads [lo, hi) owned by `rank` (blocks differ in size by at most 1)"""
+    base, extra = divmod(n_reads, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_offsets(offsets, world, rank):
+    """offsets[] of this rank's block rebased to 0, plus the base offset of the block"""
+    lo, hi = shard_bounds(len(offsets) - 1, world, rank)
+    sub = np.asarray(offsets[lo:hi + 1])
+    return (sub - sub[0]).astype(offsets.dtype), int(sub[0]), lo, hi
+
+
+def allreduce_histogram(hist_tensor):
+    """in-place SUM over ranks of a 65536-bin int64 histogram tensor (RCCL on GPU, gloo on CPU)"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(hist_tensor, op=dist.ReduceOp.SUM)
+    return hist_tensor

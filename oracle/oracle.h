@@ -7,7 +7,7 @@
  * Every function cites the reference file:line (paths into /root/reference) whose
  * behaviour it restates.  The restatement is pinned against the reference itself:
  * oracle/Makefile compiles the unmodified reference sources into oracle/_ref/ and
- * tests/test_oracle_vs_ref.py + tests/golden/ compare the two bit-for-bit.
+ * tests/test_oracle.py + tests/golden/ compare the two bit-for-bit.
  */
 #ifndef MOD_ORACLE_H
 #define MOD_ORACLE_H
@@ -109,6 +109,7 @@ const char *orcSeqString (uint64_t kmer, int len);
 
 /* Deterministic synthetic data shared by tests/bench; not from the reference. */
 uint64_t orcSplitmix64 (uint64_t x);
+uint64_t orcXorshiftBases (uint64_t state, uint8_t *out, int64_t n);   /* SURVEY §8(c) known-answer reads */
 
 /* Timed CPU baseline helper: scan (+ optional modset add) over nReads reads laid out by
  * offsets[nReads+1] in bases[]; returns total modimizers. Single thread. */

@@ -1,7 +1,7 @@
 /* oracle/orc_seqhash.c — TEST INFRASTRUCTURE ONLY.
  * CPU restatement of the seqhash scan (reference seqhash.c / seqhash.h); see oracle.h.
  * Written as closed-form array code, not as the reference's iterator state machine; pinned
- * bit-for-bit against the compiled reference (oracle/_ref) by tests/test_oracle_vs_ref.py.
+ * bit-for-bit against the compiled reference (oracle/_ref) by tests/test_oracle.py.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +30,16 @@ uint64_t orcSplitmix64 (uint64_t x)
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
+}
+
+/* The generator behind SURVEY §8(c)'s known answers: x^=x<<13; x^=x>>7; x^=x<<17; base = x>>62 */
+uint64_t orcXorshiftBases (uint64_t state, uint8_t *out, int64_t n)
+{
+  for (int64_t i = 0 ; i < n ; ++i)
+    { state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+      out[i] = (uint8_t) (state >> 62);
+    }
+  return state;
 }
 
 /* Canonical hash of the k-mer starting at each position.

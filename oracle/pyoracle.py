@@ -78,6 +78,8 @@ def lib():
         L.orcScanMany.restype = C.c_int64
         L.orcSplitmix64.argtypes = [C.c_uint64]
         L.orcSplitmix64.restype = C.c_uint64
+        L.orcXorshiftBases.argtypes = [C.c_uint64, C.c_void_p, C.c_int64]
+        L.orcXorshiftBases.restype = C.c_uint64
         L.orcSeqString.argtypes = [C.c_uint64, C.c_int]
         L.orcSeqString.restype = C.c_char_p
         L.orcReferenceCreate.argtypes = [C.POINTER(OrcModset), C.c_uint32]
@@ -105,6 +107,13 @@ def _with_file(path, fn):
         fn(C.c_void_p(f))
     finally:
         _libc.fclose(f)
+
+
+def xorshift_bases(n, state=0x9E3779B97F4A7C15):
+    """(bases, next state) of the SURVEY §8(c) generator"""
+    out = np.empty(n, np.uint8)
+    st = lib().orcXorshiftBases(state, out.ctypes.data, n)
+    return out, st
 
 
 class Hasher:

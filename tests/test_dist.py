@@ -1,0 +1,90 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Reads are sharded in contiguous blocks, each rank
+builds its own modset (here with the oracle, since there is no GPU in this container) and the
+depth histograms are summed with one all-reduce — the collective bench.py runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from modimizer_amd import dist as mdist   # noqa: E402
+from modimizer_amd import synth           # noqa: E402
+
+
+def test_shard_bounds_cover_and_are_contiguous():
+    for n in (0, 1, 7, 8, 9, 1000, 598835):
+        for world in (1, 2, 3, 8):
+            blocks = [mdist.shard_bounds(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    offs = np.array([0, 5, 5, 12, 40, 41], np.int64)
+    sub, base, lo, hi = mdist.shard_offsets(offs, 2, 1)
+    assert (lo, hi) == (3, 5) and base == 12 and list(sub) == [0, 28, 29]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    k, d = 21, 64
+    genome = synth.iid_bases(60000, 1)
+    starts, offsets, strands = synth.ont_read_plan(1_500_000, len(genome), 2, n50=4000, lo=100, hi=20000)
+    bases = synth.reads_from_genome(genome, starts, offsets, strands, 0.03, 3)
+    sub, base, lo, hi = mdist.shard_offsets(offsets.astype(np.int64), world, rank)
+    h = po.Hasher(k, d, 17)
+    ms = po.Modset(h, 22)
+    for r in range(len(sub) - 1):
+        ms.add_sequence(bases[base + sub[r]:base + sub[r + 1]])
+    hist = torch.from_numpy(ms.histogram().astype(np.int64))
+    mine = hist.clone()
+    mdist.allreduce_histogram(hist)
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, mine.numpy(), hist.numpy(), float(t.item()), ms.max))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_histogram_allreduce_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per_rank = [r[1] for r in res]
+    total = per_rank[0] + per_rank[1]
+    for r in res:
+        assert np.array_equal(r[2], total)          # every rank holds the summed histogram
+        assert r[3] == float(world)                 # MAX reduction
+    assert total.sum() == res[0][4] + res[1][4]     # one bin entry per modset entry per rank
+    # the shards are independent: rebuilding them serially gives the same per-rank histograms
+    from oracle import pyoracle as po
+    genome = synth.iid_bases(60000, 1)
+    starts, offsets, strands = synth.ont_read_plan(1_500_000, len(genome), 2, n50=4000, lo=100, hi=20000)
+    bases = synth.reads_from_genome(genome, starts, offsets, strands, 0.03, 3)
+    for rank in range(world):
+        sub, base, lo, hi = mdist.shard_offsets(offsets.astype(np.int64), world, rank)
+        ms = po.Modset(po.Hasher(21, 64, 17), 22)
+        for r in range(len(sub) - 1):
+            ms.add_sequence(bases[base + sub[r]:base + sub[r + 1]])
+        assert np.array_equal(ms.histogram().astype(np.int64), per_rank[rank])

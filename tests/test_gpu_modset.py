@@ -1,0 +1,293 @@
+"""GPU parity: the device modset (K3/K4/K5) and the C counterparts of the reference callers,
+through the C ABI, vs the oracle and the golden outputs of the reference.  Bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import modimizer_amd as mg
+from modimizer_amd import fasta, synth
+from oracle import pyoracle as po
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_build(oh, bits, batches):
+    oms = po.Modset(oh, bits)
+    tot = 0
+    for bases, offs in batches:
+        for r in range(len(offs) - 1):
+            tot += oms.add_sequence(bases[offs[r]:offs[r + 1]])
+    return oms, tot
+
+
+def assert_same_modset(ms, oms, bits, check_index=True):
+    L = mg.lib()
+    mg.check(L.modsetSyncToHost(ms, 1 if check_index else 0))
+    assert ms.contents.max == oms.max
+    v, d, i = mg.modset_arrays(ms)
+    assert np.array_equal(v[1:], oms.values()[1:]), "values / first-occurrence index order"
+    assert np.array_equal(d[1:], oms.depths()[1:]), "depths"
+    if check_index:
+        idx = np.ctypeslib.as_array(ms.contents.index, (1 << bits,))
+        assert np.array_equal(idx, oms.index_table()), "index[] slot layout (modset.c:51-57)"
+
+
+def synth_batch(total, genome_bases, seed, err=0.03, n50=4000):
+    genome = synth.iid_bases(genome_bases, seed)
+    starts, offs, strands = synth.ont_read_plan(total, genome_bases, seed + 1, n50=n50, lo=30, hi=30000)
+    return synth.reads_from_genome(genome, starts, offs, strands, err, seed + 2), offs.astype(np.int64)
+
+
+@pytest.mark.parametrize("k,w,bits", [(21, 64, 22), (31, 4, 24), (19, 31, 22), (11, 1, 24), (16, 32, 20)])
+def test_add_batches_vs_oracle(k, w, bits):
+    """two successive batches into one modset (modutils -a f1 -a f2): indices continue at max+1"""
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b1 = synth_batch(600_000 if w > 2 else 150_000, 50_000, 11)
+    b2 = synth_batch(300_000 if w > 2 else 80_000, 50_000, 11, err=0.05)     # same genome: many k-mers recur
+    ms = mg.modsetCreate(sh, bits)
+    n1 = mg.add_sequence_batch(ms, *b1)
+    max1 = ms.contents.max
+    n2 = mg.add_sequence_batch(ms, *b2)
+    oms, tot = oracle_build(oh, bits, [b1, b2])
+    assert n1 + n2 == tot and max1 <= ms.contents.max
+    assert_same_modset(ms, oms, bits)
+    mg.lib().modsetDestroy(ms)
+
+
+def test_depth_saturation_and_duplicates_in_one_read():
+    """a k-mer seen > 65535 times pins at 65535 (modutils.c:26); repeats inside one read keep the first index"""
+    k, w, bits = 3, 1, 20
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    reads = [np.zeros(70000, np.uint8), np.array([0, 1, 2, 3] * 300, np.uint8), np.zeros(10, np.uint8)]
+    batch = util.concat_reads(reads)
+    ms = mg.modsetCreate(sh, bits)
+    mg.add_sequence_batch(ms, *batch)
+    oms, _ = oracle_build(oh, bits, [batch])
+    assert oms.depths()[1] == 65535
+    assert_same_modset(ms, oms, bits)
+    # a second batch on top of a saturated depth stays saturated
+    mg.add_sequence_batch(ms, *batch)
+    oms2, _ = oracle_build(oh, bits, [batch, batch])
+    assert_same_modset(ms, oms2, bits)
+
+
+def test_find_batch_and_device_api():
+    """modsetFindBatchDevice == modsetIndexFind(ms, kmer, false) incl. misses; AddBatch returns indices"""
+    L = mg.lib()
+    k, w, bits = 21, 16, 22
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    bases, offs = synth_batch(400_000, 40_000, 5)
+    km, _, _, _ = util.oracle_scan_batch(oh, bases, offs)
+    oms = po.Modset(oh, bits)
+    expect = np.array([oms.find(x, True) for x in km], np.uint32)
+    ms = mg.modsetCreate(sh, bits)
+    d_k = mg.DeviceBuffer.from_numpy(km); d_i = mg.DeviceBuffer(len(km) * 4)
+    mg.check(L.modsetAddBatchDevice(ms, d_k.ptr, len(km), d_i.ptr, 0, None))      # withDepth = 0: modmap.c:109
+    assert np.array_equal(d_i.to_numpy(np.uint32, len(km)), expect)
+    assert ms.contents.max == oms.max
+    mg.check(L.modsetSyncToHost(ms, 0))
+    assert not mg.modset_arrays(ms)[1].any()                                      # depth untouched
+    rng = np.random.default_rng(0)
+    probe = np.concatenate([km[::7], rng.integers(0, 1 << 42, 5000).astype(np.uint64)])
+    want = np.array([oms.find(x) for x in probe], np.uint32)
+    d_p = mg.DeviceBuffer.from_numpy(probe); d_o = mg.DeviceBuffer(len(probe) * 4)
+    mg.check(L.modsetFindBatchDevice(ms, d_p.ptr, len(probe), d_o.ptr, None))
+    got = d_o.to_numpy(np.uint32, len(probe))
+    assert np.array_equal(got, want) and (got == 0).any() and (got != 0).any()
+    # round trip: every stored value finds its own index
+    vals = mg.modset_arrays(ms)[0][1:]
+    d_v = mg.DeviceBuffer.from_numpy(vals); d_o2 = mg.DeviceBuffer(len(vals) * 4)
+    mg.check(L.modsetFindBatchDevice(ms, d_v.ptr, len(vals), d_o2.ptr, None))
+    assert np.array_equal(d_o2.to_numpy(np.uint32, len(vals)), np.arange(1, len(vals) + 1, dtype=np.uint32))
+
+
+def test_host_scalar_and_device_batches_interleave():
+    """scalar modsetIndexFind on the host arrays and GPU batches on the same Modset stay coherent"""
+    L = mg.lib()
+    k, w, bits = 19, 8, 20
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b1 = synth_batch(100_000, 20_000, 21)
+    b2 = synth_batch(60_000, 20_000, 21, err=0.08)
+    km2 = util.oracle_scan_batch(oh, *b2)[0]
+    ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
+    # host scalar inserts first (reference-style loop), then a GPU batch, then scalar again
+    for x in km2[:500]:
+        assert L.modsetIndexFind(ms, int(x), 1) == oms.find(x, True)
+    mg.add_sequence_batch(ms, *b1)
+    for r in range(len(b1[1]) - 1):
+        oms.add_sequence(b1[0][b1[1][r]:b1[1][r + 1]])
+    for x in km2[500:1500]:
+        assert L.modsetIndexFind(ms, int(x), 1) == oms.find(x, True)
+    for x in km2[:200]:
+        assert L.modsetIndexFind(ms, int(x), 0) == oms.find(x, False)
+    mg.add_sequence_batch(ms, *b2)
+    for r in range(len(b2[1]) - 1):
+        oms.add_sequence(b2[0][b2[1][r]:b2[1][r + 1]])
+    assert_same_modset(ms, oms, bits)
+
+
+def test_histogram_clear_and_capacity(tmp_path):
+    L = mg.lib()
+    k, w, bits = 21, 4, 22
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b = synth_batch(500_000, 15_000, 31, err=0.01)
+    ms = mg.modsetCreate(sh, bits)
+    mg.add_sequence_batch(ms, *b)
+    oms, _ = oracle_build(oh, bits, [b])
+    d_h = mg.DeviceBuffer(65536 * 8)
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))          # before any sync: pending device counts
+    assert np.array_equal(d_h.to_numpy(np.uint64, 65536), oms.histogram())
+    tmp = str(tmp_path / "h.txt")
+    with mg.CFile(tmp, "w") as f:
+        L.mgDepthHistogram(ms, f)
+    assert open(tmp).read() == oms.hist_text(str(tmp_path / "o.txt"))
+    mg.check(L.modsetSyncToHost(ms, 0))
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))          # after a sync: same answer
+    assert np.array_equal(d_h.to_numpy(np.uint64, 65536), oms.histogram())
+    # clear = a fresh modsetCreate
+    mg.check(L.mgModsetClear(ms, None))
+    assert ms.contents.max == 0
+    mg.add_sequence_batch(ms, *b)
+    assert_same_modset(ms, oms, bits)
+    # capacity: more distinct k-mers than size -> the reference's message (modset.c:58)
+    small = mg.modsetCreate(mg.seqhashCreate(11, 1, 17), 20, 1000)
+    rnd = np.random.default_rng(1).integers(0, 4, 20000).astype(np.uint8)
+    with pytest.raises(mg.ModgpuError, match="hashTableSize 1000 is too small"):
+        mg.add_sequence_batch(small, rnd, np.array([0, 20000], np.int64))
+
+
+@pytest.mark.parametrize("tag", list(util.MODUTILS_TAGS))
+def test_golden_modutils_flow(tag, golden_dir, tmp_path):
+    """modutils -c .. -a reads.fa -a reads2.fa -wt -H -p 2 40 -H -wt through the C callers on the GPU"""
+    L = mg.lib()
+    B, k, w, s = util.MODUTILS_TAGS[tag]
+    sh = mg.seqhashCreate(k, w, s)
+    ms = mg.modsetCreate(sh, B)
+    out = str(tmp_path / "out.txt")
+    with mg.CFile(out, "w") as f:
+        L.seqhashReport(sh, f)
+        for fn in ("reads.fa", "reads2.fa"):
+            names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, fn))
+            assert L.mgAddSequences(ms, bases.ctypes.data, offs.ctypes.data, len(names), f) == 0
+            L.modsetSummary(ms, f)
+    tmp = str(tmp_path / "t.txt")
+
+    def text(fn):
+        with mg.CFile(tmp, "w") as f:
+            fn(ms, f)
+        return open(tmp).read()
+    util.check_dump(text(L.mgModsetWriteText), "modutils_%s.dump.txt" % tag)
+    assert text(L.mgDepthHistogram) == util.golden_text("modutils_%s.hist.txt" % tag)
+    L.modsetDepthPrune(ms, 2, 40)
+    with mg.CFile(out, "a") as f:
+        L.modsetSummary(ms, f)
+    assert text(L.mgDepthHistogram) == util.golden_text("modutils_%s.pruned_hist.txt" % tag)
+    util.check_dump(text(L.mgModsetWriteText), "modutils_%s.pruned_dump.txt" % tag)
+    assert open(out).read() == util.golden_text("modutils_%s.stdout.txt" % tag)
+    # after the prune the device table is rebuilt from the host arrays on the next batch
+    names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, "reads2.fa"))
+    before = ms.contents.max
+    mg.add_sequence_batch(ms, bases, offs)
+    assert ms.contents.max >= before
+
+
+@pytest.mark.parametrize("tag", list(util.MODMAP_TAGS))
+def test_golden_modmap_flow(tag, golden_dir, tmp_path):
+    """modmap -K k -W w -S 17 -B 20 -f ref.fa -q queries.fa: same report, Q and M lines as the reference"""
+    L = mg.lib()
+    k, w = util.MODMAP_TAGS[tag]
+    sh = mg.seqhashCreate(k, w, 17)
+    ms = mg.modsetCreate(sh, 20)
+    ref = L.mgReferenceCreate(ms, 1 << 26)
+    names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, "ref.fa"))
+    qn, qb, qo = fasta.read_fasta(os.path.join(golden_dir, "queries.fa"))
+    out = str(tmp_path / "mm.txt")
+    with mg.CFile(out, "w") as f:
+        _libc = C.CDLL(None)
+        _libc.fprintf.argtypes = [C.c_void_p, C.c_char_p]
+        _libc.fprintf(f, ("  modmap initialised with k = %d, w = %d, random seed = 17\n" % (k, w)).encode())
+        cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        assert L.mgReferenceRead(ref, bases.ctypes.data, offs.ctypes.data, len(names), cn, True, f) == 0
+        cq = (C.c_char_p * len(qn))(*[n.encode() for n in qn])
+        assert L.mgQueryProcess(ref, qb.ctypes.data, qo.ctypes.data, len(qn), cq, f) == 0
+    assert open(out).read() == util.golden_text("modmap_%s.stdout.txt" % tag)
+    L.mgReferenceDestroy(ref)
+
+
+def test_seed_lists_vs_oracle():
+    """mgQueryReadsDevice: Seed{index,pos} per read incl. misses (modmap.c:197-206)"""
+    L = mg.lib()
+    k, w, bits = 21, 32, 22
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    refb = synth_batch(300_000, 300_000, 41, err=0.0, n50=50_000)
+    ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
+    for r in range(len(refb[1]) - 1):
+        for x in oh.scan(refb[0][refb[1][r]:refb[1][r + 1]])[0]:
+            oms.find(x, True)
+    km_ref = util.oracle_scan_batch(oh, *refb)[0]
+    d_k = mg.DeviceBuffer.from_numpy(km_ref)
+    mg.check(L.modsetAddBatchDevice(ms, d_k.ptr, len(km_ref), None, 0, None))
+    q = synth_batch(200_000, 300_000, 41, err=0.04, n50=6000)       # reads of the same genome, with errors
+    qk, qp, _, qst = util.oracle_scan_batch(oh, *q)
+    want = np.array([oms.find(x) for x in qk], np.uint32)
+    total = int(q[1][-1])
+    d_p = mg.DeviceBuffer.from_numpy(mg.pack_host(q[0])); d_o = mg.DeviceBuffer.from_numpy(q[1].astype(np.uint64))
+    cap = len(qk) + 5
+    d_ix = mg.DeviceBuffer(cap * 4); d_pos = mg.DeviceBuffer(cap * 4); d_rid = mg.DeviceBuffer(cap * 4)
+    n = C.c_uint64()
+    mg.check(L.mgQueryReadsDevice(ms, d_p.ptr, total, d_o.ptr, len(q[1]) - 1, d_ix.ptr, d_pos.ptr, d_rid.ptr, cap, C.byref(n), None))
+    assert n.value == len(qk)
+    assert np.array_equal(d_ix.to_numpy(np.uint32, n.value), want)
+    assert np.array_equal(d_pos.to_numpy(np.uint32, n.value) & mg.MG_POS_MASK, qp.astype(np.uint32))
+    rid = d_rid.to_numpy(np.uint32, n.value)
+    assert np.array_equal(np.searchsorted(rid, np.arange(len(q[1]))), qst)
+    assert (want == 0).any() and (want != 0).any()
+
+
+def test_full_size_build_properties():
+    """BASELINE config 2 at full size (10 Gbp, table bits 30) plus a 1 Gbp run: properties that
+    hold for any correct modset build — sum of depths == number of modimizers (no saturation here),
+    every stored k-mer finds its own index, re-adding the same batch adds no entries and doubles
+    the depth sum, the DP histogram sums to max and its weighted sum to the depth sum."""
+    L = mg.lib()
+    sh = mg.seqhashCreate(21, 64, 17)
+    for gbp, bits in ((1.0, 28), (10.0, 30)):
+        total = int(gbp * 1e9); G = total // 30
+        starts, offs, strands = synth.ont_read_plan(total, G, 1000)
+        d_g = mg.DeviceBuffer(L.mgPackedWords(G) * 4)
+        mg.check(L.mgSynthGenome(d_g.ptr, G, 12345, None))
+        d_s = mg.DeviceBuffer.from_numpy(starts); d_of = mg.DeviceBuffer.from_numpy(offs); d_st = mg.DeviceBuffer.from_numpy(strands)
+        d_r = mg.DeviceBuffer(L.mgPackedWords(total) * 4)
+        mg.check(L.mgSynthReads(d_g.ptr, G, d_s.ptr, d_of.ptr, d_st.ptr, len(starts), total, 0.05, 777, d_r.ptr, None))
+        d_g.free()
+        ms = mg.modsetCreate(sh, bits)
+        n = C.c_uint64()
+        mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, len(starts), C.byref(n), None))
+        S, U = n.value, ms.contents.max
+        assert abs(S / (total / 64.0) - 1) < 0.01 and 0 < U <= S
+        d_h = mg.DeviceBuffer(65536 * 8)
+        mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+        mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+        h = d_h.to_numpy(np.uint64, 65536)
+        assert int(h.sum()) == U and h[0] == 0
+        assert int((h * np.arange(65536, dtype=np.uint64)).sum()) == S or h[65535] > 0
+        mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, len(starts), C.byref(n), None))
+        assert n.value == S and ms.contents.max == U                      # idempotent key set
+        mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+        mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+        h2 = d_h.to_numpy(np.uint64, 65536)
+        assert int(h2.sum()) == U and (h2[1::2][:30000].sum() == 0 or h2[65535] > 0)      # every depth doubled -> even
+        if gbp == 1.0:
+            mg.check(L.modsetSyncToHost(ms, 0))
+            v, d, _ = mg.modset_arrays(ms)
+            assert len(np.unique(v[1:])) == U and int(d[1:].astype(np.int64).sum()) == 2 * S
+            d_v = mg.DeviceBuffer.from_numpy(v[1:]); d_o = mg.DeviceBuffer(U * 4)
+            mg.check(L.modsetFindBatchDevice(ms, d_v.ptr, U, d_o.ptr, None))
+            assert np.array_equal(d_o.to_numpy(np.uint32, U), np.arange(1, U + 1, dtype=np.uint32))
+        L.modsetDestroy(ms)
+        d_r.free()

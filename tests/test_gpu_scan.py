@@ -1,0 +1,219 @@
+"""GPU parity: the HIP scan (K1/K2) through the C ABI vs the oracle and the golden vectors.
+Bit-exact: these are integer k-mers, positions and strand flags."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import modimizer_amd as mg
+from modimizer_amd import synth
+from oracle import pyoracle as po
+import util
+
+pytestmark = pytest.mark.gpu
+TILE = 16384
+
+
+def assert_batch_equal(sh, oh, reads):
+    bases, offs = util.concat_reads(reads)
+    km, pos, isf, st = mg.scan_batch(sh, bases, offs)
+    ek, ep, ef, est = util.oracle_scan_batch(oh, bases, offs)
+    assert np.array_equal(st, est)
+    assert np.array_equal(km, ek) and np.array_equal(pos, ep) and np.array_equal(isf, ef)
+    return len(km)
+
+
+@pytest.mark.parametrize("ci", range(9))
+def test_golden_vectors_batch_and_iterator(ci):
+    """every golden read of a config in ONE batch (ragged, incl. empty / len<k / len==k reads)"""
+    k, w, seed = util.scan_configs()[ci]
+    sh = mg.seqhashCreate(k, w, seed)
+    cases = list(util.scan_cases(ci))
+    bases, offs = util.concat_reads([c[1] for c in cases])
+    km, pos, isf, st = mg.scan_batch(sh, bases, offs)
+    for r, (name, b, gk, gp, gf) in enumerate(cases):
+        s, e = st[r], st[r + 1]
+        assert np.array_equal(km[s:e], gk) and np.array_equal(pos[s:e], gp) and np.array_equal(isf[s:e], gf), (ci, name)
+        # the per-read facade the reference callers use (modRCiterator/modRCnext)
+        a, p, f = mg.iterate(sh, b)
+        assert np.array_equal(a, gk) and np.array_equal(p, gp) and np.array_equal(f, gf), (ci, name, "iterator")
+
+
+@pytest.mark.parametrize("k,w,seed", [(21, 64, 17), (31, 4, 17), (19, 31, 17), (16, 32, 0), (11, 1, 3),
+                                      (1, 1, 17), (2, 3, 5), (31, 97, 9), (27, 1024, 17), (5, 2, 17)])
+def test_random_ragged_batches(k, w, seed):
+    sh = mg.seqhashCreate(k, w, seed); oh = po.Hasher(k, w, seed)
+    rng = np.random.default_rng(k * 7 + w)
+    lens = [0, 1, k - 1, k, k + 1, 63, 64, 65, 127, 128, 1000, 0, 0, 5, 4097, 10000, 2, 31, 32, 33, 64 + k - 1, 64 + k]
+    reads = [rng.integers(0, 4, L).astype(np.uint8) for L in lens]
+    n = assert_batch_equal(sh, oh, reads)
+    assert n > 0
+
+
+def test_tile_boundaries():
+    """reads that start/end exactly at, just before and just after 16384-base tile edges"""
+    k, w = 21, 8
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(1)
+    lens = [TILE - k + 1, k - 1, TILE, 1, TILE - 1, 2, TILE + k - 1, TILE - 20, 20, 21, 22, 3 * TILE + 5, 19, TILE // 2, TILE // 2]
+    reads = [rng.integers(0, 4, L).astype(np.uint8) for L in lens]
+    assert_batch_equal(sh, oh, reads)
+    # a batch that ends exactly on a tile edge, and one base short / over
+    for total in (TILE, TILE - 1, TILE + 1, 2 * TILE, 64, 63, 65):
+        assert_batch_equal(sh, oh, [rng.integers(0, 4, total).astype(np.uint8)])
+
+
+def test_many_short_reads():
+    """Illumina-like: 30 000 x 150 b, k=31 d=4 (config 5's shape): ~110 read boundaries per tile"""
+    k, w = 31, 4
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    genome = synth.iid_bases(200000, 3)
+    starts, offs, strands = synth.fixed_read_plan(30000, 150, len(genome), 4)
+    bases = synth.reads_from_genome(genome, starts, offs, strands, 0.005, 5)
+    km, pos, isf, st = mg.scan_batch(sh, bases, offs.astype(np.int64))
+    ek, ep, ef, est = util.oracle_scan_batch(oh, bases, offs.astype(np.int64))
+    assert np.array_equal(st, est) and np.array_equal(km, ek) and np.array_equal(pos, ep) and np.array_equal(isf, ef)
+
+
+def test_tiny_reads_stress():
+    """thousands of reads shorter than, equal to and slightly longer than k inside single tiles"""
+    k, w = 7, 3
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(9)
+    reads = [rng.integers(0, 4, int(L)).astype(np.uint8) for L in rng.integers(0, 20, 5000)]
+    assert_batch_equal(sh, oh, reads)
+
+
+def test_one_long_sequence():
+    """a 3 Mbp 'chromosome': the scan must not depend on one-wave-per-read"""
+    k, w = 21, 64
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b = synth.iid_bases(3_000_000, 77)
+    n = assert_batch_equal(sh, oh, [b])
+    assert abs(n - 3_000_000 / 64) < 2000
+
+
+def test_palindromes_and_homopolymers():
+    """hashF == hashR ties resolve to the reverse strand (seqhash.c:66-67)"""
+    for k, w in [(16, 1), (4, 1), (2, 1), (16, 2)]:
+        sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+        reads = [np.array([0, 1, 2, 3] * 50, np.uint8), np.zeros(200, np.uint8), np.full(200, 3, np.uint8),
+                 np.array([0, 3] * 100, np.uint8), np.array([1, 2] * 100, np.uint8)]
+        assert_batch_equal(sh, oh, reads)
+        km, pos, isf, st = mg.scan_batch(sh, *util.concat_reads(reads))
+        assert (isf[st[0]:st[1]] == 0).any()      # palindromic k-mers are reported as reverse
+
+
+def test_device_api_capacity_and_count():
+    """seqhashScanBatchDevice: count is the true total even when capacity is too small"""
+    L = mg.lib()
+    k, w = 21, 16
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(3)
+    reads = [rng.integers(0, 4, L_).astype(np.uint8) for L_ in (40000, 123, 70000, 9)]
+    bases, offs = util.concat_reads(reads)
+    ek, ep, ef, _ = util.oracle_scan_batch(oh, bases, offs)
+    total = len(bases)
+    d_packed = mg.DeviceBuffer.from_numpy(mg.pack_host(bases))
+    d_off = mg.DeviceBuffer.from_numpy(offs.astype(np.uint64))
+    d_work = mg.DeviceBuffer(L.mgScanWorkBytes(total, len(reads)))
+    d_cnt = mg.DeviceBuffer(16)
+    for cap in (len(ek) + 10, len(ek), 100, 0):
+        d_k = mg.DeviceBuffer(max(cap, 1) * 8); d_p = mg.DeviceBuffer(max(cap, 1) * 4); d_r = mg.DeviceBuffer(max(cap, 1) * 4)
+        mg.check(L.seqhashScanBatchDevice(sh, d_packed.ptr, total, d_off.ptr, len(reads), d_k.ptr, d_p.ptr, d_r.ptr,
+                                          cap, d_cnt.ptr, d_work.ptr, None))
+        cnt = d_cnt.to_numpy(np.uint64, 2)
+        assert cnt[0] == len(ek) and cnt[1] == (1 if cap < len(ek) else 0)
+        m = min(cap, len(ek))
+        assert np.array_equal(d_k.to_numpy(np.uint64, m), ek[:m])
+        pf = d_p.to_numpy(np.uint32, m)
+        assert np.array_equal(pf & mg.MG_POS_MASK, ep[:m].astype(np.uint32)) and np.array_equal((pf >> 31).astype(np.uint8), ef[:m])
+        rid = d_r.to_numpy(np.uint32, m)
+        assert (np.diff(rid.astype(np.int64)) >= 0).all()
+    # dReadId may be NULL
+    d_k = mg.DeviceBuffer(len(ek) * 8); d_p = mg.DeviceBuffer(len(ek) * 4)
+    mg.check(L.seqhashScanBatchDevice(sh, d_packed.ptr, total, d_off.ptr, len(reads), d_k.ptr, d_p.ptr, None,
+                                      len(ek), d_cnt.ptr, d_work.ptr, None))
+    assert np.array_equal(d_k.to_numpy(np.uint64, len(ek)), ek)
+
+
+def test_pack_unpack_and_synth_on_device():
+    L = mg.lib()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 15, 16, 17, 1000, 100003):
+        b = rng.integers(0, 4, n).astype(np.uint8)
+        d_b = mg.DeviceBuffer.from_numpy(b)
+        d_w = mg.DeviceBuffer(L.mgPackedWords(n) * 4)
+        mg.check(L.mgPackDevice(d_b.ptr, n, d_w.ptr, None))
+        assert np.array_equal(d_w.to_numpy(np.uint32, L.mgPackedWords(n)), mg.pack_host(b))
+        d_o = mg.DeviceBuffer(max(n, 1))
+        mg.check(L.mgUnpackDevice(d_w.ptr, n, d_o.ptr, None))
+        assert np.array_equal(d_o.to_numpy(np.uint8, n), b)
+    # device generators == their numpy mirrors (the bench's inputs are reproducible on the host)
+    G = 50001
+    d_g = mg.DeviceBuffer(L.mgPackedWords(G) * 4)
+    mg.check(L.mgSynthGenome(d_g.ptr, G, 12345, None))
+    genome = synth.iid_bases(G, 12345)
+    assert np.array_equal(d_g.to_numpy(np.uint32, L.mgPackedWords(G)), mg.pack_host(genome))
+    starts, offs, strands = synth.ont_read_plan(200000, G, 7, n50=3000, lo=100, hi=20000)
+    total = int(offs[-1])
+    d_s = mg.DeviceBuffer.from_numpy(starts); d_of = mg.DeviceBuffer.from_numpy(offs); d_st = mg.DeviceBuffer.from_numpy(strands)
+    d_r = mg.DeviceBuffer(L.mgPackedWords(total) * 4)
+    mg.check(L.mgSynthReads(d_g.ptr, G, d_s.ptr, d_of.ptr, d_st.ptr, len(starts), total, 0.05, 99, d_r.ptr, None))
+    host = synth.reads_from_genome(genome, starts, offs, strands, 0.05, 99)
+    assert np.array_equal(d_r.to_numpy(np.uint32, L.mgPackedWords(total)), mg.pack_host(host))
+
+
+def test_full_size_properties():
+    """1 Gbp of device-generated ONT-like reads (BASELINE config 2's shape at 1/10 scale, then the
+    full 10 Gbp): properties that need no oracle — splitting the batch at a read boundary and
+    scanning the halves gives the same multiset checksum and count (the scan is per-read);
+    positions are increasing within a read; read ids are non-decreasing."""
+    L = mg.lib()
+    sh = mg.seqhashCreate(21, 64, 17)
+    for gbp in (1.0, 10.0):
+        total = int(gbp * 1e9)
+        G = total // 30
+        starts, offs, strands = synth.ont_read_plan(total, G, 1000)
+        n_reads = len(starts)
+        d_g = mg.DeviceBuffer(L.mgPackedWords(G) * 4)
+        mg.check(L.mgSynthGenome(d_g.ptr, G, 12345, None))
+        d_s = mg.DeviceBuffer.from_numpy(starts); d_of = mg.DeviceBuffer.from_numpy(offs); d_st = mg.DeviceBuffer.from_numpy(strands)
+        d_r = mg.DeviceBuffer(L.mgPackedWords(total) * 4)
+        mg.check(L.mgSynthReads(d_g.ptr, G, d_s.ptr, d_of.ptr, d_st.ptr, n_reads, total, 0.05, 777, d_r.ptr, None))
+        d_g.free()
+        cap = int(total / 64 * 1.1)
+        d_k = mg.DeviceBuffer(cap * 8); d_p = mg.DeviceBuffer(cap * 4); d_id = mg.DeviceBuffer(cap * 4)
+        d_cnt = mg.DeviceBuffer(16); d_work = mg.DeviceBuffer(L.mgScanWorkBytes(total, n_reads))
+
+        def run(off_arr, nr, tot, packed_ptr):
+            d_o = mg.DeviceBuffer.from_numpy(off_arr)
+            mg.check(L.seqhashScanBatchDevice(sh, packed_ptr, tot, d_o.ptr, nr, d_k.ptr, d_p.ptr, d_id.ptr, cap, d_cnt.ptr, d_work.ptr, None))
+            c = d_cnt.to_numpy(np.uint64, 2)
+            assert c[1] == 0
+            n = int(c[0])
+            km = d_k.to_numpy(np.uint64, n); pf = d_p.to_numpy(np.uint32, n); rid = d_id.to_numpy(np.uint32, n)
+            return km, pf, rid
+        km, pf, rid = run(offs, n_reads, total, d_r.ptr)
+        assert abs(len(km) / (total / 64.0) - 1) < 0.01              # 1-in-d density
+        assert (np.diff(rid.astype(np.int64)) >= 0).all()
+        same = rid[1:] == rid[:-1]
+        assert ((pf[1:] & mg.MG_POS_MASK)[same] > (pf[:-1] & mg.MG_POS_MASK)[same]).all()
+        lens = (offs[1:] - offs[:-1]).astype(np.int64)
+        assert ((pf & mg.MG_POS_MASK).astype(np.int64) <= lens[rid] - 21).all()
+        full = (int(np.bitwise_xor.reduce(km + pf.astype(np.uint64))), len(km), int(km.sum(dtype=np.uint64)))
+        # first half only: the reads before a 16-base-aligned boundary -> prefix of the full result
+        cut = int(np.searchsorted(offs, total // 2))
+        while cut < n_reads and int(offs[cut]) % 16:
+            cut += 1
+        if cut < n_reads:
+            km1, pf1, rid1 = run(offs[:cut + 1].copy(), cut, int(offs[cut]), d_r.ptr)
+            n1 = len(km1)
+            assert np.array_equal(km1, km[:n1]) and np.array_equal(pf1, pf[:n1]) and (rid[:n1] < cut).all() and rid[n1] >= cut
+            off2 = (offs[cut:] - offs[cut]).copy()
+            km2, pf2, rid2 = run(off2, n_reads - cut, total - int(offs[cut]), C.c_void_p(d_r.ptr.value + int(offs[cut]) // 4))
+            assert np.array_equal(km2, km[n1:]) and np.array_equal(pf2, pf[n1:]) and np.array_equal(rid2 + cut, rid[n1:])
+        del km, pf, rid
+        for b in (d_k, d_p, d_id, d_r):
+            b.free()
+        assert full[1] > 0
