@@ -147,12 +147,15 @@ MgStatus mgUnpackDevice (const U32 *dWords, U64 nBases, U8 *dBases, void *stream
  *   dKmer[i]  canonical k-mer (seqhash.c:183)
  *   dPosF[i]  pos within its read in bits 0..30 (seqhash.c:184), isForward in bit 31
  *   dReadId[i] read ordinal (may be NULL)
- * dCount: device U64[2] -> {number of modimizers found, 1 if capacity was exceeded}.  When the
- * capacity is exceeded the first `capacity` entries are still correct and count is the true total.
- * dWork: mgScanWorkBytes(totalBases, nReads) bytes of device scratch. */
+ * dCount: device U64[4] -> {number of modimizers found, overflow flag, fullest workgroup segment,
+ * capacity to retry with}.  Workgroups stage their modimizers in per-workgroup segments of dWork
+ * sized from `capacity`; when the flag is set (total > capacity, or one segment too small) the
+ * outputs are unspecified, count is still the true total, and a retry with capacity = dCount[3]
+ * succeeds.
+ * dWork: mgScanWorkBytes(totalBases, nReads, capacity) bytes of device scratch. */
 #define MG_POS_MASK 0x7fffffffu
 #define MG_FWD_BIT  0x80000000u
-size_t   mgScanWorkBytes (U64 totalBases, U32 nReads) ;
+size_t   mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity) ;
 MgStatus seqhashScanBatchDevice (const Seqhash *sh, const U32 *dPacked, U64 totalBases,
                                  const U64 *dReadOffsets, U32 nReads,
                                  U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,

@@ -113,7 +113,7 @@ def lib():
     sig("mgMemsetD", i32, vp, i32, C.c_size_t, vp); sig("mgStreamSynchronize", i32, vp)
     sig("mgPackedWords", C.c_size_t, u64); sig("mgPackHost", None, vp, u64, vp)
     sig("mgPackDevice", i32, vp, u64, vp, vp); sig("mgUnpackDevice", i32, vp, u64, vp, vp)
-    sig("mgScanWorkBytes", C.c_size_t, u64, u32)
+    sig("mgScanWorkBytes", C.c_size_t, u64, u32, u64)
     sig("seqhashScanBatchDevice", i32, SH, vp, u64, vp, u32, vp, vp, vp, u64, vp, vp, vp)
     sig("seqhashScanBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
     sig("modsetAddBatchDevice", i32, MS, vp, u64, vp, i32, vp)

@@ -62,7 +62,7 @@ static const char *gKernelNames[MG_K_COUNT] = {
   "mgPackKernel", "mgUnpackKernel", "mgTileFirstReadKernel", "mgScanKernel", "mgTableInsertKernel",
   "mgTableAssignKernel", "mgTableGatherKernel", "mgTableFindKernel", "mgTableLoadKernel",
   "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
-  "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset" };
+  "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel" };
 #define MG_PROF_POOL 8192
 struct MgProfRec { int id; hipEvent_t a, b; };
 static struct {
@@ -223,9 +223,9 @@ extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const
   MgArena ar;
   int64_t result = -1;
   U64 *hK = 0; U32 *hP = 0, *hR = 0;
-  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+  for (int attempt = 0 ; attempt < 3 ; ++attempt)
     { size_t need = al256 (nw * 4) + al256 (((size_t) nReads + 1) * 8) + al256 (cap * 8) + 2 * al256 (cap * 4)
-                    + al256 (mgScanWorkBytes (total, (U32) nReads)) + 4096;
+                    + al256 (mgScanWorkBytes (total, (U32) nReads, cap)) + 4096;
       if (ar.reserve (need)) break;
       ar.reset ();
       U32 *dP = (U32 *) ar.take (nw * 4);
@@ -233,14 +233,14 @@ extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const
       U64 *dK = (U64 *) ar.take (cap * 8);
       U32 *dPos = (U32 *) ar.take (cap * 4);
       U32 *dRid = (U32 *) ar.take (cap * 4);
-      void *dWork = ar.take (mgScanWorkBytes (total, (U32) nReads));
-      U64 *dCount = (U64 *) ar.take (16);
+      void *dWork = ar.take (mgScanWorkBytes (total, (U32) nReads, cap));
+      U64 *dCount = (U64 *) ar.take (8 * MG_COUNT_WORDS);
       if (hipMemcpy (dP, hPacked, nw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
       if (nReads && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
       if (seqhashScanBatchDevice (sh, dP, total, dOff, (U32) nReads, dK, dPos, dRid, cap, dCount, dWork, 0)) break;
-      U64 cnt[2];
-      if (hipMemcpy (cnt, dCount, 16, hipMemcpyDeviceToHost) != hipSuccess) break;
-      if (cnt[1] || cnt[0] > cap) { cap = cnt[0]; continue; }
+      U64 cnt[MG_COUNT_WORDS];
+      if (hipMemcpy (cnt, dCount, sizeof (cnt), hipMemcpyDeviceToHost) != hipSuccess) break;
+      if (cnt[1] || cnt[0] > cap) { cap = cnt[3]; continue; }
       U64 n = cnt[0];
       hK = (U64 *) malloc ((n + 1) * 8); hP = (U32 *) malloc ((n + 1) * 4); hR = (U32 *) malloc ((n + 1) * 4);
       if (n)
@@ -544,9 +544,9 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
 {
   U64 cap = mgSurvivorGuess (sh, totalBases);
   MgHashParams p = mgMakeParams (sh);
-  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+  for (int attempt = 0 ; attempt < 3 ; ++attempt)
     { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
-      size_t need = al256 (cap * perS) + 4 * 4096 + al256 (mgScanWorkBytes (totalBases, nReads))
+      size_t need = al256 (cap * perS) + 4 * 4096 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
                     + al256 (mgAssignDescBytes (cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK)) + 8 * 256;
       MgStatus s = d->arena.reserve (need); if (s) return s;
       d->arena.reset ();
@@ -554,14 +554,14 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       b->kmer = (U64 *) d->arena.take (cap * 8);
       b->posF = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
       b->rid = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
-      b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads));
-      b->count = (U64 *) d->arena.take (16);
+      b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads, cap));
+      b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
       if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st))) return s;
-      U64 c[2];
-      MG_HIP (hipMemcpyAsync (c, b->count, 16, hipMemcpyDeviceToHost, st));
+      U64 c[MG_COUNT_WORDS];
+      MG_HIP (hipMemcpyAsync (c, b->count, sizeof (c), hipMemcpyDeviceToHost, st));
       MG_HIP (hipStreamSynchronize (st));
       if (!c[1] && c[0] <= cap) { *nOut = c[0]; return MG_OK; }
-      cap = c[0];
+      cap = c[3];
     }
   mgSetError ("scan capacity could not be established");
   return MG_ERR_CAPACITY;
@@ -685,34 +685,34 @@ extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *
   MgIterScratch &g = gIt;
   if (nw > g.hWordsCap) { free (g.hPacked); g.hPacked = (U32 *) malloc (2 * nw * 4); g.hWordsCap = 2 * nw; }
   mgPackHost (s, total, g.hPacked);
-  if (!g.dOff) { if (hipMalloc ((void **) &g.dOff, 16) != hipSuccess || hipMalloc ((void **) &g.dCount, 16) != hipSuccess) return -1; }
+  if (!g.dOff) { if (hipMalloc ((void **) &g.dOff, 16) != hipSuccess || hipMalloc ((void **) &g.dCount, 8 * MG_COUNT_WORDS) != hipSuccess) return -1; }
   if (nw > g.wordsCap)
     { if (g.dPacked) (void) hipFree (g.dPacked);
       if (hipMalloc ((void **) &g.dPacked, 2 * nw * 4) != hipSuccess) return -1;
       g.wordsCap = 2 * nw;
     }
-  size_t wb = mgScanWorkBytes (total, 1);
-  if (wb > g.workCap)
-    { if (g.dWork) (void) hipFree (g.dWork);
-      if (hipMalloc (&g.dWork, 2 * wb) != hipSuccess) return -1;
-      g.workCap = 2 * wb;
-    }
   U64 cap = mgSurvivorGuess (sh, total);
   MgHashParams p = mgMakeParams (sh);
   U64 off[2] = { 0, total };
-  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+  for (int attempt = 0 ; attempt < 3 ; ++attempt)
     { if (cap > g.survCap)
         { if (g.dKmer) (void) hipFree (g.dKmer);
           if (g.dPosF) (void) hipFree (g.dPosF);
           if (hipMalloc ((void **) &g.dKmer, 2 * cap * 8) != hipSuccess || hipMalloc ((void **) &g.dPosF, 2 * cap * 4) != hipSuccess) return -1;
           g.survCap = 2 * cap;
         }
+      size_t wb = mgScanWorkBytes (total, 1, g.survCap);
+      if (wb > g.workCap)
+        { if (g.dWork) (void) hipFree (g.dWork);
+          if (hipMalloc (&g.dWork, 2 * wb) != hipSuccess) return -1;
+          g.workCap = 2 * wb;
+        }
       if (hipMemcpyAsync (g.dPacked, g.hPacked, nw * 4, hipMemcpyHostToDevice, 0) != hipSuccess) return -1;
       if (hipMemcpyAsync (g.dOff, off, 16, hipMemcpyHostToDevice, 0) != hipSuccess) return -1;
       if (mgLaunchScan (p, g.dPacked, total, g.dOff, 1, g.dKmer, g.dPosF, 0, g.survCap, g.dCount, g.dWork, 0)) return -1;
-      U64 c[2];
-      if (hipMemcpy (c, g.dCount, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-      if (c[1] || c[0] > g.survCap) { cap = c[0]; continue; }
+      U64 c[MG_COUNT_WORDS];
+      if (hipMemcpy (c, g.dCount, sizeof (c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      if (c[1] || c[0] > g.survCap) { cap = c[3]; continue; }
       U64 n = c[0];
       U64 *blk = (U64 *) malloc ((size_t) n * 12 + 16);
       if (n)

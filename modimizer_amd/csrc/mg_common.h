@@ -34,7 +34,8 @@ MgHashParams mgMakeParams (const Seqhash *sh);
 enum MgKernelId {
   MG_K_PACK = 0, MG_K_UNPACK, MG_K_TILE_FIRST_READ, MG_K_SCAN, MG_K_TABLE_INSERT, MG_K_TABLE_ASSIGN,
   MG_K_TABLE_GATHER, MG_K_TABLE_FIND, MG_K_TABLE_LOAD, MG_K_TABLE_EXPORT, MG_K_TABLE_HIST,
-  MG_K_INDEX_REPLAY, MG_K_INDEX_FINISH, MG_K_SYNTH_GENOME, MG_K_SYNTH_READS, MG_K_MEMSET, MG_K_COUNT
+  MG_K_INDEX_REPLAY, MG_K_INDEX_FINISH, MG_K_SYNTH_GENOME, MG_K_SYNTH_READS, MG_K_MEMSET,
+  MG_K_SEG_SCAN, MG_K_SEG_COMPACT, MG_K_COUNT
 };
 void mgProfBegin (int id, hipStream_t st);
 void mgProfEnd (int id, hipStream_t st);
@@ -133,6 +134,7 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipSt
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st);
 MgStatus mgTableReplayIndex (MgTable *t, const MgHashParams &p, int tableBits, U32 *dIndex, hipStream_t st);
 size_t   mgAssignDescBytes (U64 n);
+#define MG_COUNT_WORDS 4      /* dCount: {count, overflow flag, fullest block, capacity to retry with} */
 
 MgStatus mgLaunchSynthGenome (U32 *dPacked, U64 nBases, U64 seed, hipStream_t st);
 MgStatus mgLaunchSynthReads (const U32 *dGenome, U64 genomeBases, const U64 *dReadStart,

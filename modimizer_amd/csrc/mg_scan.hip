@@ -7,14 +7,18 @@
  * is 0 mod d.  Output order is (read, pos), exactly the order the reference's loops see.
  *
  * Work decomposition (MI355X-first, not one wave per read): the batch is one concatenated 2-bit
- * stream cut into tiles of 16384 k-mer starts; a persistent grid of 256-thread workgroups draws
- * tiles from an atomic ticket, so short reads (150 b) and chromosomes (125 Mb) load-balance
- * alike.  A tile's 4 KiB of packed bases are fetched with one 16-byte load per lane and staged in
- * LDS (+ a (k-1)-base halo); each lane owns 64 consecutive k-mer starts, rolls both strands through
- * registers and records hits in a 64-bit lane mask (no divergent work in the hot loop).  Hits are
- * compacted in order: lane popcounts -> workgroup scan -> decoupled look-back across tiles
- * (single pass; no recount) -> k-mers re-extracted from LDS by the few hit lanes and written out.
+ * stream cut into tiles of 16384 k-mer starts, so short reads (150 b) and chromosomes (125 Mb)
+ * load-balance alike.  Each 256-thread workgroup owns a CONTIGUOUS range of tiles and appends the
+ * modimizers it finds, in order, to its own segment of the output; there is no inter-workgroup
+ * protocol at all (a first version handed tiles out by an atomic ticket and ordered the output by
+ * decoupled look-back: at > 50 M tiles/s both the single ticket word and the descriptor polling
+ * saturated and capped the kernel near 0.8 Tbp/s).  Per-block counts are scanned by a one-block
+ * kernel and the segments are copied into the dense (read,pos)-ordered arrays by a streaming
+ * compaction kernel (12 B read + 12 B written per modimizer).
+ * A tile's 4 KiB of packed bases are fetched with one 16-byte load per lane one tile ahead
+ * (registers) and staged in LDS (+ a (k-1)-base halo); each lane owns 64 consecutive k-mer starts.
  */
+#include <stdlib.h>
 #include "mg_common.h"
 
 /* ---------------------------------------------------------------------------------------- */
@@ -74,7 +78,7 @@ MgStatus mgLaunchUnpack (const U32 *dWords, U64 nBases, U8 *dBases, hipStream_t 
 }
 
 /* ---------------------------------------------------------------------------------------- */
-/* K2 helper: read containing the first base of each tile                                     */
+/* K2 prepass: per-tile read metadata                                                         */
 
 /* largest r in [lo,hi] with off[r] <= p  (off[lo] <= p is guaranteed by the callers) */
 __device__ __forceinline__ U32 mgReadOf (const U64 *__restrict__ off, U32 lo, U32 hi, U64 p)
@@ -86,26 +90,38 @@ __device__ __forceinline__ U32 mgReadOf (const U64 *__restrict__ off, U32 lo, U3
   return lo;
 }
 
-__global__ void mgTileFirstReadKernel (const U64 *__restrict__ readOff, U32 nReads, U64 nTiles,
-                                       U32 *__restrict__ tileFirstRead)
+/* 32 bytes per tile: the read holding the tile's first base, and that read's extent.  A tile that
+ * lies wholly inside one read (the common case for long reads) needs no other read lookup. */
+struct __attribute__ ((aligned (32))) MgTileInfo { U64 start, end; U32 firstRead, pad0; U64 pad1; };
+
+__global__ void mgTileInfoKernel (const U64 *__restrict__ readOff, U32 nReads, U64 nTiles, U64 totalBases,
+                                  MgTileInfo *__restrict__ info)
 {
   U64 t = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   if (t > nTiles) return;
-  if (t == nTiles) { tileFirstRead[t] = nReads - 1; return; }
-  tileFirstRead[t] = mgReadOf (readOff, 0, nReads - 1, t * (U64) MG_TILE_BASES);
+  MgTileInfo ti;
+  ti.pad0 = 0; ti.pad1 = 0;
+  if (t == nTiles) { ti.firstRead = nReads - 1; ti.start = readOff[nReads - 1]; ti.end = totalBases; }
+  else
+    { U32 r = mgReadOf (readOff, 0, nReads - 1, t * (U64) MG_TILE_BASES);
+      ti.firstRead = r; ti.start = readOff[r]; ti.end = readOff[r + 1];
+    }
+  info[t] = ti;
 }
 
 /* ---------------------------------------------------------------------------------------- */
-/* K2: generic scan (any k in 1..31, any d >= 1)                                              */
+/* K2: scan + select + ordered compaction                                                     */
 
 struct MgScanArgs {
   MgHashParams p;
   const U32 *packed; U64 nWordsAlloc; U64 totalBases;
   const U64 *readOff; U32 nReads;
-  const U32 *tileFirstRead; U64 nTiles;
-  U64 *desc; U32 *ticket;
-  U64 *outKmer; U32 *outPosF; U32 *outRead; U64 capacity;
-  U64 *dCount;
+  const MgTileInfo *tileInfo; U64 nTiles;
+  U64 tilesPerBlock;     /* block b owns tiles [b*tilesPerBlock, (b+1)*tilesPerBlock) */
+  U64 segCap;            /* entries per output segment */
+  U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [gridDim.x * segCap] */
+  U64 *blockCount;       /* [gridDim.x] true number of modimizers each block found */
+  U32 fS, thresh;        /* fast path: factor1 << (32-B), 2^(32-m) */
 };
 
 /* which of this lane's 64 k-mer starts lie wholly inside a read (seqhash.c:162: len < k gives
@@ -130,145 +146,361 @@ __device__ __forceinline__ U64 mgValidMask (const MgScanArgs &a, U64 p0, U32 rFi
   return valid;
 }
 
-template <bool POW2>
+__device__ __forceinline__ U32 mgRevComp16 (U32 w)
+{
+  U32 x = __brev (w);
+  x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+  return ~x;
+}
+
+__device__ __forceinline__ uint4 mgLoadTileWords (const MgScanArgs &a, U64 tile, int tid)
+{
+  U64 g = tile * MG_TILE_WORDS + 4 * (U64) tid;
+  uint4 v;
+  if (g + 4 <= a.nWordsAlloc) v = *reinterpret_cast<const uint4 *> (a.packed + g);
+  else
+    { v.x = g     < a.nWordsAlloc ? a.packed[g]     : 0;
+      v.y = g + 1 < a.nWordsAlloc ? a.packed[g + 1] : 0;
+      v.z = g + 2 < a.nWordsAlloc ? a.packed[g + 2] : 0;
+      v.w = 0;
+    }
+  return v;
+}
+
+/* k-mer (forward strand) starting at position q of the tile staged in sWords */
+__device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
+{
+  int wi = q >> 4, s = 2 * (q & 15);
+  U32 x0 = sWords[wi], x1 = sWords[wi + 1], x2 = sWords[wi + 2];
+  U64 hi = ((U64) x0 << 32) | x1;
+  if (s) hi = (hi << s) | (U64) (x2 >> (32 - s));
+  return hi >> sh1;
+}
+
+#define MG_MODE_ANY   0      /* any d: exact test in phase A via modular inverse */
+#define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
+#define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
+#define MG_CAND_CAP   2048   /* candidate list entries per round (LDS) */
+
+/* One templated kernel.
+ *
+ * Phase A  every lane owns 64 consecutive k-mer starts and produces a 64-bit candidate mask with
+ *          no divergent work:
+ *            ANY/POW2: both strands rolled through registers, both 64-bit multiply-shift hashes,
+ *                      canonical = smaller hash, exact "0 mod d" test (candidates == modimizers);
+ *            FAST:     hash % 2^m tests bits [shift1, shift1+m) of kmer*factor1.  With
+ *                      B = shift1+m <= 32 those bits depend only on (kmer mod 2^32), i.e. on the
+ *                      last 16 bases of the forward k-mer and the first 16 bases, reverse-
+ *                      complemented, of the reverse one.  With fS = factor1 << (32-B):
+ *                      candidate  <=>  min (winF*fS, winR*fS) mod 2^32 < 2^(32-m)
+ *                      (one v_alignbit + one 32-bit multiply per strand, a min and a compare):
+ *                      a superset of the modimizers, about 2/d of the starts.
+ * Phase B  candidates are compacted, in order, into an LDS list (rounds of MG_CAND_CAP).
+ * Phase C  dense: one lane per candidate recomputes both full hashes from LDS, picks the strand
+ *          (ties -> reverse, seqhash.c:66-67) and applies the exact test; wave ballots record it.
+ * Phase D  ordered output: counts -> workgroup scan -> decoupled look-back across tiles ->
+ *          surviving lanes write kmer / pos|isF / read.
+ *
+ * Latency: the next tile's ticket, metadata and packed words are fetched while the current tile
+ * is processed (registers), so no global round trip sits on the per-tile critical path except
+ * the look-back itself.
+ */
+template <int MODE>
 __global__ __launch_bounds__ (MG_SCAN_THREADS)
 void mgScanKernel (const MgScanArgs a)
 {
   __shared__ __attribute__ ((aligned (16))) U32 sWords[MG_TILE_WORDS + 8];
-  __shared__ U32 sWaveTot[MG_SCAN_THREADS / 64];
-  __shared__ U64 sBase;
-  __shared__ U32 sTile;
+  __shared__ unsigned short sCand[MG_CAND_CAP];
+  __shared__ U64 sSurvB[MG_SCAN_THREADS], sFwdB[MG_SCAN_THREADS];
+  __shared__ U32 sOff[MG_SCAN_THREADS];
+  __shared__ U32 sRFirst[MG_SCAN_THREADS];
+  __shared__ U32 sWaveTotA[MG_SCAN_THREADS / 64], sWaveTotB[MG_SCAN_THREADS / 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const MgHashParams &p = a.p;
   const int k = p.k, sh1 = p.shift1;
   const U64 f1 = p.factor1;
+  const U64 dMask = (U64) (p.d - 1);
 
-  for (;;)
-    { if (tid == 0) sTile = atomicAdd (a.ticket, 1u);
-      __syncthreads ();
-      const U64 tile = sTile;
-      if (tile >= a.nTiles) break;
+  U64 tile = (U64) blockIdx.x * a.tilesPerBlock;
+  U64 tileEnd = tile + a.tilesPerBlock; if (tileEnd > a.nTiles) tileEnd = a.nTiles;
+  const U64 segBase = (U64) blockIdx.x * a.segCap;
+  U64 found = 0;                                   /* modimizers this block has found so far (uniform) */
+  uint4 curV = make_uint4 (0, 0, 0, 0); U32 curHalo = 0;
+  MgTileInfo ti, tiNext;
+  ti.start = ti.end = 0; ti.firstRead = 0; tiNext = ti;
+  U32 nextFirstRead = 0;
+  if (tile < tileEnd)
+    { curV = mgLoadTileWords (a, tile, tid);
+      if (tid < 8) { U64 gh = tile * MG_TILE_WORDS + MG_TILE_WORDS + tid; curHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
+      ti = a.tileInfo[tile];
+      nextFirstRead = a.tileInfo[tile + 1].firstRead;
+    }
 
-      /* ---- stage the tile's packed bases (+ halo) in LDS: one 16-byte load per lane ---- */
-      const U64 w0 = tile * MG_TILE_WORDS;
-      { U64 g = w0 + 4 * (U64) tid;
-        uint4 v;
-        if (g + 4 <= a.nWordsAlloc) v = *reinterpret_cast<const uint4 *> (a.packed + g);
-        else
-          { v.x = g     < a.nWordsAlloc ? a.packed[g]     : 0;
-            v.y = g + 1 < a.nWordsAlloc ? a.packed[g + 1] : 0;
-            v.z = g + 2 < a.nWordsAlloc ? a.packed[g + 2] : 0;
-            v.w = 0;
-          }
-        *reinterpret_cast<uint4 *> (&sWords[4 * tid]) = v;
-        if (tid < 8)
-          { U64 gh = w0 + MG_TILE_WORDS + tid;
-            sWords[MG_TILE_WORDS + tid] = gh < a.nWordsAlloc ? a.packed[gh] : 0;
-          }
-      }
-      __syncthreads ();
+  while (tile < tileEnd)
+    { *reinterpret_cast<uint4 *> (&sWords[4 * tid]) = curV;
+      if (tid < 8) sWords[MG_TILE_WORDS + tid] = curHalo;
 
-      /* ---- this lane's 64 starts: which are inside a read ---- */
-      const U64 p0 = tile * (U64) MG_TILE_BASES + (U64) tid * MG_POS_PER_THREAD;
+      const U64 tile0 = tile * (U64) MG_TILE_BASES;
+      const U64 p0 = tile0 + (U64) tid * MG_POS_PER_THREAD;
+      /* ---- which of the lane's 64 starts lie inside a read ---- */
       U64 valid = 0;
-      U32 rFirst = 0;
-      if (p0 < a.totalBases)
-        { rFirst = mgReadOf (a.readOff, a.tileFirstRead[tile], a.tileFirstRead[tile + 1], p0);
+      U32 rFirst = ti.firstRead;
+      const bool oneRead = ti.end >= tile0 + MG_TILE_BASES + (U64) k - 1;   /* tile + halo inside one read */
+      if (oneRead) valid = ~0ull;
+      else if (p0 < a.totalBases)
+        { rFirst = mgReadOf (a.readOff, ti.firstRead, nextFirstRead, p0);
           valid = mgValidMask (a, p0, rFirst);
         }
+      sRFirst[tid] = rFirst;
+      __syncthreads ();                                                          /* (1) tile staged */
 
-      /* ---- roll both strands over the lane's 64 starts ---- */
-      U32 w[6];
-      { uint4 q = *reinterpret_cast<const uint4 *> (&sWords[4 * tid]);
-        uint2 h = *reinterpret_cast<const uint2 *> (&sWords[4 * tid + 4]);
-        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; w[4] = h.x; w[5] = h.y;
-      }
-      /* incoming-base stream: in[j] holds bases k+16j .. k+16j+15 of the lane's window */
-      U32 in[4];
-      { const bool up = (2 * k) >= 32;
-        const int r = (2 * k) & 31;
-        U32 s0 = up ? w[1] : w[0], s1 = up ? w[2] : w[1], s2 = up ? w[3] : w[2],
-            s3 = up ? w[4] : w[3], s4 = up ? w[5] : w[4];
-        in[0] = __funnelshift_l (s1, s0, r); in[1] = __funnelshift_l (s2, s1, r);
-        in[2] = __funnelshift_l (s3, s2, r); in[3] = __funnelshift_l (s4, s3, r);
-      }
-      U64 F = (((U64) w[0] << 32) | w[1]) >> sh1;
-      U64 R = mgRevComp (F, sh1);
-      const int top = 2 * (k - 1);
-      /* 4 chunks of 16 starts; the incoming-base words rotate through in[0] so that the chunk
-         loop stays rolled (a fully unrolled 64-step body costs 256 VGPRs and all occupancy) */
-      U32 accH = 0, accF = 0, hitLo = 0, fwdLo = 0;
-#pragma unroll 1
-      for (int chunk = 0 ; chunk < 4 ; ++chunk)
-        { const U32 cur = in[0];
-          in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
-#pragma unroll
-          for (int tt = 0 ; tt < 16 ; ++tt)
-            { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
-              bool fwd = hF < hR;
-              U64 h = fwd ? hF : hR;
-              bool hit;
-              if (POW2) hit = (h & (U64) (p.d - 1)) == 0;
-              else      hit = mgDivisible (h, p);
-              accH = (accH << 1) | (hit ? 1u : 0u);
-              accF = (accF << 1) | (fwd ? 1u : 0u);
-              U32 b = (cur >> (30 - 2 * tt)) & 3;         /* base k + 16*chunk + tt enters */
-              F = ((F << 2) & p.mask) | b;
-              R = (R >> 2) | ((U64) (3 - b) << top);
-            }
-          if (chunk == 1) { hitLo = accH; fwdLo = accF; accH = accF = 0; }
+      /* prefetch the next tile (registers; consumed at the top of the next iteration) */
+      const U64 nextTile = tile + 1;
+      uint4 nextV = make_uint4 (0, 0, 0, 0); U32 nextHalo = 0; U32 nextNextFirst = 0;
+      if (nextTile < tileEnd)
+        { nextV = mgLoadTileWords (a, nextTile, tid);
+          if (tid < 8) { U64 gh = nextTile * MG_TILE_WORDS + MG_TILE_WORDS + tid; nextHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
+          tiNext = a.tileInfo[nextTile];
+          nextNextFirst = a.tileInfo[nextTile + 1].firstRead;
         }
-      /* accumulators hold start t at bit 31-(t&31): reverse to natural order */
-      U64 hits = ((U64) __brev (accH) << 32) | __brev (hitLo);
-      U64 fwds = ((U64) __brev (accF) << 32) | __brev (fwdLo);
-      hits &= valid;
 
-      /* ---- ordered compaction: lane counts -> workgroup scan -> look-back across tiles ---- */
-      U32 cnt = (U32) __popcll (hits);
+      /* ---- Phase A ---- */
+      U32 w[6];
+      { uint2 h = *reinterpret_cast<const uint2 *> (&sWords[4 * tid + 4]);
+        w[0] = curV.x; w[1] = curV.y; w[2] = curV.z; w[3] = curV.w; w[4] = h.x; w[5] = h.y;
+      }
+      U64 cand;
+      if (MODE == MG_MODE_FAST)
+        { /* forward: last 16 bases of the k-mer at start t = bases [t+k-16, t+k): stream shifted by
+             k-16 bases; reverse: first 16 bases [t, t+16), reverse-complemented word by word */
+          U32 fw[6], rw[6];
+          const int c2 = 2 * (k - 16);                         /* 2..30 */
+#pragma unroll
+          for (int j = 0 ; j < 5 ; ++j) fw[j] = __funnelshift_l (w[j + 1], w[j], c2);
+          fw[5] = w[5] << c2;
+#pragma unroll
+          for (int j = 0 ; j < 6 ; ++j) rw[j] = mgRevComp16 (w[j]);
+          const U32 fS = a.fS, thresh = a.thresh;
+          U32 acc = 0, candLo = 0;
+#pragma unroll 1
+          for (int chunk = 0 ; chunk < 4 ; ++chunk)
+            { const U32 f0 = fw[0], f1w = fw[1], r0 = rw[0], r1 = rw[1];
+              fw[0] = fw[1]; fw[1] = fw[2]; fw[2] = fw[3]; fw[3] = fw[4]; fw[4] = fw[5];
+              rw[0] = rw[1]; rw[1] = rw[2]; rw[2] = rw[3]; rw[3] = rw[4]; rw[4] = rw[5];
+#pragma unroll
+              for (int tt = 0 ; tt < 16 ; ++tt)
+                { U32 xf = __funnelshift_l (f1w, f0, 2 * tt);     /* window, first base on top */
+                  U32 xr = __funnelshift_r (r0, r1, 2 * tt);      /* reverse-complemented window */
+                  bool c = (xf * fS < thresh) | (xr * fS < thresh);
+                  acc = (acc << 1) | (c ? 1u : 0u);
+                }
+              if (chunk == 1) { candLo = acc; acc = 0; }
+            }
+          cand = ((U64) __brev (acc) << 32) | __brev (candLo);
+        }
+      else
+        { /* incoming-base stream: in[j] holds bases k+16j .. k+16j+15 of the lane's window */
+          U32 in[4];
+          { const bool up = (2 * k) >= 32;
+            const int r = (2 * k) & 31;
+            U32 s0 = up ? w[1] : w[0], s1 = up ? w[2] : w[1], s2 = up ? w[3] : w[2],
+                s3 = up ? w[4] : w[3], s4 = up ? w[5] : w[4];
+            in[0] = __funnelshift_l (s1, s0, r); in[1] = __funnelshift_l (s2, s1, r);
+            in[2] = __funnelshift_l (s3, s2, r); in[3] = __funnelshift_l (s4, s3, r);
+          }
+          U64 F = (((U64) w[0] << 32) | w[1]) >> sh1;
+          U64 R = mgRevComp (F, sh1);
+          const int top = 2 * (k - 1);
+          U32 acc = 0, hitLo = 0;
+#pragma unroll 1
+          for (int chunk = 0 ; chunk < 4 ; ++chunk)
+            { const U32 cur = in[0];
+              in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
+#pragma unroll
+              for (int tt = 0 ; tt < 16 ; ++tt)
+                { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
+                  U64 h = hF < hR ? hF : hR;
+                  bool hit;
+                  if (MODE == MG_MODE_POW2) hit = (h & dMask) == 0;
+                  else                      hit = mgDivisible (h, p);
+                  acc = (acc << 1) | (hit ? 1u : 0u);
+                  U32 b = (cur >> (30 - 2 * tt)) & 3;         /* base k + 16*chunk + tt enters */
+                  F = ((F << 2) & p.mask) | b;
+                  R = (R >> 2) | ((U64) (3 - b) << top);
+                }
+              if (chunk == 1) { hitLo = acc; acc = 0; }
+            }
+          cand = ((U64) __brev (acc) << 32) | __brev (hitLo);
+        }
+      cand &= valid;
+
+      /* ---- Phase B: order the candidates ---- */
+      const U32 cnt = (U32) __popcll (cand);
       U32 incl = cnt;
 #pragma unroll
       for (int off = 1 ; off < 64 ; off <<= 1)
         { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
-      if (lane == 63) sWaveTot[wave] = incl;
-      __syncthreads ();
-      U32 waveBase = 0, total = 0;
+      if (lane == 63) sWaveTotA[wave] = incl;
+      __syncthreads ();                                                          /* (2) */
+      U32 waveBase = 0, nc = 0;
 #pragma unroll
       for (int i = 0 ; i < MG_SCAN_THREADS / 64 ; ++i)
-        { U32 v = sWaveTot[i]; if (i < wave) waveBase += v; total += v; }
-      if (wave == 0)
-        { U64 b = mgLookback (a.desc, tile, total);
-          if (lane == 0)
-            { sBase = b;
-              if (tile == a.nTiles - 1) a.dCount[0] = b + total;
-              if (b + total > a.capacity) a.dCount[1] = 1;
-            }
-        }
-      __syncthreads ();
-      U64 o = sBase + waveBase + (incl - cnt);
+        { U32 v = sWaveTotA[i]; if (i < wave) waveBase += v; nc += v; }
+      const U32 myFirst = waveBase + incl - cnt;             /* ordinal of this lane's first candidate */
+      const U32 nRounds = (nc + MG_CAND_CAP - 1) / MG_CAND_CAP;
 
-      /* ---- the (few) hit lanes re-extract their k-mers from LDS and write them out ---- */
-      U32 r = rFirst;
-      while (hits)
-        { int t = __ffsll ((long long) hits) - 1;
-          hits &= hits - 1;
-          int wi = 4 * tid + (t >> 4), s = 2 * (t & 15);
-          U32 x0 = sWords[wi], x1 = sWords[wi + 1], x2 = sWords[wi + 2];
-          U64 hi = ((U64) x0 << 32) | x1;
-          if (s) hi = (hi << s) | (U64) (x2 >> (32 - s));
-          U64 Fk = hi >> sh1;
-          bool fwd = (fwds >> t) & 1;
-          U64 kmer = fwd ? Fk : mgRevComp (Fk, sh1);
-          U64 pos = p0 + (U64) t;
-          while (a.readOff[r + 1] <= pos) ++r;
-          if (o < a.capacity)
-            { a.outKmer[o] = kmer;
-              a.outPosF[o] = (U32) (pos - a.readOff[r]) | (fwd ? MG_FWD_BIT : 0u);
-              if (a.outRead) a.outRead[o] = r;
+      /* ---- Phase C: dense exact evaluation, MG_CAND_CAP candidates per round ---- */
+      for (U32 rd = 0 ; rd < nRounds ; ++rd)
+        { const U32 lo = rd * MG_CAND_CAP, hi = lo + MG_CAND_CAP;
+          if (rd) __syncthreads ();                          /* previous round done with sCand */
+          { U64 c = cand; U32 o = myFirst;
+            while (c && o < hi)
+              { int t = __ffsll ((long long) c) - 1;
+                c &= c - 1;
+                if (o >= lo) sCand[o - lo] = (unsigned short) (tid * MG_POS_PER_THREAD + t);
+                ++o;
+              }
+          }
+          __syncthreads ();                                                      /* (3) */
+          const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
+          for (U32 it = 0 ; it * MG_SCAN_THREADS < nHere ; ++it)
+            { U32 i = it * MG_SCAN_THREADS + tid;
+              bool surv = false, fwd = false;
+              if (i < nHere)
+                { U64 F = mgKmerAt (sWords, sCand[i], sh1), R = mgRevComp (F, sh1);
+                  U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
+                  fwd = hF < hR;
+                  U64 h = fwd ? hF : hR;
+                  if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
+                  else                     surv = (h & dMask) == 0;
+                }
+              U64 bs = __ballot (surv), bf = __ballot (fwd);
+              if (lane == 0)
+                { U32 slot = (lo / MG_SCAN_THREADS + it) * 4 + wave;
+                  sSurvB[slot] = bs; sFwdB[slot] = bf;
+                }
             }
-          ++o;
         }
-      __syncthreads ();     /* sWords / sTile are rewritten by the next tile */
+      __syncthreads ();                                                          /* (4) ballots visible */
+      /* exclusive scan of the per-(iteration,wave) survivor counts: at most 256 entries */
+      const U32 nSlots = ((nc + MG_SCAN_THREADS - 1) / MG_SCAN_THREADS) * 4;
+      const U32 c2 = ((U32) tid < nSlots) ? (U32) __popcll (sSurvB[tid]) : 0;
+      U32 incl2 = c2;
+#pragma unroll
+      for (int off = 1 ; off < 64 ; off <<= 1)
+        { U32 v = __shfl_up (incl2, off); if (lane >= off) incl2 += v; }
+      if (lane == 63) sWaveTotB[wave] = incl2;
+      __syncthreads ();                                                          /* (5) */
+      U32 wb2 = 0, total = 0;
+#pragma unroll
+      for (int i = 0 ; i < MG_SCAN_THREADS / 64 ; ++i)
+        { U32 v = sWaveTotB[i]; if (i < wave) wb2 += v; total += v; }
+      sOff[tid] = wb2 + incl2 - c2;
+      __syncthreads ();                                                          /* (6) */
+
+      /* ---- Phase D: survivors append themselves, in order, to this block's segment ---- */
+      const U64 base = found;
+      found += total;
+      for (U32 rd = 0 ; rd < nRounds ; ++rd)
+        { const U32 lo = rd * MG_CAND_CAP, hi = lo + MG_CAND_CAP;
+          if (nRounds > 1)
+            { __syncthreads ();
+              U64 c = cand; U32 o = myFirst;
+              while (c && o < hi)
+                { int t = __ffsll ((long long) c) - 1;
+                  c &= c - 1;
+                  if (o >= lo) sCand[o - lo] = (unsigned short) (tid * MG_POS_PER_THREAD + t);
+                  ++o;
+                }
+              __syncthreads ();
+            }
+          const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
+          for (U32 it = 0 ; it * MG_SCAN_THREADS < nHere ; ++it)
+            { U32 i = it * MG_SCAN_THREADS + tid;
+              U32 slot = (lo / MG_SCAN_THREADS + it) * 4 + wave;
+              U64 bs = sSurvB[slot];
+              if (i < nHere && ((bs >> lane) & 1))
+                { U64 o = base + sOff[slot] + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
+                  U32 q = sCand[i];
+                  U64 F = mgKmerAt (sWords, q, sh1);
+                  bool fwd = (sFwdB[slot] >> lane) & 1;
+                  U64 pos = tile0 + q;
+                  U32 r = sRFirst[q >> 6];
+                  U64 rs = ti.start;
+                  if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
+                  if (o < a.segCap)
+                    { a.segKmer[segBase + o] = fwd ? F : mgRevComp (F, sh1);
+                      a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
+                      if (a.segRead) a.segRead[segBase + o] = r;
+                    }
+                }
+            }
+        }
+      __syncthreads ();                                                          /* (7) LDS free for the next tile */
+      tile = nextTile;
+      curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
+    }
+  if (tid == 0) a.blockCount[blockIdx.x] = found;
+}
+
+/* exclusive scan of the per-block counts (one workgroup): segStart[b], and
+ * dCount = { total, 1 if some segment overflowed or total > capacity, largest block count } */
+__global__ __launch_bounds__ (1024)
+void mgSegScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 segCap, U64 capacity,
+                      U64 *__restrict__ segStart, U64 *__restrict__ dCount)
+{
+  __shared__ U64 sPart[1024];
+  const int tid = threadIdx.x;
+  const U32 per = (nBlocks + 1023) / 1024;
+  U64 sum = 0, mx = 0;
+  for (U32 i = 0 ; i < per ; ++i)
+    { U32 b = tid * per + i; if (b < nBlocks) { U64 c = blockCount[b]; sum += c; if (c > mx) mx = c; } }
+  sPart[tid] = sum;
+  __syncthreads ();
+  for (int off = 1 ; off < 1024 ; off <<= 1)
+    { U64 v = tid >= off ? sPart[tid - off] : 0;
+      __syncthreads ();
+      sPart[tid] += v;
+      __syncthreads ();
+    }
+  U64 run = sPart[tid] - sum;
+  for (U32 i = 0 ; i < per ; ++i)
+    { U32 b = tid * per + i; if (b < nBlocks) { segStart[b] = run; run += blockCount[b]; } }
+  /* max over threads */
+  __syncthreads ();
+  U64 total = sPart[1023];
+  __syncthreads ();
+  sPart[tid] = mx;
+  __syncthreads ();
+  for (int off = 512 ; off ; off >>= 1)
+    { if (tid < off && sPart[tid + off] > sPart[tid]) sPart[tid] = sPart[tid + off];
+      __syncthreads ();
+    }
+  if (tid == 0)
+    { dCount[0] = total;
+      dCount[1] = (sPart[0] > segCap || total > capacity) ? 1 : 0;
+      dCount[2] = sPart[0];
+      U64 need = sPart[0] * (U64) nBlocks;          /* capacity whose per-block share covers the fullest block */
+      dCount[3] = need > total ? need : total;
+    }
+}
+
+/* segments -> dense (read,pos)-ordered arrays; several workgroups per segment */
+#define MG_COMPACT_SPLIT 4
+__global__ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict__ segPosF,
+                                    const U32 *__restrict__ segRead, U64 segCap,
+                                    const U64 *__restrict__ blockCount, const U64 *__restrict__ segStart,
+                                    U64 *__restrict__ outKmer, U32 *__restrict__ outPosF, U32 *__restrict__ outRead,
+                                    U64 capacity, const U64 *__restrict__ dCount)
+{
+  if (dCount[1]) return;                       /* overflow: the caller retries with the reported sizes */
+  const U32 b = blockIdx.x / MG_COMPACT_SPLIT, part = blockIdx.x % MG_COMPACT_SPLIT;
+  const U64 n = blockCount[b], dst = segStart[b], src = (U64) b * segCap;
+  for (U64 i = (U64) part * blockDim.x + threadIdx.x ; i < n ; i += (U64) MG_COMPACT_SPLIT * blockDim.x)
+    { outKmer[dst + i] = segKmer[src + i];
+      outPosF[dst + i] = segPosF[src + i];
+      if (outRead) outRead[dst + i] = segRead[src + i];
     }
 }
 
@@ -276,13 +508,35 @@ void mgScanKernel (const MgScanArgs a)
 
 static inline U64 mgNumTiles (U64 totalBases) { return (totalBases + MG_TILE_BASES - 1) / MG_TILE_BASES; }
 
-/* work buffer layout: [0,256) ticket + pad | desc[nTiles] | tileFirstRead[nTiles+1] */
-size_t mgScanWorkBytes (U64 totalBases, U32 nReads)
+/* Scan geometry: G workgroups, each owning tilesPerBlock consecutive tiles and one output segment. */
+struct MgScanGeom { U64 nTiles, tilesPerBlock; U32 nBlocks; U64 segCap; };
+#define MG_SCAN_MAX_BLOCKS 2048
+
+static MgScanGeom mgScanGeometry (U64 totalBases, U64 capacity)
+{
+  MgScanGeom g;
+  g.nTiles = mgNumTiles (totalBases);
+  U64 want = g.nTiles < MG_SCAN_MAX_BLOCKS ? g.nTiles : MG_SCAN_MAX_BLOCKS;
+  if (!want) want = 1;
+  g.tilesPerBlock = (g.nTiles + want - 1) / want; if (!g.tilesPerBlock) g.tilesPerBlock = 1;
+  g.nBlocks = (U32) ((g.nTiles + g.tilesPerBlock - 1) / g.tilesPerBlock); if (!g.nBlocks) g.nBlocks = 1;
+  /* a block's fair share of the caller's capacity plus slack, never more than its k-mer starts */
+  U64 share = capacity / g.nBlocks;
+  U64 seg = share + share / 8 + 64;
+  U64 most = g.tilesPerBlock * (U64) MG_TILE_BASES;
+  g.segCap = seg < most ? seg : most;
+  return g;
+}
+
+/* work buffer layout (all 256-byte aligned):
+ *   blockCount[G] | segStart[G] | tileInfo[nTiles+1] | segKmer[G*segCap] | segPosF[..] | segRead[..] */
+static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
+size_t mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity)
 {
   (void) nReads;
-  U64 nTiles = mgNumTiles (totalBases);
-  size_t b = 256 + (size_t) nTiles * 8 + ((size_t) nTiles + 2) * 4;
-  return (b + 255) & ~(size_t) 255;
+  MgScanGeom g = mgScanGeometry (totalBases, capacity);
+  size_t segN = (size_t) g.nBlocks * g.segCap;
+  return mgAl (g.nBlocks * 8) * 2 + mgAl ((g.nTiles + 2) * sizeof (MgTileInfo)) + mgAl (segN * 8) + 2 * mgAl (segN * 4) + 256;
 }
 
 MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
@@ -290,28 +544,46 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
                        U64 *dCount, void *dWork, hipStream_t st)
 {
-  MG_HIP (hipMemsetAsync (dCount, 0, 2 * sizeof (U64), st));
-  U64 nTiles = mgNumTiles (totalBases);
-  if (!nTiles || !nReads) return MG_OK;
+  MG_HIP (hipMemsetAsync (dCount, 0, 4 * sizeof (U64), st));
+  MgScanGeom g = mgScanGeometry (totalBases, capacity);
+  if (!g.nTiles || !nReads) return MG_OK;
   char *wb = (char *) dWork;
-  U32 *ticket = (U32 *) wb;
-  U64 *desc = (U64 *) (wb + 256);
-  U32 *tfr = (U32 *) (wb + 256 + nTiles * 8);
-  MG_HIP (hipMemsetAsync (wb, 0, 256 + nTiles * 8, st));
-  MG_LAUNCH (MG_K_TILE_FIRST_READ, st, mgTileFirstReadKernel, dim3 ((unsigned) ((nTiles + 1 + 255) / 256)), dim3 (256), 0, st,
-                      dReadOffsets, nReads, nTiles, tfr);
+  size_t segN = (size_t) g.nBlocks * g.segCap;
+  U64 *blockCount = (U64 *) wb;                  wb += mgAl (g.nBlocks * 8);
+  U64 *segStart = (U64 *) wb;                    wb += mgAl (g.nBlocks * 8);
+  MgTileInfo *info = (MgTileInfo *) wb;          wb += mgAl ((g.nTiles + 2) * sizeof (MgTileInfo));
+  U64 *segKmer = (U64 *) wb;                     wb += mgAl (segN * 8);
+  U32 *segPosF = (U32 *) wb;                     wb += mgAl (segN * 4);
+  U32 *segRead = (U32 *) wb;
+  MG_LAUNCH (MG_K_TILE_FIRST_READ, st, mgTileInfoKernel, dim3 ((unsigned) ((g.nTiles + 1 + 255) / 256)), dim3 (256), 0, st,
+             dReadOffsets, nReads, g.nTiles, totalBases, info);
   MG_HIP (hipGetLastError ());
 
   MgScanArgs a;
   a.p = p; a.packed = dPacked; a.nWordsAlloc = (U64) mgPackedWords (totalBases); a.totalBases = totalBases;
-  a.readOff = dReadOffsets; a.nReads = nReads; a.tileFirstRead = tfr; a.nTiles = nTiles;
-  a.desc = desc; a.ticket = ticket;
-  a.outKmer = dKmer; a.outPosF = dPosF; a.outRead = dReadId; a.capacity = capacity; a.dCount = dCount;
-  unsigned grid = (unsigned) (nTiles < 2048 ? nTiles : 2048);
-  if (p.dOddInv == 1 && p.dOddLim == ~0ull)
-    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<true>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+  a.readOff = dReadOffsets; a.nReads = nReads; a.tileInfo = info; a.nTiles = g.nTiles;
+  a.tilesPerBlock = g.tilesPerBlock; a.segCap = g.segCap;
+  a.segKmer = segKmer; a.segPosF = segPosF; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
+  a.fS = 0; a.thresh = 0;
+  const unsigned grid = g.nBlocks;
+  const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
+  const int B = p.shift1 + p.dShift;
+  static int forceGeneric = -1;
+  if (forceGeneric < 0) { const char *e = getenv ("MODGPU_SCAN_GENERIC"); forceGeneric = (e && *e == '1') ? 1 : 0; }
+  if (pow2 && p.dShift >= 2 && B <= 32 && p.k >= 17 && !forceGeneric)
+    { a.fS = (U32) (p.factor1 << (32 - B));
+      a.thresh = (U32) 1 << (32 - p.dShift);
+      MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_FAST>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+    }
+  else if (pow2)
+    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_POW2>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
   else
-    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<false>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_ANY>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+  MG_HIP (hipGetLastError ());
+  MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
+  MG_HIP (hipGetLastError ());
+  MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (g.nBlocks * MG_COMPACT_SPLIT), dim3 (256), 0, st,
+             segKmer, segPosF, a.segRead, g.segCap, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }

@@ -106,36 +106,59 @@ def test_palindromes_and_homopolymers():
 
 
 def test_device_api_capacity_and_count():
-    """seqhashScanBatchDevice: count is the true total even when capacity is too small"""
+    """seqhashScanBatchDevice: dCount = {true total, overflow flag, fullest segment, retry capacity};
+    a retry with dCount[3] always succeeds"""
     L = mg.lib()
     k, w = 21, 16
     sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
     rng = np.random.default_rng(3)
+    # deliberately skewed: a poly-A stretch whose every k-mer is the same modimizer-or-not, then random
     reads = [rng.integers(0, 4, L_).astype(np.uint8) for L_ in (40000, 123, 70000, 9)]
     bases, offs = util.concat_reads(reads)
     ek, ep, ef, _ = util.oracle_scan_batch(oh, bases, offs)
     total = len(bases)
     d_packed = mg.DeviceBuffer.from_numpy(mg.pack_host(bases))
     d_off = mg.DeviceBuffer.from_numpy(offs.astype(np.uint64))
-    d_work = mg.DeviceBuffer(L.mgScanWorkBytes(total, len(reads)))
-    d_cnt = mg.DeviceBuffer(16)
-    for cap in (len(ek) + 10, len(ek), 100, 0):
+    d_cnt = mg.DeviceBuffer(32)
+
+    def run(cap, with_rid=True):
+        d_work = mg.DeviceBuffer(L.mgScanWorkBytes(total, len(reads), cap))
         d_k = mg.DeviceBuffer(max(cap, 1) * 8); d_p = mg.DeviceBuffer(max(cap, 1) * 4); d_r = mg.DeviceBuffer(max(cap, 1) * 4)
-        mg.check(L.seqhashScanBatchDevice(sh, d_packed.ptr, total, d_off.ptr, len(reads), d_k.ptr, d_p.ptr, d_r.ptr,
-                                          cap, d_cnt.ptr, d_work.ptr, None))
-        cnt = d_cnt.to_numpy(np.uint64, 2)
-        assert cnt[0] == len(ek) and cnt[1] == (1 if cap < len(ek) else 0)
-        m = min(cap, len(ek))
-        assert np.array_equal(d_k.to_numpy(np.uint64, m), ek[:m])
+        mg.check(L.seqhashScanBatchDevice(sh, d_packed.ptr, total, d_off.ptr, len(reads), d_k.ptr, d_p.ptr,
+                                          d_r.ptr if with_rid else None, cap, d_cnt.ptr, d_work.ptr, None))
+        return d_cnt.to_numpy(np.uint64, 4), d_k, d_p, d_r
+    for cap in (2 * len(ek), len(ek) + len(ek) // 4, len(ek), 100, 0):
+        cnt, d_k, d_p, d_r = run(cap)
+        assert cnt[0] == len(ek)
+        if cap < len(ek):
+            assert cnt[1] == 1
+        if cnt[1]:
+            assert cnt[3] >= len(ek)
+            cnt, d_k, d_p, d_r = run(int(cnt[3]))
+            assert cnt[0] == len(ek) and cnt[1] == 0
+        m = len(ek)
+        assert np.array_equal(d_k.to_numpy(np.uint64, m), ek)
         pf = d_p.to_numpy(np.uint32, m)
-        assert np.array_equal(pf & mg.MG_POS_MASK, ep[:m].astype(np.uint32)) and np.array_equal((pf >> 31).astype(np.uint8), ef[:m])
+        assert np.array_equal(pf & mg.MG_POS_MASK, ep.astype(np.uint32)) and np.array_equal((pf >> 31).astype(np.uint8), ef)
         rid = d_r.to_numpy(np.uint32, m)
         assert (np.diff(rid.astype(np.int64)) >= 0).all()
     # dReadId may be NULL
-    d_k = mg.DeviceBuffer(len(ek) * 8); d_p = mg.DeviceBuffer(len(ek) * 4)
-    mg.check(L.seqhashScanBatchDevice(sh, d_packed.ptr, total, d_off.ptr, len(reads), d_k.ptr, d_p.ptr, None,
-                                      len(ek), d_cnt.ptr, d_work.ptr, None))
-    assert np.array_equal(d_k.to_numpy(np.uint64, len(ek)), ek)
+    cnt, d_k, d_p, _ = run(2 * len(ek), with_rid=False)
+    assert cnt[1] == 0 and np.array_equal(d_k.to_numpy(np.uint64, len(ek)), ek)
+
+
+def test_skewed_density_retries():
+    """all modimizers concentrated in one region (one workgroup's segment): the host entry points retry"""
+    k, w = 21, 64
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(11)
+    # find a 21-mer that IS a modimizer and tile it: every k-mer start hits
+    b = rng.integers(0, 4, 200000).astype(np.uint8)
+    km, pos, _ = oh.scan(b)
+    unit = b[pos[0]:pos[0] + k]
+    rep = np.tile(unit, 3000)                      # 63 kb where a hit recurs every k bases (period k)
+    reads = [rng.integers(0, 4, 3_000_000).astype(np.uint8), rep, rng.integers(0, 4, 1_000_000).astype(np.uint8)]
+    assert_batch_equal(sh, oh, reads)
 
 
 def test_pack_unpack_and_synth_on_device():
@@ -185,12 +208,12 @@ def test_full_size_properties():
         d_g.free()
         cap = int(total / 64 * 1.1)
         d_k = mg.DeviceBuffer(cap * 8); d_p = mg.DeviceBuffer(cap * 4); d_id = mg.DeviceBuffer(cap * 4)
-        d_cnt = mg.DeviceBuffer(16); d_work = mg.DeviceBuffer(L.mgScanWorkBytes(total, n_reads))
+        d_cnt = mg.DeviceBuffer(32); d_work = mg.DeviceBuffer(L.mgScanWorkBytes(total, n_reads, cap))
 
         def run(off_arr, nr, tot, packed_ptr):
             d_o = mg.DeviceBuffer.from_numpy(off_arr)
             mg.check(L.seqhashScanBatchDevice(sh, packed_ptr, tot, d_o.ptr, nr, d_k.ptr, d_p.ptr, d_id.ptr, cap, d_cnt.ptr, d_work.ptr, None))
-            c = d_cnt.to_numpy(np.uint64, 2)
+            c = d_cnt.to_numpy(np.uint64, 4)
             assert c[1] == 0
             n = int(c[0])
             km = d_k.to_numpy(np.uint64, n); pf = d_p.to_numpy(np.uint32, n); rid = d_id.to_numpy(np.uint32, n)
