@@ -59,10 +59,12 @@ extern "C" MgStatus mgStreamSynchronize (void *stream)
 /* per-kernel event timing (bench.py's roofline object)                                       */
 
 static const char *gKernelNames[MG_K_COUNT] = {
-  "mgPackKernel", "mgUnpackKernel", "mgTileFirstReadKernel", "mgScanKernel", "mgTableInsertKernel",
-  "mgTableAssignKernel", "mgTableGatherKernel", "mgTableFindKernel", "mgTableLoadKernel",
+  "mgPackKernel", "mgUnpackKernel", "mgTileInfoKernel", "mgScanKernel", "mgTableInsertKernel",
+  "mgRankAssignKernel", "mgDirectFlagKernel", "mgTableFindKernel", "mgTableLoadKernel",
   "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
-  "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel" };
+  "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel",
+  "mgPartition(hist+scan+scatter)", "mgRankCountKernel", "mgRankScanKernel", "mgBucketDedupKernel",
+  "mgBucketMergeKernel" };
 #define MG_PROF_POOL 8192
 struct MgProfRec { int id; hipEvent_t a, b; };
 static struct {
@@ -292,7 +294,7 @@ static void mgDevFree (MgDev *d)
 {
   if (!d) return;
   if (d->built)
-    { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.slotOfIndex);
+    { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
       (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters);
     }
   d->arena.release ();
@@ -306,16 +308,19 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
     { mgSetError ("device modset supports table bits 20..32 (got %d)", ms->tableBits); return MG_ERR_ARG; }
   memset (&t, 0, sizeof (t));
   t.nSlots = (U64) 1 << (ms->tableBits - 1);          /* >= 2 * size: load factor <= 0.5 */
-  t.slotMask = t.nSlots - 1;
+  t.R = 2048;                                          /* 32 KiB of LDS per bucket */
+  t.log2NB = ms->tableBits - 1 - 11;
+  while (t.log2NB > 18) { t.R <<= 1; --t.log2NB; }     /* at most 2^18 buckets (two 9-bit partition passes) */
   t.size = ms->size;
   U64 cap = (ms->tableSize >> 2);                      /* device arrays cover the largest legal size */
   MG_HIP (hipMalloc ((void **) &t.slots, t.nSlots * sizeof (MgSlot)));
   MG_HIP (hipMalloc ((void **) &t.value, cap * sizeof (U64)));
-  MG_HIP (hipMalloc ((void **) &t.slotOfIndex, cap * sizeof (U32)));
+  MG_HIP (hipMalloc ((void **) &t.occ, ((size_t) 1 << t.log2NB) * sizeof (U32)));
   MG_HIP (hipMalloc ((void **) &t.baseDepth, cap * sizeof (U16)));
   MG_HIP (hipMalloc ((void **) &t.counters, 64));
   d->built = true;
   MG_HIP (hipMemsetAsync (t.slots, 0, t.nSlots * sizeof (MgSlot), st));
+  MG_HIP (hipMemsetAsync (t.occ, 0, ((size_t) 1 << t.log2NB) * sizeof (U32), st));
   MG_HIP (hipMemsetAsync (t.baseDepth, 0, cap * sizeof (U16), st));
   MG_HIP (hipMemsetAsync (t.counters, 0, 64, st));
   t.max = 0; t.syncedMax = 0;
@@ -389,6 +394,7 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
       mgProfBegin (MG_K_MEMSET, st);
       MG_HIP (hipMemsetAsync (t.slots, 0, t.nSlots * sizeof (MgSlot), st));
       mgProfEnd (MG_K_MEMSET, st);
+      MG_HIP (hipMemsetAsync (t.occ, 0, ((size_t) 1 << t.log2NB) * sizeof (U32), st));
       if (t.syncedMax) MG_HIP (hipMemsetAsync (t.baseDepth, 0, ((size_t) t.syncedMax + 1) * sizeof (U16), st));
       t.max = t.syncedMax = 0;
       d->hostIndexMax = 0;
@@ -427,14 +433,12 @@ extern "C" int mgHookHasDevice (Modset *ms) { return mgDevLookup (ms) != 0; }
 #define MG_ADD_CHUNK ((U64) 1 << 30)
 
 static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            U32 *dSlotId, void *dDesc, hipStream_t st)
+                            void *scratch, hipStream_t st)
 {
   MgTable &t = d->t;
   MgStatus s;
   MG_HIP (hipMemsetAsync (t.counters, 0, 16, st));
-  if ((s = mgTableInsert (&t, dKmer, n, dSlotId, withDepth, st))) return s;
-  if ((s = mgTableAssign (&t, dKmer, n, dSlotId, dDesc, st))) return s;
-  if (dIndexOut && (s = mgTableGather (&t, dSlotId, n, dIndexOut, st))) return s;
+  if ((s = mgTableAdd (&t, dKmer, n, withDepth, scratch, st))) return s;
   U64 c[2];
   MG_HIP (hipMemcpyAsync (c, t.counters, 16, hipMemcpyDeviceToHost, st));
   MG_HIP (hipStreamSynchronize (st));
@@ -446,6 +450,7 @@ static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
     }
   t.max = (U32) newMax;
   ms->max = t.max;
+  if (dIndexOut && (s = mgTableFind (&t, dKmer, n, dIndexOut, st))) return s;
   return MG_OK;
 }
 
@@ -456,7 +461,7 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
 {
   if (!n) return MG_OK;
   U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
-  size_t need = al256 (chunk * 4) + al256 (mgAssignDescBytes (chunk)) + 4096;
+  size_t need = mgTableAddScratchBytes (&d->t, chunk) + 4096;
   MgStatus s = MG_OK;
   if (!arenaLive)
     { if ((s = d->arena.reserve (need))) return s;
@@ -464,11 +469,10 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
     }
   else if (d->arena.bytes - d->arena.used < need)
     { mgSetError ("internal: arena too small for insert temporaries"); return MG_ERR_NOMEM; }
-  U32 *dSlotId = (U32 *) d->arena.take (chunk * 4);
-  void *dDesc = d->arena.take (mgAssignDescBytes (chunk));
+  void *scratch = d->arena.take (mgTableAddScratchBytes (&d->t, chunk));
   for (U64 off = 0 ; off < n && !s ; off += chunk)
     { U64 m = n - off < chunk ? n - off : chunk;
-      s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, dSlotId, dDesc, st);
+      s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, scratch, st);
     }
   return s;
 }
@@ -503,7 +507,7 @@ extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
   if (t.max)
     { /* depth[i] = min (65535, depth[i] + pending)   (modutils.c:26 applied `pending` times) */
       U16 *dDelta; MG_HIP (hipMalloc ((void **) &dDelta, (size_t) t.max * sizeof (U16)));
-      MgStatus s = mgTableExportDepth (&t, dDelta, 1, t.max, st);
+      MgStatus s = mgTableExportDepth (&t, dDelta, st);
       U16 *h = (U16 *) malloc ((size_t) t.max * sizeof (U16));
       hipError_t e = s ? hipSuccess : hipMemcpy (h, dDelta, (size_t) t.max * sizeof (U16), hipMemcpyDeviceToHost);
       (void) hipFree (dDelta);
@@ -547,7 +551,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
   for (int attempt = 0 ; attempt < 3 ; ++attempt)
     { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
       size_t need = al256 (cap * perS) + 4 * 4096 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
-                    + al256 (mgAssignDescBytes (cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK)) + 8 * 256;
+                    + (extraPerSurvivor ? mgTableAddScratchBytes (&d->t, cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK) + 8192 : 0) + 8 * 256;
       MgStatus s = d->arena.reserve (need); if (s) return s;
       d->arena.reset ();
       b->cap = cap;

@@ -33,9 +33,10 @@ MgHashParams mgMakeParams (const Seqhash *sh);
 
 enum MgKernelId {
   MG_K_PACK = 0, MG_K_UNPACK, MG_K_TILE_FIRST_READ, MG_K_SCAN, MG_K_TABLE_INSERT, MG_K_TABLE_ASSIGN,
-  MG_K_TABLE_GATHER, MG_K_TABLE_FIND, MG_K_TABLE_LOAD, MG_K_TABLE_EXPORT, MG_K_TABLE_HIST,
+  MG_K_TABLE_FLAG, MG_K_TABLE_FIND, MG_K_TABLE_LOAD, MG_K_TABLE_EXPORT, MG_K_TABLE_HIST,
   MG_K_INDEX_REPLAY, MG_K_INDEX_FINISH, MG_K_SYNTH_GENOME, MG_K_SYNTH_READS, MG_K_MEMSET,
-  MG_K_SEG_SCAN, MG_K_SEG_COMPACT, MG_K_COUNT
+  MG_K_SEG_SCAN, MG_K_SEG_COMPACT, MG_K_PART, MG_K_RANK_COUNT, MG_K_RANK_SCAN, MG_K_BUCKET_DEDUP,
+  MG_K_BUCKET_MERGE, MG_K_COUNT
 };
 void mgProfBegin (int id, hipStream_t st);
 void mgProfEnd (int id, hipStream_t st);
@@ -111,29 +112,28 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
                        U64 *dCount, void *dWork, hipStream_t st);
 
-/* device modset table */
-struct MgSlot { U64 key; U32 ordIdx; U32 cnt; };   /* 16 bytes; key = kmer+1, 0 = empty */
+/* device modset table: NB = 2^log2NB buckets of R slots; see mg_table.hip */
+struct MgSlot { U64 key; U32 ord; U32 cnt; };      /* 16 bytes; key = kmer+1, 0 = empty */
 struct MgTable {
-  MgSlot *slots; U64 nSlots; U64 slotMask;
-  U64 *value;          /* [size] device mirror of ms->value for device-assigned entries */
-  U32 *slotOfIndex;    /* [size] */
+  MgSlot *slots; U64 nSlots;
+  U32 R; int log2NB;
+  U32 *occ;            /* [NB] non-zero when the bucket may hold entries */
+  U64 *value;          /* [size] device copy of ms->value */
   U16 *baseDepth;      /* [size] host depth at last sync */
   U32 size;            /* capacity in entries (ms->size) */
   U32 max;             /* entries known to the device table */
   U32 syncedMax;       /* entries whose value[] the host already has */
-  U64 *scratch; size_t scratchBytes;     /* arena for per-call temporaries */
-  U64 *counters;       /* device U64[8] */
-  int device;
+  U64 *counters;       /* device U64[8]: 0 = new entries of the last add, 1 = bucket overflow */
 };
-MgStatus mgTableInsert (MgTable *t, const U64 *dKmer, U64 n, U32 *dSlotId, int withDepth, hipStream_t st);
-MgStatus mgTableAssign (MgTable *t, const U64 *dKmer, U64 n, const U32 *dSlotId, void *dDesc, hipStream_t st);
-MgStatus mgTableGather (MgTable *t, const U32 *dSlotId, U64 n, U32 *dIndexOut, hipStream_t st);
+size_t   mgTableAddScratchBytes (const MgTable *t, U64 n);
+bool     mgTableUseBuckets (const MgTable *t, U64 n);
+MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st);
+MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st);
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);
-MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipStream_t st);
+MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st);
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st);
 MgStatus mgTableReplayIndex (MgTable *t, const MgHashParams &p, int tableBits, U32 *dIndex, hipStream_t st);
-size_t   mgAssignDescBytes (U64 n);
 #define MG_COUNT_WORDS 4      /* dCount: {count, overflow flag, fullest block, capacity to retry with} */
 
 MgStatus mgLaunchSynthGenome (U32 *dPacked, U64 nBases, U64 seed, hipStream_t st);

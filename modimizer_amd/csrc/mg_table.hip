@@ -5,25 +5,37 @@
  * order of FIRST OCCURRENCE in the (read,pos)-ordered modimizer stream, and every occurrence bumps
  * a saturating 16-bit depth (modutils.c:26).
  *
- * The device table is not the reference's index[] array: with a power-of-two modulus d every
- * primary slot of the reference table has its low log2(d) bits zero (the hash that picks the slot
- * is the hash that was just tested to be 0 mod d), so that layout is only materialised on request
- * (mgReplayIndexKernel, for .mod files and host-side scalar lookups).  Here slots are 16 bytes
- * {kmer+1, ordIdx, cnt} in an open-addressed, linearly probed array addressed by a remix of the
- * k-mer, zero-initialised (key 0 = empty).
+ * Layout.  The device table is not the reference's index[] array (with a power-of-two modulus d
+ * every primary slot of that table has its low log2(d) bits zero, because the hash that picks the
+ * slot is the hash that was just tested to be 0 mod d; that layout is only materialised on
+ * request by mgReplayIndexKernel).  Here: NB buckets of R slots of 16 bytes {kmer+1, ord, cnt};
+ * a k-mer's bucket is the top bits of a 64-bit remix, its home slot the low bits, and linear
+ * probing wraps INSIDE the bucket, so a bucket is a self-contained little table that fits LDS.
+ * ord: 0 = none, bit 31 set = assigned index, otherwise a transient first-occurrence token.
  *
- * Deterministic first-occurrence indices without a sort: every occurrence o of a not-yet-indexed
- * k-mer posts a token that is larger the smaller o is (atomicMax).  A second, streaming pass asks
- * each occurrence "is the slot's token mine?" - exactly the first occurrences say yes - and an
- * ordered prefix sum over those flags (decoupled look-back, as in the scan) turns them into
- * max+1, max+2, ... in stream order.  Assigned indices have bit 31 clear, tokens have it set, so
- * the two value spaces cannot be confused while the pass is rewriting slots.
+ * Two build paths, same table, same results:
+ *
+ *  direct   (small batches)  global atomics: CAS the key in, post a token that is larger the
+ *           earlier the occurrence (atomicMax: assigned indices have bit 31 set, so they are never
+ *           lowered), atomicAdd the count; then a streaming pass asks every occurrence "is the
+ *           slot's token mine?" - exactly the first occurrences say yes - and an ordered count
+ *           over those flags turns them into max+1, max+2, ...
+ *
+ *  bucketed (large batches)  no global atomics on the data path.  Measured on MI355X: a random
+ *           global atomic costs ~1/17 G/s (three on one slot serialise), a random load ~1/45 G/s,
+ *           streaming ~5 TB/s.  So: (1) radix-partition the batch by bucket (two streaming passes),
+ *           (2) one workgroup per bucket dedups its occurrences in LDS (LDS atomics) and flags the
+ *           first occurrence of every k-mer that is new to the table, (3) an ordered count over the
+ *           flags gives every new k-mer its index and writes value[] in order, (4) one workgroup
+ *           per bucket merges the bucket's unique k-mers into its LDS copy of the table bucket and
+ *           streams it back.
  */
+#include <stdlib.h>
 #include "mg_common.h"
 
-#define MG_TOKEN_BIT 0x80000000u
-__device__ __forceinline__ U32 mgToken (U64 o) { return MG_TOKEN_BIT | (0x7fffffffu - (U32) o); }
-__device__ __forceinline__ bool mgAssigned (U32 v) { return v != 0 && !(v & MG_TOKEN_BIT); }
+#define MG_ASSIGNED 0x80000000u
+__device__ __forceinline__ U32 mgToken (U64 o) { return 0x7fffffffu - (U32) o; }     /* 1..0x7fffffff */
+__device__ __forceinline__ bool mgIsAssigned (U32 v) { return (v & MG_ASSIGNED) != 0; }
 
 __device__ __forceinline__ U64 mgMix (U64 x)
 {
@@ -33,183 +45,256 @@ __device__ __forceinline__ U64 mgMix (U64 x)
   return x;
 }
 
-/* counters[]: 0 = new entries this call, 1 = probe overflow flag */
+/* bucket geometry */
+struct MgGeom { U32 R, rMask; int log2NB; };
+__device__ __forceinline__ U32 mgBucketOf (U64 h, const MgGeom &g) { return g.log2NB ? (U32) (h >> (64 - g.log2NB)) : 0u; }
+__device__ __forceinline__ U32 mgHomeOf (U64 h, const MgGeom &g) { return (U32) h & g.rMask; }
 
-__global__ void mgTableInsertKernel (MgSlot *__restrict__ slots, U64 mask, const U64 *__restrict__ kmer, U64 n,
+/* counters[]: 0 = new entries this call, 1 = bucket overflow flag */
+
+/* ======================================================================================== */
+/* direct path                                                                                */
+
+__global__ void mgTableInsertKernel (MgSlot *__restrict__ slots, MgGeom g, const U64 *__restrict__ kmer, U64 n,
                                      U32 *__restrict__ slotId, int withDepth, U64 *counters)
 {
   U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; o < n ; o += stride)
     { const U64 km = kmer[o], key = km + 1;
-      U64 s = mgMix (km) & mask;
-      U64 probes = 0;
-      bool ok = true;
-      for (;;)
-        { U64 cur = slots[s].key;                 /* plain load: a stale "empty" is repaired by the CAS */
+      const U64 h = mgMix (km);
+      const U64 base = (U64) mgBucketOf (h, g) * g.R;
+      U32 at = mgHomeOf (h, g);
+      bool ok = false;
+      for (U32 probes = 0 ; probes < g.R ; ++probes)
+        { U64 cur = slots[base + at].key;          /* plain load: a stale "empty" is repaired by the CAS */
           if (cur == 0)
-            { cur = atomicCAS ((unsigned long long *) &slots[s].key, 0ull, (unsigned long long) key);
+            { cur = atomicCAS ((unsigned long long *) &slots[base + at].key, 0ull, (unsigned long long) key);
               if (cur == 0) cur = key;
             }
-          if (cur == key) break;
-          s = (s + 1) & mask;
-          if (++probes > mask) { ok = false; break; }
+          if (cur == key) { ok = true; break; }
+          at = (at + 1) & g.rMask;
         }
       if (!ok) { counters[1] = 1; slotId[o] = 0xffffffffu; continue; }
-      U32 v = slots[s].ordIdx;                    /* tokens only grow, so a stale read is only ever too small */
+      const U64 s = base + at;
+      U32 v = slots[s].ord;                        /* tokens only grow: a stale read is only ever too small */
       U32 tok = mgToken (o);
-      if (!mgAssigned (v) && v < tok) atomicMax (&slots[s].ordIdx, tok);
+      if (v < tok) atomicMax (&slots[s].ord, tok); /* an assigned index (bit 31) is never below a token */
       if (withDepth) atomicAdd (&slots[s].cnt, 1u);
       slotId[o] = (U32) s;
     }
 }
 
-#define MG_ASSIGN_PER_THREAD 8
-#define MG_ASSIGN_TILE (256 * MG_ASSIGN_PER_THREAD)
+/* ordered count of flags over contiguous block ranges: pass A counts, pass B assigns */
+#define MG_RANK_PER_THREAD 16
+#define MG_RANK_TILE (256 * MG_RANK_PER_THREAD)
 
 __global__ __launch_bounds__ (256)
-void mgTableAssignKernel (MgSlot *__restrict__ slots, const U64 *__restrict__ kmer, const U32 *__restrict__ slotId,
-                          U64 n, U64 nTiles, U64 *desc, U32 *ticket,
-                          U64 *__restrict__ value, U32 *__restrict__ slotOfIndex, U32 baseMax, U32 size,
-                          U64 *counters)
-{
-  __shared__ U32 sWaveTot[4];
-  __shared__ U64 sBase;
-  __shared__ U32 sTile;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (;;)
-    { if (tid == 0) sTile = atomicAdd (ticket, 1u);
-      __syncthreads ();
-      const U64 tile = sTile;
-      if (tile >= nTiles) break;
-      const U64 o0 = tile * MG_ASSIGN_TILE + (U64) tid * MG_ASSIGN_PER_THREAD;
-      U32 sid[MG_ASSIGN_PER_THREAD];
-      U32 flags = 0;
-#pragma unroll
-      for (int j = 0 ; j < MG_ASSIGN_PER_THREAD ; ++j)
-        { U64 o = o0 + j;
-          sid[j] = 0xffffffffu;
-          if (o < n)
-            { sid[j] = slotId[o];
-              if (sid[j] != 0xffffffffu && slots[sid[j]].ordIdx == mgToken (o)) flags |= 1u << j;
-            }
-        }
-      U32 cnt = __popc (flags), incl = cnt;
-#pragma unroll
-      for (int off = 1 ; off < 64 ; off <<= 1)
-        { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
-      if (lane == 63) sWaveTot[wave] = incl;
-      __syncthreads ();
-      U32 waveBase = 0, total = 0;
-#pragma unroll
-      for (int i = 0 ; i < 4 ; ++i) { U32 v = sWaveTot[i]; if (i < wave) waveBase += v; total += v; }
-      if (wave == 0)
-        { U64 b = mgLookback (desc, tile, total);
-          if (lane == 0) { sBase = b; if (tile == nTiles - 1) counters[0] = b + total; }
-        }
-      __syncthreads ();
-      U64 rank = sBase + waveBase + (incl - cnt);
-#pragma unroll
-      for (int j = 0 ; j < MG_ASSIGN_PER_THREAD ; ++j)
-        if (flags & (1u << j))
-          { U64 idx = (U64) baseMax + 1 + rank++;
-            if (idx < size)
-              { slots[sid[j]].ordIdx = (U32) idx;
-                value[idx] = kmer[o0 + j];
-                slotOfIndex[idx] = sid[j];
-              }
-          }
-      __syncthreads ();
-    }
-}
-
-__global__ void mgTableGatherKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ slotId, U64 n,
-                                     U32 *__restrict__ out)
+void mgDirectFlagKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ slotId, U64 n,
+                         unsigned char *__restrict__ flags)
 {
   U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; o < n ; o += stride)
     { U32 s = slotId[o];
-      U32 v = s == 0xffffffffu ? 0 : slots[s].ordIdx;
-      out[o] = mgAssigned (v) ? v : 0;
+      flags[o] = (s != 0xffffffffu && slots[s].ord == mgToken (o)) ? 1 : 0;
     }
 }
 
-__global__ void mgTableFindKernel (const MgSlot *__restrict__ slots, U64 mask, const U64 *__restrict__ kmer, U64 n,
+__device__ __forceinline__ U32 mgFlags16 (const unsigned char *__restrict__ flags, U64 o0, U64 n)
+{
+  U32 m = 0;
+  if (o0 + 16 <= n)
+    { uint4 v = *reinterpret_cast<const uint4 *> (flags + o0);
+      U32 q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+      for (int j = 0 ; j < 4 ; ++j)
+        { U32 x = q[j] & 0x01010101u;               /* bytes -> 4 bits */
+          m |= ((x & 1) | ((x >> 7) & 2) | ((x >> 14) & 4) | ((x >> 21) & 8)) << (4 * j);
+        }
+    }
+  else
+    for (int j = 0 ; j < 16 && o0 + j < n ; ++j) m |= (U32) (flags[o0 + j] & 1) << j;
+  return m;
+}
+
+__global__ __launch_bounds__ (256)
+void mgRankCountKernel (const unsigned char *__restrict__ flags, U64 n, U64 tilesPerBlock, U64 *__restrict__ blockCount)
+{
+  __shared__ U32 sW[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  U64 tile = (U64) blockIdx.x * tilesPerBlock, tEnd = tile + tilesPerBlock;
+  const U64 nTiles = (n + MG_RANK_TILE - 1) / MG_RANK_TILE;
+  if (tEnd > nTiles) tEnd = nTiles;
+  U32 c = 0;
+  for ( ; tile < tEnd ; ++tile)
+    c += __popc (mgFlags16 (flags, tile * MG_RANK_TILE + (U64) tid * MG_RANK_PER_THREAD, n));
+  for (int off = 32 ; off ; off >>= 1) c += __shfl_xor (c, off);
+  if (lane == 0) sW[wave] = c;
+  __syncthreads ();
+  if (tid == 0) blockCount[blockIdx.x] = (U64) sW[0] + sW[1] + sW[2] + sW[3];
+}
+
+/* exclusive scan of up to a few thousand block counts (one workgroup); counters[0] = total */
+__global__ __launch_bounds__ (1024)
+void mgRankScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 *__restrict__ blockBase, U64 *__restrict__ counters)
+{
+  __shared__ U64 sPart[1024];
+  const int tid = threadIdx.x;
+  const U32 per = (nBlocks + 1023) / 1024;
+  U64 sum = 0;
+  for (U32 i = 0 ; i < per ; ++i) { U32 b = tid * per + i; if (b < nBlocks) sum += blockCount[b]; }
+  sPart[tid] = sum;
+  __syncthreads ();
+  for (int off = 1 ; off < 1024 ; off <<= 1)
+    { U64 v = tid >= off ? sPart[tid - off] : 0;
+      __syncthreads ();
+      sPart[tid] += v;
+      __syncthreads ();
+    }
+  U64 run = sPart[tid] - sum;
+  for (U32 i = 0 ; i < per ; ++i) { U32 b = tid * per + i; if (b < nBlocks) { blockBase[b] = run; run += blockCount[b]; } }
+  if (tid == 1023) counters[0] = sPart[1023];
+}
+
+/* pass B: every flagged ordinal o gets index baseMax+1+rank(o); value[index] = kmer[o].
+ * DIRECT: also store the index in the slot.  BUCKETED: record the rank structure
+ * (64-ordinal groups: bitmap + number of flags before the group) for the merge kernel. */
+template <bool DIRECT>
+__global__ __launch_bounds__ (256)
+void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__restrict__ kmer, U64 n, U64 tilesPerBlock,
+                         const U64 *__restrict__ blockBase, U32 baseMax, U32 size,
+                         U64 *__restrict__ value, MgSlot *__restrict__ slots, const U32 *__restrict__ slotId,
+                         U64 *__restrict__ grpBits, U32 *__restrict__ grpRank)
+{
+  __shared__ U32 sW[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  U64 tile = (U64) blockIdx.x * tilesPerBlock, tEnd = tile + tilesPerBlock;
+  const U64 nTiles = (n + MG_RANK_TILE - 1) / MG_RANK_TILE;
+  if (tEnd > nTiles) tEnd = nTiles;
+  U64 run = blockBase[blockIdx.x];
+  for ( ; tile < tEnd ; ++tile)
+    { const U64 o0 = tile * MG_RANK_TILE + (U64) tid * MG_RANK_PER_THREAD;
+      U32 m = mgFlags16 (flags, o0, n);
+      U32 cnt = __popc (m), incl = cnt;
+#pragma unroll
+      for (int off = 1 ; off < 64 ; off <<= 1)
+        { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
+      if (lane == 63) sW[wave] = incl;
+      __syncthreads ();
+      U32 wb = 0, tot = 0;
+#pragma unroll
+      for (int i = 0 ; i < 4 ; ++i) { U32 v = sW[i]; if (i < wave) wb += v; tot += v; }
+      U64 rank = run + wb + (incl - cnt);                 /* flags before this lane's 16 ordinals */
+      if (!DIRECT)
+        { /* 4 lanes x 16 ordinals = one 64-ordinal group */
+          U32 m1 = __shfl_down (m, 1), m2 = __shfl_down (m, 2), m3 = __shfl_down (m, 3);
+          if ((lane & 3) == 0 && o0 < n)
+            { grpBits[o0 >> 6] = (U64) m | ((U64) m1 << 16) | ((U64) m2 << 32) | ((U64) m3 << 48);
+              grpRank[o0 >> 6] = (U32) rank;
+            }
+        }
+      while (m)
+        { int j = __ffs ((int) m) - 1;
+          m &= m - 1;
+          U64 idx = (U64) baseMax + 1 + rank++;
+          if (idx < size)
+            { value[idx] = kmer[o0 + j];
+              if (DIRECT) slots[slotId[o0 + j]].ord = (U32) idx | MG_ASSIGNED;
+            }
+        }
+      run += tot;
+      __syncthreads ();
+    }
+}
+
+__device__ __forceinline__ U32 mgProbeFind (const MgSlot *__restrict__ slots, const MgGeom &g, U64 km)
+{
+  const U64 key = km + 1, h = mgMix (km);
+  const U64 base = (U64) mgBucketOf (h, g) * g.R;
+  U32 at = mgHomeOf (h, g);
+  for (U32 probes = 0 ; probes < g.R ; ++probes)
+    { U64 cur = slots[base + at].key;
+      if (cur == key) { U32 v = slots[base + at].ord; return mgIsAssigned (v) ? (v & ~MG_ASSIGNED) : 0; }
+      if (cur == 0) return 0;
+      at = (at + 1) & g.rMask;
+    }
+  return 0;
+}
+
+__global__ void mgTableFindKernel (const MgSlot *__restrict__ slots, MgGeom g, const U64 *__restrict__ kmer, U64 n,
                                    U32 *__restrict__ out)
 {
   U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; o < n ; o += stride)
-    { const U64 km = kmer[o], key = km + 1;
-      U64 s = mgMix (km) & mask;
-      U32 res = 0;
-      for (U64 probes = 0 ; probes <= mask ; ++probes)
-        { U64 cur = slots[s].key;
-          if (cur == key) { U32 v = slots[s].ordIdx; res = mgAssigned (v) ? v : 0; break; }
-          if (cur == 0) break;
-          s = (s + 1) & mask;
-        }
-      out[o] = res;
-    }
+  for ( ; o < n ; o += stride) out[o] = mgProbeFind (slots, g, kmer[o]);
 }
 
 /* entries first..last (with their existing indices) from a host modset into the device table */
-__global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, U64 mask, const U64 *__restrict__ value,
-                                   U32 first, U32 last, U32 *__restrict__ slotOfIndex, U64 *counters)
+__global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, MgGeom g, const U64 *__restrict__ value,
+                                   U32 first, U32 last, U32 *__restrict__ occ, U64 *counters)
 {
   U64 i = (U64) first + (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; i <= last ; i += stride)
-    { const U64 km = value[i], key = km + 1;
-      U64 s = mgMix (km) & mask;
-      U64 probes = 0;
-      for (;;)
-        { U64 cur = slots[s].key;
+    { const U64 km = value[i], key = km + 1, h = mgMix (km);
+      const U32 b = mgBucketOf (h, g);
+      const U64 base = (U64) b * g.R;
+      U32 at = mgHomeOf (h, g);
+      bool placed = false, dup = false;
+      for (U32 probes = 0 ; probes < g.R ; ++probes)
+        { U64 cur = slots[base + at].key;
           if (cur == 0)
-            { cur = atomicCAS ((unsigned long long *) &slots[s].key, 0ull, (unsigned long long) key);
-              if (cur == 0) break;
+            { cur = atomicCAS ((unsigned long long *) &slots[base + at].key, 0ull, (unsigned long long) key);
+              if (cur == 0) { placed = true; break; }
             }
-          if (cur == key) break;        /* duplicate value in the host arrays: keep the first */
-          s = (s + 1) & mask;
-          if (++probes > mask) { counters[1] = 1; break; }
+          if (cur == key) { dup = true; break; }     /* duplicate value in the host arrays: keep the first */
+          at = (at + 1) & g.rMask;
         }
-      slots[s].ordIdx = (U32) i;
-      slotOfIndex[i] = (U32) s;
+      if (placed) { slots[base + at].ord = (U32) i | MG_ASSIGNED; atomicAdd (&occ[b], 1u); }
+      else if (!dup) counters[1] = 1;
     }
 }
 
-/* pending depth counts of entries first..last -> delta16[], folded into baseDepth, cnt zeroed */
-__global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, const U32 *__restrict__ slotOfIndex,
-                                          U16 *__restrict__ baseDepth, U16 *__restrict__ delta, U32 first, U32 last)
+/* ======================================================================================== */
+/* whole-table streaming passes (export / histogram)                                          */
+
+/* pending depth counts -> delta16[idx-1], folded into baseDepth, cnt zeroed */
+__global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, U64 nSlots, U16 *__restrict__ baseDepth,
+                                          U16 *__restrict__ delta, U32 max)
 {
-  U64 i = (U64) first + (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; i <= last ; i += stride)
-    { U32 s = slotOfIndex[i];
-      U32 c = slots[s].cnt;
-      slots[s].cnt = 0;
+  for ( ; s < nSlots ; s += stride)
+    { uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
+      if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
+      U32 idx = v.z & ~MG_ASSIGNED, c = v.w;
+      if (idx > max) continue;
       U32 cl = c > 0xffffu ? 0xffffu : c;
-      delta[i - first] = (U16) cl;
-      U32 b = (U32) baseDepth[i] + cl;
-      baseDepth[i] = (U16) (b > 0xffffu ? 0xffffu : b);
+      delta[idx - 1] = (U16) cl;
+      U32 b = (U32) baseDepth[idx] + cl;
+      baseDepth[idx] = (U16) (b > 0xffffu ? 0xffffu : b);
+      if (c) slots[s].cnt = 0;
     }
 }
 
-/* K5: histogram of min(65535, baseDepth + pending) over entries 1..max (modutils.c:53-63) */
+/* K5: histogram of min(65535, baseDepth + pending) over all entries (modutils.c:53-63) */
 #define MG_HIST_LDS_BINS 8192
 __global__ __launch_bounds__ (256)
-void mgTableHistKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ slotOfIndex,
-                        const U16 *__restrict__ baseDepth, U32 max, unsigned long long *__restrict__ hist)
+void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U16 *__restrict__ baseDepth,
+                        unsigned long long *__restrict__ hist)
 {
   __shared__ U32 sBins[MG_HIST_LDS_BINS];
   for (int b = threadIdx.x ; b < MG_HIST_LDS_BINS ; b += blockDim.x) sBins[b] = 0;
   __syncthreads ();
-  U64 i = 1 + (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; i <= max ; i += stride)
-    { U32 d = (U32) baseDepth[i] + slots[slotOfIndex[i]].cnt;
-      if (d > 0xffffu || d < baseDepth[i]) d = 0xffffu;
+  for ( ; s < nSlots ; s += stride)
+    { uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
+      if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
+      U32 idx = v.z & ~MG_ASSIGNED;
+      U32 d = (U32) baseDepth[idx] + v.w;
+      if (d > 0xffffu || d < v.w) d = 0xffffu;
       if (d < MG_HIST_LDS_BINS) atomicAdd (&sBins[d], 1u);
       else atomicAdd (&hist[d], 1ull);
     }
@@ -255,42 +340,412 @@ __global__ void mgIndexFinishKernel (U32 *__restrict__ index, U64 n)
   for ( ; i < n ; i += stride) if (index[i] == 0xffffffffu) index[i] = 0;
 }
 
-/* ---------------------------------------------------------------------------------------- */
+/* ======================================================================================== */
+/* bucketed path, step 1: radix partition of (kmer, ordinal) by bucket id                     */
+
+#define MG_PART_CHUNK 16384          /* elements per workgroup pass */
+#define MG_PART_MAXBINS 512
+
+/* digit of element = bits [shift, shift+bits) of its bucket id */
+__device__ __forceinline__ U32 mgDigit (U64 km, const MgGeom &g, int shift, U32 binMask)
+{ return (mgBucketOf (mgMix (km), g) >> shift) & binMask; }
+
+/* chunk -> (segment, range): segments are [segStart[s], segStart[s+1]); chunkBase[s] = first chunk of s */
+__device__ __forceinline__ bool mgChunkRange (const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
+                                              U32 chunk, U32 *seg, U64 *lo, U64 *hi)
+{
+  if (chunk >= chunkBase[nSeg]) return false;
+  U32 a = 0, b = nSeg - 1;                       /* largest s with chunkBase[s] <= chunk */
+  while (a < b) { U32 m = a + (b - a + 1) / 2; if (chunkBase[m] <= chunk) a = m; else b = m - 1; }
+  *seg = a;
+  *lo = segStart[a] + (U64) (chunk - chunkBase[a]) * MG_PART_CHUNK;
+  U64 e = segStart[a + 1];
+  *hi = *lo + MG_PART_CHUNK < e ? *lo + MG_PART_CHUNK : e;
+  return true;
+}
+
+__global__ __launch_bounds__ (MG_PART_MAXBINS)
+void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 *__restrict__ chunkBase)
+{
+  __shared__ U32 sS[MG_PART_MAXBINS];
+  const U32 t = threadIdx.x;
+  U32 c = t < nSeg ? (U32) ((segStart[t + 1] - segStart[t] + MG_PART_CHUNK - 1) / MG_PART_CHUNK) : 0;
+  sS[t] = c;
+  __syncthreads ();
+  for (int off = 1 ; off < MG_PART_MAXBINS ; off <<= 1)
+    { U32 v = t >= (U32) off ? sS[t - off] : 0;
+      __syncthreads ();
+      sS[t] += v;
+      __syncthreads ();
+    }
+  if (t < nSeg) chunkBase[t] = sS[t] - c;
+  if (t == nSeg - 1) chunkBase[nSeg] = sS[t];
+}
+
+__global__ __launch_bounds__ (256)
+void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, int shift, U32 nBins,
+                       const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
+                       U32 *__restrict__ binCount)
+{
+  __shared__ U32 sH[MG_PART_MAXBINS];
+  U32 seg; U64 lo, hi;
+  if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
+  for (U32 b = threadIdx.x ; b < nBins ; b += 256) sH[b] = 0;
+  __syncthreads ();
+  for (U64 i = lo + threadIdx.x ; i < hi ; i += 256) atomicAdd (&sH[mgDigit (kIn[i], g, shift, nBins - 1)], 1u);
+  __syncthreads ();
+  for (U32 b = threadIdx.x ; b < nBins ; b += 256) if (sH[b]) atomicAdd (&binCount[(U64) seg * nBins + b], sH[b]);
+}
+
+/* per segment: binStart = segStart + exclusive scan of its bin counts; cursor = binStart */
+__global__ __launch_bounds__ (MG_PART_MAXBINS)
+void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *__restrict__ segStart,
+                       U64 *__restrict__ binStart, unsigned long long *__restrict__ cursor, U32 nSeg, U64 n)
+{
+  __shared__ U32 sS[MG_PART_MAXBINS];
+  const U32 seg = blockIdx.x, t = threadIdx.x;
+  U32 c = t < nBins ? binCount[(U64) seg * nBins + t] : 0;
+  sS[t] = c;
+  __syncthreads ();
+  for (int off = 1 ; off < MG_PART_MAXBINS ; off <<= 1)
+    { U32 v = t >= (U32) off ? sS[t - off] : 0;
+      __syncthreads ();
+      sS[t] += v;
+      __syncthreads ();
+    }
+  if (t < nBins)
+    { U64 st = segStart[seg] + (sS[t] - c);
+      binStart[(U64) seg * nBins + t] = st;
+      cursor[(U64) seg * nBins + t] = st;
+    }
+  if (seg == nSeg - 1 && t == 0) binStart[(U64) nSeg * nBins] = n;
+}
+
+template <bool FIRST>     /* FIRST: input ordinal is the element's position */
+__global__ __launch_bounds__ (256)
+void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, MgGeom g, int shift, U32 nBins,
+                          const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
+                          unsigned long long *__restrict__ cursor, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
+{
+  __shared__ U32 sH[MG_PART_MAXBINS];
+  __shared__ unsigned long long sBase[MG_PART_MAXBINS];
+  U32 seg; U64 lo, hi;
+  if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
+  for (U32 b = threadIdx.x ; b < nBins ; b += 256) sH[b] = 0;
+  __syncthreads ();
+  for (U64 i = lo + threadIdx.x ; i < hi ; i += 256) atomicAdd (&sH[mgDigit (kIn[i], g, shift, nBins - 1)], 1u);
+  __syncthreads ();
+  for (U32 b = threadIdx.x ; b < nBins ; b += 256)
+    { U32 c = sH[b];
+      sBase[b] = c ? atomicAdd (&cursor[(U64) seg * nBins + b], (unsigned long long) c) : 0;
+      sH[b] = 0;
+    }
+  __syncthreads ();
+  for (U64 i = lo + threadIdx.x ; i < hi ; i += 256)
+    { U64 km = kIn[i];
+      U32 d = mgDigit (km, g, shift, nBins - 1);
+      U64 at = sBase[d] + atomicAdd (&sH[d], 1u);
+      kOut[at] = km;
+      tOut[at] = FIRST ? (U32) i : tIn[i];
+    }
+}
+
+/* ======================================================================================== */
+/* bucketed path, steps 2 and 4: one workgroup per bucket, the bucket lives in LDS             */
+
+#define MG_BUCKET_THREADS 256
+
+struct MgBucketArgs {
+  MgSlot *slots; MgGeom g; U32 nBuckets;
+  const U64 *bucketStart;          /* [NB+1] ranges into pK/pT/pC */
+  U64 *pK; U32 *pT; U32 *pC;       /* in: occurrences (kmer, ordinal); out (in place): uniques (kmer, ord field, count) */
+  U32 *uniqCount;                  /* [NB] */
+  U32 *occ;                        /* [NB] entries per bucket */
+  unsigned char *flags;            /* [n] first occurrence of a k-mer new to the table */
+  const U64 *grpBits; const U32 *grpRank; U32 baseMax; U32 size;
+  int withDepth;
+  U64 *counters;
+};
+
+extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
+
+__device__ __forceinline__ void mgBucketLoad (const MgBucketArgs &a, U32 b, bool loadCnt,
+                                              unsigned long long *sKey, U32 *sOrd, U32 *sCnt)
+{
+  const U32 R = a.g.R;
+  if (a.occ[b])
+    for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS)
+      { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
+        sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z; sCnt[i] = loadCnt ? v.w : 0;
+      }
+  else
+    for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+}
+
+/* find-or-claim the LDS slot of key; returns R on overflow */
+__device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 rMask, U32 home, unsigned long long key)
+{
+  U32 at = home;
+  for (U32 probes = 0 ; probes < R ; ++probes)
+    { unsigned long long cur = sKey[at];
+      if (cur == 0)
+        { cur = atomicCAS (&sKey[at], 0ull, key);
+          if (cur == 0) cur = key;
+        }
+      if (cur == key) return at;
+      at = (at + 1) & rMask;
+    }
+  return R;
+}
+
+/* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
+__global__ __launch_bounds__ (MG_BUCKET_THREADS)
+void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
+{
+  const U32 R = a.g.R;
+  unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
+  U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
+  U32 *sCnt = sOrd + R;
+  U32 &sN = *(sCnt + R);
+  U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
+  if (bEnd > a.nBuckets) bEnd = a.nBuckets;
+  for ( ; b < bEnd ; ++b)
+    { const U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
+      if (hi == lo) { if (threadIdx.x == 0) a.uniqCount[b] = 0; continue; }
+      mgBucketLoad (a, b, false, sKey, sOrd, sCnt);
+      if (threadIdx.x == 0) sN = 0;
+      __syncthreads ();
+      for (U64 i = lo + threadIdx.x ; i < hi ; i += MG_BUCKET_THREADS)
+        { const U64 km = a.pK[i];
+          U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
+          if (at == R) { a.counters[1] = 1; continue; }
+          atomicMax (&sOrd[at], mgToken (a.pT[i]));          /* assigned entries (bit 31) stay as they are */
+          atomicAdd (&sCnt[at], 1u);
+        }
+      __syncthreads ();
+      for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS)
+        { U32 c = sCnt[i];
+          if (!c) continue;
+          U32 at = atomicAdd (&sN, 1u);
+          U32 ord = sOrd[i];
+          a.pK[lo + at] = sKey[i] - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
+          if (!mgIsAssigned (ord)) a.flags[0x7fffffffu - ord] = 1;
+        }
+      __syncthreads ();
+      if (threadIdx.x == 0) a.uniqCount[b] = sN;
+    }
+}
+
+/* step 4: merge the bucket's uniques into the table bucket and stream it back */
+__global__ __launch_bounds__ (MG_BUCKET_THREADS)
+void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
+{
+  const U32 R = a.g.R;
+  unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
+  U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
+  U32 *sCnt = sOrd + R;
+  U32 &sNew = *(sCnt + R);
+  U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
+  if (bEnd > a.nBuckets) bEnd = a.nBuckets;
+  for ( ; b < bEnd ; ++b)
+    { const U32 nu = a.uniqCount[b];
+      if (!nu) continue;
+      const U64 lo = a.bucketStart[b];
+      mgBucketLoad (a, b, true, sKey, sOrd, sCnt);
+      if (threadIdx.x == 0) sNew = 0;
+      __syncthreads ();
+      for (U32 i = threadIdx.x ; i < nu ; i += MG_BUCKET_THREADS)
+        { const U64 km = a.pK[lo + i];
+          const U32 ord = a.pT[lo + i], c = a.withDepth ? a.pC[lo + i] : 0;
+          U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
+          if (at == R) { a.counters[1] = 1; continue; }
+          if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
+          else
+            { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
+              U64 grp = tok >> 6;
+              U32 rank = a.grpRank[grp] + (U32) __popcll (a.grpBits[grp] & (((U64) 1 << (tok & 63)) - 1));
+              U64 idx = (U64) a.baseMax + 1 + rank;
+              sOrd[at] = idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
+              sCnt[at] = c;
+              atomicAdd (&sNew, 1u);
+            }
+        }
+      __syncthreads ();
+      for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS)
+        { unsigned long long k = sKey[i];
+          uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
+          *reinterpret_cast<uint4 *> (&a.slots[(U64) b * R + i]) = v;
+        }
+      if (threadIdx.x == 0 && sNew) a.occ[b] += sNew;
+      __syncthreads ();
+    }
+}
+
+/* ======================================================================================== */
+/* host side                                                                                  */
 
 static inline unsigned mgGrid (U64 n, unsigned per = 256, unsigned cap = 16384)
 { U64 b = (n + per - 1) / per; if (b > cap) b = cap; if (b < 1) b = 1; return (unsigned) b; }
+static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
+static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.rMask = t->R - 1; g.log2NB = t->log2NB; return g; }
 
-size_t mgAssignDescBytes (U64 n)
-{ U64 nTiles = (n + MG_ASSIGN_TILE - 1) / MG_ASSIGN_TILE; return (size_t) (256 + nTiles * 8 + 255) & ~(size_t) 255; }
-
-MgStatus mgTableInsert (MgTable *t, const U64 *dKmer, U64 n, U32 *dSlotId, int withDepth, hipStream_t st)
+#define MG_RANK_BLOCKS 2048
+static inline U64 mgRankTilesPerBlock (U64 n, U32 *nBlocks)
 {
-  if (!n) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_INSERT, st, mgTableInsertKernel, dim3 (mgGrid (n)), dim3 (256), 0, st,
-                      t->slots, t->slotMask, dKmer, n, dSlotId, withDepth, t->counters);
+  U64 nTiles = (n + MG_RANK_TILE - 1) / MG_RANK_TILE;
+  U64 want = nTiles < MG_RANK_BLOCKS ? nTiles : MG_RANK_BLOCKS; if (!want) want = 1;
+  U64 per = (nTiles + want - 1) / want; if (!per) per = 1;
+  *nBlocks = (U32) ((nTiles + per - 1) / per); if (!*nBlocks) *nBlocks = 1;
+  return per;
+}
+
+/* scratch needed by mgTableAdd for a batch of n */
+size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
+{
+  U64 NB = (U64) 1 << t->log2NB;
+  size_t rank = mgAl (n) /*flags*/ + 2 * mgAl (MG_RANK_BLOCKS * 8) + mgAl ((n / 64 + 2) * 8) + mgAl ((n / 64 + 2) * 4);
+  size_t direct = mgAl (n * 4);
+  size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
+              + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3
+              + mgAl ((MG_PART_MAXBINS + 2) * 4) * 2;
+  return rank + (direct > part ? direct : part) + 4096;
+}
+
+static int mgPathOverride (void)
+{
+  static int v = -1;
+  if (v < 0)
+    { const char *e = getenv ("MODGPU_TABLE_PATH");
+      v = !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0));
+    }
+  return v;
+}
+
+bool mgTableUseBuckets (const MgTable *t, U64 n)
+{
+  int ov = mgPathOverride ();
+  if (ov == 1) return false;
+  if (ov == 2) return true;
+  return n >= t->nSlots / 16;           /* streaming every touched bucket twice beats ~100 ps/modimizer of atomics */
+}
+
+/* one partition pass: nSeg segments of kIn -> nBins bins each */
+static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const U32 *tIn, U64 n,
+                            const U64 *segStart, U32 nSeg, int shift, U32 nBins,
+                            U64 *kOut, U32 *tOut, U64 *binStart, unsigned long long *cursor, U32 *binCount, U32 *chunkBase,
+                            hipStream_t st)
+{
+  MgGeom g = mgGeomOf (t);
+  MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
+  MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkBase);
+  unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
+  MG_LAUNCH (MG_K_PART, st, mgPartHistKernel, dim3 (maxChunks), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
+  MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
+  if (first)
+    MG_LAUNCH (MG_K_PART, st, mgPartScatterKernel<true>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+  else
+    MG_LAUNCH (MG_K_PART, st, mgPartScatterKernel<false>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
 
-MgStatus mgTableAssign (MgTable *t, const U64 *dKmer, U64 n, const U32 *dSlotId, void *dDesc, hipStream_t st)
+/* insert a batch (ordinal order = array order); counters[0] = number of new entries afterwards */
+MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st)
 {
   if (!n) return MG_OK;
-  U64 nTiles = (n + MG_ASSIGN_TILE - 1) / MG_ASSIGN_TILE;
-  MG_HIP (hipMemsetAsync (dDesc, 0, 256 + nTiles * 8, st));
-  U32 *ticket = (U32 *) dDesc;
-  U64 *desc = (U64 *) ((char *) dDesc + 256);
-  unsigned grid = (unsigned) (nTiles < 2048 ? nTiles : 2048);
-  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgTableAssignKernel, dim3 (grid), dim3 (256), 0, st,
-                      t->slots, dKmer, dSlotId, n, nTiles, desc, ticket,
-                      t->value, t->slotOfIndex, t->max, t->size, t->counters);
+  MgGeom g = mgGeomOf (t);
+  char *wb = (char *) scratch;
+  unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
+  U64 *blockCount = (U64 *) wb;                      wb += mgAl (MG_RANK_BLOCKS * 8);
+  U64 *blockBase = (U64 *) wb;                       wb += mgAl (MG_RANK_BLOCKS * 8);
+  U64 *grpBits = (U64 *) wb;                         wb += mgAl ((n / 64 + 2) * 8);
+  U32 *grpRank = (U32 *) wb;                         wb += mgAl ((n / 64 + 2) * 4);
+  U32 nRankBlocks; U64 rankTiles = mgRankTilesPerBlock (n, &nRankBlocks);
+
+  if (!mgTableUseBuckets (t, n))
+    { U32 *slotId = (U32 *) wb;
+      MG_LAUNCH (MG_K_TABLE_INSERT, st, mgTableInsertKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, g, dKmer, n, slotId, withDepth, t->counters);
+      MG_LAUNCH (MG_K_TABLE_FLAG, st, mgDirectFlagKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, slotId, n, flags);
+      MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
+      MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks, blockBase, t->counters);
+      MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<true>, dim3 (nRankBlocks), dim3 (256), 0, st,
+                 flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, slotId, grpBits, grpRank);
+      MG_HIP (hipGetLastError ());
+      /* occ[] is kept exact only by the bucketed path and the loader; the direct path marks buckets non-empty */
+      return mgTableMarkOccupied (t, dKmer, n, st);
+    }
+
+  /* ---- bucketed ---- */
+  const U64 NB = (U64) 1 << t->log2NB;
+  U64 *kA = (U64 *) wb;  wb += mgAl (n * 8);
+  U32 *tA = (U32 *) wb;  wb += mgAl (n * 4);
+  U64 *kB = (U64 *) wb;  wb += mgAl (n * 8);
+  U32 *tB = (U32 *) wb;  wb += mgAl (n * 4);
+  U32 *cB = (U32 *) wb;  wb += mgAl (n * 4);
+  U64 *fineStart = (U64 *) wb;                wb += mgAl ((NB + 2) * 8);
+  unsigned long long *fineCursor = (unsigned long long *) wb; wb += mgAl ((NB + 2) * 8);
+  U64 *spare64 = (U64 *) wb;                  wb += mgAl ((NB + 2) * 8);
+  U32 *fineCount = (U32 *) wb;                wb += mgAl ((NB + 2) * 4);
+  U32 *uniqCount = (U32 *) wb;                wb += mgAl ((NB + 2) * 4);
+  U64 *coarseStart = (U64 *) wb;              wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
+  unsigned long long *coarseCursor = (unsigned long long *) wb; wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
+  U64 *whole = (U64 *) wb;                    wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
+  U32 *coarseCount = (U32 *) wb;              wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
+  U32 *chunkBase = (U32 *) wb;                wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
+  (void) spare64;
+
+  /* split the bucket-id bits into a coarse digit (high) and a fine digit (low), each <= 9 bits */
+  const int j = t->log2NB;
+  int hiB, loB;
+  if (j <= 9) { hiB = j; loB = 0; } else { loB = j / 2; hiB = j - loB; }
+  U64 segInit[2] = { 0, n };
+  MG_HIP (hipMemcpyAsync (whole, segInit, 16, hipMemcpyHostToDevice, st));
+  MgStatus s;
+  const U64 *bucketStart = fineStart;
+  if (!loB)
+    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s; }
+  else
+    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st))) return s;
+      if ((s = mgPartPass (t, false, kA, tA, n, coarseStart, (U32) 1 << hiB, 0, (U32) 1 << loB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s;
+    }
+
+  MG_HIP (hipMemsetAsync (flags, 0, n, st));
+  MgBucketArgs a;
+  a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
+  a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
+  a.grpBits = grpBits; a.grpRank = grpRank; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
+  a.counters = t->counters;
+  const size_t lds = (size_t) t->R * 16 + 16;
+  if (lds > 48 * 1024)
+    { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    }
+  unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
+  U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
+  bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
+  MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel, dim3 (bGrid), dim3 (MG_BUCKET_THREADS), lds, st, a, perBlock);
+  MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
+  MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks, blockBase, t->counters);
+  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nRankBlocks), dim3 (256), 0, st,
+             flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grpBits, grpRank);
+  MG_LAUNCH (MG_K_BUCKET_MERGE, st, mgBucketMergeKernel, dim3 (bGrid), dim3 (MG_BUCKET_THREADS), lds, st, a, perBlock);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
 
-MgStatus mgTableGather (MgTable *t, const U32 *dSlotId, U64 n, U32 *dIndexOut, hipStream_t st)
+__global__ void mgMarkOccKernel (MgGeom g, const U64 *__restrict__ kmer, U64 n, U32 *__restrict__ occ)
 {
-  if (!n) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_GATHER, st, mgTableGatherKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, dSlotId, n, dIndexOut);
+  U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for ( ; o < n ; o += stride)
+    { U32 b = mgBucketOf (mgMix (kmer[o]), g);
+      if (!occ[b]) occ[b] = 1;
+    }
+}
+
+MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st)
+{
+  MG_LAUNCH (MG_K_TABLE_FLAG, st, mgMarkOccKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, mgGeomOf (t), dKmer, n, t->occ);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -298,7 +753,7 @@ MgStatus mgTableGather (MgTable *t, const U32 *dSlotId, U64 n, U32 *dIndexOut, h
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st)
 {
   if (!n) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, t->slotMask, dKmer, n, dIndexOut);
+  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, mgGeomOf (t), dKmer, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -307,16 +762,17 @@ MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hi
 {
   if (last < first) return MG_OK;
   MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
-                      t->slots, t->slotMask, dValue, first, last, t->slotOfIndex, t->counters);
+             t->slots, mgGeomOf (t), dValue, first, last, t->occ, t->counters);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
 
-MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipStream_t st)
+MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st)
 {
-  if (last < first) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
-                      t->slots, t->slotOfIndex, t->baseDepth, dDelta, first, last);
+  if (!t->max) return MG_OK;
+  MG_HIP (hipMemsetAsync (dDelta, 0, (size_t) t->max * sizeof (U16), st));
+  MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid (t->nSlots, 256, 8192)), dim3 (256), 0, st,
+             t->slots, t->nSlots, t->baseDepth, dDelta, t->max);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -324,8 +780,8 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, U32 first, U32 last, hipSt
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st)
 {
   if (!t->max) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->max, 256, 1024)), dim3 (256), 0, st,
-                      t->slots, t->slotOfIndex, t->baseDepth, t->max, (unsigned long long *) dHist);
+  MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->nSlots, 256, 2048)), dim3 (256), 0, st,
+             t->slots, t->nSlots, t->baseDepth, (unsigned long long *) dHist);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
