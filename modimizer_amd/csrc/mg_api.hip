@@ -63,7 +63,7 @@ static const char *gKernelNames[MG_K_COUNT] = {
   "mgRankAssignKernel", "mgDirectFlagKernel", "mgTableFindKernel", "mgTableLoadKernel",
   "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
   "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel",
-  "mgPartition(hist+scan+scatter)", "mgRankCountKernel", "mgRankScanKernel", "mgBucketDedupKernel",
+  "mgPartChunks+ScanKernel", "mgPartHistKernel", "mgPartScatterKernel", "mgRankCountKernel", "mgRankScanKernel", "mgBucketDedupKernel",
   "mgBucketMergeKernel" };
 #define MG_PROF_POOL 8192
 struct MgProfRec { int id; hipEvent_t a, b; };

@@ -421,32 +421,79 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
   if (seg == nSeg - 1 && t == 0) binStart[(U64) nSeg * nBins] = n;
 }
 
+/* Scatter with LDS staging: a sub-chunk of 4096 elements is counting-sorted by bin in LDS, so the
+ * elements of one bin leave as one contiguous run written by consecutive lanes (plain scattered
+ * 8-byte stores ran at ~22 G/s: 9 ms per 1.5e8 elements for the two passes). */
+#define MG_PART_SUB 4096
+#define MG_PART_PER_THREAD (MG_PART_SUB / 256)
 template <bool FIRST>     /* FIRST: input ordinal is the element's position */
 __global__ __launch_bounds__ (256)
 void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, MgGeom g, int shift, U32 nBins,
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                           unsigned long long *__restrict__ cursor, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
 {
-  __shared__ U32 sH[MG_PART_MAXBINS];
+  __shared__ U64 stK[MG_PART_SUB];
+  __shared__ U32 stT[MG_PART_SUB];
+  __shared__ unsigned short stB[MG_PART_SUB];
+  __shared__ U32 sH[MG_PART_MAXBINS], sOff[MG_PART_MAXBINS];
   __shared__ unsigned long long sBase[MG_PART_MAXBINS];
+  __shared__ U32 sWave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   U32 seg; U64 lo, hi;
   if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
-  for (U32 b = threadIdx.x ; b < nBins ; b += 256) sH[b] = 0;
-  __syncthreads ();
-  for (U64 i = lo + threadIdx.x ; i < hi ; i += 256) atomicAdd (&sH[mgDigit (kIn[i], g, shift, nBins - 1)], 1u);
-  __syncthreads ();
-  for (U32 b = threadIdx.x ; b < nBins ; b += 256)
-    { U32 c = sH[b];
-      sBase[b] = c ? atomicAdd (&cursor[(U64) seg * nBins + b], (unsigned long long) c) : 0;
-      sH[b] = 0;
-    }
-  __syncthreads ();
-  for (U64 i = lo + threadIdx.x ; i < hi ; i += 256)
-    { U64 km = kIn[i];
-      U32 d = mgDigit (km, g, shift, nBins - 1);
-      U64 at = sBase[d] + atomicAdd (&sH[d], 1u);
-      kOut[at] = km;
-      tOut[at] = FIRST ? (U32) i : tIn[i];
+  for (U64 sub = lo ; sub < hi ; sub += MG_PART_SUB)
+    { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
+      const U32 cnt = (U32) (subHi - sub);
+      for (U32 b = tid ; b < nBins ; b += 256) sH[b] = 0;
+      __syncthreads ();
+      U64 km[MG_PART_PER_THREAD]; U32 tk[MG_PART_PER_THREAD]; U32 dr[MG_PART_PER_THREAD];
+#pragma unroll
+      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+        { U64 i = sub + (U64) j * 256 + tid;
+          dr[j] = 0xffffffffu;
+          if (i < subHi)
+            { km[j] = kIn[i];
+              tk[j] = FIRST ? (U32) i : tIn[i];
+              U32 d = mgDigit (km[j], g, shift, nBins - 1);
+              dr[j] = (d << 16) | atomicAdd (&sH[d], 1u);        /* rank within (sub-chunk, bin) */
+            }
+        }
+      __syncthreads ();
+      /* exclusive scan of the bin counts (two bins per thread) + reservation of the output runs */
+      { U32 c0 = (U32) (2 * tid) < nBins ? sH[2 * tid] : 0, c1 = (U32) (2 * tid + 1) < nBins ? sH[2 * tid + 1] : 0;
+        U32 pair = c0 + c1, incl = pair;
+#pragma unroll
+        for (int off = 1 ; off < 64 ; off <<= 1) { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads ();
+        U32 wb = 0;
+#pragma unroll
+        for (int w = 0 ; w < 4 ; ++w) if (w < wave) wb += sWave[w];
+        U32 ex = wb + incl - pair;
+        if ((U32) (2 * tid) < nBins)
+          { sOff[2 * tid] = ex;
+            sBase[2 * tid] = c0 ? atomicAdd (&cursor[(U64) seg * nBins + 2 * tid], (unsigned long long) c0) : 0;
+          }
+        if ((U32) (2 * tid + 1) < nBins)
+          { sOff[2 * tid + 1] = ex + c0;
+            sBase[2 * tid + 1] = c1 ? atomicAdd (&cursor[(U64) seg * nBins + 2 * tid + 1], (unsigned long long) c1) : 0;
+          }
+      }
+      __syncthreads ();
+#pragma unroll
+      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+        if (dr[j] != 0xffffffffu)
+          { U32 d = dr[j] >> 16, p = sOff[d] + (dr[j] & 0xffffu);
+            stK[p] = km[j]; stT[p] = tk[j]; stB[p] = (unsigned short) d;
+          }
+      __syncthreads ();
+      for (U32 p = tid ; p < cnt ; p += 256)
+        { U32 d = stB[p];
+          U64 at = sBase[d] + (p - sOff[d]);
+          kOut[at] = stK[p];
+          tOut[at] = stT[p];
+        }
+      __syncthreads ();
     }
 }
 
@@ -639,12 +686,12 @@ static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const 
   MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkBase);
   unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
-  MG_LAUNCH (MG_K_PART, st, mgPartHistKernel, dim3 (maxChunks), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
+  MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
   if (first)
-    MG_LAUNCH (MG_K_PART, st, mgPartScatterKernel<true>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   else
-    MG_LAUNCH (MG_K_PART, st, mgPartScatterKernel<false>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<false>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
