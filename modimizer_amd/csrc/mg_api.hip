@@ -308,8 +308,9 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
     { mgSetError ("device modset supports table bits 20..32 (got %d)", ms->tableBits); return MG_ERR_ARG; }
   memset (&t, 0, sizeof (t));
   t.nSlots = (U64) 1 << (ms->tableBits - 1);          /* >= 2 * size: load factor <= 0.5 */
-  t.R = 2048;                                          /* 32 KiB of LDS per bucket */
-  t.log2NB = ms->tableBits - 1 - 11;
+  t.R = 4096;                                          /* 64 KiB of LDS per bucket, 1024-thread workgroups (measured best) */
+  { const char *e = getenv ("MODGPU_BUCKET_R"); if (e && atoi (e) >= 256) t.R = (U32) atoi (e); }
+  { int lg = 0; while (((U32) 1 << lg) < t.R) ++lg; t.R = (U32) 1 << lg; t.log2NB = ms->tableBits - 1 - lg; if (t.log2NB < 0) { t.log2NB = 0; t.R = (U32) t.nSlots; } }
   while (t.log2NB > 18) { t.R <<= 1; --t.log2NB; }     /* at most 2^18 buckets (two 9-bit partition passes) */
   t.size = ms->size;
   U64 cap = (ms->tableSize >> 2);                      /* device arrays cover the largest legal size */

@@ -85,9 +85,11 @@ __global__ void mgTableInsertKernel (MgSlot *__restrict__ slots, MgGeom g, const
     }
 }
 
-/* ordered count of flags over contiguous block ranges: pass A counts, pass B assigns */
-#define MG_RANK_PER_THREAD 16
-#define MG_RANK_TILE (256 * MG_RANK_PER_THREAD)
+/* Ordered count of first-occurrence flags.  The ordinal range is cut into contiguous pieces, one
+ * per wave ("rank unit"); a wave walks its piece in rows of 64 ordinals, so flags, k-mers and the
+ * value[] it writes are all lane-contiguous.  Pass A counts per unit, a one-block scan turns the
+ * counts into bases, pass B assigns. */
+struct __attribute__ ((aligned (16))) MgRankGrp { U64 bits; U32 rank; U32 pad; };   /* per 64 ordinals */
 
 __global__ __launch_bounds__ (256)
 void mgDirectFlagKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ slotId, U64 n,
@@ -101,38 +103,19 @@ void mgDirectFlagKernel (const MgSlot *__restrict__ slots, const U32 *__restrict
     }
 }
 
-__device__ __forceinline__ U32 mgFlags16 (const unsigned char *__restrict__ flags, U64 o0, U64 n)
-{
-  U32 m = 0;
-  if (o0 + 16 <= n)
-    { uint4 v = *reinterpret_cast<const uint4 *> (flags + o0);
-      U32 q[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-      for (int j = 0 ; j < 4 ; ++j)
-        { U32 x = q[j] & 0x01010101u;               /* bytes -> 4 bits */
-          m |= ((x & 1) | ((x >> 7) & 2) | ((x >> 14) & 4) | ((x >> 21) & 8)) << (4 * j);
-        }
-    }
-  else
-    for (int j = 0 ; j < 16 && o0 + j < n ; ++j) m |= (U32) (flags[o0 + j] & 1) << j;
-  return m;
-}
 
 __global__ __launch_bounds__ (256)
-void mgRankCountKernel (const unsigned char *__restrict__ flags, U64 n, U64 tilesPerBlock, U64 *__restrict__ blockCount)
+void mgRankCountKernel (const unsigned char *__restrict__ flags, U64 n, U64 rowsPerUnit, U64 *__restrict__ unitCount)
 {
-  __shared__ U32 sW[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  U64 tile = (U64) blockIdx.x * tilesPerBlock, tEnd = tile + tilesPerBlock;
-  const U64 nTiles = (n + MG_RANK_TILE - 1) / MG_RANK_TILE;
-  if (tEnd > nTiles) tEnd = nTiles;
+  const int lane = threadIdx.x & 63;
+  const U64 unit = (U64) blockIdx.x * 4 + (threadIdx.x >> 6);
+  const U64 nRows = (n + 63) / 64;
+  U64 row = unit * rowsPerUnit, rEnd = row + rowsPerUnit;
+  if (rEnd > nRows) rEnd = nRows;
   U32 c = 0;
-  for ( ; tile < tEnd ; ++tile)
-    c += __popc (mgFlags16 (flags, tile * MG_RANK_TILE + (U64) tid * MG_RANK_PER_THREAD, n));
+  for ( ; row < rEnd ; ++row) { U64 o = row * 64 + lane; c += (o < n) ? (flags[o] & 1) : 0; }
   for (int off = 32 ; off ; off >>= 1) c += __shfl_xor (c, off);
-  if (lane == 0) sW[wave] = c;
-  __syncthreads ();
-  if (tid == 0) blockCount[blockIdx.x] = (U64) sW[0] + sW[1] + sW[2] + sW[3];
+  if (lane == 0) unitCount[unit] = c;
 }
 
 /* exclusive scan of up to a few thousand block counts (one workgroup); counters[0] = total */
@@ -158,53 +141,37 @@ void mgRankScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 *__r
 }
 
 /* pass B: every flagged ordinal o gets index baseMax+1+rank(o); value[index] = kmer[o].
- * DIRECT: also store the index in the slot.  BUCKETED: record the rank structure
- * (64-ordinal groups: bitmap + number of flags before the group) for the merge kernel. */
+ * DIRECT: also store the index in the slot.  BUCKETED: record, per row of 64 ordinals, the flag
+ * bitmap and the number of flags before the row, for the merge kernel's rank(o) lookups. */
 template <bool DIRECT>
 __global__ __launch_bounds__ (256)
-void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__restrict__ kmer, U64 n, U64 tilesPerBlock,
-                         const U64 *__restrict__ blockBase, U32 baseMax, U32 size,
+void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__restrict__ kmer, U64 n, U64 rowsPerUnit,
+                         const U64 *__restrict__ unitBase, U32 baseMax, U32 size,
                          U64 *__restrict__ value, MgSlot *__restrict__ slots, const U32 *__restrict__ slotId,
-                         U64 *__restrict__ grpBits, U32 *__restrict__ grpRank)
+                         MgRankGrp *__restrict__ grp)
 {
-  __shared__ U32 sW[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  U64 tile = (U64) blockIdx.x * tilesPerBlock, tEnd = tile + tilesPerBlock;
-  const U64 nTiles = (n + MG_RANK_TILE - 1) / MG_RANK_TILE;
-  if (tEnd > nTiles) tEnd = nTiles;
-  U64 run = blockBase[blockIdx.x];
-  for ( ; tile < tEnd ; ++tile)
-    { const U64 o0 = tile * MG_RANK_TILE + (U64) tid * MG_RANK_PER_THREAD;
-      U32 m = mgFlags16 (flags, o0, n);
-      U32 cnt = __popc (m), incl = cnt;
-#pragma unroll
-      for (int off = 1 ; off < 64 ; off <<= 1)
-        { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
-      if (lane == 63) sW[wave] = incl;
-      __syncthreads ();
-      U32 wb = 0, tot = 0;
-#pragma unroll
-      for (int i = 0 ; i < 4 ; ++i) { U32 v = sW[i]; if (i < wave) wb += v; tot += v; }
-      U64 rank = run + wb + (incl - cnt);                 /* flags before this lane's 16 ordinals */
-      if (!DIRECT)
-        { /* 4 lanes x 16 ordinals = one 64-ordinal group */
-          U32 m1 = __shfl_down (m, 1), m2 = __shfl_down (m, 2), m3 = __shfl_down (m, 3);
-          if ((lane & 3) == 0 && o0 < n)
-            { grpBits[o0 >> 6] = (U64) m | ((U64) m1 << 16) | ((U64) m2 << 32) | ((U64) m3 << 48);
-              grpRank[o0 >> 6] = (U32) rank;
-            }
-        }
-      while (m)
-        { int j = __ffs ((int) m) - 1;
-          m &= m - 1;
-          U64 idx = (U64) baseMax + 1 + rank++;
+  const int lane = threadIdx.x & 63;
+  const U64 unit = (U64) blockIdx.x * 4 + (threadIdx.x >> 6);
+  const U64 nRows = (n + 63) / 64;
+  U64 row = unit * rowsPerUnit, rEnd = row + rowsPerUnit;
+  if (rEnd > nRows) rEnd = nRows;
+  if (row >= rEnd) return;
+  U64 run = unitBase[unit];
+  const U64 below = ((U64) 1 << lane) - 1;
+  for ( ; row < rEnd ; ++row)
+    { const U64 o = row * 64 + lane;
+      const bool f = (o < n) && (flags[o] & 1);
+      const U64 km = (o < n) ? kmer[o] : 0;
+      const U64 bits = __ballot (f);
+      if (!DIRECT && lane == 0) { MgRankGrp g; g.bits = bits; g.rank = (U32) run; g.pad = 0; grp[row] = g; }
+      if (f)
+        { U64 idx = (U64) baseMax + 1 + run + (U32) __popcll (bits & below);
           if (idx < size)
-            { value[idx] = kmer[o0 + j];
-              if (DIRECT) slots[slotId[o0 + j]].ord = (U32) idx | MG_ASSIGNED;
+            { value[idx] = km;
+              if (DIRECT) slots[slotId[o]].ord = (U32) idx | MG_ASSIGNED;
             }
         }
-      run += tot;
-      __syncthreads ();
+      run += (U32) __popcll (bits);
     }
 }
 
@@ -500,7 +467,6 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
 /* ======================================================================================== */
 /* bucketed path, steps 2 and 4: one workgroup per bucket, the bucket lives in LDS             */
 
-#define MG_BUCKET_THREADS 256
 
 struct MgBucketArgs {
   MgSlot *slots; MgGeom g; U32 nBuckets;
@@ -509,7 +475,7 @@ struct MgBucketArgs {
   U32 *uniqCount;                  /* [NB] */
   U32 *occ;                        /* [NB] entries per bucket */
   unsigned char *flags;            /* [n] first occurrence of a k-mer new to the table */
-  const U64 *grpBits; const U32 *grpRank; U32 baseMax; U32 size;
+  const MgRankGrp *grp; U32 baseMax; U32 size;
   int withDepth;
   U64 *counters;
 };
@@ -521,12 +487,12 @@ __device__ __forceinline__ void mgBucketLoad (const MgBucketArgs &a, U32 b, bool
 {
   const U32 R = a.g.R;
   if (a.occ[b])
-    for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS)
+    for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
       { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
         sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z; sCnt[i] = loadCnt ? v.w : 0;
       }
   else
-    for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+    for (U32 i = threadIdx.x ; i < R ; i += blockDim.x) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
 }
 
 /* find-or-claim the LDS slot of key; returns R on overflow */
@@ -546,7 +512,7 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
 }
 
 /* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
-__global__ __launch_bounds__ (MG_BUCKET_THREADS)
+__global__ __launch_bounds__ (1024)
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
   const U32 R = a.g.R;
@@ -562,7 +528,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
       mgBucketLoad (a, b, false, sKey, sOrd, sCnt);
       if (threadIdx.x == 0) sN = 0;
       __syncthreads ();
-      for (U64 i = lo + threadIdx.x ; i < hi ; i += MG_BUCKET_THREADS)
+      for (U64 i = lo + threadIdx.x ; i < hi ; i += blockDim.x)
         { const U64 km = a.pK[i];
           U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
           if (at == R) { a.counters[1] = 1; continue; }
@@ -570,7 +536,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           atomicAdd (&sCnt[at], 1u);
         }
       __syncthreads ();
-      for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS)
+      for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
         { U32 c = sCnt[i];
           if (!c) continue;
           U32 at = atomicAdd (&sN, 1u);
@@ -584,7 +550,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 }
 
 /* step 4: merge the bucket's uniques into the table bucket and stream it back */
-__global__ __launch_bounds__ (MG_BUCKET_THREADS)
+__global__ __launch_bounds__ (1024)
 void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
   const U32 R = a.g.R;
@@ -601,7 +567,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
       mgBucketLoad (a, b, true, sKey, sOrd, sCnt);
       if (threadIdx.x == 0) sNew = 0;
       __syncthreads ();
-      for (U32 i = threadIdx.x ; i < nu ; i += MG_BUCKET_THREADS)
+      for (U32 i = threadIdx.x ; i < nu ; i += blockDim.x)
         { const U64 km = a.pK[lo + i];
           const U32 ord = a.pT[lo + i], c = a.withDepth ? a.pC[lo + i] : 0;
           U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
@@ -609,8 +575,9 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
           else
             { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
-              U64 grp = tok >> 6;
-              U32 rank = a.grpRank[grp] + (U32) __popcll (a.grpBits[grp] & (((U64) 1 << (tok & 63)) - 1));
+              uint4 gv = *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);      /* one 16-byte load */
+              U64 gbits = ((U64) gv.y << 32) | gv.x;
+              U32 rank = gv.z + (U32) __popcll (gbits & (((U64) 1 << (tok & 63)) - 1));
               U64 idx = (U64) a.baseMax + 1 + rank;
               sOrd[at] = idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
               sCnt[at] = c;
@@ -618,7 +585,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
             }
         }
       __syncthreads ();
-      for (U32 i = threadIdx.x ; i < R ; i += MG_BUCKET_THREADS)
+      for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
         { unsigned long long k = sKey[i];
           uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
           *reinterpret_cast<uint4 *> (&a.slots[(U64) b * R + i]) = v;
@@ -636,13 +603,13 @@ static inline unsigned mgGrid (U64 n, unsigned per = 256, unsigned cap = 16384)
 static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
 static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.rMask = t->R - 1; g.log2NB = t->log2NB; return g; }
 
-#define MG_RANK_BLOCKS 2048
-static inline U64 mgRankTilesPerBlock (U64 n, U32 *nBlocks)
+#define MG_RANK_UNITS 8192           /* waves that share the ordered flag count */
+static inline U64 mgRankRowsPerUnit (U64 n, U32 *nBlocks)
 {
-  U64 nTiles = (n + MG_RANK_TILE - 1) / MG_RANK_TILE;
-  U64 want = nTiles < MG_RANK_BLOCKS ? nTiles : MG_RANK_BLOCKS; if (!want) want = 1;
-  U64 per = (nTiles + want - 1) / want; if (!per) per = 1;
-  *nBlocks = (U32) ((nTiles + per - 1) / per); if (!*nBlocks) *nBlocks = 1;
+  U64 nRows = (n + 63) / 64;
+  U64 per = (nRows + MG_RANK_UNITS - 1) / MG_RANK_UNITS; if (!per) per = 1;
+  U64 units = (nRows + per - 1) / per; if (!units) units = 1;
+  *nBlocks = (U32) ((units + 3) / 4);
   return per;
 }
 
@@ -650,7 +617,7 @@ static inline U64 mgRankTilesPerBlock (U64 n, U32 *nBlocks)
 size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
 {
   U64 NB = (U64) 1 << t->log2NB;
-  size_t rank = mgAl (n) /*flags*/ + 2 * mgAl (MG_RANK_BLOCKS * 8) + mgAl ((n / 64 + 2) * 8) + mgAl ((n / 64 + 2) * 4);
+  size_t rank = mgAl (n) /*flags*/ + 2 * mgAl ((MG_RANK_UNITS + 8) * 8) + mgAl ((n / 64 + 2) * sizeof (MgRankGrp));
   size_t direct = mgAl (n * 4);
   size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
               + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3
@@ -703,20 +670,20 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
-  U64 *blockCount = (U64 *) wb;                      wb += mgAl (MG_RANK_BLOCKS * 8);
-  U64 *blockBase = (U64 *) wb;                       wb += mgAl (MG_RANK_BLOCKS * 8);
-  U64 *grpBits = (U64 *) wb;                         wb += mgAl ((n / 64 + 2) * 8);
-  U32 *grpRank = (U32 *) wb;                         wb += mgAl ((n / 64 + 2) * 4);
-  U32 nRankBlocks; U64 rankTiles = mgRankTilesPerBlock (n, &nRankBlocks);
+  U64 *blockCount = (U64 *) wb;                      wb += mgAl ((MG_RANK_UNITS + 8) * 8);
+  U64 *blockBase = (U64 *) wb;                       wb += mgAl ((MG_RANK_UNITS + 8) * 8);
+  MgRankGrp *grp = (MgRankGrp *) wb;                 wb += mgAl ((n / 64 + 2) * sizeof (MgRankGrp));
+  U32 nRankBlocks; U64 rankTiles = mgRankRowsPerUnit (n, &nRankBlocks);
+  MG_HIP (hipMemsetAsync (blockCount, 0, (MG_RANK_UNITS + 8) * 8, st));
 
   if (!mgTableUseBuckets (t, n))
     { U32 *slotId = (U32 *) wb;
       MG_LAUNCH (MG_K_TABLE_INSERT, st, mgTableInsertKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, g, dKmer, n, slotId, withDepth, t->counters);
       MG_LAUNCH (MG_K_TABLE_FLAG, st, mgDirectFlagKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, slotId, n, flags);
       MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
-      MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks, blockBase, t->counters);
+      MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
       MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<true>, dim3 (nRankBlocks), dim3 (256), 0, st,
-                 flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, slotId, grpBits, grpRank);
+                 flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, slotId, grp);
       MG_HIP (hipGetLastError ());
       /* occ[] is kept exact only by the bucketed path and the loader; the direct path marks buckets non-empty */
       return mgTableMarkOccupied (t, dKmer, n, st);
@@ -760,22 +727,25 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   MgBucketArgs a;
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
-  a.grpBits = grpBits; a.grpRank = grpRank; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
+  a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
   a.counters = t->counters;
   const size_t lds = (size_t) t->R * 16 + 16;
   if (lds > 48 * 1024)
     { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
+  static int bThreadsEnv = -1;
+  if (bThreadsEnv < 0) { const char *e = getenv ("MODGPU_BUCKET_T"); bThreadsEnv = e ? atoi (e) : 0; }
+  unsigned bThreads = bThreadsEnv ? (unsigned) bThreadsEnv : (t->R >= 8192 ? 1024u : (t->R >= 4096 ? 512u : 256u));
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
   U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
-  MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel, dim3 (bGrid), dim3 (MG_BUCKET_THREADS), lds, st, a, perBlock);
+  MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
-  MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks, blockBase, t->counters);
+  MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
   MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nRankBlocks), dim3 (256), 0, st,
-             flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grpBits, grpRank);
-  MG_LAUNCH (MG_K_BUCKET_MERGE, st, mgBucketMergeKernel, dim3 (bGrid), dim3 (MG_BUCKET_THREADS), lds, st, a, perBlock);
+             flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grp);
+  MG_LAUNCH (MG_K_BUCKET_MERGE, st, mgBucketMergeKernel, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
