@@ -122,6 +122,7 @@ struct MgScanArgs {
   U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [gridDim.x * segCap] */
   U64 *blockCount;       /* [gridDim.x] true number of modimizers each block found */
   U32 fS, thresh;        /* fast path: factor1 << (32-B), 2^(32-m) */
+  U32 debug;             /* dev only: bit0 = stop after phase B (timing ablation; output meaningless) */
 };
 
 /* which of this lane's 64 k-mer starts lie wholly inside a read (seqhash.c:162: len < k gives
@@ -180,7 +181,8 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_MODE_ANY   0      /* any d: exact test in phase A via modular inverse */
 #define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
 #define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
-#define MG_CAND_CAP   2048   /* candidate list entries per round (LDS) */
+#define MG_CAND_CAP   1024   /* candidate list entries per round (LDS) */
+#define MG_CAND_ITERS (MG_CAND_CAP / MG_SCAN_THREADS)   /* 64-candidate steps per wave and round */
 
 /* One templated kernel.
  *
@@ -211,8 +213,6 @@ void mgScanKernel (const MgScanArgs a)
 {
   __shared__ __attribute__ ((aligned (16))) U32 sWords[MG_TILE_WORDS + 8];
   __shared__ unsigned short sCand[MG_CAND_CAP];
-  __shared__ U64 sSurvB[MG_SCAN_THREADS], sFwdB[MG_SCAN_THREADS];
-  __shared__ U32 sOff[MG_SCAN_THREADS];
   __shared__ U32 sRFirst[MG_SCAN_THREADS];
   __shared__ U32 sWaveTotA[MG_SCAN_THREADS / 64], sWaveTotB[MG_SCAN_THREADS / 64];
 
@@ -349,11 +349,21 @@ void mgScanKernel (const MgScanArgs a)
         { U32 v = sWaveTotA[i]; if (i < wave) waveBase += v; nc += v; }
       const U32 myFirst = waveBase + incl - cnt;             /* ordinal of this lane's first candidate */
       const U32 nRounds = (nc + MG_CAND_CAP - 1) / MG_CAND_CAP;
+      if (a.debug & 1)                                      /* dev ablation: phases A+B only */
+        { __syncthreads ();
+          tile = nextTile; curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
+          found += nc >> 20;
+          continue;
+        }
 
-      /* ---- Phase C: dense exact evaluation, MG_CAND_CAP candidates per round ---- */
+      /* ---- Phases C+D, MG_CAND_CAP candidates per round ----
+         The round's candidates are split into four contiguous, 64-aligned ranges, one per wave, so a
+         wave's modimizers are contiguous in the output: it evaluates its range (at most
+         MG_CAND_ITERS x 64 candidates), keeps k-mer / position / rank in registers, and after ONE
+         barrier (the four wave totals) writes them straight to the block's segment. */
       for (U32 rd = 0 ; rd < nRounds ; ++rd)
         { const U32 lo = rd * MG_CAND_CAP, hi = lo + MG_CAND_CAP;
-          if (rd) __syncthreads ();                          /* previous round done with sCand */
+          if (rd) __syncthreads ();                          /* previous round done with sCand / sWaveTotB */
           { U64 c = cand; U32 o = myFirst;
             while (c && o < hi)
               { int t = __ffsll ((long long) c) - 1;
@@ -362,80 +372,56 @@ void mgScanKernel (const MgScanArgs a)
                 ++o;
               }
           }
-          __syncthreads ();                                                      /* (3) */
+          __syncthreads ();                                                      /* (3) candidates listed */
           const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
-          for (U32 it = 0 ; it * MG_SCAN_THREADS < nHere ; ++it)
-            { U32 i = it * MG_SCAN_THREADS + tid;
+          const U32 per = (((nHere + 3) / 4) + 63) & ~63u;   /* candidates per wave, multiple of 64 */
+          const U32 wLo = wave * per;
+          U64 keepK[MG_CAND_ITERS]; U32 keepQ[MG_CAND_ITERS]; U32 keepR[MG_CAND_ITERS];
+          U32 waveRun = 0;
+#pragma unroll
+          for (int it = 0 ; it < MG_CAND_ITERS ; ++it)
+            { const U32 i = wLo + it * 64 + lane;
               bool surv = false, fwd = false;
-              if (i < nHere)
-                { U64 F = mgKmerAt (sWords, sCand[i], sh1), R = mgRevComp (F, sh1);
+              U64 F = 0; U32 q = 0;
+              if (it * 64 < (int) per && i < nHere)
+                { q = sCand[i];
+                  F = mgKmerAt (sWords, q, sh1);
+                  U64 R = mgRevComp (F, sh1);
                   U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
                   fwd = hF < hR;
                   U64 h = fwd ? hF : hR;
                   if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
                   else                     surv = (h & dMask) == 0;
+                  if (!fwd) F = R;
                 }
-              U64 bs = __ballot (surv), bf = __ballot (fwd);
-              if (lane == 0)
-                { U32 slot = (lo / MG_SCAN_THREADS + it) * 4 + wave;
-                  sSurvB[slot] = bs; sFwdB[slot] = bf;
-                }
+              const U64 bs = __ballot (surv);
+              keepK[it] = F;
+              keepQ[it] = q | (fwd ? MG_FWD_BIT : 0u);
+              keepR[it] = surv ? waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1)) : 0xffffffffu;
+              waveRun += (U32) __popcll (bs);
             }
-        }
-      __syncthreads ();                                                          /* (4) ballots visible */
-      /* exclusive scan of the per-(iteration,wave) survivor counts: at most 256 entries */
-      const U32 nSlots = ((nc + MG_SCAN_THREADS - 1) / MG_SCAN_THREADS) * 4;
-      const U32 c2 = ((U32) tid < nSlots) ? (U32) __popcll (sSurvB[tid]) : 0;
-      U32 incl2 = c2;
+          if (lane == 0) sWaveTotB[wave] = waveRun;
+          __syncthreads ();                                                      /* (4) wave totals */
+          U32 before = 0, total = 0;
 #pragma unroll
-      for (int off = 1 ; off < 64 ; off <<= 1)
-        { U32 v = __shfl_up (incl2, off); if (lane >= off) incl2 += v; }
-      if (lane == 63) sWaveTotB[wave] = incl2;
-      __syncthreads ();                                                          /* (5) */
-      U32 wb2 = 0, total = 0;
+          for (int w = 0 ; w < MG_SCAN_THREADS / 64 ; ++w)
+            { U32 v = sWaveTotB[w]; if (w < wave) before += v; total += v; }
 #pragma unroll
-      for (int i = 0 ; i < MG_SCAN_THREADS / 64 ; ++i)
-        { U32 v = sWaveTotB[i]; if (i < wave) wb2 += v; total += v; }
-      sOff[tid] = wb2 + incl2 - c2;
-      __syncthreads ();                                                          /* (6) */
-
-      /* ---- Phase D: survivors append themselves, in order, to this block's segment ---- */
-      const U64 base = found;
-      found += total;
-      for (U32 rd = 0 ; rd < nRounds ; ++rd)
-        { const U32 lo = rd * MG_CAND_CAP, hi = lo + MG_CAND_CAP;
-          if (nRounds > 1)
-            { __syncthreads ();
-              U64 c = cand; U32 o = myFirst;
-              while (c && o < hi)
-                { int t = __ffsll ((long long) c) - 1;
-                  c &= c - 1;
-                  if (o >= lo) sCand[o - lo] = (unsigned short) (tid * MG_POS_PER_THREAD + t);
-                  ++o;
-                }
-              __syncthreads ();
-            }
-          const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
-          for (U32 it = 0 ; it * MG_SCAN_THREADS < nHere ; ++it)
-            { U32 i = it * MG_SCAN_THREADS + tid;
-              U32 slot = (lo / MG_SCAN_THREADS + it) * 4 + wave;
-              U64 bs = sSurvB[slot];
-              if (i < nHere && ((bs >> lane) & 1))
-                { U64 o = base + sOff[slot] + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
-                  U32 q = sCand[i];
-                  U64 F = mgKmerAt (sWords, q, sh1);
-                  bool fwd = (sFwdB[slot] >> lane) & 1;
-                  U64 pos = tile0 + q;
-                  U32 r = sRFirst[q >> 6];
-                  U64 rs = ti.start;
-                  if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
-                  if (o < a.segCap)
-                    { a.segKmer[segBase + o] = fwd ? F : mgRevComp (F, sh1);
-                      a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
-                      if (a.segRead) a.segRead[segBase + o] = r;
-                    }
-                }
-            }
+          for (int it = 0 ; it < MG_CAND_ITERS ; ++it)
+            if (keepR[it] != 0xffffffffu)
+              { const U64 o = found + before + keepR[it];
+                const U32 q = keepQ[it] & 0xffffu;
+                const U64 pos = tile0 + q;
+                U32 r = sRFirst[q >> 6];
+                U64 rs = ti.start;
+                if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
+                if (o < a.segCap)
+                  { a.segKmer[segBase + o] = keepK[it];
+                    a.segPosF[segBase + o] = (U32) (pos - rs) | (keepQ[it] & MG_FWD_BIT);
+                    if (a.segRead) a.segRead[segBase + o] = r;
+                  }
+              }
+          found += total;
         }
       __syncthreads ();                                                          /* (7) LDS free for the next tile */
       tile = nextTile;
@@ -565,6 +551,7 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
   a.tilesPerBlock = g.tilesPerBlock; a.segCap = g.segCap;
   a.segKmer = segKmer; a.segPosF = segPosF; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
   a.fS = 0; a.thresh = 0;
+  { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
   const unsigned grid = g.nBlocks;
   const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
   const int B = p.shift1 + p.dShift;
