@@ -383,7 +383,7 @@ void mgScanKernel (const MgScanArgs a)
             { const U32 i = wLo + it * 64 + lane;
               bool surv = false, fwd = false;
               U64 F = 0; U32 q = 0;
-              if (it * 64 < (int) per && i < nHere)
+              if (it * 64 < (int) per && i < nHere && !(a.debug & 4))
                 { q = sCand[i];
                   F = mgKmerAt (sWords, q, sh1);
                   U64 R = mgRevComp (F, sh1);
@@ -415,7 +415,7 @@ void mgScanKernel (const MgScanArgs a)
                 U32 r = sRFirst[q >> 6];
                 U64 rs = ti.start;
                 if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
-                if (o < a.segCap)
+                if (o < a.segCap && !(a.debug & 2))
                   { a.segKmer[segBase + o] = keepK[it];
                     a.segPosF[segBase + o] = (U32) (pos - rs) | (keepQ[it] & MG_FWD_BIT);
                     if (a.segRead) a.segRead[segBase + o] = r;

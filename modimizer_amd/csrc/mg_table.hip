@@ -482,19 +482,6 @@ struct MgBucketArgs {
 
 extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
 
-__device__ __forceinline__ void mgBucketLoad (const MgBucketArgs &a, U32 b, bool loadCnt,
-                                              unsigned long long *sKey, U32 *sOrd, U32 *sCnt)
-{
-  const U32 R = a.g.R;
-  if (a.occ[b])
-    for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
-      { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
-        sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z; sCnt[i] = loadCnt ? v.w : 0;
-      }
-  else
-    for (U32 i = threadIdx.x ; i < R ; i += blockDim.x) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
-}
-
 /* find-or-claim the LDS slot of key; returns R on overflow */
 __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 rMask, U32 home, unsigned long long key)
 {
@@ -511,41 +498,85 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
   return R;
 }
 
+/* Both bucket kernels run a workgroup over a contiguous range of buckets.  Per bucket there is
+ * little arithmetic and several dependent global round trips (bounds -> elements -> rank record),
+ * so the next bucket's bounds and first elements are fetched into registers while the current
+ * bucket is processed, and the LDS image is kept all-zero between buckets by clearing exactly the
+ * slots the closing sweep visits (no 64 KiB re-zeroing per bucket). */
+#define MG_BUCKET_PREFETCH 2
+
 /* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
 __global__ __launch_bounds__ (1024)
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
-  const U32 R = a.g.R;
+  const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
   unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
   U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
   U32 *sCnt = sOrd + R;
   U32 &sN = *(sCnt + R);
   U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
   if (bEnd > a.nBuckets) bEnd = a.nBuckets;
+  if (b >= bEnd) return;
+  for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+  if (tid == 0) sN = 0;
+  U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
+  U64 ck[MG_BUCKET_PREFETCH]; U32 ct[MG_BUCKET_PREFETCH];
+#pragma unroll
+  for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
+    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (i < hi) { ck[j] = a.pK[i]; ct[j] = a.pT[i]; } }
+  __syncthreads ();
   for ( ; b < bEnd ; ++b)
-    { const U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
-      if (hi == lo) { if (threadIdx.x == 0) a.uniqCount[b] = 0; continue; }
-      mgBucketLoad (a, b, false, sKey, sOrd, sCnt);
-      if (threadIdx.x == 0) sN = 0;
-      __syncthreads ();
-      for (U64 i = lo + threadIdx.x ; i < hi ; i += blockDim.x)
-        { const U64 km = a.pK[i];
-          U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
-          if (at == R) { a.counters[1] = 1; continue; }
-          atomicMax (&sOrd[at], mgToken (a.pT[i]));          /* assigned entries (bit 31) stay as they are */
-          atomicAdd (&sCnt[at], 1u);
+    { /* fetch the next bucket while this one is processed */
+      U64 nlo = hi, nhi = hi;
+      U64 nk[MG_BUCKET_PREFETCH]; U32 nt[MG_BUCKET_PREFETCH];
+#pragma unroll
+      for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j) { nk[j] = 0; nt[j] = 0; }
+      if (b + 1 < bEnd)
+        { nhi = a.bucketStart[b + 2];
+#pragma unroll
+          for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
+            { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = a.pK[i]; nt[j] = a.pT[i]; } }
         }
-      __syncthreads ();
-      for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
-        { U32 c = sCnt[i];
-          if (!c) continue;
-          U32 at = atomicAdd (&sN, 1u);
-          U32 ord = sOrd[i];
-          a.pK[lo + at] = sKey[i] - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
-          if (!mgIsAssigned (ord)) a.flags[0x7fffffffu - ord] = 1;
+      if (hi == lo) { if (tid == 0) a.uniqCount[b] = 0; }
+      else
+        { if (a.occ[b])
+            { for (U32 i = tid ; i < R ; i += T)
+                { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
+                  sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z;
+                }
+              __syncthreads ();
+            }
+#pragma unroll
+          for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
+            if (lo + (U64) j * T + tid < hi)
+              { U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (ck[j]), a.g), ck[j] + 1);
+                if (at == R) a.counters[1] = 1;
+                else { atomicMax (&sOrd[at], mgToken (ct[j])); atomicAdd (&sCnt[at], 1u); }
+              }
+          for (U64 i = lo + (U64) MG_BUCKET_PREFETCH * T + tid ; i < hi ; i += T)
+            { const U64 km = a.pK[i];
+              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
+              if (at == R) { a.counters[1] = 1; continue; }
+              atomicMax (&sOrd[at], mgToken (a.pT[i]));          /* assigned entries (bit 31) stay as they are */
+              atomicAdd (&sCnt[at], 1u);
+            }
+          __syncthreads ();
+          for (U32 i = tid ; i < R ; i += T)
+            { unsigned long long k = sKey[i];
+              if (!k) continue;
+              U32 c = sCnt[i], ord = sOrd[i];
+              sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;               /* leave the image clean for the next bucket */
+              if (!c) continue;
+              U32 at = atomicAdd (&sN, 1u);
+              a.pK[lo + at] = k - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
+              if (!mgIsAssigned (ord)) a.flags[0x7fffffffu - ord] = 1;
+            }
+          __syncthreads ();
+          if (tid == 0) { a.uniqCount[b] = sN; sN = 0; }
         }
-      __syncthreads ();
-      if (threadIdx.x == 0) a.uniqCount[b] = sN;
+      lo = nlo; hi = nhi;
+#pragma unroll
+      for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j) { ck[j] = nk[j]; ct[j] = nt[j]; }
     }
 }
 
@@ -553,45 +584,69 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 __global__ __launch_bounds__ (1024)
 void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
-  const U32 R = a.g.R;
+  const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
   unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
   U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
   U32 *sCnt = sOrd + R;
   U32 &sNew = *(sCnt + R);
   U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
   if (bEnd > a.nBuckets) bEnd = a.nBuckets;
+  if (b >= bEnd) return;
+  for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+  if (tid == 0) sNew = 0;
+  U32 nu = a.uniqCount[b];
+  U64 lo = a.bucketStart[b];
+  U64 ck = 0; U32 co = 0, cc = 0;
+  if (tid < nu) { ck = a.pK[lo + tid]; co = a.pT[lo + tid]; cc = a.pC[lo + tid]; }
+  __syncthreads ();
   for ( ; b < bEnd ; ++b)
-    { const U32 nu = a.uniqCount[b];
-      if (!nu) continue;
-      const U64 lo = a.bucketStart[b];
-      mgBucketLoad (a, b, true, sKey, sOrd, sCnt);
-      if (threadIdx.x == 0) sNew = 0;
-      __syncthreads ();
-      for (U32 i = threadIdx.x ; i < nu ; i += blockDim.x)
-        { const U64 km = a.pK[lo + i];
-          const U32 ord = a.pT[lo + i], c = a.withDepth ? a.pC[lo + i] : 0;
-          U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
-          if (at == R) { a.counters[1] = 1; continue; }
-          if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
-          else
-            { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
-              uint4 gv = *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);      /* one 16-byte load */
-              U64 gbits = ((U64) gv.y << 32) | gv.x;
-              U32 rank = gv.z + (U32) __popcll (gbits & (((U64) 1 << (tok & 63)) - 1));
-              U64 idx = (U64) a.baseMax + 1 + rank;
-              sOrd[at] = idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
-              sCnt[at] = c;
-              atomicAdd (&sNew, 1u);
+    { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0;
+      if (b + 1 < bEnd)
+        { nnu = a.uniqCount[b + 1]; nlo = a.bucketStart[b + 1];
+          if (tid < nnu) { nk = a.pK[nlo + tid]; no = a.pT[nlo + tid]; ncc = a.pC[nlo + tid]; }
+        }
+      if (nu)
+        { /* the rank record of this lane's first unique: in flight while the bucket image is set up */
+          uint4 gv = make_uint4 (0, 0, 0, 0);
+          const bool isNew0 = tid < nu && !mgIsAssigned (co);
+          if (isNew0) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
+          if (a.occ[b])
+            { for (U32 i = tid ; i < R ; i += T)
+                { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
+                  sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z; sCnt[i] = v.w;
+                }
+              __syncthreads ();
             }
+          for (U32 i = tid ; i < nu ; i += T)
+            { U64 km; U32 ord, c;
+              if (i == tid) { km = ck; ord = co; c = cc; }
+              else { km = a.pK[lo + i]; ord = a.pT[lo + i]; c = a.pC[lo + i]; }
+              if (!a.withDepth) c = 0;
+              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
+              if (at == R) { a.counters[1] = 1; continue; }
+              if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
+              else
+                { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
+                  uint4 g4 = (i == tid) ? gv : *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);
+                  U64 gbits = ((U64) g4.y << 32) | g4.x;
+                  U32 rank = g4.z + (U32) __popcll (gbits & (((U64) 1 << (tok & 63)) - 1));
+                  U64 idx = (U64) a.baseMax + 1 + rank;
+                  sOrd[at] = idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
+                  sCnt[at] = c;
+                  atomicAdd (&sNew, 1u);
+                }
+            }
+          __syncthreads ();
+          for (U32 i = tid ; i < R ; i += T)
+            { unsigned long long k = sKey[i];
+              uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
+              *reinterpret_cast<uint4 *> (&a.slots[(U64) b * R + i]) = v;
+              if (k) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+            }
+          __syncthreads ();
+          if (tid == 0 && sNew) { a.occ[b] += sNew; sNew = 0; }
         }
-      __syncthreads ();
-      for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
-        { unsigned long long k = sKey[i];
-          uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
-          *reinterpret_cast<uint4 *> (&a.slots[(U64) b * R + i]) = v;
-        }
-      if (threadIdx.x == 0 && sNew) a.occ[b] += sNew;
-      __syncthreads ();
+      nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc;
     }
 }
 

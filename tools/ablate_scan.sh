@@ -1,0 +1,8 @@
+#!/bin/bash
+for d in 0 1 2 4 6; do
+  MODGPU_SCAN_DEBUG=$d python bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); print('debug=$d scan ms', j['roofline']['kernels_ms_per_step'].get('mgScanKernel'))"
+done
