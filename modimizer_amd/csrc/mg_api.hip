@@ -307,23 +307,18 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
   if (ms->tableBits < 20 || ms->tableBits > 32)
     { mgSetError ("device modset supports table bits 20..32 (got %d)", ms->tableBits); return MG_ERR_ARG; }
   memset (&t, 0, sizeof (t));
-  t.nSlots = (U64) 1 << (ms->tableBits - 1);          /* >= 2 * size: load factor <= 0.5 */
-  t.R = 4096;                                          /* 64 KiB of LDS per bucket, 1024-thread workgroups (measured best) */
-  { const char *e = getenv ("MODGPU_BUCKET_R"); if (e && atoi (e) >= 256) t.R = (U32) atoi (e); }
-  { int lg = 0; while (((U32) 1 << lg) < t.R) ++lg; t.R = (U32) 1 << lg; t.log2NB = ms->tableBits - 1 - lg; if (t.log2NB < 0) { t.log2NB = 0; t.R = (U32) t.nSlots; } }
-  while (t.log2NB > 18) { t.R <<= 1; --t.log2NB; }     /* at most 2^18 buckets (two 9-bit partition passes) */
+  t.maxLog2Slots = ms->tableBits - 1;                 /* load <= 0.5 at the largest legal fill */
+  t.wantR = 4096;                                      /* 64 KiB of LDS per bucket, 1024-thread workgroups (measured best) */
+  { const char *e = getenv ("MODGPU_BUCKET_R"); if (e && atoi (e) >= 256) t.wantR = (U32) atoi (e); }
   t.size = ms->size;
   U64 cap = (ms->tableSize >> 2);                      /* device arrays cover the largest legal size */
-  MG_HIP (hipMalloc ((void **) &t.slots, t.nSlots * sizeof (MgSlot)));
   MG_HIP (hipMalloc ((void **) &t.value, cap * sizeof (U64)));
-  MG_HIP (hipMalloc ((void **) &t.occ, ((size_t) 1 << t.log2NB) * sizeof (U32)));
   MG_HIP (hipMalloc ((void **) &t.baseDepth, cap * sizeof (U16)));
   MG_HIP (hipMalloc ((void **) &t.counters, 64));
   d->built = true;
-  MG_HIP (hipMemsetAsync (t.slots, 0, t.nSlots * sizeof (MgSlot), st));
-  MG_HIP (hipMemsetAsync (t.occ, 0, ((size_t) 1 << t.log2NB) * sizeof (U32), st));
   MG_HIP (hipMemsetAsync (t.baseDepth, 0, cap * sizeof (U16), st));
   MG_HIP (hipMemsetAsync (t.counters, 0, 64, st));
+  { MgStatus s0 = mgTableEnsure (&t, ms->max, st); if (s0) return s0; }   /* slots sized to the content; grows on demand */
   t.max = 0; t.syncedMax = 0;
   if (ms->max)
     { MG_HIP (hipMemcpyAsync (t.value, ms->value, ((size_t) ms->max + 1) * sizeof (U64), hipMemcpyHostToDevice, st));
@@ -392,10 +387,7 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
   U32 hostUsed = d ? d->t.syncedMax : ms->max;
   if (d)
     { MgTable &t = d->t;
-      mgProfBegin (MG_K_MEMSET, st);
-      MG_HIP (hipMemsetAsync (t.slots, 0, t.nSlots * sizeof (MgSlot), st));
-      mgProfEnd (MG_K_MEMSET, st);
-      MG_HIP (hipMemsetAsync (t.occ, 0, ((size_t) 1 << t.log2NB) * sizeof (U32), st));
+      mgTableForget (&t, st);          /* buckets are re-initialised by whoever writes them next (no 8 GB memset) */
       if (t.syncedMax) MG_HIP (hipMemsetAsync (t.baseDepth, 0, ((size_t) t.syncedMax + 1) * sizeof (U16), st));
       t.max = t.syncedMax = 0;
       d->hostIndexMax = 0;
@@ -462,8 +454,8 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
 {
   if (!n) return MG_OK;
   U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
+  MgStatus s = mgTableEnsure (&d->t, chunk, st); if (s) return s;
   size_t need = mgTableAddScratchBytes (&d->t, chunk) + 4096;
-  MgStatus s = MG_OK;
   if (!arenaLive)
     { if ((s = d->arena.reserve (need))) return s;
       d->arena.reset ();
@@ -473,7 +465,8 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
   void *scratch = d->arena.take (mgTableAddScratchBytes (&d->t, chunk));
   for (U64 off = 0 ; off < n && !s ; off += chunk)
     { U64 m = n - off < chunk ? n - off : chunk;
-      s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, scratch, st);
+      if (off) s = mgTableEnsure (&d->t, m, st);
+      if (!s) s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, scratch, st);
     }
   return s;
 }

@@ -124,7 +124,14 @@ struct MgTable {
   U32 max;             /* entries known to the device table */
   U32 syncedMax;       /* entries whose value[] the host already has */
   U64 *counters;       /* device U64[8]: 0 = new entries of the last add, 1 = bucket overflow */
+  bool dirty;          /* buckets with occ == 0 hold undefined bytes (never zeroed): see mgTableClean */
+  int  maxLog2Slots;   /* tableBits - 1: the size at which load <= 0.5 for the largest legal set */
+  U32  wantR;          /* preferred slots per bucket */
 };
+MgStatus mgTableAlloc (MgTable *t, int log2Slots, hipStream_t st);       /* (re)allocate slots/occ, empty table */
+MgStatus mgTableEnsure (MgTable *t, U64 nIncoming, hipStream_t st);      /* grow (rehash) so that max+nIncoming fits at load <= 0.6 */
+MgStatus mgTableClean (MgTable *t, hipStream_t st);                      /* zero the never-written buckets; dirty = false */
+void     mgTableForget (MgTable *t, hipStream_t st);                     /* all buckets empty again (no memset of the slots) */
 size_t   mgTableAddScratchBytes (const MgTable *t, U64 n);
 bool     mgTableUseBuckets (const MgTable *t, U64 n);
 MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st);

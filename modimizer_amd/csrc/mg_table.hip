@@ -175,10 +175,12 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
     }
 }
 
-__device__ __forceinline__ U32 mgProbeFind (const MgSlot *__restrict__ slots, const MgGeom &g, U64 km)
+__device__ __forceinline__ U32 mgProbeFind (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, const MgGeom &g, U64 km)
 {
   const U64 key = km + 1, h = mgMix (km);
-  const U64 base = (U64) mgBucketOf (h, g) * g.R;
+  const U32 bkt = mgBucketOf (h, g);
+  if (!occ[bkt]) return 0;                         /* never written: its bytes are undefined */
+  const U64 base = (U64) bkt * g.R;
   U32 at = mgHomeOf (h, g);
   for (U32 probes = 0 ; probes < g.R ; ++probes)
     { U64 cur = slots[base + at].key;
@@ -189,12 +191,12 @@ __device__ __forceinline__ U32 mgProbeFind (const MgSlot *__restrict__ slots, co
   return 0;
 }
 
-__global__ void mgTableFindKernel (const MgSlot *__restrict__ slots, MgGeom g, const U64 *__restrict__ kmer, U64 n,
-                                   U32 *__restrict__ out)
+__global__ void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, MgGeom g,
+                                   const U64 *__restrict__ kmer, U64 n, U32 *__restrict__ out)
 {
   U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; o < n ; o += stride) out[o] = mgProbeFind (slots, g, kmer[o]);
+  for ( ; o < n ; o += stride) out[o] = mgProbeFind (slots, occ, g, kmer[o]);
 }
 
 /* entries first..last (with their existing indices) from a host modset into the device table */
@@ -227,13 +229,14 @@ __global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, MgGeom g, const U
 /* whole-table streaming passes (export / histogram)                                          */
 
 /* pending depth counts -> delta16[idx-1], folded into baseDepth, cnt zeroed */
-__global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, U64 nSlots, U16 *__restrict__ baseDepth,
-                                          U16 *__restrict__ delta, U32 max)
+__global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, U64 nSlots, const U32 *__restrict__ occ, int log2R,
+                                          U16 *__restrict__ baseDepth, U16 *__restrict__ delta, U32 max)
 {
   U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; s < nSlots ; s += stride)
-    { uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
+    { if (!occ[s >> log2R]) continue;
+      uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
       if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
       U32 idx = v.z & ~MG_ASSIGNED, c = v.w;
       if (idx > max) continue;
@@ -248,8 +251,8 @@ __global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, U64 nSlots
 /* K5: histogram of min(65535, baseDepth + pending) over all entries (modutils.c:53-63) */
 #define MG_HIST_LDS_BINS 8192
 __global__ __launch_bounds__ (256)
-void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U16 *__restrict__ baseDepth,
-                        unsigned long long *__restrict__ hist)
+void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U32 *__restrict__ occ, int log2R,
+                        const U16 *__restrict__ baseDepth, unsigned long long *__restrict__ hist)
 {
   __shared__ U32 sBins[MG_HIST_LDS_BINS];
   for (int b = threadIdx.x ; b < MG_HIST_LDS_BINS ; b += blockDim.x) sBins[b] = 0;
@@ -257,7 +260,8 @@ void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U16 
   U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; s < nSlots ; s += stride)
-    { uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
+    { if (!occ[s >> log2R]) continue;
+      uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
       if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
       U32 idx = v.z & ~MG_ASSIGNED;
       U32 d = (U32) baseDepth[idx] + v.w;
@@ -656,6 +660,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 static inline unsigned mgGrid (U64 n, unsigned per = 256, unsigned cap = 16384)
 { U64 b = (n + per - 1) / per; if (b > cap) b = cap; if (b < 1) b = 1; return (unsigned) b; }
 static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
+static inline int mgLog2 (U64 x) { int l = 0; while (((U64) 1 << l) < x) ++l; return l; }
 static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.rMask = t->R - 1; g.log2NB = t->log2NB; return g; }
 
 #define MG_RANK_UNITS 8192           /* waves that share the ordered flag count */
@@ -733,6 +738,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
 
   if (!mgTableUseBuckets (t, n))
     { U32 *slotId = (U32 *) wb;
+      { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
       MG_LAUNCH (MG_K_TABLE_INSERT, st, mgTableInsertKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, g, dKmer, n, slotId, withDepth, t->counters);
       MG_LAUNCH (MG_K_TABLE_FLAG, st, mgDirectFlagKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, slotId, n, flags);
       MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
@@ -825,7 +831,7 @@ MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t s
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st)
 {
   if (!n) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, mgGeomOf (t), dKmer, n, dIndexOut);
+  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, t->occ, mgGeomOf (t), dKmer, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -833,6 +839,7 @@ MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipSt
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st)
 {
   if (last < first) return MG_OK;
+  { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
   MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
              t->slots, mgGeomOf (t), dValue, first, last, t->occ, t->counters);
   MG_HIP (hipGetLastError ());
@@ -844,7 +851,7 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st)
   if (!t->max) return MG_OK;
   MG_HIP (hipMemsetAsync (dDelta, 0, (size_t) t->max * sizeof (U16), st));
   MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid (t->nSlots, 256, 8192)), dim3 (256), 0, st,
-             t->slots, t->nSlots, t->baseDepth, dDelta, t->max);
+             t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, dDelta, t->max);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -853,7 +860,7 @@ MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st)
 {
   if (!t->max) return MG_OK;
   MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->nSlots, 256, 2048)), dim3 (256), 0, st,
-             t->slots, t->nSlots, t->baseDepth, (unsigned long long *) dHist);
+             t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, (unsigned long long *) dHist);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -869,5 +876,110 @@ MgStatus mgTableReplayIndex (MgTable *t, const MgHashParams &p, int tableBits, U
     }
   MG_LAUNCH (MG_K_INDEX_FINISH, st, mgIndexFinishKernel, dim3 (mgGrid (n, 256, 8192)), dim3 (256), 0, st, dIndex, n);
   MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+/* ======================================================================================== */
+/* table life cycle: allocation, lazy zeroing, growth                                         */
+
+/* zero the buckets nothing has been written to (occ == 0); everything else is left alone */
+__global__ __launch_bounds__ (256)
+void mgCleanEmptyBucketsKernel (MgSlot *__restrict__ slots, MgGeom g, const U32 *__restrict__ occ, U32 nBuckets)
+{
+  const uint4 z = make_uint4 (0, 0, 0, 0);
+  for (U32 b = blockIdx.x ; b < nBuckets ; b += gridDim.x)
+    { if (occ[b]) continue;
+      for (U32 i = threadIdx.x ; i < g.R ; i += blockDim.x) *reinterpret_cast<uint4 *> (&slots[(U64) b * g.R + i]) = z;
+    }
+}
+
+/* old table -> new (larger) table: every assigned entry is re-inserted with its index and count */
+__global__ void mgRehashKernel (const MgSlot *__restrict__ oldSlots, U64 oldN, const U32 *__restrict__ oldOcc, int oldLog2R,
+                                MgSlot *__restrict__ slots, MgGeom g, U32 *__restrict__ occ, U64 *counters)
+{
+  U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for ( ; s < oldN ; s += stride)
+    { if (!oldOcc[s >> oldLog2R]) continue;
+      uint4 v = *reinterpret_cast<const uint4 *> (&oldSlots[s]);
+      if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
+      const unsigned long long key = ((unsigned long long) v.y << 32) | v.x;
+      const U64 h = mgMix (key - 1);
+      const U32 b = mgBucketOf (h, g);
+      const U64 base = (U64) b * g.R;
+      U32 at = mgHomeOf (h, g);
+      bool placed = false;
+      for (U32 probes = 0 ; probes < g.R ; ++probes)
+        { if (slots[base + at].key == 0 && atomicCAS ((unsigned long long *) &slots[base + at].key, 0ull, key) == 0) { placed = true; break; }
+          at = (at + 1) & g.rMask;
+        }
+      if (!placed) { counters[1] = 1; continue; }
+      slots[base + at].ord = v.z; slots[base + at].cnt = v.w;
+      if (!occ[b]) occ[b] = 1;
+    }
+}
+
+static void mgSetGeometry (MgTable *t, int log2Slots)
+{
+  t->nSlots = (U64) 1 << log2Slots;
+  U32 R = t->wantR ? t->wantR : 4096;
+  int lgR = mgLog2 (R); R = (U32) 1 << lgR;
+  if (lgR > log2Slots) { lgR = log2Slots; R = (U32) 1 << lgR; }
+  int lgNB = log2Slots - lgR;
+  while (lgNB > 18) { ++lgR; R <<= 1; --lgNB; }      /* at most 2^18 buckets (two 9-bit partition passes) */
+  t->R = R; t->log2NB = lgNB;
+}
+
+MgStatus mgTableAlloc (MgTable *t, int log2Slots, hipStream_t st)
+{
+  if (t->slots) { MG_HIP (hipStreamSynchronize (st)); MG_HIP (hipFree (t->slots)); MG_HIP (hipFree (t->occ)); t->slots = 0; t->occ = 0; }
+  mgSetGeometry (t, log2Slots);
+  MG_HIP (hipMalloc ((void **) &t->slots, t->nSlots * sizeof (MgSlot)));
+  MG_HIP (hipMalloc ((void **) &t->occ, ((size_t) 1 << t->log2NB) * sizeof (U32)));
+  mgTableForget (t, st);
+  return MG_OK;
+}
+
+void mgTableForget (MgTable *t, hipStream_t st)
+{
+  (void) hipMemsetAsync (t->occ, 0, ((size_t) 1 << t->log2NB) * sizeof (U32), st);
+  t->dirty = true;               /* no memset of the slots: a bucket is defined once something wrote all of it */
+}
+
+MgStatus mgTableClean (MgTable *t, hipStream_t st)
+{
+  if (!t->dirty) return MG_OK;
+  U32 NB = (U32) 1 << t->log2NB;
+  MG_LAUNCH (MG_K_MEMSET, st, mgCleanEmptyBucketsKernel, dim3 (NB < 4096 ? NB : 4096), dim3 (256), 0, st, t->slots, mgGeomOf (t), t->occ, NB);
+  MG_HIP (hipGetLastError ());
+  t->dirty = false;
+  return MG_OK;
+}
+
+/* slots needed so that `entries` fit at load <= 0.6 */
+static int mgLog2SlotsFor (const MgTable *t, U64 entries)
+{
+  U64 need = entries + entries * 2 / 3 + 1;          /* entries / 0.6 */
+  int lg = mgLog2 (need);
+  if (lg < 16) lg = 16;
+  if (lg > t->maxLog2Slots) lg = t->maxLog2Slots;
+  return lg;
+}
+
+MgStatus mgTableEnsure (MgTable *t, U64 nIncoming, hipStream_t st)
+{
+  int want = mgLog2SlotsFor (t, (U64) t->max + nIncoming);
+  if (t->slots && ((U64) 1 << want) <= t->nSlots) return MG_OK;
+  if (!t->slots || !t->max) return mgTableAlloc (t, want, st);
+  /* grow: rehash the assigned entries into a fresh, zeroed table */
+  MgSlot *oldSlots = t->slots; U32 *oldOcc = t->occ; const U64 oldN = t->nSlots; const int oldLog2R = mgLog2 (t->R);
+  t->slots = 0; t->occ = 0;
+  MgStatus s = mgTableAlloc (t, want, st); if (s) return s;
+  if ((s = mgTableClean (t, st))) return s;
+  MG_LAUNCH (MG_K_TABLE_LOAD, st, mgRehashKernel, dim3 (mgGrid (oldN, 256, 8192)), dim3 (256), 0, st,
+             oldSlots, oldN, oldOcc, oldLog2R, t->slots, mgGeomOf (t), t->occ, t->counters);
+  MG_HIP (hipGetLastError ());
+  MG_HIP (hipStreamSynchronize (st));
+  MG_HIP (hipFree (oldSlots)); MG_HIP (hipFree (oldOcc));
   return MG_OK;
 }
