@@ -125,12 +125,15 @@ def main():
     L.mgProfileEnable(0)
     S = n_hash.value
     entries = ms.contents.max
-    n_slots = 1 << (bits - 1)
     alg_bytes = {                                   # algorithmic bytes per launch
         "mgScanKernel": (0.25 + 12.0 / d) * total,  # 2-bit read + (kmer 8 + pos 4) per modimizer
-        "mgTableInsertKernel": 16.0 * S,            # one 16-byte slot (key 8 + index 4 + depth 4) per modimizer
-        "mgTableAssignKernel": 8.0 * S + 12.0 * entries,
-        "memset": 16.0 * n_slots,
+        "mgSegCompactKernel": 16.0 * S,             # kmer read + written
+        "mgPartHistKernel": 8.0 * S,
+        "mgPartScatterKernel": 24.0 * S,            # (kmer 8 + ordinal 4) read and written, per pass
+        "mgBucketDedupKernel": 12.0 * S + 16.0 * entries,
+        "mgRankAssignKernel": 9.0 * S + 8.0 * entries,
+        "mgBucketMergeKernel": 16.0 * entries + 16.0 * entries / 0.6,   # uniques in, table buckets out
+        "mgTableInsertKernel": 16.0 * S,
     }
     dom = max(kern.items(), key=lambda kv: kv[1][0])[0] if kern else None
     roofline = None

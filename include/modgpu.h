@@ -146,7 +146,7 @@ MgStatus mgUnpackDevice (const U32 *dWords, U64 nBases, U8 *dBases, void *stream
  * Outputs, in (read, pos) order, one entry per modimizer:
  *   dKmer[i]  canonical k-mer (seqhash.c:183)
  *   dPosF[i]  pos within its read in bits 0..30 (seqhash.c:184), isForward in bit 31
- *   dReadId[i] read ordinal (may be NULL)
+ *   dReadId[i] read ordinal (may be NULL; so may dPosF)
  * dCount: device U64[4] -> {number of modimizers found, overflow flag, fullest workgroup segment,
  * capacity to retry with}.  Workgroups stage their modimizers in per-workgroup segments of dWork
  * sized from `capacity`; when the flag is set (total > capacity, or one segment too small) the

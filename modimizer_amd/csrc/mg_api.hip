@@ -573,9 +573,8 @@ extern "C" MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalB
   if (nHash) *nHash = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
-  /* posF is not needed by addSequence (modutils.c:24 passes 0 for isF and ignores pos) but the
-     scan kernel writes it unconditionally; slotId shares the arena (4 B per survivor). */
-  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, 4, &b, &n, st))) return s;
+  /* pos / isF / read are not needed by addSequence (modutils.c:24 passes 0 for isF and ignores pos) */
+  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, false, 4, &b, &n, st))) return s;
   if (nHash) *nHash = n;
   return mgAddBatch (ms, d, b.kmer, n, 0, 1, true, st);
 }

@@ -417,7 +417,7 @@ void mgScanKernel (const MgScanArgs a)
                 if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
                 if (o < a.segCap && !(a.debug & 2))
                   { a.segKmer[segBase + o] = keepK[it];
-                    a.segPosF[segBase + o] = (U32) (pos - rs) | (keepQ[it] & MG_FWD_BIT);
+                    if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (keepQ[it] & MG_FWD_BIT);
                     if (a.segRead) a.segRead[segBase + o] = r;
                   }
               }
@@ -485,7 +485,7 @@ __global__ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *
   const U64 n = blockCount[b], dst = segStart[b], src = (U64) b * segCap;
   for (U64 i = (U64) part * blockDim.x + threadIdx.x ; i < n ; i += (U64) MG_COMPACT_SPLIT * blockDim.x)
     { outKmer[dst + i] = segKmer[src + i];
-      outPosF[dst + i] = segPosF[src + i];
+      if (outPosF) outPosF[dst + i] = segPosF[src + i];
       if (outRead) outRead[dst + i] = segRead[src + i];
     }
 }
@@ -549,7 +549,7 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
   a.p = p; a.packed = dPacked; a.nWordsAlloc = (U64) mgPackedWords (totalBases); a.totalBases = totalBases;
   a.readOff = dReadOffsets; a.nReads = nReads; a.tileInfo = info; a.nTiles = g.nTiles;
   a.tilesPerBlock = g.tilesPerBlock; a.segCap = g.segCap;
-  a.segKmer = segKmer; a.segPosF = segPosF; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
+  a.segKmer = segKmer; a.segPosF = dPosF ? segPosF : 0; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
   a.fS = 0; a.thresh = 0;
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
   const unsigned grid = g.nBlocks;
@@ -570,7 +570,7 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
   MG_HIP (hipGetLastError ());
   MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (g.nBlocks * MG_COMPACT_SPLIT), dim3 (256), 0, st,
-             segKmer, segPosF, a.segRead, g.segCap, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount);
+             segKmer, a.segPosF, a.segRead, g.segCap, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
