@@ -396,9 +396,10 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
  * elements of one bin leave as one contiguous run written by consecutive lanes (plain scattered
  * 8-byte stores ran at ~22 G/s: 9 ms per 1.5e8 elements for the two passes). */
 #define MG_PART_SUB 4096
-#define MG_PART_PER_THREAD (MG_PART_SUB / 256)
+#define MG_PART_THREADS 1024
+#define MG_PART_PER_THREAD (MG_PART_SUB / MG_PART_THREADS)
 template <bool FIRST>     /* FIRST: input ordinal is the element's position */
-__global__ __launch_bounds__ (256)
+__global__ __launch_bounds__ (MG_PART_THREADS)
 void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, MgGeom g, int shift, U32 nBins,
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                           unsigned long long *__restrict__ cursor, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
@@ -408,19 +409,19 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
   __shared__ unsigned short stB[MG_PART_SUB];
   __shared__ U32 sH[MG_PART_MAXBINS], sOff[MG_PART_MAXBINS];
   __shared__ unsigned long long sBase[MG_PART_MAXBINS];
-  __shared__ U32 sWave[4];
+  __shared__ U32 sWave[MG_PART_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   U32 seg; U64 lo, hi;
   if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
   for (U64 sub = lo ; sub < hi ; sub += MG_PART_SUB)
     { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
       const U32 cnt = (U32) (subHi - sub);
-      for (U32 b = tid ; b < nBins ; b += 256) sH[b] = 0;
+      for (U32 b = tid ; b < nBins ; b += MG_PART_THREADS) sH[b] = 0;
       __syncthreads ();
       U64 km[MG_PART_PER_THREAD]; U32 tk[MG_PART_PER_THREAD]; U32 dr[MG_PART_PER_THREAD];
 #pragma unroll
       for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
-        { U64 i = sub + (U64) j * 256 + tid;
+        { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
           dr[j] = 0xffffffffu;
           if (i < subHi)
             { km[j] = kIn[i];
@@ -439,7 +440,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
         __syncthreads ();
         U32 wb = 0;
 #pragma unroll
-        for (int w = 0 ; w < 4 ; ++w) if (w < wave) wb += sWave[w];
+        for (int w = 0 ; w < MG_PART_THREADS / 64 ; ++w) if (w < wave) wb += sWave[w];
         U32 ex = wb + incl - pair;
         if ((U32) (2 * tid) < nBins)
           { sOff[2 * tid] = ex;
@@ -458,7 +459,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
             stK[p] = km[j]; stT[p] = tk[j]; stB[p] = (unsigned short) d;
           }
       __syncthreads ();
-      for (U32 p = tid ; p < cnt ; p += 256)
+      for (U32 p = tid ; p < cnt ; p += MG_PART_THREADS)
         { U32 d = stB[p];
           U64 at = sBase[d] + (p - sOff[d]);
           kOut[at] = stK[p];
@@ -716,9 +717,9 @@ static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const 
   MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
   if (first)
-    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (maxChunks), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   else
-    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<false>, dim3 (maxChunks), dim3 (256), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<false>, dim3 (maxChunks), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
