@@ -423,7 +423,14 @@ extern "C" int mgHookHasDevice (Modset *ms) { return mgDevLookup (ms) != 0; }
 /* ---------------------------------------------------------------------------------------- */
 /* batch insert / find                                                                        */
 
-#define MG_ADD_CHUNK ((U64) 1 << 30)
+/* modimizers per insert pass (tokens are 31-bit ordinals); MODGPU_ADD_CHUNK shrinks it for tests */
+static U64 mgAddChunkSize (void)
+{
+  static U64 v = 0;
+  if (!v) { const char *e = getenv ("MODGPU_ADD_CHUNK"); v = e && atoll (e) > 0 ? (U64) atoll (e) : ((U64) 1 << 30); if (v > ((U64) 1 << 30)) v = (U64) 1 << 30; }
+  return v;
+}
+#define MG_ADD_CHUNK (mgAddChunkSize ())
 
 static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
                             void *scratch, hipStream_t st)

@@ -291,3 +291,59 @@ def test_full_size_build_properties():
             assert np.array_equal(d_o.to_numpy(np.uint32, U), np.arange(1, U + 1, dtype=np.uint32))
         L.modsetDestroy(ms)
         d_r.free()
+
+
+def test_table_growth_and_lazy_zeroing():
+    """the device table starts small and grows by rehashing; buckets nothing wrote to are zeroed
+    lazily.  Interleave large (bucketed) and tiny (atomic path) batches, lookups and a clear."""
+    L = mg.lib()
+    k, w, bits = 15, 1, 24                      # every k-mer start is a modimizer: many distinct keys quickly
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(123)
+    ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
+    sizes = [300, 40_000, 50, 200_000, 7, 600_000, 1000]      # crosses the 2^16-slot start size several times
+    for i, n in enumerate(sizes):
+        b = rng.integers(0, 4, n).astype(np.uint8)
+        offs = np.array([0, n], np.int64)
+        assert mg.add_sequence_batch(ms, b, offs) == oms.add_sequence(b)
+        assert ms.contents.max == oms.max
+        probe = np.concatenate([oh.scan(b)[0][:500], rng.integers(0, 1 << 30, 200).astype(np.uint64)])
+        d_p = mg.DeviceBuffer.from_numpy(probe); d_o = mg.DeviceBuffer(len(probe) * 4)
+        mg.check(L.modsetFindBatchDevice(ms, d_p.ptr, len(probe), d_o.ptr, None))
+        assert np.array_equal(d_o.to_numpy(np.uint32, len(probe)), np.array([oms.find(x) for x in probe], np.uint32)), i
+    assert_same_modset(ms, oms, bits)
+    # clear, then a tiny batch first (atomic path on a table whose buckets are all "never written")
+    mg.check(L.mgModsetClear(ms, None))
+    oms2 = po.Modset(oh, bits)
+    for n in (40, 90_000, 13):
+        b = rng.integers(0, 4, n).astype(np.uint8)
+        assert mg.add_sequence_batch(ms, b, np.array([0, n], np.int64)) == oms2.add_sequence(b)
+    assert_same_modset(ms, oms2, bits)
+
+
+def test_chunked_insert_matches(monkeypatch):
+    """inserts are split into passes of at most MG_ADD_CHUNK modimizers; a tiny chunk size must not change anything"""
+    import subprocess, sys, os
+    code = r"""
+import numpy as np, modimizer_amd as mg
+from oracle import pyoracle as po
+from modimizer_amd import synth
+sh = mg.seqhashCreate(17, 4, 17); oh = po.Hasher(17, 4, 17)
+g = synth.iid_bases(30000, 3)
+st, offs, sd = synth.ont_read_plan(400000, len(g), 4, n50=3000, lo=50, hi=9000)
+b = synth.reads_from_genome(g, st, offs, sd, 0.02, 5)
+ms = mg.modsetCreate(sh, 22); oms = po.Modset(oh, 22)
+n = mg.add_sequence_batch(ms, b, offs.astype(np.int64))
+t = sum(oms.add_sequence(b[int(offs[r]):int(offs[r+1])]) for r in range(len(st)))
+mg.check(mg.lib().modsetSyncToHost(ms, 1))
+v, d, _ = mg.modset_arrays(ms)
+assert n == t and ms.contents.max == oms.max
+assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(d[1:], oms.depths()[1:])
+assert np.array_equal(np.ctypeslib.as_array(ms.contents.index, (1 << 22,)), oms.index_table())
+print("chunked ok", n)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for chunk, path in (("7000", "bucket"), ("5000", "direct"), ("33333", "auto")):
+        env = dict(os.environ, MODGPU_ADD_CHUNK=chunk, MODGPU_TABLE_PATH=path, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "chunked ok" in r.stdout, (chunk, path, r.stderr[-1500:])
