@@ -206,10 +206,14 @@ void orcModsetWriteText (const OrcModset *ms, FILE *f)
 /* modutils.c:19-31: depth is a U16 that is bumped and, on wrap to 0, pinned at 65535. */
 int64_t orcAddSequence (OrcModset *ms, const uint8_t *s, int64_t len)
 {
+  /* per-thread scratch that only grows: a malloc/free pair per read turns into mmap/munmap for
+     long reads and serialises threads on the kernel's mm lock */
+  static __thread uint64_t *km = 0;
+  static __thread int64_t kmCap = 0;
   const OrcHasher *h = &ms->hasher;
   if (len < h->k) return 0;
   int64_t cap = len - h->k + 1;
-  uint64_t *km = (uint64_t *) malloc ((size_t) cap * sizeof (uint64_t));
+  if (cap > kmCap) { free (km); kmCap = cap + cap / 2; km = (uint64_t *) malloc ((size_t) kmCap * sizeof (uint64_t)); }
   int64_t n = orcScanRead (h, s, len, km, 0, 0, cap);
   for (int64_t i = 0 ; i < n ; ++i)
     { uint32_t ix = orcModsetFind (ms, km[i], 1);
@@ -217,7 +221,6 @@ int64_t orcAddSequence (OrcModset *ms, const uint8_t *s, int64_t len)
       uint16_t d = (uint16_t) (ms->depth[ix] + 1);
       ms->depth[ix] = d ? d : 0xffff;
     }
-  free (km);
   return n;
 }
 
