@@ -139,6 +139,8 @@ size_t   mgPackedWords (U64 nBases) ;
 void     mgPackHost (const char *bases, U64 nBases, U32 *words) ;
 MgStatus mgPackDevice (const U8 *dBases, U64 nBases, U32 *dWords, void *stream) ;
 MgStatus mgUnpackDevice (const U32 *dWords, U64 nBases, U8 *dBases, void *stream) ;
+/* host bytes -> packed words in HBM (dPacked: mgPackedWords(n) words): PCIe copy in pieces + K1 on the device */
+MgStatus mgUploadPack (const char *bases, U64 nBases, U32 *dPacked, void *stream) ;
 
 /* Scan (seqhash.c:154-196 over a whole batch).
  * dPacked: the batch, reads concatenated without padding; dReadOffsets[nReads+1]: start of each

@@ -48,7 +48,7 @@ EXPORTS = [
     "modsetPack", "modsetDepthPrune", "modsetMerge",
     "mgLastError", "mgDeviceCount", "mgSetDevice", "mgVersion", "mgDeviceAlloc", "mgDeviceFree",
     "mgMemcpyH2D", "mgMemcpyD2H", "mgMemsetD", "mgStreamSynchronize",
-    "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice",
+    "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice", "mgUploadPack",
     "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch",
     "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgModsetDeviceRelease",
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
@@ -112,7 +112,7 @@ def lib():
     sig("mgMemcpyH2D", i32, vp, vp, C.c_size_t, vp); sig("mgMemcpyD2H", i32, vp, vp, C.c_size_t, vp)
     sig("mgMemsetD", i32, vp, i32, C.c_size_t, vp); sig("mgStreamSynchronize", i32, vp)
     sig("mgPackedWords", C.c_size_t, u64); sig("mgPackHost", None, vp, u64, vp)
-    sig("mgPackDevice", i32, vp, u64, vp, vp); sig("mgUnpackDevice", i32, vp, u64, vp, vp)
+    sig("mgUploadPack", i32, vp, u64, vp, vp); sig("mgPackDevice", i32, vp, u64, vp, vp); sig("mgUnpackDevice", i32, vp, u64, vp, vp)
     sig("mgScanWorkBytes", C.c_size_t, u64, u32, u64)
     sig("seqhashScanBatchDevice", i32, SH, vp, u64, vp, u32, vp, vp, vp, u64, vp, vp, vp)
     sig("seqhashScanBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))

@@ -211,6 +211,34 @@ static U64 mgSurvivorGuess (const Seqhash *sh, U64 totalBases)
   return g < totalBases ? g : totalBases;
 }
 
+/* Host bytes (one base per byte) -> 2-bit packed words in HBM: the bytes cross PCIe as they are, in
+ * pieces through two device staging buffers, and K1 packs them on the device (a single host thread
+ * packs at only ~3.6 GB/s, far below the link). */
+extern "C" MgStatus mgUploadPack (const char *bases, U64 nBases, U32 *dPacked, void *stream)
+{
+  MgStatus s = mgEnsureDevice (); if (s) return s;
+  hipStream_t st = (hipStream_t) stream;
+  if (!nBases) { MG_HIP (hipMemsetAsync (dPacked, 0, mgPackedWords (0) * 4, st)); return MG_OK; }
+  const U64 piece = (U64) 64 << 20;                      /* bases per piece, a multiple of 16 */
+  U8 *dStage[2] = { 0, 0 };
+  const U64 stageBytes = nBases < piece ? ((nBases + 15) & ~(U64) 15) : piece;
+  MG_HIP (hipMalloc ((void **) &dStage[0], stageBytes));
+  if (nBases > piece) MG_HIP (hipMalloc ((void **) &dStage[1], stageBytes));
+  hipEvent_t done[2]; MG_HIP (hipEventCreate (&done[0])); MG_HIP (hipEventCreate (&done[1]));
+  int i = 0;
+  for (U64 off = 0 ; off < nBases && !s ; off += piece, i ^= 1)
+    { U64 len = nBases - off < piece ? nBases - off : piece;
+      if (off >= 2 * piece) MG_HIP (hipEventSynchronize (done[i]));       /* the pack that last read this stage */
+      MG_HIP (hipMemcpyAsync (dStage[i], bases + off, len, hipMemcpyHostToDevice, st));
+      s = mgLaunchPack (dStage[i], len, dPacked + off / 16, st);           /* also zeroes the pad words after the piece */
+      MG_HIP (hipEventRecord (done[i], st));
+    }
+  MG_HIP (hipStreamSynchronize (st));
+  (void) hipEventDestroy (done[0]); (void) hipEventDestroy (done[1]);
+  (void) hipFree (dStage[0]); if (dStage[1]) (void) hipFree (dStage[1]);
+  return s;
+}
+
 extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
                                      U64 **kmerOut, int **posOut, bool **isFOut, int64_t **survStartOut)
 {
@@ -219,8 +247,6 @@ extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const
     { mgSetError ("seqhashScanBatch: bad read offsets"); return -1; }
   U64 total = nReads ? (U64) readOffsets[nReads] : 0;
   size_t nw = mgPackedWords (total);
-  U32 *hPacked = (U32 *) malloc (nw * sizeof (U32));
-  mgPackHost (bases, total, hPacked);
   U64 cap = mgSurvivorGuess (sh, total);
   MgArena ar;
   int64_t result = -1;
@@ -237,7 +263,7 @@ extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const
       U32 *dRid = (U32 *) ar.take (cap * 4);
       void *dWork = ar.take (mgScanWorkBytes (total, (U32) nReads, cap));
       U64 *dCount = (U64 *) ar.take (8 * MG_COUNT_WORDS);
-      if (hipMemcpy (dP, hPacked, nw * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+      if (mgUploadPack (bases, total, dP, 0)) break;
       if (nReads && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
       if (seqhashScanBatchDevice (sh, dP, total, dOff, (U32) nReads, dK, dPos, dRid, cap, dCount, dWork, 0)) break;
       U64 cnt[MG_COUNT_WORDS];
@@ -254,7 +280,6 @@ extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const
       break;
     }
   ar.release ();
-  free (hPacked);
   if (result < 0)
     { if (!gErr[0]) mgSetError ("seqhashScanBatch: device failure");
       free (hK); free (hP); free (hR); return -1;
@@ -630,12 +655,10 @@ extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int6
   if (nReads <= 0) return 0;
   U64 total = (U64) readOffsets[nReads];
   size_t nw = mgPackedWords (total);
-  U32 *hPacked = (U32 *) malloc (nw * sizeof (U32));
-  mgPackHost (bases, total, hPacked);
   U32 *dP = 0; U64 *dOff = 0;
   int64_t res = -1;
   if (hipMalloc ((void **) &dP, nw * 4) == hipSuccess && hipMalloc ((void **) &dOff, ((size_t) nReads + 1) * 8) == hipSuccess
-      && hipMemcpy (dP, hPacked, nw * 4, hipMemcpyHostToDevice) == hipSuccess
+      && mgUploadPack (bases, total, dP, 0) == MG_OK
       && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess)
     { U64 nHash = 0;
       if (mgAddReadsDevice (ms, dP, total, dOff, (U32) nReads, &nHash, 0) == MG_OK) res = (int64_t) nHash;
@@ -643,7 +666,6 @@ extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int6
   else mgSetError ("mgAddSequenceBatch: device allocation or copy failed");
   if (dP) (void) hipFree (dP);
   if (dOff) (void) hipFree (dOff);
-  free (hPacked);
   return res;
 }
 

@@ -21,12 +21,9 @@ static void batchUpload (DevBatch *b, const char *bases, const int64_t *offsets,
   b->nReads = (U32) nReads;
   b->total = nReads ? (U64) offsets[nReads] : 0;
   size_t nw = mgPackedWords (b->total);
-  U32 *h = (U32 *) malloc (nw * sizeof (U32));
-  mgPackHost (bases, b->total, h);
   if (mgDeviceAlloc (&b->dPacked, nw * 4) || mgDeviceAlloc (&b->dOff, ((size_t) nReads + 1) * 8)) fatal ("device alloc");
-  if (mgMemcpyH2D (b->dPacked, h, nw * 4, 0) || mgMemcpyH2D (b->dOff, offsets, ((size_t) nReads + 1) * 8, 0)
+  if (mgUploadPack (bases, b->total, (U32 *) b->dPacked, 0) || mgMemcpyH2D (b->dOff, offsets, ((size_t) nReads + 1) * 8, 0)
       || mgStreamSynchronize (0)) fatal ("H2D");
-  free (h);
 }
 
 static void batchFree (DevBatch *b) { mgDeviceFree (b->dPacked); mgDeviceFree (b->dOff); }
