@@ -112,6 +112,15 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
                        U64 *dCount, void *dWork, hipStream_t st);
 
+U64      mgScanTiles (U64 totalBases);
+size_t   mgScanInfoBytes (U64 totalBases);
+MgStatus mgScanPrepare (const U64 *dReadOffsets, U32 nReads, U64 totalBases, void *dInfo, hipStream_t st);
+size_t   mgScanRangeWorkBytes (U64 nTilesRange, U64 capacity);
+MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
+                            const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
+                            U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
+                            U64 *dCount, void *dWork, hipStream_t st);
+
 /* device modset table: NB = 2^log2NB buckets of R slots; see mg_table.hip */
 struct MgSlot { U64 key; U32 ord; U32 cnt; };      /* 16 bytes; key = kmer+1, 0 = empty */
 struct MgTable {

@@ -116,7 +116,8 @@ struct MgScanArgs {
   MgHashParams p;
   const U32 *packed; U64 nWordsAlloc; U64 totalBases;
   const U64 *readOff; U32 nReads;
-  const MgTileInfo *tileInfo; U64 nTiles;
+  const MgTileInfo *tileInfo;
+  U64 tileBegin, tileLimit;      /* this launch covers tiles [tileBegin, tileLimit) */
   U64 tilesPerBlock;     /* block b owns tiles [b*tilesPerBlock, (b+1)*tilesPerBlock) */
   U64 segCap;            /* entries per output segment */
   U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [gridDim.x * segCap] */
@@ -222,8 +223,8 @@ void mgScanKernel (const MgScanArgs a)
   const U64 f1 = p.factor1;
   const U64 dMask = (U64) (p.d - 1);
 
-  U64 tile = (U64) blockIdx.x * a.tilesPerBlock;
-  U64 tileEnd = tile + a.tilesPerBlock; if (tileEnd > a.nTiles) tileEnd = a.nTiles;
+  U64 tile = a.tileBegin + (U64) blockIdx.x * a.tilesPerBlock;
+  U64 tileEnd = tile + a.tilesPerBlock; if (tileEnd > a.tileLimit) tileEnd = a.tileLimit;
   const U64 segBase = (U64) blockIdx.x * a.segCap;
   U64 found = 0;                                   /* modimizers this block has found so far (uniform) */
   uint4 curV = make_uint4 (0, 0, 0, 0); U32 curHalo = 0;
@@ -498,10 +499,10 @@ static inline U64 mgNumTiles (U64 totalBases) { return (totalBases + MG_TILE_BAS
 struct MgScanGeom { U64 nTiles, tilesPerBlock; U32 nBlocks; U64 segCap; };
 #define MG_SCAN_MAX_BLOCKS 2048
 
-static MgScanGeom mgScanGeometry (U64 totalBases, U64 capacity)
+static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
 {
   MgScanGeom g;
-  g.nTiles = mgNumTiles (totalBases);
+  g.nTiles = nTiles;
   U64 want = g.nTiles < MG_SCAN_MAX_BLOCKS ? g.nTiles : MG_SCAN_MAX_BLOCKS;
   if (!want) want = 1;
   g.tilesPerBlock = (g.nTiles + want - 1) / want; if (!g.tilesPerBlock) g.tilesPerBlock = 1;
@@ -514,40 +515,57 @@ static MgScanGeom mgScanGeometry (U64 totalBases, U64 capacity)
   return g;
 }
 
-/* work buffer layout (all 256-byte aligned):
- *   blockCount[G] | segStart[G] | tileInfo[nTiles+1] | segKmer[G*segCap] | segPosF[..] | segRead[..] */
 static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
+
+U64 mgScanTiles (U64 totalBases) { return mgNumTiles (totalBases); }
+size_t mgScanInfoBytes (U64 totalBases) { return mgAl ((mgNumTiles (totalBases) + 2) * sizeof (MgTileInfo)); }
+
+/* per-tile read metadata for a whole batch (shared by every range launch over it) */
+MgStatus mgScanPrepare (const U64 *dReadOffsets, U32 nReads, U64 totalBases, void *dInfo, hipStream_t st)
+{
+  U64 nTiles = mgNumTiles (totalBases);
+  if (!nTiles || !nReads) return MG_OK;
+  MG_LAUNCH (MG_K_TILE_FIRST_READ, st, mgTileInfoKernel, dim3 ((unsigned) ((nTiles + 1 + 255) / 256)), dim3 (256), 0, st,
+             dReadOffsets, nReads, nTiles, totalBases, (MgTileInfo *) dInfo);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+/* range work buffer (all 256-byte aligned): blockCount[G] | segStart[G] | segKmer[G*segCap] | segPosF[..] | segRead[..] */
+size_t mgScanRangeWorkBytes (U64 nTilesRange, U64 capacity)
+{
+  MgScanGeom g = mgScanGeometryTiles (nTilesRange, capacity);
+  size_t segN = (size_t) g.nBlocks * g.segCap;
+  return mgAl (g.nBlocks * 8) * 2 + mgAl (segN * 8) + 2 * mgAl (segN * 4) + 256;
+}
+
 size_t mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity)
 {
   (void) nReads;
-  MgScanGeom g = mgScanGeometry (totalBases, capacity);
-  size_t segN = (size_t) g.nBlocks * g.segCap;
-  return mgAl (g.nBlocks * 8) * 2 + mgAl ((g.nTiles + 2) * sizeof (MgTileInfo)) + mgAl (segN * 8) + 2 * mgAl (segN * 4) + 256;
+  return mgScanRangeWorkBytes (mgNumTiles (totalBases), capacity) + mgScanInfoBytes (totalBases);
 }
 
-MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
-                       const U64 *dReadOffsets, U32 nReads,
-                       U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                       U64 *dCount, void *dWork, hipStream_t st)
+/* scan tiles [tile0, tile1) of the batch: the modimizers of those k-mer starts, dense and in order */
+MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
+                            const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
+                            U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
+                            U64 *dCount, void *dWork, hipStream_t st)
 {
   MG_HIP (hipMemsetAsync (dCount, 0, 4 * sizeof (U64), st));
-  MgScanGeom g = mgScanGeometry (totalBases, capacity);
-  if (!g.nTiles || !nReads) return MG_OK;
+  if (tile1 <= tile0 || !nReads) return MG_OK;
+  MgScanGeom g = mgScanGeometryTiles (tile1 - tile0, capacity);
   char *wb = (char *) dWork;
   size_t segN = (size_t) g.nBlocks * g.segCap;
   U64 *blockCount = (U64 *) wb;                  wb += mgAl (g.nBlocks * 8);
   U64 *segStart = (U64 *) wb;                    wb += mgAl (g.nBlocks * 8);
-  MgTileInfo *info = (MgTileInfo *) wb;          wb += mgAl ((g.nTiles + 2) * sizeof (MgTileInfo));
   U64 *segKmer = (U64 *) wb;                     wb += mgAl (segN * 8);
   U32 *segPosF = (U32 *) wb;                     wb += mgAl (segN * 4);
   U32 *segRead = (U32 *) wb;
-  MG_LAUNCH (MG_K_TILE_FIRST_READ, st, mgTileInfoKernel, dim3 ((unsigned) ((g.nTiles + 1 + 255) / 256)), dim3 (256), 0, st,
-             dReadOffsets, nReads, g.nTiles, totalBases, info);
-  MG_HIP (hipGetLastError ());
 
   MgScanArgs a;
   a.p = p; a.packed = dPacked; a.nWordsAlloc = (U64) mgPackedWords (totalBases); a.totalBases = totalBases;
-  a.readOff = dReadOffsets; a.nReads = nReads; a.tileInfo = info; a.nTiles = g.nTiles;
+  a.readOff = dReadOffsets; a.nReads = nReads; a.tileInfo = (const MgTileInfo *) dInfo;
+  a.tileBegin = tile0; a.tileLimit = tile1;
   a.tilesPerBlock = g.tilesPerBlock; a.segCap = g.segCap;
   a.segKmer = segKmer; a.segPosF = dPosF ? segPosF : 0; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
   a.fS = 0; a.thresh = 0;
@@ -573,4 +591,16 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
              segKmer, a.segPosF, a.segRead, g.segCap, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount);
   MG_HIP (hipGetLastError ());
   return MG_OK;
+}
+
+MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
+                       const U64 *dReadOffsets, U32 nReads,
+                       U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
+                       U64 *dCount, void *dWork, hipStream_t st)
+{
+  const U64 nTiles = mgNumTiles (totalBases);
+  char *info = (char *) dWork + mgScanRangeWorkBytes (nTiles, capacity);
+  MgStatus s = mgScanPrepare (dReadOffsets, nReads, totalBases, info, st); if (s) return s;
+  return mgLaunchScanRange (p, dPacked, totalBases, dReadOffsets, nReads, info, 0, nTiles,
+                            dKmer, dPosF, dReadId, capacity, dCount, dWork, st);
 }
