@@ -347,3 +347,23 @@ print("chunked ok", n)
         env = dict(os.environ, MODGPU_ADD_CHUNK=chunk, MODGPU_TABLE_PATH=path, PYTHONPATH=root)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "chunked ok" in r.stdout, (chunk, path, r.stderr[-1500:])
+
+
+def test_large_table_bits_geometry():
+    """table bits 31/32 (the device limit): the device table is sized by content, so this is cheap"""
+    L = mg.lib()
+    sh = mg.seqhashCreate(21, 16, 17); oh = po.Hasher(21, 16, 17)
+    b = synth_batch(400_000, 30_000, 77)
+    for bits in (31, 32):
+        ms = mg.modsetCreate(sh, bits)
+        n = mg.add_sequence_batch(ms, *b)
+        oms = po.Modset(oh, 24)
+        t = sum(oms.add_sequence(b[0][b[1][r]:b[1][r + 1]]) for r in range(len(b[1]) - 1))
+        assert n == t and ms.contents.max == oms.max
+        mg.check(L.modsetSyncToHost(ms, 0))
+        v, d, _ = mg.modset_arrays(ms)
+        assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(d[1:], oms.depths()[1:])
+        L.modsetDestroy(ms)
+    with pytest.raises(mg.ModgpuError, match="table bits 20..32"):
+        ms = mg.modsetCreate(sh, 33)
+        mg.add_sequence_batch(ms, *b)

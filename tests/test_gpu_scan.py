@@ -241,3 +241,15 @@ def test_full_size_properties():
         for b in (d_k, d_p, d_id, d_r):
             b.free()
         assert full[1] > 0
+
+
+def test_upload_pack_multi_piece():
+    """mgUploadPack: host bytes -> HBM in 64 Mbase pieces, packed on the device == mgPackHost"""
+    L = mg.lib()
+    rng = np.random.default_rng(17)
+    for n in (0, 1, 17, (64 << 20) - 3, (64 << 20) + 5, 150_000_001):
+        b = rng.integers(0, 4, n, dtype=np.uint8)
+        d_w = mg.DeviceBuffer(L.mgPackedWords(n) * 4)
+        mg.check(L.mgUploadPack(b.ctypes.data, n, d_w.ptr, None))
+        got = d_w.to_numpy(np.uint32, L.mgPackedWords(n))
+        assert np.array_equal(got, mg.pack_host(b)), n
