@@ -677,7 +677,8 @@ static inline U64 mgRankRowsPerUnit (U64 n, U32 *nBlocks)
 /* scratch needed by mgTableAdd for a batch of n */
 size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
 {
-  U64 NB = (U64) 1 << t->log2NB;
+  (void) t;
+  U64 NB = (U64) 1 << 18;               /* the largest bucket count: the table may grow between passes of one call */
   size_t rank = mgAl (n) /*flags*/ + 2 * mgAl ((MG_RANK_UNITS + 8) * 8) + mgAl ((n / 64 + 2) * sizeof (MgRankGrp));
   size_t direct = mgAl (n * 4);
   size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
