@@ -426,6 +426,105 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
   return MG_OK;
 }
 
+/* device forms of the whole-set passes, used when the modset lives on the device ------------- */
+static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
+                            bool arenaLive, hipStream_t st);
+
+/* fold the pending device counts into baseDepth (afterwards baseDepth[i] IS depth[i]) */
+static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
+{
+  MgTable &t = d->t;
+  if (!t.max) return MG_OK;
+  U16 *dDelta; MG_HIP (hipMalloc ((void **) &dDelta, (size_t) t.max * sizeof (U16)));
+  MgStatus s = mgTableExportDepth (&t, dDelta, st);
+  MG_HIP (hipStreamSynchronize (st));
+  (void) hipFree (dDelta);
+  return s;
+}
+
+/* modset.c:106-128 with ms1 on the device.  The caller (mg_host.c) has checked the hashers and
+ * regrown ms1's host arrays; ms2's host arrays are current.  Returns 0 on success. */
+extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
+{
+  hipStream_t st = 0;
+  MgDev *d; if (mgDevGet (ms1, &d, st)) return -1;
+  MgTable &t = d->t;
+  const U32 n2 = ms2->max, max1 = t.max;
+  if (mgFoldCounts (d, st)) return -1;
+  if (!n2) return 0;
+  U64 *dV2 = 0; U16 *dD2 = 0; U8 *dI2 = 0, *dI1 = 0; U32 *dIdx = 0;
+  int rc = -1;
+  const size_t cap1 = (size_t) max1 + n2 + 2;
+  do {
+    if (hipMalloc ((void **) &dV2, (size_t) n2 * 8) || hipMalloc ((void **) &dD2, (size_t) n2 * 2) || hipMalloc ((void **) &dI2, n2)
+        || hipMalloc ((void **) &dI1, cap1) || hipMalloc ((void **) &dIdx, (size_t) n2 * 4)) break;
+    if (hipMemcpy (dV2, ms2->value + 1, (size_t) n2 * 8, hipMemcpyHostToDevice) || hipMemcpy (dD2, ms2->depth + 1, (size_t) n2 * 2, hipMemcpyHostToDevice)
+        || hipMemcpy (dI2, ms2->info + 1, n2, hipMemcpyHostToDevice) || hipMemset (dI1, 0, cap1)
+        || hipMemcpy (dI1, ms1->info, (size_t) max1 + 1, hipMemcpyHostToDevice)) break;
+    /* ms2's values in ms2 index order: existing ones are found, new ones get max1+1, max1+2, ... (modset.c:120) */
+    MgStatus as = mgAddBatch (ms1, d, dV2, n2, dIdx, 0, false, st);
+    if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }
+    if (as) break;
+    if (mgTableMergeApply (dIdx, dD2, dI2, n2, t.baseDepth, dI1, st)) break;
+    if (hipStreamSynchronize (st)) break;
+    /* bring the host mirror up to date wholesale: values of the new entries, all depths and info */
+    if (t.max > t.syncedMax)
+      { if (hipMemcpy (ms1->value + t.syncedMax + 1, t.value + t.syncedMax + 1, (size_t) (t.max - t.syncedMax) * 8, hipMemcpyDeviceToHost)) break;
+        t.syncedMax = t.max;
+      }
+    if (hipMemcpy (ms1->depth, t.baseDepth, ((size_t) t.max + 1) * 2, hipMemcpyDeviceToHost)) break;
+    if (hipMemcpy (ms1->info, dI1, (size_t) t.max + 1, hipMemcpyDeviceToHost)) break;
+    ms1->depth[0] = 0;
+    ms1->max = t.max;
+    rc = 0;
+  } while (0);
+  if (rc && !gErr[0]) mgSetError ("device merge failed");
+  (void) hipFree (dV2); (void) hipFree (dD2); (void) hipFree (dI2); (void) hipFree (dI1); (void) hipFree (dIdx);
+  return rc;
+}
+
+/* modset.c:64-77 with ms on the device: survivors keep their order, the table is rebuilt from them */
+extern "C" int mgHookPruneDevice (Modset *ms, int lo, int hi)
+{
+  hipStream_t st = 0;
+  MgDev *d; if (mgDevGet (ms, &d, st)) return -1;
+  MgTable &t = d->t;
+  const U32 n = t.max;
+  if (mgFoldCounts (d, st)) return -1;
+  /* values of device-only entries must reach the host before the arrays are rewritten?  No: the
+     survivors are compacted on the device and copied back as a whole. */
+  U8 *dInfo = 0, *dNewInfo = 0; U64 *dNewValue = 0; U16 *dNewDepth = 0; void *scratch = 0;
+  int rc = -1;
+  do {
+    if (hipMalloc ((void **) &dInfo, (size_t) n + 1) || hipMalloc ((void **) &dNewInfo, (size_t) n + 2) || hipMalloc ((void **) &dNewValue, ((size_t) n + 2) * 8)
+        || hipMalloc ((void **) &dNewDepth, ((size_t) n + 2) * 2) || hipMalloc (&scratch, mgTablePruneScratchBytes (n ? n : 1))) break;
+    if (hipMemcpy (dInfo, ms->info, (size_t) n + 1, hipMemcpyHostToDevice)) break;
+    if (mgTablePrune (&t, dInfo, lo, hi, dNewValue, dNewDepth, dNewInfo, scratch, st)) break;
+    U64 c[2];
+    if (hipMemcpyAsync (c, t.counters, 16, hipMemcpyDeviceToHost, st) || hipStreamSynchronize (st)) break;
+    const U32 m = (U32) c[0];
+    /* new arrays replace the old ones on both sides */
+    if (m)
+      { if (hipMemcpy (t.value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToDevice) || hipMemcpy (t.baseDepth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToDevice)
+            || hipMemcpy (ms->value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToHost) || hipMemcpy (ms->depth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToHost)
+            || hipMemcpy (ms->info + 1, dNewInfo + 1, m, hipMemcpyDeviceToHost)) break;
+      }
+    if (n > m && hipMemset (t.baseDepth + m + 1, 0, (size_t) (n - m) * 2)) break;
+    mgTableForget (&t, st);
+    t.max = 0;
+    if (mgTableEnsure (&t, m, st)) break;
+    if (m && mgTableLoadHost (&t, t.value, 1, m, st)) break;
+    if (hipStreamSynchronize (st)) break;
+    t.max = t.syncedMax = m;
+    ms->max = m;
+    d->hostIndexMax = 0;                 /* index[] is rebuilt (replayed) when somebody needs it */
+    rc = 0;
+  } while (0);
+  if (rc && !gErr[0]) mgSetError ("device prune failed");
+  (void) hipFree (dInfo); (void) hipFree (dNewInfo); (void) hipFree (dNewValue); (void) hipFree (dNewDepth); (void) hipFree (scratch);
+  return rc;
+}
+
 /* hooks for mg_host.c */
 extern "C" void mgHookDestroy (Modset *ms) { mgModsetHostChanged (ms); }
 extern "C" void mgHookHostRewrote (Modset *ms) { mgModsetHostChanged (ms); }

@@ -150,6 +150,10 @@ MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hi
 MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st);
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st);
 MgStatus mgTableReplayIndex (MgTable *t, const MgHashParams &p, int tableBits, U32 *dIndex, hipStream_t st);
+MgStatus mgTableMergeApply (const U32 *dIdx, const U16 *dDepth2, const U8 *dInfo2, U32 n2, U16 *dBaseDepth, U8 *dInfo1, hipStream_t st);
+size_t   mgTablePruneScratchBytes (U32 n);
+MgStatus mgTablePrune (MgTable *t, const U8 *dInfo, int lo, int hi, U64 *dNewValue, U16 *dNewDepth, U8 *dNewInfo,
+                       void *scratch, hipStream_t st);
 #define MG_COUNT_WORDS 4      /* dCount: {count, overflow flag, fullest block, capacity to retry with} */
 
 MgStatus mgLaunchSynthGenome (U32 *dPacked, U64 nBases, U64 seed, hipStream_t st);

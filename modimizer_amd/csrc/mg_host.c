@@ -276,7 +276,13 @@ U32 modsetIndexFind (Modset *ms, U64 kmer, int isAdd)
 
 void modsetDepthPrune (Modset *ms, int min, int max)
 {
-  if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 0);
+  if (mgLiveDeviceModsets && mgHookHasDevice (ms))
+    { /* the set lives on the device: compact it there (same survivors, same order, same renumbering) */
+      U32 before = ms->max;
+      if (mgHookPruneDevice (ms, min, max)) die ("modsetDepthPrune on the device failed: %s", mgLastError ());
+      fprintf (stderr, "  pruned Modset from %d to %d with min %d <= depth < max %d\n", before, ms->max, min, max);
+      return;
+    }
   U32 n = ms->max;
   ms->max = 0;
   memset (ms->index, 0, ms->tableSize * sizeof (U32));
@@ -326,10 +332,15 @@ bool modsetMerge (Modset *ms1, Modset *ms2)
 {
   Seqhash *a = ms1->hasher, *b = ms2->hasher;
   if (a->w != b->w || a->k != b->k || a->factor1 != b->factor1) return false;
-  if (mgLiveDeviceModsets) { mgHookNeedHostAll (ms1, 1); mgHookNeedHostAll (ms2, 0); }
+  const bool onDevice = mgLiveDeviceModsets && mgHookHasDevice (ms1);
+  if (mgLiveDeviceModsets) { mgHookNeedHostAll (ms1, onDevice ? 0 : 1); mgHookNeedHostAll (ms2, 0); }
   U64 want = (U64) ms1->max + ms2->max + 1;
   if (want >= (ms1->tableSize >> 2)) want = (ms1->tableSize >> 2) - 1;
   regrow (ms1, (U32) want);
+  if (onDevice)
+    { if (mgHookMergeDevice (ms1, ms2)) die ("modsetMerge on the device failed: %s", mgLastError ());
+      return true;
+    }
   for (U32 i = 1 ; i <= ms2->max ; ++i)
     { U32 j = hostFind (ms1, ms2->value[i], 1);
       U32 d = (U32) ms1->depth[j] + ms2->depth[i];

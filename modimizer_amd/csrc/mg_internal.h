@@ -12,6 +12,8 @@ void mgHookHostRewrote (Modset *ms);               /* host arrays were rebuilt: 
 void mgHookNeedHost (Modset *ms, int wantIndex);   /* make value[] (and index[]) current; cheap when they are */
 void mgHookNeedHostAll (Modset *ms, int wantIndex);/* also fold pending device depth counts into depth[] */
 int  mgHookHasDevice (Modset *ms);
+int  mgHookMergeDevice (Modset *ms1, Modset *ms2);   /* modsetMerge with ms1 on the device; 0 = done */
+int  mgHookPruneDevice (Modset *ms, int lo, int hi);  /* modsetDepthPrune on the device; 0 = done */
 /* one GPU scan of one read for the iterator facade: *rec = malloc()ed {U64 kmer[n]; U32 posF[n]} */
 int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
 #ifdef __cplusplus

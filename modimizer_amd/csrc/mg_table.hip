@@ -985,3 +985,86 @@ MgStatus mgTableEnsure (MgTable *t, U64 nIncoming, hipStream_t st)
   MG_HIP (hipFree (oldSlots)); MG_HIP (hipFree (oldOcc));
   return MG_OK;
 }
+
+/* ======================================================================================== */
+/* whole-set passes on the device: merge (modset.c:106-128) and depth prune (modset.c:64-77)  */
+
+/* after ms2's values were inserted (idx[i] = their index in ms1): depth adds saturate at 65535;
+ * copy bits add and saturate at 3 while the entry's other info bits are cleared (modset.c:120-126) */
+__global__ void mgMergeApplyKernel (const U32 *__restrict__ idx, const U16 *__restrict__ depth2, const U8 *__restrict__ info2,
+                                    U32 n2, U16 *__restrict__ baseDepth, U8 *__restrict__ info1)
+{
+  U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for ( ; i < n2 ; i += stride)
+    { U32 j = idx[i];
+      if (!j) continue;
+      U32 d = (U32) baseDepth[j] + depth2[i];
+      baseDepth[j] = (U16) (d > 0xffffu ? 0xffffu : d);
+      U32 a = info1[j] & 3, c = a + (info2[i] & 3);
+      if (c > 3) c = 3;
+      info1[j] = (U8) (a | c);
+    }
+}
+
+/* keep[i-1] = 1 when entry i survives the prune */
+__global__ void mgPruneFlagKernel (const U16 *__restrict__ depth, U32 n, int lo, int hi, unsigned char *__restrict__ keep)
+{
+  U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for ( ; i < n ; i += stride)
+    { int d = depth[i + 1];
+      keep[i] = (d >= lo && (!hi || d < hi)) ? 1 : 0;
+    }
+}
+
+/* depth/info of the survivors move to their new index (rank structure from mgRankAssignKernel<false>) */
+__global__ void mgPruneMoveKernel (const unsigned char *__restrict__ keep, const MgRankGrp *__restrict__ grp, U32 n,
+                                   const U16 *__restrict__ depth, const U8 *__restrict__ info,
+                                   U16 *__restrict__ newDepth, U8 *__restrict__ newInfo)
+{
+  U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for ( ; i < n ; i += stride)
+    { if (!keep[i]) continue;
+      MgRankGrp g = grp[i >> 6];
+      U32 r = 1 + g.rank + (U32) __popcll (g.bits & (((U64) 1 << (i & 63)) - 1));
+      newDepth[r] = depth[i + 1]; newInfo[r] = info[i + 1];
+    }
+}
+
+MgStatus mgTableMergeApply (const U32 *dIdx, const U16 *dDepth2, const U8 *dInfo2, U32 n2, U16 *dBaseDepth, U8 *dInfo1, hipStream_t st)
+{
+  if (!n2) return MG_OK;
+  MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgMergeApplyKernel, dim3 (mgGrid (n2)), dim3 (256), 0, st, dIdx, dDepth2, dInfo2, n2, dBaseDepth, dInfo1);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+size_t mgTablePruneScratchBytes (U32 n)
+{ return mgAl (n) + 2 * mgAl ((MG_RANK_UNITS + 8) * 8) + mgAl (((U64) n / 64 + 2) * sizeof (MgRankGrp)) + 4096; }
+
+/* survivors of (lo <= depth < hi) keep their relative order: newValue/newDepth/newInfo[1..*]; counters[0] = how many */
+MgStatus mgTablePrune (MgTable *t, const U8 *dInfo, int lo, int hi, U64 *dNewValue, U16 *dNewDepth, U8 *dNewInfo,
+                       void *scratch, hipStream_t st)
+{
+  const U32 n = t->max;
+  MG_HIP (hipMemsetAsync (t->counters, 0, 16, st));
+  if (!n) return MG_OK;
+  char *wb = (char *) scratch;
+  unsigned char *keep = (unsigned char *) wb;        wb += mgAl (n);
+  U64 *unitCount = (U64 *) wb;                       wb += mgAl ((MG_RANK_UNITS + 8) * 8);
+  U64 *unitBase = (U64 *) wb;                        wb += mgAl ((MG_RANK_UNITS + 8) * 8);
+  MgRankGrp *grp = (MgRankGrp *) wb;
+  U32 nBlocks; U64 rows = mgRankRowsPerUnit (n, &nBlocks);
+  MG_HIP (hipMemsetAsync (unitCount, 0, (MG_RANK_UNITS + 8) * 8, st));
+  MG_LAUNCH (MG_K_TABLE_FLAG, st, mgPruneFlagKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->baseDepth, n, lo, hi, keep);
+  MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nBlocks), dim3 (256), 0, st, keep, (U64) n, rows, unitCount);
+  MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, unitCount, nBlocks * 4, unitBase, t->counters);
+  /* value[i+1] of survivor i -> newValue[1 + rank]: the assign kernel with "kmer" = value + 1, base 0 */
+  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nBlocks), dim3 (256), 0, st,
+             keep, t->value + 1, (U64) n, rows, unitBase, 0u, 0xffffffffu, dNewValue, t->slots, (const U32 *) 0, grp);
+  MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgPruneMoveKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, keep, grp, n, t->baseDepth, dInfo, dNewDepth, dNewInfo);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}

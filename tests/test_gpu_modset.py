@@ -367,3 +367,45 @@ def test_large_table_bits_geometry():
     with pytest.raises(mg.ModgpuError, match="table bits 20..32"):
         ms = mg.modsetCreate(sh, 33)
         mg.add_sequence_batch(ms, *b)
+
+
+def test_merge_and_prune_on_device_vs_golden(golden_dir, tmp_path):
+    """modsetMerge / modsetDepthPrune / modsetPack with the sets built and living on the GPU: same
+    values, depths, info bits, index[] layout and summaries as the reference (tests/golden/modset_ops.npz)"""
+    L = mg.lib()
+    g = np.load(os.path.join(util.GOLDEN, "modset_ops.npz"))
+    k, w, seed, B = (int(x) for x in g["params"])
+    sh = mg.seqhashCreate(k, w, seed)
+    a, b = mg.modsetCreate(sh, B), mg.modsetCreate(sh, B)
+    for ms, fn in ((a, "reads.fa"), (b, "reads2.fa")):
+        names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, fn))
+        mg.add_sequence_batch(ms, bases, offs)
+        mg.check(L.modsetSyncToHost(ms, 0))
+    for i in range(1, b.contents.max + 1):
+        b.contents.info[i] = (i % 4) | ((i % 3 == 0) * 8)
+    for i in range(1, a.contents.max + 1):
+        a.contents.info[i] = ((i // 2) % 4) | ((i % 5 == 0) * 16)
+    tmp = str(tmp_path / "s.txt")
+
+    def check(ms, tag):
+        mg.check(L.modsetSyncToHost(ms, 1))
+        v, d, i = mg.modset_arrays(ms)
+        assert np.array_equal(v[1:], g[tag + "_value"][1:]), tag
+        assert np.array_equal(d, g[tag + "_depth"]) and np.array_equal(i, g[tag + "_info"]), tag
+        idx = np.ctypeslib.as_array(ms.contents.index, (1 << B,))
+        nz = np.nonzero(idx)[0]
+        assert np.array_equal(nz.astype(np.uint32), g[tag + "_index_pos"]) and np.array_equal(idx[nz], g[tag + "_index_val"]), tag
+        with mg.CFile(tmp, "w") as f:
+            L.modsetSummary(ms, f)
+        assert open(tmp, "rb").read() == g[tag + "_summary"].tobytes(), tag
+    check(a, "a"); check(b, "b")
+    assert L.modsetMerge(a, b)                      # a lives on the device: merged there
+    check(a, "merged")
+    L.modsetDepthPrune(a, 2, 30)                    # compacted and re-tabled on the device
+    check(a, "pruned")
+    assert L.modsetPack(a) and a.contents.size == int(g["packed_size"][0])
+    # and the device table still answers lookups after all that
+    vals = mg.modset_arrays(a)[0][1:]
+    d_v = mg.DeviceBuffer.from_numpy(vals); d_o = mg.DeviceBuffer(len(vals) * 4)
+    mg.check(L.modsetFindBatchDevice(a, d_v.ptr, len(vals), d_o.ptr, None))
+    assert np.array_equal(d_o.to_numpy(np.uint32, len(vals)), np.arange(1, len(vals) + 1, dtype=np.uint32))
