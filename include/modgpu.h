@@ -222,6 +222,10 @@ MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
                               U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
                               U64 *nSeeds, void *stream) ;
 
+/* modsetMerge (modset.c:106-128) with the second set given as bare arrays, entries at [1..n2]: merging
+ * per-GPU modsets in rank order reproduces the single-stream build exactly. */
+bool mgModsetMergeArrays (Modset *ms1, U64 *value2, U16 *depth2, U8 *info2, U32 n2) ;
+
 /* Host-side batch mirrors of the reference callers' loops. */
 /* modutils.c:19-31 over nReads reads; returns total hashes, -1 on error. ms->max updated. */
 int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads) ;

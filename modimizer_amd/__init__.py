@@ -55,7 +55,7 @@ EXPORTS = [
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
     "mgReferenceRead", "mgQueryProcess",
-    "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
@@ -131,6 +131,7 @@ def lib():
     sig("mgReferenceCreate", vp, MS, u32); sig("mgReferenceDestroy", None, vp)
     sig("mgReferenceRead", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), C.c_bool, vp)
     sig("mgQueryProcess", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), vp)
+    sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetClear", i32, MS, vp)
     sig("mgProfileEnable", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)
     sig("mgProfileGet", i32, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), U64P)

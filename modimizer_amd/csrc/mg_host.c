@@ -353,6 +353,18 @@ bool modsetMerge (Modset *ms1, Modset *ms2)
   return true;
 }
 
+/* modsetMerge where the second set is given as bare arrays (entries 1..n2 at value2[1..n2] etc.):
+ * what a rank receives from its peers when per-GPU modsets are merged in rank order. */
+bool mgModsetMergeArrays (Modset *ms1, U64 *value2, U16 *depth2, U8 *info2, U32 n2)
+{
+  Modset view;
+  memset (&view, 0, sizeof (view));
+  view.hasher = ms1->hasher; view.tableBits = ms1->tableBits; view.size = n2 + 1;
+  view.tableSize = ms1->tableSize; view.tableMask = ms1->tableMask;
+  view.value = value2; view.depth = depth2; view.info = info2; view.max = n2;
+  return modsetMerge (ms1, &view);
+}
+
 void modsetSummary (Modset *ms, FILE *f)
 {
   if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 0);

@@ -25,3 +25,32 @@ def allreduce_histogram(hist_tensor):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(hist_tensor, op=dist.ReduceOp.SUM)
     return hist_tensor
+
+
+def merge_modsets_in_rank_order(ms, lib):
+    """Exact global modset from per-rank modsets built over CONTIGUOUS blocks of reads: every rank's
+    (value, depth, info) arrays are gathered and folded into rank 0's modset in rank order with
+    modsetMerge semantics (modset.c:106-128).  Because the blocks are contiguous, first-occurrence
+    index order and saturated depths equal those of the single-stream build.  Returns on rank 0 the
+    merged Modset* (ms itself); other ranks return None.  Uses only torch.distributed object/tensor
+    collectives, so it runs over RCCL or gloo alike."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if hasattr(lib, "modsetSyncToHost"):
+        lib.modsetSyncToHost(ms, 0)
+    m = ms.contents
+    n = m.max
+    mine = (np.ctypeslib.as_array(m.value, (n + 1,)).copy(), np.ctypeslib.as_array(m.depth, (n + 1,)).copy(),
+            np.ctypeslib.as_array(m.info, (n + 1,)).copy())
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    if rank != 0:
+        return None
+    for r in range(1, world):
+        v, d, i = (np.ascontiguousarray(a) for a in gathered[r])
+        ok = lib.mgModsetMergeArrays(ms, v.ctypes.data, d.ctypes.data, i.ctypes.data, len(v) - 1)
+        if not ok:
+            raise RuntimeError("modsets of different hashers cannot be merged")
+    return ms

@@ -88,3 +88,56 @@ def test_histogram_allreduce_gloo_world2():
         for r in range(len(sub) - 1):
             ms.add_sequence(bases[base + sub[r]:base + sub[r + 1]])
         assert np.array_equal(ms.histogram().astype(np.int64), per_rank[rank])
+
+
+def _merge_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ["MODGPU_NO_TORCH"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import modimizer_amd as mg
+    from oracle import pyoracle as po
+    L = mg.lib()
+    k, d, bits = 21, 16, 20
+    genome = synth.iid_bases(50000, 11)
+    starts, offsets, strands = synth.ont_read_plan(900_000, len(genome), 12, n50=3000, lo=100, hi=15000)
+    bases = synth.reads_from_genome(genome, starts, offsets, strands, 0.02, 13)
+    sub, base, lo, hi = mdist.shard_offsets(offsets.astype(np.int64), world, rank)
+    sh = mg.seqhashCreate(k, d, 17); oh = po.Hasher(k, d, 17)
+    ms = mg.modsetCreate(sh, bits)
+    # this rank's shard, built with the reference-style scalar loop on the host arrays (no GPU here)
+    for r in range(len(sub) - 1):
+        for km in oh.scan(bases[base + sub[r]:base + sub[r + 1]])[0]:
+            ix = L.modsetIndexFind(ms, int(km), 1)
+            dd = (int(ms.contents.depth[ix]) + 1) & 0xffff
+            ms.contents.depth[ix] = dd if dd else 0xffff
+    merged = mdist.merge_modsets_in_rank_order(ms, L)
+    if rank == 0:
+        v, dep, _ = mg.modset_arrays(merged)
+        q.put((v, dep))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_order_merge_equals_single_stream_gloo_world2():
+    """per-rank modsets over contiguous read blocks, merged in rank order (modsetMerge semantics),
+    reproduce the single-stream build bit for bit: same first-occurrence index order, same depths"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    v, dep = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import pyoracle as po
+    genome = synth.iid_bases(50000, 11)
+    starts, offsets, strands = synth.ont_read_plan(900_000, len(genome), 12, n50=3000, lo=100, hi=15000)
+    bases = synth.reads_from_genome(genome, starts, offsets, strands, 0.02, 13)
+    oms = po.Modset(po.Hasher(21, 16, 17), 20)
+    for r in range(len(starts)):
+        oms.add_sequence(bases[int(offsets[r]):int(offsets[r + 1])])
+    assert len(v) - 1 == oms.max
+    assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(dep[1:], oms.depths()[1:])
