@@ -395,7 +395,7 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
 /* Scatter with LDS staging: a sub-chunk of 4096 elements is counting-sorted by bin in LDS, so the
  * elements of one bin leave as one contiguous run written by consecutive lanes (plain scattered
  * 8-byte stores ran at ~22 G/s: 9 ms per 1.5e8 elements for the two passes). */
-#define MG_PART_SUB 4096
+#define MG_PART_SUB 8192
 #define MG_PART_THREADS 1024
 #define MG_PART_PER_THREAD (MG_PART_SUB / MG_PART_THREADS)
 template <bool FIRST>     /* FIRST: input ordinal is the element's position */
