@@ -497,13 +497,18 @@ static inline U64 mgNumTiles (U64 totalBases) { return (totalBases + MG_TILE_BAS
 
 /* Scan geometry: G workgroups, each owning tilesPerBlock consecutive tiles and one output segment. */
 struct MgScanGeom { U64 nTiles, tilesPerBlock; U32 nBlocks; U64 segCap; };
-#define MG_SCAN_MAX_BLOCKS 2048
+#define MG_SCAN_MAX_BLOCKS 12288   /* measured: 2048 -> 4.63 ms, 6144 -> 4.16, 12288 -> 4.07 per 10 Gbp (6 workgroups/CU resident; more, shorter ranges balance the tail) */
 
 static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
 {
   MgScanGeom g;
   g.nTiles = nTiles;
-  U64 want = g.nTiles < MG_SCAN_MAX_BLOCKS ? g.nTiles : MG_SCAN_MAX_BLOCKS;
+  static long maxBlocks = -1;
+  if (maxBlocks < 0)
+    { const char *e = getenv ("MODGPU_SCAN_GRID");           /* dev knob */
+      maxBlocks = e && atol (e) > 0 ? atol (e) : MG_SCAN_MAX_BLOCKS;
+    }
+  U64 want = g.nTiles < (U64) maxBlocks ? g.nTiles : (U64) maxBlocks;
   if (!want) want = 1;
   g.tilesPerBlock = (g.nTiles + want - 1) / want; if (!g.tilesPerBlock) g.tilesPerBlock = 1;
   g.nBlocks = (U32) ((g.nTiles + g.tilesPerBlock - 1) / g.tilesPerBlock); if (!g.nBlocks) g.nBlocks = 1;
