@@ -293,8 +293,11 @@ void mgScanKernel (const MgScanArgs a)
               for (int tt = 0 ; tt < 16 ; ++tt)
                 { U32 xf = __funnelshift_l (f1w, f0, 2 * tt);     /* window, first base on top */
                   U32 xr = __funnelshift_r (r0, r1, 2 * tt);      /* reverse-complemented window */
-                  bool c = (xf * fS < thresh) | (xr * fS < thresh);
-                  acc = (acc << 1) | (c ? 1u : 0u);
+                  U32 hf = xf * fS, hr = xr * fS;
+                  U32 mn = hf < hr ? hf : hr;
+                  /* acc = 2*acc + (mn < thresh): compare into vcc, add-with-carry of acc to itself */
+                  asm ("v_cmp_gt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                       : "+v" (acc) : "s" (thresh), "v" (mn) : "vcc");
                 }
               if (chunk == 1) { candLo = acc; acc = 0; }
             }
