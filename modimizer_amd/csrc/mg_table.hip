@@ -113,6 +113,12 @@ void mgRankCountKernel (const unsigned char *__restrict__ flags, U64 n, U64 rows
   U64 row = unit * rowsPerUnit, rEnd = row + rowsPerUnit;
   if (rEnd > nRows) rEnd = nRows;
   U32 c = 0;
+  for ( ; row + 4 <= rEnd ; row += 4)
+    { U32 v[4];
+#pragma unroll
+      for (int j = 0 ; j < 4 ; ++j) { U64 o = (row + j) * 64 + lane; v[j] = (o < n) ? (flags[o] & 1) : 0; }
+      c += v[0] + v[1] + v[2] + v[3];
+    }
   for ( ; row < rEnd ; ++row) { U64 o = row * 64 + lane; c += (o < n) ? (flags[o] & 1) : 0; }
   for (int off = 32 ; off ; off >>= 1) c += __shfl_xor (c, off);
   if (lane == 0) unitCount[unit] = c;
@@ -143,6 +149,7 @@ void mgRankScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 *__r
 /* pass B: every flagged ordinal o gets index baseMax+1+rank(o); value[index] = kmer[o].
  * DIRECT: also store the index in the slot.  BUCKETED: record, per row of 64 ordinals, the flag
  * bitmap and the number of flags before the row, for the merge kernel's rank(o) lookups. */
+#define MG_RANK_ROWS 8
 template <bool DIRECT>
 __global__ __launch_bounds__ (256)
 void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__restrict__ kmer, U64 n, U64 rowsPerUnit,
@@ -158,20 +165,31 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
   if (row >= rEnd) return;
   U64 run = unitBase[unit];
   const U64 below = ((U64) 1 << lane) - 1;
-  for ( ; row < rEnd ; ++row)
-    { const U64 o = row * 64 + lane;
-      const bool f = (o < n) && (flags[o] & 1);
-      const U64 km = (o < n) ? kmer[o] : 0;
-      const U64 bits = __ballot (f);
-      if (!DIRECT && lane == 0) { MgRankGrp g; g.bits = bits; g.rank = (U32) run; g.pad = 0; grp[row] = g; }
-      if (f)
-        { U64 idx = (U64) baseMax + 1 + run + (U32) __popcll (bits & below);
-          if (idx < size)
-            { value[idx] = km;
-              if (DIRECT) slots[slotId[o]].ord = (U32) idx | MG_ASSIGNED;
-            }
+  /* MG_RANK_ROWS rows per step: the loads of all four are in flight before the first ballot */
+  for ( ; row < rEnd ; row += MG_RANK_ROWS)
+    { bool f[MG_RANK_ROWS]; U64 km[MG_RANK_ROWS];
+#pragma unroll
+      for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
+        { const U64 o = (row + j) * 64 + lane;
+          const bool in = (row + j < rEnd) && (o < n);
+          f[j] = in && (flags[o] & 1);
+          km[j] = in ? kmer[o] : 0;
         }
-      run += (U32) __popcll (bits);
+#pragma unroll
+      for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
+        { if (row + j >= rEnd) break;
+          const U64 o = (row + j) * 64 + lane;
+          const U64 bits = __ballot (f[j]);
+          if (!DIRECT && lane == 0) { MgRankGrp g; g.bits = bits; g.rank = (U32) run; g.pad = 0; grp[row + j] = g; }
+          if (f[j])
+            { U64 idx = (U64) baseMax + 1 + run + (U32) __popcll (bits & below);
+              if (idx < size)
+                { value[idx] = km[j];
+                  if (DIRECT) slots[slotId[o]].ord = (U32) idx | MG_ASSIGNED;
+                }
+            }
+          run += (U32) __popcll (bits);
+        }
     }
 }
 
