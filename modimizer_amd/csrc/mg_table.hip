@@ -501,6 +501,7 @@ struct MgBucketArgs {
   const MgRankGrp *grp; U32 baseMax; U32 size;
   int withDepth;
   U64 *counters;
+  int debug;                       /* dev ablation (MODGPU_BUCKET_DEBUG): 1 = no flag stores, 2 = no rank loads; results are wrong */
 };
 
 extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
@@ -592,7 +593,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (!c) continue;
               U32 at = atomicAdd (&sN, 1u);
               a.pK[lo + at] = k - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
-              if (!mgIsAssigned (ord)) a.flags[0x7fffffffu - ord] = 1;
+              if (!mgIsAssigned (ord) && !(a.debug & 1)) a.flags[0x7fffffffu - ord] = 1;
             }
           __syncthreads ();
           if (tid == 0) { a.uniqCount[b] = sN; sN = 0; }
@@ -632,7 +633,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
         { /* the rank record of this lane's first unique: in flight while the bucket image is set up */
           uint4 gv = make_uint4 (0, 0, 0, 0);
           const bool isNew0 = tid < nu && !mgIsAssigned (co);
-          if (isNew0) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
+          if (isNew0 && !(a.debug & 2)) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
           if (a.occ[b])
             { for (U32 i = tid ; i < R ; i += T)
                 { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
@@ -650,7 +651,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
               else
                 { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
-                  uint4 g4 = (i == tid) ? gv : *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);
+                  uint4 g4 = (i == tid || (a.debug & 2)) ? gv : *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);
                   U64 gbits = ((U64) g4.y << 32) | g4.x;
                   U32 rank = g4.z + (U32) __popcll (gbits & (((U64) 1 << (tok & 63)) - 1));
                   U64 idx = (U64) a.baseMax + 1 + rank;
@@ -810,6 +811,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
   a.counters = t->counters;
+  { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_BUCKET_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = dbg; }
   const size_t lds = (size_t) t->R * 16 + 16;
   if (lds > 48 * 1024)
     { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -817,7 +819,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
     }
   static int bThreadsEnv = -1;
   if (bThreadsEnv < 0) { const char *e = getenv ("MODGPU_BUCKET_T"); bThreadsEnv = e ? atoi (e) : 0; }
-  unsigned bThreads = bThreadsEnv ? (unsigned) bThreadsEnv : (t->R >= 8192 ? 1024u : (t->R >= 4096 ? 512u : 256u));
+  unsigned bThreads = bThreadsEnv ? (unsigned) bThreadsEnv : (t->R >= 4096 ? 1024u : (t->R >= 2048 ? 512u : 256u));
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
   U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
