@@ -501,7 +501,7 @@ struct MgBucketArgs {
   const MgRankGrp *grp; U32 baseMax; U32 size;
   int withDepth;
   U64 *counters;
-  int debug;                       /* dev ablation (MODGPU_BUCKET_DEBUG): 1 = no flag stores, 2 = no rank loads; results are wrong */
+  int debug;                       /* dev ablation (MODGPU_BUCKET_DEBUG): 1 = no flag stores; results are wrong */
 };
 
 extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
@@ -633,7 +633,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
         { /* the rank record of this lane's first unique: in flight while the bucket image is set up */
           uint4 gv = make_uint4 (0, 0, 0, 0);
           const bool isNew0 = tid < nu && !mgIsAssigned (co);
-          if (isNew0 && !(a.debug & 2)) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
+          if (isNew0) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
           if (a.occ[b])
             { for (U32 i = tid ; i < R ; i += T)
                 { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
@@ -651,7 +651,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
               else
                 { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
-                  uint4 g4 = (i == tid || (a.debug & 2)) ? gv : *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);
+                  uint4 g4 = (i == tid) ? gv : *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);
                   U64 gbits = ((U64) g4.y << 32) | g4.x;
                   U32 rank = g4.z + (U32) __popcll (gbits & (((U64) 1 << (tok & 63)) - 1));
                   U64 idx = (U64) a.baseMax + 1 + rank;

@@ -1,0 +1,4 @@
+#!/bin/bash
+for d in 0 1; do
+  MODGPU_BUCKET_DEBUG=$d python bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null | python tools/kern_ms.py "debug=$d" | grep -o "^.*ms/step\|'mgBucket[A-Za-z]*': [0-9.]*\|'mgRank[A-Za-z]*': [0-9.]*" | tr '\n' ' '; echo
+done
