@@ -257,6 +257,11 @@ void mgReferenceDestroy (MgReference *ref) ;                                    
  * report lines to out.  Returns 0 on success. */
 int  mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,
                       const char **names, bool isAdd, FILE *out) ;
+/* modmap.c:136-182: <root>.mod + <root>.ref in the reference's on-disk format (gzip streams, as its
+ * fzopen writes them; gzip or plain accepted on read), interchangeable with modmap -w / -r.
+ * mgReferenceLoad also creates the Modset (ref->ms, with its own Seqhash) as referenceRead does. */
+void mgReferenceWrite (MgReference *ref, const char *root) ;
+MgReference *mgReferenceLoad (const char *root) ;
 /* modmap.c:188-281: "Q" line and "M" lines for every read. */
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
                      const char **names, FILE *out) ;

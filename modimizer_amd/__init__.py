@@ -40,6 +40,12 @@ class Modset(C.Structure):             # reference modset.h:17-28
                 ("max", C.c_uint32)]
 
 
+class MgReference(C.Structure):       # include/modgpu.h (modmap.c:35-47)
+    _fields_ = [("ms", C.POINTER(Modset)), ("size", C.c_uint32), ("max", C.c_uint32),
+                ("index", U32P), ("offset", U32P), ("id", U32P), ("depth", U32P), ("rev", U32P), ("loc", U32P),
+                ("nSeq", C.c_int), ("names", C.POINTER(C.c_char_p)), ("len", U32P)]
+
+
 # every symbol include/modgpu.h declares (tests check the library exports all of them)
 EXPORTS = [
     "seqhashCreate", "seqhashWrite", "seqhashRead", "seqhashReport", "modRCiterator", "modRCnext",
@@ -54,7 +60,7 @@ EXPORTS = [
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
-    "mgReferenceRead", "mgQueryProcess",
+    "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
@@ -131,6 +137,7 @@ def lib():
     sig("mgReferenceCreate", vp, MS, u32); sig("mgReferenceDestroy", None, vp)
     sig("mgReferenceRead", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), C.c_bool, vp)
     sig("mgQueryProcess", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), vp)
+    sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetClear", i32, MS, vp)
     sig("mgProfileEnable", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)

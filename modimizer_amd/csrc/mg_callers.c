@@ -6,8 +6,10 @@
  * reference's own serial bookkeeping, restated with its quirks because its printed output is the
  * parity target.
  */
+#define _GNU_SOURCE             /* fopencookie */
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
 #include "modgpu.h"
 
 static void fatal (const char *what)
@@ -158,6 +160,179 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
   if (isAdd) modsetPack (ms);
   referencePack (ref);
   return 0;
+}
+
+/* ---- the reference's files: <root>.mod + <root>.ref (modmap.c:136-182) ----
+ * Both go through the reference's fzopen (utils.c:107-127): gzopen wrapped as a FILE*, so files it
+ * writes are gzip streams and it reads gzip or plain alike.  Same here, with glibc's fopencookie in
+ * the place of BSD funopen. */
+static ssize_t gzCookieRead (void *c, char *buf, size_t n) { int r = gzread ((gzFile) c, buf, (unsigned) n); return r < 0 ? -1 : r; }
+static ssize_t gzCookieWrite (void *c, const char *buf, size_t n) { int r = gzwrite ((gzFile) c, buf, (unsigned) n); return r <= 0 ? 0 : r; }
+static int gzCookieClose (void *c) { return gzclose ((gzFile) c) == Z_OK ? 0 : -1; }
+
+static FILE *tagOpen (const char *root, const char *tag, const char *mode)      /* utils.c:129-139 */
+{
+  char *name = (char *) malloc (strlen (root) + strlen (tag) + 2);
+  sprintf (name, "%s.%s", root, tag);
+  gzFile z = gzopen (name, mode);
+  FILE *f = 0;
+  if (z)
+    { cookie_io_functions_t io = { gzCookieRead, gzCookieWrite, 0, gzCookieClose };
+      f = fopencookie (z, mode, io);
+      if (!f) gzclose (z);
+    }
+  free (name);
+  return f;
+}
+
+static void die1 (const char *fmt, const char *arg)
+{ fprintf (stderr, "FATAL ERROR: "); fprintf (stderr, fmt, arg); fprintf (stderr, "\n"); exit (-1); }
+
+/* The reference keeps sequence lengths in an Array and names in a DICT and dumps both raw
+ * (array.c:213-218, dict.c:90-103), so the file holds their in-memory shape: the Array header
+ * (with a stale pointer) plus `dim` allocated elements, and the DICT's open-addressed table.
+ * These two restate how that shape comes about, so the reference can read what is written here. */
+typedef struct { int magic; char *base; int dim, size, max; } RefArrayHeader;     /* array.h:41-50, 32 bytes */
+#define REF_ARRAY_MAGIC 8918274                                                    /* array.h:56 */
+
+static int refArrayDim (int n)             /* allocated elements after n appends to arrayCreate (1024, U32): array.c:144-170,180-183 */
+{
+  int dim = 1024;
+  for (int i = 0 ; i < n ; ++i)
+    if (i >= dim)
+      { if ((long) dim * 4 < (1 << 23)) dim *= 2; else dim += 1024 + ((1 << 23) / 4);
+        if (i >= dim) dim = i + 1;
+      }
+  return dim;
+}
+
+static unsigned refNameHash (const char *s, int bits, int forStep)               /* dict.c:44-62 (its fold loop never runs: i starts at bits >= 10 > sizeof(int)) */
+{
+  const int rot = forStep ? 21 : 13;
+  unsigned x = 0;
+  for ( ; *s ; ++s) x = (unsigned) (int) *s ^ ((x >> (32 - rot)) | (x << rot));
+  x &= (1u << bits) - 1;
+  return forStep ? (x | 1) : x;
+}
+
+static void refDictPlace (int *table, int bits, char **names, int i)             /* names[i-1] takes entry i */
+{
+  const unsigned mask = (1u << bits) - 1;
+  unsigned x = refNameHash (names[i - 1], bits, 0);
+  if (table[x])
+    { unsigned d = refNameHash (names[i - 1], bits, 1);
+      do x = (x + d) & mask; while (table[x]);
+    }
+  table[x] = i;
+}
+
+/* the DICT table after dictAdd of names[0..n) in order (dict.c:66-74,155-189): 1024 slots, doubled
+ * and rebuilt whenever the count exceeds 0.3 of the size */
+static int *refDictTable (char **names, int n, int *bitsOut)
+{
+  int bits = 10, size = 1024;
+  int *table = (int *) calloc ((size_t) size, sizeof (int));
+  for (int i = 1 ; i <= n ; ++i)
+    { refDictPlace (table, bits, names, i);
+      if (i > 0.3 * size)
+        { ++bits; size *= 2;
+          free (table); table = (int *) calloc ((size_t) size, sizeof (int));
+          for (int j = 1 ; j <= i ; ++j) refDictPlace (table, bits, names, j);
+        }
+    }
+  *bitsOut = bits;
+  return table;
+}
+
+#define WR(ptr, sz, cnt, what) do { if (fwrite ((ptr), (sz), (cnt), f) != (size_t) (cnt)) die1 ("failed to write %s", what); } while (0)
+#define RD(ptr, sz, cnt, what) do { if (fread ((ptr), (sz), (cnt), f) != (size_t) (cnt)) die1 ("failed to read %s", what); } while (0)
+
+void mgReferenceWrite (MgReference *ref, const char *root)                       /* modmap.c:136-156 */
+{
+  FILE *f;
+  if (!(f = tagOpen (root, "mod", "w"))) die1 ("failed to open %s.mod to write", root);
+  modsetWrite (ref->ms, f);
+  fclose (f);
+  if (!(f = tagOpen (root, "ref", "w"))) die1 ("failed to open %s.ref to write", root);
+  const U32 size = ref->max, m = ref->ms->max + 1;
+  WR ("RFMSHv1", 8, 1, "reference header");
+  WR (&size, sizeof (U32), 1, "size");
+  WR (&ref->max, sizeof (U32), 1, "max");
+  WR (ref->index, sizeof (U32), size, "ref index");
+  WR (ref->offset, sizeof (U32), size, "ref offset");
+  WR (ref->id, sizeof (U32), size, "ref id");
+  WR (ref->depth, sizeof (U32), m, "depth");
+  WR (ref->rev, sizeof (U32), size, "rev");
+  WR (ref->loc, sizeof (U32), m, "loc");
+  /* len: Array header + dim elements */
+  RefArrayHeader ah; memset (&ah, 0, sizeof (ah));
+  ah.magic = REF_ARRAY_MAGIC; ah.dim = refArrayDim (ref->nSeq); ah.size = (int) sizeof (U32); ah.max = ref->nSeq;
+  U32 *lenBuf = (U32 *) calloc ((size_t) ah.dim, sizeof (U32));
+  memcpy (lenBuf, ref->len, (size_t) ref->nSeq * sizeof (U32));
+  WR (&ah, sizeof (ah), 1, "ref len");
+  WR (lenBuf, sizeof (U32), ah.dim, "ref len");
+  free (lenBuf);
+  /* dict: dim, max, table, the (max+1) name pointers (meaningless in a file; zero here), then the names */
+  int bits; int *table = refDictTable (ref->names, ref->nSeq, &bits);
+  char **noPtr = (char **) calloc ((size_t) ref->nSeq + 1, sizeof (char *));
+  WR (&bits, sizeof (int), 1, "ref dict");
+  WR (&ref->nSeq, sizeof (int), 1, "ref dict");
+  WR (table, sizeof (int), (size_t) 1 << bits, "ref dict");
+  WR (noPtr, sizeof (char *), (size_t) ref->nSeq + 1, "ref dict");
+  for (int i = 0 ; i < ref->nSeq ; ++i)
+    { int len = (int) strlen (ref->names[i]);
+      WR (&len, sizeof (int), 1, "ref dict");
+      if (len) WR (ref->names[i], 1, len, "ref dict");
+    }
+  free (table); free (noPtr);
+  if (fclose (f)) die1 ("failed to close %s.ref", root);
+}
+
+MgReference *mgReferenceLoad (const char *root)                                  /* modmap.c:158-182 */
+{
+  FILE *f;
+  if (!(f = tagOpen (root, "mod", "r"))) die1 ("failed to open %s.mod to read", root);
+  Modset *ms = modsetRead (f);
+  fclose (f);
+  if (!(f = tagOpen (root, "ref", "r"))) die1 ("failed to open %s.ref to read", root);
+  char tag[8];
+  RD (tag, 8, 1, "reference header");
+  if (memcmp (tag, "RFMSHv1", 8)) die1 ("bad reference header%s", "");
+  U32 size; RD (&size, sizeof (U32), 1, "size");
+  MgReference *ref = mgReferenceCreate (ms, size ? size : 1);
+  RD (&ref->max, sizeof (U32), 1, "max");
+  const U32 m = ms->max + 1;
+  if ((size_t) m > (size_t) ms->size) ref->depth = (U32 *) realloc (ref->depth, (size_t) m * sizeof (U32));   /* the reference under-allocates here (modmap.c:54,171) */
+  ref->rev = (U32 *) malloc ((size_t) (size ? size : 1) * sizeof (U32));
+  ref->loc = (U32 *) malloc ((size_t) m * sizeof (U32));
+  RD (ref->index, sizeof (U32), size, "ref index");
+  RD (ref->offset, sizeof (U32), size, "ref offset");
+  RD (ref->id, sizeof (U32), size, "ref id");
+  RD (ref->depth, sizeof (U32), m, "depth");
+  RD (ref->rev, sizeof (U32), size, "rev");
+  RD (ref->loc, sizeof (U32), m, "loc");
+  RefArrayHeader ah; RD (&ah, sizeof (ah), 1, "ref len");
+  if (ah.magic != REF_ARRAY_MAGIC || ah.size != (int) sizeof (U32) || ah.max < 0 || ah.dim < ah.max) die1 ("failed read ref len%s", "");
+  U32 *lenBuf = (U32 *) malloc ((size_t) (ah.dim ? ah.dim : 1) * sizeof (U32));
+  RD (lenBuf, sizeof (U32), ah.dim, "ref len");
+  int bits, nNames; RD (&bits, sizeof (int), 1, "ref dict"); RD (&nNames, sizeof (int), 1, "ref dict");
+  if (bits < 10 || bits > 30 || nNames < 0 || nNames > ah.max) die1 ("failed read ref dict%s", "");
+  { size_t skip = ((size_t) 1 << bits) * sizeof (int) + ((size_t) nNames + 1) * sizeof (char *);   /* table + stale pointers */
+    char *junk = (char *) malloc (skip); RD (junk, 1, skip, "ref dict"); free (junk);
+  }
+  ref->nSeq = nNames;
+  ref->names = (char **) calloc ((size_t) nNames + 1, sizeof (char *));
+  ref->len = (U32 *) malloc (((size_t) nNames + 1) * sizeof (U32));
+  memcpy (ref->len, lenBuf, (size_t) nNames * sizeof (U32));
+  free (lenBuf);
+  for (int i = 0 ; i < nNames ; ++i)
+    { int len; RD (&len, sizeof (int), 1, "ref dict");
+      if (len < 0 || len > (1 << 20)) die1 ("failed read ref dict%s", "");
+      ref->names[i] = (char *) calloc ((size_t) len + 1, 1);
+      if (len) RD (ref->names[i], 1, len, "ref dict");
+    }
+  fclose (f);
+  return ref;
 }
 
 /* one end-of-block test, modmap.c:232-241 (repeated at :245-254 without the "no block" clause) */

@@ -160,6 +160,30 @@ def gen_modmap():
               sum(l.startswith("Q\t") for l in out.splitlines()), "Q lines")
 
 
+def gen_modmap_files():
+    """modmap -f ref.fa -w stem, then -r stem -q queries.fa: the reference's own .mod/.ref pair (gzip
+    streams, utils.c:107-127) and what it prints when it reads them back."""
+    mm = os.path.join(REFDIR, "modmap_ref")
+    for tag, (k, w) in {"k21d64": (21, 64), "k15d8": (15, 8)}.items():
+        stem = "modmap_%s_files" % tag
+        run([mm, "-K", str(k), "-W", str(w), "-S", "17", "-B", "20", "-f", "ref.fa", "-w", stem])
+        out = run([mm, "-r", stem, "-q", "queries.fa"])
+        open(os.path.join(HERE, "%s.stdout.txt" % stem), "w").write(strip_timing(out))
+        print("modmap files", tag, [os.path.getsize(os.path.join(HERE, stem + e)) for e in (".mod", ".ref")],
+              sum(l.startswith("M\t") for l in out.splitlines()), "M lines")
+
+
+def gen_modmap_many():
+    """1100 short reference sequences: the DICT table doubles twice (dict.c:166) and the length Array
+    once (array.c:144) before modmap -w dumps them"""
+    mm = os.path.join(REFDIR, "modmap_ref")
+    g = synth.iid_bases(1100 * 64, 4242)
+    seqs = [g[i * 64:i * 64 + 40 + (i * 7) % 24] for i in range(1100)]
+    fasta.write_fasta(os.path.join(HERE, "many.fa"), ["ctg%d_%s" % (i, "x" * (i % 5)) for i in range(1100)], seqs)
+    run([mm, "-K", "15", "-W", "8", "-S", "17", "-B", "20", "-f", "many.fa", "-w", "modmap_many_files"])
+    print("modmap many", [os.path.getsize(os.path.join(HERE, "modmap_many_files" + e)) for e in (".mod", ".ref")])
+
+
 def gen_modset_ops():
     """modsetMerge / modsetDepthPrune / modsetPack / modsetWrite through the reference library."""
     out = {}
@@ -230,6 +254,8 @@ if __name__ == "__main__":
     gen_modutils()
     make_modmap_inputs()
     gen_modmap()
+    gen_modmap_files()
+    gen_modmap_many()
     gen_modset_ops()
     digest_dumps()
     for fn in ("/tmp/_golden_sum.txt", "/tmp/_golden_a.mod"):
