@@ -266,6 +266,21 @@ MgReference *mgReferenceLoad (const char *root) ;
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
                      const char **names, FILE *out) ;
 
+/* The file front end (seqio.c:30-346 for FASTA / FASTQ text, plain or gzip, with the callers'
+ * dna2indexConv + N->0 conversion): records are cut out of the text and converted by a pool of
+ * threads, a batch at a time.  bases hold 0..3 (FASTQ keeps other bytes as (char)-2, as the
+ * reference does); offsets[nSeq+1]; names = the record ids. */
+typedef struct MgSeqReader MgSeqReader ;
+typedef struct { char *bases ; int64_t *offsets ; char **names ; int nSeq ; int64_t total ; int isFastq ; int64_t basesCap ; } MgSeqBatch ;   /* release with mgSeqBatchFree only */
+MgSeqReader *mgSeqOpen (const char *filename) ;                        /* 0 if unreadable, empty or not FASTA/FASTQ text */
+int  mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out) ; /* whole records, at least one; 0 at the end */
+void mgSeqBatchFree (MgSeqBatch *b) ;
+void mgSeqClose (MgSeqReader *r) ;
+/* the callers' per-file loops: parsing of the next batch overlaps the GPU work on the current one */
+int  mgAddSequenceFile (Modset *ms, const char *filename, FILE *out) ;                        /* modutils.c:33-51 */
+int  mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out) ;   /* modmap.c:93-134 */
+int  mgQueryFile (MgReference *ref, const char *filename, FILE *out) ;                        /* modmap.c:188-281 */
+
 /* Deterministic synthetic reads generated directly in HBM (not from the reference):
  *   mgSynthGenome: nBases iid-uniform bases, base g = splitmix64(seed ^ g*0x9E3779B97F4A7C15) >> 62
  *   mgSynthReads : read r = genome[start[r], start[r]+len[r]) reverse-complemented when

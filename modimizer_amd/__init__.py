@@ -46,6 +46,11 @@ class MgReference(C.Structure):       # include/modgpu.h (modmap.c:35-47)
                 ("nSeq", C.c_int), ("names", C.POINTER(C.c_char_p)), ("len", U32P)]
 
 
+class MgSeqBatch(C.Structure):        # include/modgpu.h
+    _fields_ = [("bases", C.POINTER(C.c_int8)), ("offsets", C.POINTER(C.c_int64)), ("names", C.POINTER(C.c_char_p)),
+                ("nSeq", C.c_int), ("total", C.c_int64), ("isFastq", C.c_int), ("basesCap", C.c_int64)]
+
+
 # every symbol include/modgpu.h declares (tests check the library exports all of them)
 EXPORTS = [
     "seqhashCreate", "seqhashWrite", "seqhashRead", "seqhashReport", "modRCiterator", "modRCnext",
@@ -61,6 +66,7 @@ EXPORTS = [
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
+    "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
     "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
@@ -137,6 +143,10 @@ def lib():
     sig("mgReferenceCreate", vp, MS, u32); sig("mgReferenceDestroy", None, vp)
     sig("mgReferenceRead", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), C.c_bool, vp)
     sig("mgQueryProcess", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), vp)
+    sig("mgSeqOpen", vp, C.c_char_p); sig("mgSeqNextBatch", i32, vp, C.c_int64, C.POINTER(MgSeqBatch))
+    sig("mgSeqBatchFree", None, C.POINTER(MgSeqBatch)); sig("mgSeqClose", None, vp)
+    sig("mgAddSequenceFile", i32, MS, C.c_char_p, vp); sig("mgReferenceFastaRead", i32, vp, C.c_char_p, C.c_bool, vp)
+    sig("mgQueryFile", i32, vp, C.c_char_p, vp)
     sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetClear", i32, MS, vp)

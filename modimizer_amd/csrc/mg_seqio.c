@@ -1,0 +1,531 @@
+/* mg_seqio.c — the front end of the hot path: FASTA / FASTQ text (plain or gzip) -> bases 0..3.
+ *
+ * Restates what the reference's callers get from seqIOopenRead + seqIOread (seqio.c:30-110,187-346)
+ * with dna2indexConv after their N->0 patch (seqio.c:643-652, modutils.c:39, modmap.c:97):
+ *   - the type is decided by the first byte: '>' FASTA, '@' FASTQ (seqio.c:47-73); the binary,
+ *     ONEcode and BAM inputs of seqio.c are not handled here;
+ *   - id = the characters after the marker up to the first white space (seqio.c:302-304);
+ *   - FASTA: the sequence is everything up to the next line that starts with '>'; A/a C/c G/g T/t
+ *     N/n become 0 1 2 3 0, every other byte (line ends included) is dropped, so the sequence
+ *     shortens (seqio.c:316-323);
+ *   - FASTQ: four lines; the sequence line is converted in place, bytes outside ACGTN stay in the
+ *     sequence as (char)-2 (seqio.c:325-331); the '+' line and the quality length are checked
+ *     (seqio.c:333-339);
+ *   - a last record that is not closed by a newline is reported ("incomplete sequence record line
+ *     N") and not returned (seqio.c:213-217).
+ * Unlike the reference (one record at a time, one thread) a batch of records is cut out of the
+ * text serially (memchr) and converted by a pool of threads; batches stream, so memory is bounded
+ * by the batch size, not by the file.
+ */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <time.h>
+#include "modgpu.h"
+static double nowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+#define TIMING(tag) do { if (getenv ("MODGPU_PARSE_TIMING")) { double t_ = nowS (); fprintf (stderr, "  [parse] %-10s %.3f s\n", tag, t_ - tLast); tLast = t_; } } while (0)
+
+#define UNIT_BYTES ((size_t) 1 << 20)        /* raw text per conversion work unit */
+
+struct MgSeqReader {
+  gzFile gz;                                 /* gzip stream, or 0: plain text read straight from fd */
+  int fd;
+  size_t fileSize, consumed;                 /* plain regular file: its size, and bytes read so far */
+  char *buf; size_t cap, len, pos;           /* raw text window: [pos, len) not yet consumed */
+  int eof, isFastq, finished;
+  U64 line;                                  /* 1-based line number at buf[pos] */
+  U64 nSeq;
+  int nThreads;
+} ;
+
+/* Large buffers are touched once, front to back: first-touch page faults cost more than the parsing,
+ * so they come straight from mmap and the last two given back are kept for the next batch.
+ * (Requesting transparent huge pages was tried: direct compaction made first touch 20x slower.) */
+static pthread_mutex_t bigMu = PTHREAD_MUTEX_INITIALIZER;
+static int bigReaders;                           /* open readers: spares are only kept while there is one */
+static struct { void *p; size_t n; } bigSpare[2];   /* the last buffers given back: batches alternate between two sizes */
+
+static void *bigAlloc (size_t n)
+{
+  if (!n) n = 1;
+  pthread_mutex_lock (&bigMu);
+  for (int i = 0 ; i < 2 ; ++i)
+    if (bigSpare[i].p && bigSpare[i].n >= n && bigSpare[i].n / 2 <= n)
+      { void *p = bigSpare[i].p; bigSpare[i].p = 0;
+        pthread_mutex_unlock (&bigMu);
+        return p;                              /* its mapped length stays bigSpare[i].n: see bigSize */
+      }
+  pthread_mutex_unlock (&bigMu);
+  void *p = mmap (0, n + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) { fprintf (stderr, "FATAL ERROR: sequence buffer of %zu bytes\n", n); exit (-1); }
+  *(size_t *) p = n + 4096;                     /* mapped length, kept in a leading page */
+  return (char *) p + 4096;
+}
+static void bigRelease (void *p) { char *base = (char *) p - 4096; munmap (base, *(size_t *) base); }
+static void bigFree (void *p, size_t unused)
+{
+  (void) unused;
+  if (!p) return;
+  size_t n = *(size_t *) ((char *) p - 4096) - 4096;
+  void *drop = p;
+  pthread_mutex_lock (&bigMu);
+  if (bigReaders > 0)
+    for (int i = 0 ; i < 2 ; ++i) if (!bigSpare[i].p) { bigSpare[i].p = p; bigSpare[i].n = n; drop = 0; break; }
+  if (drop && bigReaders > 0)                                    /* both slots taken: keep the larger ones */
+    for (int i = 0 ; i < 2 ; ++i) if (bigSpare[i].n < n) { drop = bigSpare[i].p; bigSpare[i].p = p; bigSpare[i].n = n; break; }
+  pthread_mutex_unlock (&bigMu);
+  if (drop) bigRelease (drop);
+}
+static void bigFlush (void)                     /* mgSeqClose: nothing stays mapped after the last reader */
+{
+  pthread_mutex_lock (&bigMu);
+  if (--bigReaders > 0) { pthread_mutex_unlock (&bigMu); return; }
+  for (int i = 0 ; i < 2 ; ++i) if (bigSpare[i].p) { bigRelease (bigSpare[i].p); bigSpare[i].p = 0; bigSpare[i].n = 0; }
+  pthread_mutex_unlock (&bigMu);
+}
+
+static signed char convTable[256];
+static pthread_once_t convOnce = PTHREAD_ONCE_INIT;
+static void convInit (void)
+{
+  memset (convTable, -2, sizeof (convTable));
+  convTable['A'] = convTable['a'] = 0; convTable['C'] = convTable['c'] = 1;
+  convTable['G'] = convTable['g'] = 2; convTable['T'] = convTable['t'] = 3;
+  convTable['N'] = convTable['n'] = 0;       /* the callers' patch */
+}
+
+static void dieLine (const char *fmt, U64 line)
+{ fprintf (stderr, "FATAL ERROR: "); fprintf (stderr, fmt, (unsigned long long) line); fprintf (stderr, "\n"); exit (-1); }
+
+static int threadCount (void)
+{
+  const char *e = getenv ("MODGPU_PARSE_THREADS");
+  long n = e ? atol (e) : sysconf (_SC_NPROCESSORS_ONLN);
+  if (n < 1) n = 1;
+  if (n > 32) n = 32;
+  return (int) n;
+}
+
+static size_t readSome (MgSeqReader *r, char *dst, size_t room)
+{
+  if (room > ((size_t) 1 << 30)) room = (size_t) 1 << 30;
+  if (r->gz) { int got = gzread (r->gz, dst, (unsigned) room); return got > 0 ? (size_t) got : 0; }
+  ssize_t got = read (r->fd, dst, room);
+  if (got > 0) r->consumed += (size_t) got;
+  return got > 0 ? (size_t) got : 0;
+}
+/* plain regular file: the pool reads disjoint slices with pread (the copy out of the page cache and
+ * the first touch of the window are the cost, and both spread over the threads) */
+typedef struct { int fd; char *dst; size_t fileOff, n, slice, next; size_t got; } ReadJob;
+static void *readWorker (void *arg)
+{
+  ReadJob *j = (ReadJob *) arg;
+  for (;;)
+    { size_t at = __atomic_fetch_add (&j->next, j->slice, __ATOMIC_RELAXED);
+      if (at >= j->n) break;
+      size_t len = at + j->slice < j->n ? j->slice : j->n - at, done = 0;
+      while (done < len)
+        { ssize_t g = pread (j->fd, j->dst + at + done, len - done, (off_t) (j->fileOff + at + done));
+          if (g <= 0) break;
+          done += (size_t) g;
+        }
+      __atomic_fetch_add (&j->got, done, __ATOMIC_RELAXED);
+    }
+  return 0;
+}
+static size_t readParallel (MgSeqReader *r, char *dst, size_t n)
+{
+  ReadJob j; j.fd = r->fd; j.dst = dst; j.fileOff = r->consumed; j.n = n; j.slice = (size_t) 8 << 20; j.next = 0; j.got = 0;
+  pthread_t th[32]; int started[32];
+  int nt = r->nThreads; if ((size_t) nt > n / j.slice + 1) nt = (int) (n / j.slice + 1);
+  for (int i = 1 ; i < nt ; ++i) started[i] = pthread_create (&th[i], 0, readWorker, &j) == 0;
+  readWorker (&j);
+  for (int i = 1 ; i < nt ; ++i) if (started[i]) pthread_join (th[i], 0);
+  r->consumed += j.got;
+  (void) lseek (r->fd, (off_t) r->consumed, SEEK_SET);
+  return j.got;
+}
+
+static void closeInput (MgSeqReader *r) { if (r->gz) gzclose (r->gz); else close (r->fd); }
+
+MgSeqReader *mgSeqOpen (const char *filename)
+{
+  pthread_once (&convOnce, convInit);
+  /* the reference reads everything through gzread (seqio.c:33-40), which passes plain text through;
+     plain text is read directly here (zlib's pass-through copies at a fraction of memcpy speed) */
+  int fd = strcmp (filename, "-") ? open (filename, O_RDONLY) : dup (0);
+  if (fd < 0) return 0;
+  unsigned char magic[2] = { 0, 0 };
+  gzFile gz = 0;
+  if (pread (fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b))   /* gzip, or not seekable: let zlib decide */
+    { gz = gzdopen (fd, "r");
+      if (!gz) { close (fd); return 0; }
+      gzbuffer (gz, 1 << 20);
+    }
+  MgSeqReader *r = (MgSeqReader *) calloc (1, sizeof (MgSeqReader));
+  pthread_mutex_lock (&bigMu); ++bigReaders; pthread_mutex_unlock (&bigMu);
+  r->gz = gz; r->fd = fd;
+  r->cap = (size_t) 1 << 24;                                     /* seqio.c:36 */
+  { struct stat st;                                              /* plain file: the window it will need is known */
+    if (!gz && fstat (fd, &st) == 0 && S_ISREG (st.st_mode)) r->fileSize = (size_t) st.st_size;
+  }
+  r->buf = (char *) bigAlloc (r->cap);
+  r->len = readSome (r, r->buf, r->cap);
+  if (!r->len)
+    { fprintf (stderr, "sequence file %s unreadable or empty\n", filename);   /* seqio.c:41-45 */
+      closeInput (r); bigFree (r->buf, r->cap); free (r); bigFlush ();
+      return 0;
+    }
+  if (r->buf[0] == '>') r->isFastq = 0;
+  else if (r->buf[0] == '@') r->isFastq = 1;
+  else
+    { fprintf (stderr, "sequence file %s is neither FASTA nor FASTQ text\n", filename);
+      closeInput (r); bigFree (r->buf, r->cap); free (r); bigFlush ();
+      return 0;
+    }
+  r->line = 1;
+  r->nThreads = threadCount ();
+  return r;
+}
+
+void mgSeqClose (MgSeqReader *r)
+{
+  if (!r) return;
+  closeInput (r); bigFree (r->buf, r->cap); free (r);
+  bigFlush ();
+}
+
+/* read until the window holds at least `want` unread bytes or the file ends (the buffer doubles as
+ * it fills, seqio.c:197-205) */
+static void refill (MgSeqReader *r, size_t want)
+{
+  if (r->eof) return;
+  if (r->pos)
+    { memmove (r->buf, r->buf + r->pos, r->len - r->pos);
+      r->len -= r->pos; r->pos = 0;
+    }
+  if (r->fileSize && want > r->len + (r->fileSize - r->consumed) + 1)       /* never more than what is left of the file */
+    want = r->len + (r->fileSize - r->consumed) + 1;
+  if (r->fileSize && want > r->cap)                                         /* one allocation instead of doublings */
+    { char *grown = (char *) bigAlloc (want);
+      memcpy (grown, r->buf, r->len);
+      bigFree (r->buf, r->cap);
+      r->buf = grown; r->cap = want;
+    }
+  if (r->fileSize && want > r->len && want - r->len >= ((size_t) 32 << 20))
+    { size_t left = r->fileSize - r->consumed, n = want - r->len < left ? want - r->len : left;
+      size_t got = readParallel (r, r->buf + r->len, n);
+      r->len += got;
+      if (got < n || r->consumed >= r->fileSize) { r->eof = (r->consumed >= r->fileSize || got < n); }
+    }
+  while (r->len < want && !r->eof)
+    { if (r->len == r->cap)
+        { char *grown = (char *) bigAlloc (r->cap * 2);
+          memcpy (grown, r->buf, r->len);
+          bigFree (r->buf, r->cap);
+          r->buf = grown; r->cap *= 2;
+        }
+      size_t room = r->cap - r->len;
+      if (room > want - r->len && want - r->len >= ((size_t) 1 << 20)) room = want - r->len;
+      size_t got = readSome (r, r->buf + r->len, room);
+      if (!got) { r->eof = 1; break; }
+      r->len += got;
+    }
+}
+
+static U64 countLines (const char *s, const char *e)
+{ U64 n = 0; for ( ; s < e ; ++s) n += (*s == '\n'); return n; }
+
+/* ---- records cut out of the window ---- */
+typedef struct { size_t id, idLen, seq, seqEnd, end; } RawRec;      /* offsets into buf; [seq, seqEnd) is the text that holds the sequence */
+
+/* returns 1 and fills *rec when a whole record starts at `at`; 0 when the window ends inside it */
+static int cutFasta (MgSeqReader *r, size_t at, RawRec *rec, U64 line)
+{
+  const char *b = r->buf, *end = r->buf + r->len;
+  if (b[at] != '>') dieLine ("no initial > for FASTA record line %llu", line);
+  const char *nl = (const char *) memchr (b + at, '\n', (size_t) (end - (b + at)));
+  if (!nl) return 0;
+  const char *p = b + at + 1;
+  while (p < nl && !isspace ((unsigned char) *p)) ++p;
+  rec->id = at + 1; rec->idLen = (size_t) (p - (b + at + 1));
+  rec->seq = (size_t) (nl + 1 - b);
+  const char *q = nl + 1;
+  for (;;)
+    { const char *g = (const char *) memchr (q, '>', (size_t) (end - q));
+      if (!g) break;
+      if (g[-1] == '\n') { rec->seqEnd = rec->end = (size_t) (g - b); return 1; }
+      q = g + 1;
+    }
+  if (!r->eof) return 0;
+  if (end[-1] != '\n') return 0;             /* unterminated last line: the caller reports it */
+  rec->seqEnd = rec->end = r->len;
+  return 1;
+}
+
+static int cutFastq (MgSeqReader *r, size_t at, RawRec *rec, U64 line)
+{
+  const char *b = r->buf, *end = r->buf + r->len;
+  if (b[at] != '@') dieLine ("no initial @ for FASTQ record line %llu", line);
+  const char *l1 = (const char *) memchr (b + at, '\n', (size_t) (end - (b + at)));
+  if (!l1) return 0;
+  const char *l2 = (const char *) memchr (l1 + 1, '\n', (size_t) (end - (l1 + 1)));
+  if (!l2) return 0;
+  if (l2 + 1 >= end) return 0;
+  if (l2[1] != '+') dieLine ("missing + FASTQ line %llu", line + 2);
+  const char *l3 = (const char *) memchr (l2 + 1, '\n', (size_t) (end - (l2 + 1)));
+  if (!l3) return 0;
+  const char *l4 = (const char *) memchr (l3 + 1, '\n', (size_t) (end - (l3 + 1)));
+  if (!l4) return 0;
+  if ((l4 - (l3 + 1)) != (l2 - (l1 + 1))) dieLine ("qual not same length as seq line %llu", line + 3);
+  const char *p = b + at + 1;
+  while (p < l1 && !isspace ((unsigned char) *p)) ++p;
+  rec->id = at + 1; rec->idLen = (size_t) (p - (b + at + 1));
+  rec->seq = (size_t) (l1 + 1 - b); rec->seqEnd = (size_t) (l2 - b);
+  rec->end = (size_t) (l4 + 1 - b);
+  return 1;
+}
+
+/* ---- parallel conversion ----
+ * Two passes over the raw text, both by the pool: count what each unit keeps (FASTA only; a FASTQ
+ * line keeps every byte), then, the destinations being known, convert straight into the batch. */
+typedef struct { size_t from, to; int rec; size_t outLen, lines; } Unit;  /* raw range of one record */
+typedef struct {
+  const char *raw; Unit *units; size_t nUnits, grain; int isFastq;
+  size_t next;
+  char *dst; const size_t *unitDst;                               /* second pass */
+  int phase;
+} Job;
+
+static size_t countKept (const unsigned char *s, const unsigned char *e)      /* bytes convTable keeps; no table: vectorises */
+{
+  size_t n = 0;
+  for ( ; s < e ; ++s)
+    { unsigned char c = (unsigned char) (*s | 0x20);
+      n += (c == 'a') | (c == 'c') | (c == 'g') | (c == 't') | (c == 'n');
+    }
+  return n;
+}
+
+static void *worker (void *arg)
+{
+  Job *j = (Job *) arg;
+  for (;;)
+    { size_t u0 = __atomic_fetch_add (&j->next, j->grain, __ATOMIC_RELAXED);
+      if (u0 >= j->nUnits) break;
+      size_t u1 = u0 + j->grain < j->nUnits ? u0 + j->grain : j->nUnits;
+      for (size_t u = u0 ; u < u1 ; ++u)
+        { Unit *un = &j->units[u];
+          const unsigned char *s = (const unsigned char *) j->raw + un->from, *e = (const unsigned char *) j->raw + un->to;
+          if (j->phase == 0)
+            { un->outLen = j->isFastq ? (size_t) (e - s) : countKept (s, e);
+              un->lines = j->isFastq ? 0 : (size_t) countLines ((const char *) s, (const char *) e);
+            }
+          else
+            { char *t = j->dst + j->unitDst[u];
+              if (j->isFastq) { for ( ; s < e ; ++s) *t++ = (char) convTable[*s]; }
+              else for ( ; s < e ; ++s) { signed char c = convTable[*s]; if (c >= 0) *t++ = (char) c; }   /* no store for a dropped byte: the next unit's bytes start right there */
+            }
+        }
+    }
+  return 0;
+}
+
+static void runJob (Job *j, int nThreads)
+{
+  j->next = 0;
+  j->grain = j->nUnits / ((size_t) nThreads * 16) + 1;
+  if (nThreads > 1 && j->nUnits > 1)
+    { pthread_t th[32]; int started[32];
+      int n = nThreads < (int) j->nUnits ? nThreads : (int) j->nUnits;
+      for (int i = 1 ; i < n ; ++i) started[i] = pthread_create (&th[i], 0, worker, j) == 0;
+      worker (j);
+      for (int i = 1 ; i < n ; ++i) if (started[i]) pthread_join (th[i], 0);
+    }
+  else worker (j);
+}
+
+/* Next batch of whole records: at least one, and no more once `maxBases` sequence characters have
+ * been taken.  Returns the number of records (0 at the end of the file). */
+int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
+{
+  memset (out, 0, sizeof (*out));
+  out->isFastq = r->isFastq;
+  if (r->finished) return 0;
+  if (maxBases < 1) maxBases = 1;
+  if (maxBases > ((int64_t) 1 << 60)) maxBases = (int64_t) 1 << 60;
+  size_t want = (size_t) maxBases + (size_t) maxBases / 4 + ((size_t) 1 << 24);
+  double tLast = nowS ();
+  if (r->len - r->pos < want) refill (r, want);
+  TIMING ("refill");
+
+  RawRec *recs = 0; size_t nRec = 0, capRec = 0;
+  size_t at = r->pos; U64 line = r->line; size_t rawSeq = 0;
+  while (at < r->len && (int64_t) rawSeq < maxBases)
+    { RawRec rec;
+      int ok = r->isFastq ? cutFastq (r, at, &rec, line) : cutFasta (r, at, &rec, line);
+      if (!ok)
+        { if (!r->eof)
+            { if (nRec) break;                                   /* hand over what is whole; the rest next time */
+              size_t have = r->len - r->pos;
+              refill (r, have * 2 > want ? have * 2 : want);     /* one record larger than the window */
+              at = r->pos;
+              continue;
+            }
+          /* FASTA lines of this batch are only counted by the pool below: count here what was cut so far */
+          fprintf (stderr, "incomplete sequence record line %llu\n",
+                   (unsigned long long) (r->line + countLines (r->buf + r->pos, r->buf + r->len)));
+          r->finished = 1;
+          break;
+        }
+      if (nRec == capRec) { capRec = capRec ? capRec * 2 : 1024; recs = (RawRec *) realloc (recs, capRec * sizeof (RawRec)); }
+      recs[nRec++] = rec;
+      rawSeq += rec.seqEnd - rec.seq;
+      if (r->isFastq) line += 4;
+      at = rec.end;
+    }
+  if (at >= r->len && r->eof) r->finished = 1;
+  if (!nRec) { free (recs); r->pos = at; r->line = line; return 0; }
+  TIMING ("cut");
+
+  /* units: raw ranges of at most UNIT_BYTES, never across records */
+  size_t nUnits = 0;
+  for (size_t i = 0 ; i < nRec ; ++i) nUnits += (recs[i].seqEnd - recs[i].seq) / UNIT_BYTES + 1;
+  Unit *units = (Unit *) malloc (nUnits * sizeof (Unit));
+  size_t u = 0;
+  for (size_t i = 0 ; i < nRec ; ++i)
+    { size_t s = recs[i].seq;
+      do
+        { size_t e = s + UNIT_BYTES < recs[i].seqEnd ? s + UNIT_BYTES : recs[i].seqEnd;
+          units[u].from = s; units[u].to = e; units[u].rec = (int) i; units[u].outLen = 0; units[u].lines = 0; ++u;
+          s = e;
+        }
+      while (s < recs[i].seqEnd);
+    }
+  nUnits = u;
+  Job j; memset (&j, 0, sizeof (j));
+  j.raw = r->buf; j.units = units; j.nUnits = nUnits; j.isFastq = r->isFastq;
+  j.phase = 0;
+  runJob (&j, r->nThreads);
+  TIMING ("count");
+
+  out->nSeq = (int) nRec;
+  out->offsets = (int64_t *) malloc ((nRec + 1) * sizeof (int64_t));
+  out->names = (char **) malloc (nRec * sizeof (char *));
+  size_t *unitDst = (size_t *) malloc (nUnits * sizeof (size_t));
+  size_t total = 0; u = 0;
+  for (size_t i = 0 ; i < nRec ; ++i)
+    { out->offsets[i] = (int64_t) total;
+      while (u < nUnits && units[u].rec == (int) i) { unitDst[u] = total; total += units[u].outLen; line += units[u].lines; ++u; }
+      if (!r->isFastq) ++line;                                   /* the header line */
+      out->names[i] = (char *) malloc (recs[i].idLen + 1);
+      memcpy (out->names[i], r->buf + recs[i].id, recs[i].idLen); out->names[i][recs[i].idLen] = 0;
+    }
+  out->offsets[nRec] = (int64_t) total;
+  out->total = (int64_t) total;
+  out->basesCap = (int64_t) (total ? total : 1);
+  out->bases = (char *) bigAlloc ((size_t) out->basesCap);
+  j.phase = 1; j.dst = out->bases; j.unitDst = unitDst;
+  runJob (&j, r->nThreads);
+  TIMING ("convert");
+  free (unitDst); free (units); free (recs);
+
+  r->pos = at; r->line = line; r->nSeq += nRec;
+  return (int) nRec;
+}
+
+void mgSeqBatchFree (MgSeqBatch *b)
+{
+  if (!b) return;
+  for (int i = 0 ; i < b->nSeq ; ++i) free (b->names[i]);
+  free (b->names); free (b->offsets); bigFree (b->bases, (size_t) b->basesCap);
+  memset (b, 0, sizeof (*b));
+}
+
+/* ---- the callers' file loops ---- */
+
+typedef struct { MgSeqReader *r; int64_t maxBases; MgSeqBatch batch; int n; } Prefetch;
+static void *prefetchMain (void *arg) { Prefetch *p = (Prefetch *) arg; p->n = mgSeqNextBatch (p->r, p->maxBases, &p->batch); return 0; }
+
+static int64_t batchBases (void)
+{
+  const char *e = getenv ("MODGPU_FILE_BATCH_MBP");
+  long mbp = e ? atol (e) : 512;          /* parse of the next batch overlaps the GPU work on this one */
+  if (mbp < 1) mbp = 1;
+  return (int64_t) mbp * 1000000;
+}
+
+/* every batch of the file through fn, the next batch being parsed while fn works on this one */
+static int forEachBatch (const char *filename, int (*fn) (MgSeqBatch *, void *), void *ctx)
+{
+  MgSeqReader *r = mgSeqOpen (filename);
+  if (!r) return -1;
+  Prefetch p; memset (&p, 0, sizeof (p)); p.r = r; p.maxBases = batchBases ();
+  prefetchMain (&p);
+  int rc = 0;
+  while (p.n > 0 && !rc)
+    { MgSeqBatch cur = p.batch;
+      pthread_t th;
+      memset (&p.batch, 0, sizeof (p.batch)); p.n = 0;
+      int threaded = pthread_create (&th, 0, prefetchMain, &p) == 0;
+      rc = fn (&cur, ctx);
+      if (threaded) pthread_join (th, 0); else prefetchMain (&p);
+      mgSeqBatchFree (&cur);
+    }
+  if (p.n > 0) mgSeqBatchFree (&p.batch);
+  mgSeqClose (r);
+  return rc;
+}
+
+typedef struct { Modset *ms; U64 nSeq, totLen, totHash; } AddCtx;
+static int addBatch (MgSeqBatch *b, void *v)
+{
+  AddCtx *c = (AddCtx *) v;
+  int64_t h = mgAddSequenceBatch (c->ms, b->bases, b->offsets, b->nSeq);
+  if (h < 0) return -1;
+  c->nSeq += (U64) b->nSeq; c->totLen += (U64) b->total; c->totHash += (U64) h;
+  return 0;
+}
+
+int mgAddSequenceFile (Modset *ms, const char *filename, FILE *out)            /* modutils.c:33-51 */
+{
+  AddCtx c; memset (&c, 0, sizeof (c)); c.ms = ms;
+  int rc = forEachBatch (filename, addBatch, &c);
+  if (rc) return rc;
+  fprintf (out, "added %llu sequences total length %llu total hashes %llu, new max %u\n",
+           (unsigned long long) c.nSeq, (unsigned long long) c.totLen, (unsigned long long) c.totHash, ms->max);
+  return 0;
+}
+
+/* modmap reads the whole reference before it classifies and packs (modmap.c:93-134), and its report
+ * lines are per file: one batch holding every record */
+int mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out)
+{
+  MgSeqReader *r = mgSeqOpen (filename);
+  if (!r) { fprintf (stderr, "FATAL ERROR: failed to read reference sequence file %s\n", filename); exit (-1); }   /* modmap.c:99 */
+  MgSeqBatch b;
+  int n = mgSeqNextBatch (r, INT64_MAX, &b);
+  int rc = mgReferenceRead (ref, b.bases, b.offsets, n, (const char **) b.names, isAdd, out);
+  mgSeqBatchFree (&b);
+  mgSeqClose (r);
+  return rc;
+}
+
+typedef struct { MgReference *ref; FILE *out; } QueryCtx;
+static int queryBatch (MgSeqBatch *b, void *v)
+{ QueryCtx *c = (QueryCtx *) v; return mgQueryProcess (c->ref, b->bases, b->offsets, b->nSeq, (const char **) b->names, c->out); }
+
+int mgQueryFile (MgReference *ref, const char *filename, FILE *out)            /* modmap.c:188-196 */
+{
+  QueryCtx c; c.ref = ref; c.out = out;
+  int rc = forEachBatch (filename, queryBatch, &c);
+  if (rc == -1 && access (filename, R_OK)) { fprintf (stderr, "FATAL ERROR: failed to read query sequence file %s\n", filename); exit (-1); }   /* modmap.c:196 */
+  return rc;
+}

@@ -184,6 +184,72 @@ def gen_modmap_many():
     print("modmap many", [os.path.getsize(os.path.join(HERE, "modmap_many_files" + e)) for e in (".mod", ".ref")])
 
 
+def make_seqio_inputs():
+    """text files that exercise seqio.c's FASTA/FASTQ parsing (seqio.c:296-343) and dna2indexConv
+    (seqio.c:643-652): wrapped lines of several widths, lower case, N, IUPAC codes and junk (dropped in
+    FASTA), CR LF line ends, blank lines, descriptions, an empty record, a '>' inside a line."""
+    rng = np.random.default_rng(99)
+    g = synth.iid_bases(40000, 2024)
+    letters = np.array(list("ACGT"))
+
+    def text(b, lower_rate=0.0, n_rate=0.0, junk=None, junk_rate=0.0):
+        t = letters[b].copy()
+        r = rng.random(len(t))
+        t[r < n_rate] = "N"
+        if junk:
+            m = (r >= n_rate) & (r < n_rate + junk_rate)
+            t[m] = rng.choice(list(junk), int(m.sum()))
+        low = rng.random(len(t)) < lower_rate
+        t[low] = np.char.lower(t[low])
+        return "".join(t)
+
+    def wrap(sq, width, eol="\n"):
+        return eol.join(sq[i:i + width] for i in range(0, len(sq), width)) + eol if sq else ""
+    recs = []
+    recs.append(">plain60 first record\n" + wrap(text(g[0:3000]), 60))
+    recs.append(">lower\tmixed case, tab before the description\n" + wrap(text(g[3000:6500], lower_rate=0.5), 80))
+    recs.append(">withN\n" + wrap(text(g[6500:9000], n_rate=0.02), 70))
+    recs.append(">iupac codes and junk are dropped\n" + wrap(text(g[9000:12000], junk="RYKMSWBDHVryk*-.0123 ", junk_rate=0.03), 61))
+    recs.append(">crlf\r\n" + wrap(text(g[12000:14000]), 50, eol="\r\n"))
+    recs.append(">empty\n")
+    recs.append(">blank_lines\n" + wrap(text(g[14000:15000]), 100) + "\n\n" + wrap(text(g[15000:16000]), 100))
+    recs.append(">gt_inside\n" + text(g[16000:16050]) + ">notaheader " + text(g[16050:16100]) + "\n" + wrap(text(g[16100:17000]), 60))
+    recs.append(">oneline\n" + text(g[17000:25000]) + "\n")
+    recs.append(">short\nACGTAC\n")
+    for i in range(40):
+        a = int(rng.integers(0, 38000)); L = int(rng.integers(30, 1500))
+        recs.append(">r%d len=%d\n" % (i, L) + wrap(text(g[a:a + L], lower_rate=0.1, n_rate=0.005), int(rng.integers(20, 120))))
+    open(os.path.join(HERE, "mixed.fa"), "w", newline="").write("".join(recs))
+    open(os.path.join(HERE, "unterminated.fa"), "w", newline="").write("".join(recs[:3]) + ">last\n" + text(g[100:400]))
+    import gzip as _gz
+    with _gz.GzipFile(os.path.join(HERE, "mixed.fa.gz"), "wb", mtime=0) as f:
+        f.write("".join(recs).encode())
+    fq = []
+    for i in range(60):
+        a = int(rng.integers(0, 38000)); L = int(rng.integers(25, 400))
+        sq = text(g[a:a + L], lower_rate=0.2, n_rate=0.01)
+        fq.append("@fq%d some description\n%s\n+%s\n%s\n" % (i, sq, "fq%d" % i if i % 2 else "", "".join(rng.choice(list("!#5:?I@+"), L))))
+    fq.append("@fqempty\n\n+\n\n")
+    open(os.path.join(HERE, "mixed.fq"), "w", newline="").write("".join(fq))
+
+
+def gen_seqio():
+    mu = os.path.join(REFDIR, "modutils_ref")
+    for name in ("mixed.fa", "mixed.fa.gz", "unterminated.fa", "mixed.fq"):
+        tag = name.replace(".", "_")
+        r = subprocess.run([mu, "-c", "20", "15", "4", "17", "-a", name, "-wt", "seqio_%s.dump.txt" % tag],
+                           capture_output=True, text=True, cwd=HERE)
+        assert r.returncode == 0, r.stderr[-500:]
+        open(os.path.join(HERE, "seqio_%s.stdout.txt" % tag), "w").write(strip_timing(r.stdout))
+        open(os.path.join(HERE, "seqio_%s.stderr.txt" % tag), "w").write(
+            "".join(l + "\n" for l in r.stderr.splitlines() if not l.startswith("COMMAND")))
+        print("seqio", name, [l for l in r.stdout.splitlines() if l.startswith("added")], r.stderr.splitlines()[-1:])
+    # the gzip'd copy must give the same set: keep one dump
+    a, b = (os.path.join(HERE, "seqio_mixed_fa%s.dump.txt" % x) for x in ("", "_gz"))
+    assert open(a).read() == open(b).read()
+    os.remove(b)
+
+
 def gen_modset_ops():
     """modsetMerge / modsetDepthPrune / modsetPack / modsetWrite through the reference library."""
     out = {}
@@ -256,6 +322,8 @@ if __name__ == "__main__":
     gen_modmap()
     gen_modmap_files()
     gen_modmap_many()
+    make_seqio_inputs()
+    gen_seqio()
     gen_modset_ops()
     digest_dumps()
     for fn in ("/tmp/_golden_sum.txt", "/tmp/_golden_a.mod"):

@@ -1,0 +1,172 @@
+"""The file front end (mg_seqio.c) against the reference's seqio.c, through what modutils/modmap print.
+
+Fixtures: tests/golden/make_golden.py (make_seqio_inputs, gen_seqio): `modutils -c 20 15 4 17 -a <file>
+-wt dump` run by the reference program on each text file.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import modimizer_amd as mg
+from tests import util
+
+FILES = {"mixed.fa": "mixed_fa", "mixed.fa.gz": "mixed_fa", "unterminated.fa": "unterminated_fa", "mixed.fq": "mixed_fq"}
+
+
+def parse_file(path, max_bases, threads):
+    """every record of the file through mgSeqOpen/mgSeqNextBatch: (names, [bases arrays])"""
+    L = mg.lib()
+    os.environ["MODGPU_PARSE_THREADS"] = str(threads)
+    r = L.mgSeqOpen(path.encode())
+    assert r
+    names, seqs = [], []
+    b = mg.MgSeqBatch()
+    while True:
+        n = L.mgSeqNextBatch(r, max_bases, C.byref(b))
+        if n == 0:
+            break
+        offs = np.ctypeslib.as_array(b.offsets, shape=(n + 1,)).copy()
+        assert offs[0] == 0 and offs[-1] == b.total and np.all(np.diff(offs) >= 0)
+        bases = np.ctypeslib.as_array(b.bases, shape=(max(int(b.total), 1),))[:b.total].astype(np.uint8)
+        for i in range(n):
+            names.append(b.names[i].decode()); seqs.append(bases[offs[i]:offs[i + 1]].copy())
+        L.mgSeqBatchFree(C.byref(b))
+    L.mgSeqClose(r)
+    del os.environ["MODGPU_PARSE_THREADS"]
+    return names, seqs
+
+
+def added_line(golden_stdout):
+    return [l for l in golden_stdout.splitlines() if l.startswith("added ")][0]
+
+
+@pytest.mark.parametrize("fname", list(FILES))
+@pytest.mark.parametrize("max_bases,threads", [(1 << 40, 1), (1, 3), (5000, 8)])
+def test_parse_matches_reference_program(fname, max_bases, threads, golden_dir, tmp_path):
+    """parse here, add with the oracle: the line and the -wt dump the reference prints for the file"""
+    from oracle import pyoracle as orc
+    names, seqs = parse_file(os.path.join(golden_dir, fname), max_bases, threads)
+    h = orc.Hasher(15, 4, 17)
+    ms = orc.Modset(h, 20)
+    tot_hash = sum(ms.add_sequence(s) for s in seqs)
+    line = "added %d sequences total length %d total hashes %d, new max %d" % (
+        len(seqs), sum(len(s) for s in seqs), tot_hash, ms.max)
+    tag = fname.replace(".", "_")
+    assert line == added_line(util.golden_text("seqio_%s.stdout.txt" % tag))
+    assert ms.text_dump(str(tmp_path / "d.txt")) == util.golden_text("seqio_%s.dump.txt" % FILES[fname])
+    ms.close()
+
+
+def test_names_and_shapes(golden_dir):
+    names, seqs = parse_file(os.path.join(golden_dir, "mixed.fa"), 1 << 40, 4)
+    assert names[:10] == ["plain60", "lower", "withN", "iupac", "crlf", "empty", "blank_lines", "gt_inside", "oneline", "short"]
+    assert len(seqs[5]) == 0 and list(seqs[9]) == [0, 1, 2, 3, 0, 1]
+    assert len(seqs[0]) == 3000 and len(seqs[4]) == 2000 and len(seqs[6]) == 2000 and len(seqs[7]) == 1004   # ">notaheader " inside a line: n, t, a, a are bases
+    assert all(int(s.max(initial=0)) <= 3 for s in seqs)
+    fq_names, fq = parse_file(os.path.join(golden_dir, "mixed.fq"), 700, 2)
+    assert fq_names[0] == "fq0" and fq_names[-1] == "fqempty" and len(fq[-1]) == 0 and len(fq) == 61
+
+
+def test_unterminated_last_record_is_reported(golden_dir, capfd):
+    names, seqs = parse_file(os.path.join(golden_dir, "unterminated.fa"), 1 << 40, 2)
+    assert names == ["plain60", "lower", "withN"]
+    assert capfd.readouterr().err == util.golden_text("seqio_unterminated_fa.stderr.txt")
+
+
+def test_unreadable_and_empty(tmp_path, capfd):
+    L = mg.lib()
+    assert not L.mgSeqOpen(str(tmp_path / "absent.fa").encode())
+    (tmp_path / "empty.fa").write_text("")
+    assert not L.mgSeqOpen(str(tmp_path / "empty.fa").encode())
+    assert "unreadable or empty" in capfd.readouterr().err          # seqio.c:42
+
+
+BAD = {
+    "no_plus": ("@a\nACGT\nIIII\n@b\nAC\n+\nII\n", "missing + FASTQ line 3"),
+    "qual_len": ("@a\nACGT\n+\nIII\n", "qual not same length as seq line 4"),
+    "no_at": ("@a\nACGT\n+\nIIII\nACGT\n+\nIIII\n", "no initial @ for FASTQ record line 5"),
+}
+
+
+@pytest.mark.parametrize("case", list(BAD))
+def test_malformed_fastq_dies_like_the_reference(case, tmp_path):
+    text, msg = BAD[case]
+    path = tmp_path / "bad.fq"
+    path.write_text(text)
+    code = ("import ctypes as C, modimizer_amd as mg; L = mg.lib(); r = L.mgSeqOpen(%r.encode()); "
+            "b = mg.MgSeqBatch(); L.mgSeqNextBatch(r, 1 << 30, C.byref(b))" % str(path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=util.ROOT,
+                       env=dict(os.environ, MODGPU_NO_TORCH="1"))
+    assert r.returncode == 255 and ("FATAL ERROR: " + msg) in r.stderr
+
+
+def test_large_record_and_many_small(tmp_path):
+    """one record larger than the first window (16 MiB, seqio.c:36) and many tiny ones after it"""
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 4, 20_000_000).astype(np.uint8)
+    small = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(1, 200, 5000)]
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    path = tmp_path / "big.fa"
+    with open(path, "wb") as f:
+        f.write(b">big\n")
+        t = letters[big]
+        for i in range(0, len(t), 1_000_000):
+            f.write(t[i:i + 1_000_000].tobytes() + b"\n")
+        for i, s in enumerate(small):
+            f.write(b">s%d\n" % i + letters[s].tobytes() + b"\n")
+    for max_bases, threads in ((1 << 40, 8), (1000, 2)):
+        names, seqs = parse_file(str(path), max_bases, threads)
+        assert len(seqs) == 5001 and names[0] == "big" and names[-1] == "s4999"
+        assert np.array_equal(seqs[0], big)
+        assert all(np.array_equal(a, b) for a, b in zip(seqs[1:], small))
+
+
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", list(FILES))
+def test_add_sequence_file_gpu(fname, golden_dir, tmp_path):
+    """modutils -c 20 15 4 17 -a <file> -wt: file -> parse -> pack -> scan -> modset, all here"""
+    L = mg.lib()
+    sh = mg.seqhashCreate(15, 4, 17)
+    ms = mg.modsetCreate(sh, 20)
+    out = str(tmp_path / "o.txt")
+    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"
+    try:
+        with mg.CFile(out, "w") as f:
+            assert L.mgAddSequenceFile(ms, os.path.join(golden_dir, fname).encode(), f) == 0
+    finally:
+        del os.environ["MODGPU_FILE_BATCH_MBP"]
+    tag = fname.replace(".", "_")
+    assert open(out).read().strip() == added_line(util.golden_text("seqio_%s.stdout.txt" % tag))
+    dump = str(tmp_path / "d.txt")
+    with mg.CFile(dump, "w") as f:
+        L.mgModsetWriteText(ms, f)
+    assert open(dump).read() == util.golden_text("seqio_%s.dump.txt" % FILES[fname])
+    L.modsetDestroy(ms)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(util.MODMAP_TAGS))
+def test_modmap_from_files_gpu(tag, golden_dir, tmp_path):
+    """modmap -f ref.fa -q queries.fa from the files themselves (queries in several batches)"""
+    L = mg.lib()
+    k, w = util.MODMAP_TAGS[tag]
+    sh = mg.seqhashCreate(k, w, 17)
+    ms = mg.modsetCreate(sh, 20)
+    ref = L.mgReferenceCreate(ms, 1 << 26)
+    out = str(tmp_path / "mm.txt")
+    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"
+    try:
+        with mg.CFile(out, "w") as f:
+            assert L.mgReferenceFastaRead(ref, os.path.join(golden_dir, "ref.fa").encode(), True, f) == 0
+            assert L.mgQueryFile(ref, os.path.join(golden_dir, "queries.fa").encode(), f) == 0
+    finally:
+        del os.environ["MODGPU_FILE_BATCH_MBP"]
+    want = util.golden_text("modmap_%s.stdout.txt" % tag).splitlines()[1:]      # without the "initialised" line
+    assert open(out).read().splitlines() == want
+    L.mgReferenceDestroy(ref)
