@@ -266,6 +266,30 @@ MgReference *mgReferenceLoad (const char *root) ;
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
                      const char **names, FILE *out) ;
 
+/* modasm's long-read set (modasm.c:30-57,79-86) as readsetFileRead + invBuild leave it:
+ * per read its length, hit / miss counts and copy-class tallies; the hits (modset index, bit 31 =
+ * forward) with the 16-bit distance to the previous hit; per mod the reads that hit it.  Reads are
+ * numbered from 1 as in the reference; the scan + lookup of every read is one GPU batch call. */
+typedef struct {
+  Modset *ms ;
+  int nReads, capReads ;
+  int *len, *nHit, *nMiss ;     /* [1..nReads] */
+  int (*nCopy)[4] ;             /* [1..nReads]: hits on copy 0 / 1 / 2 / M mods */
+  U64 *hitStart ;               /* hits of read i: hit/dx[hitStart[i] .. hitStart[i+1]) */
+  U32 *hit ; U16 *dx ;
+  U64 totHit, capHit ;
+  U64 *invStart ;               /* [ms->max+2]: mod i is hit by the reads invSpace[invStart[i] .. invStart[i+1]) */
+  U32 *invSpace ;               /* (one entry per hit, read order; none for mods whose depth saturated, modasm.c:266,278) */
+} MgReadset ;
+MgReadset *mgReadsetCreate (Modset *ms) ;                                                   /* modasm.c:90-98 */
+void mgReadsetDestroy (MgReadset *rs) ;
+/* modasm.c:151-191 + 258-287: depth[] is rebuilt from these reads (modasm.c:158) */
+int  mgReadsetRead (MgReadset *rs, const char *bases, const int64_t *offsets, int nReads) ;
+int  mgReadsetFileRead (MgReadset *rs, const char *filename) ;
+void mgReadsetStats (MgReadset *rs, FILE *out) ;                                            /* modasm.c:193-253 */
+void mgReadsetWrite (MgReadset *rs, const char *root) ;                                     /* modasm.c:108-126 */
+MgReadset *mgReadsetLoad (const char *root) ;                                               /* modasm.c:128-149 */
+
 /* The file front end (seqio.c:30-346 for FASTA / FASTQ text, plain or gzip, with the callers'
  * dna2indexConv + N->0 conversion): records are cut out of the text and converted by a pool of
  * threads, a batch at a time.  bases hold 0..3 (FASTQ keeps other bytes as (char)-2, as the

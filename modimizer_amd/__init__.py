@@ -46,6 +46,13 @@ class MgReference(C.Structure):       # include/modgpu.h (modmap.c:35-47)
                 ("nSeq", C.c_int), ("names", C.POINTER(C.c_char_p)), ("len", U32P)]
 
 
+class MgReadset(C.Structure):         # include/modgpu.h (modasm.c:30-57,79-86)
+    _fields_ = [("ms", C.POINTER(Modset)), ("nReads", C.c_int), ("capReads", C.c_int),
+                ("len", C.POINTER(C.c_int)), ("nHit", C.POINTER(C.c_int)), ("nMiss", C.POINTER(C.c_int)),
+                ("nCopy", C.POINTER(C.c_int * 4)), ("hitStart", U64P), ("hit", U32P), ("dx", C.POINTER(C.c_uint16)),
+                ("totHit", C.c_uint64), ("capHit", C.c_uint64), ("invStart", U64P), ("invSpace", U32P)]
+
+
 class MgSeqBatch(C.Structure):        # include/modgpu.h
     _fields_ = [("bases", C.POINTER(C.c_int8)), ("offsets", C.POINTER(C.c_int64)), ("names", C.POINTER(C.c_char_p)),
                 ("nSeq", C.c_int), ("total", C.c_int64), ("isFastq", C.c_int), ("basesCap", C.c_int64)]
@@ -66,6 +73,7 @@ EXPORTS = [
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
+    "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
     "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
@@ -143,6 +151,10 @@ def lib():
     sig("mgReferenceCreate", vp, MS, u32); sig("mgReferenceDestroy", None, vp)
     sig("mgReferenceRead", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), C.c_bool, vp)
     sig("mgQueryProcess", i32, vp, vp, vp, i32, C.POINTER(C.c_char_p), vp)
+    RS = C.POINTER(MgReadset)
+    sig("mgReadsetCreate", RS, MS); sig("mgReadsetDestroy", None, RS)
+    sig("mgReadsetRead", i32, RS, vp, vp, i32); sig("mgReadsetFileRead", i32, RS, C.c_char_p)
+    sig("mgReadsetStats", None, RS, vp); sig("mgReadsetWrite", None, RS, C.c_char_p); sig("mgReadsetLoad", RS, C.c_char_p)
     sig("mgSeqOpen", vp, C.c_char_p); sig("mgSeqNextBatch", i32, vp, C.c_int64, C.POINTER(MgSeqBatch))
     sig("mgSeqBatchFree", None, C.POINTER(MgSeqBatch)); sig("mgSeqClose", None, vp)
     sig("mgAddSequenceFile", i32, MS, C.c_char_p, vp); sig("mgReferenceFastaRead", i32, vp, C.c_char_p, C.c_bool, vp)

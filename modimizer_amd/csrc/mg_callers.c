@@ -11,14 +11,14 @@
 #include <string.h>
 #include <zlib.h>
 #include "modgpu.h"
+#include "mg_internal.h"
 
 static void fatal (const char *what)
 { fprintf (stderr, "FATAL ERROR: %s: %s\n", what, mgLastError ()); exit (-1); }
 
 /* ---- packed batch on the device (host bytes -> 2-bit words -> HBM) ---- */
-typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } DevBatch;
 
-static void batchUpload (DevBatch *b, const char *bases, const int64_t *offsets, int nReads)
+void mgBatchUpload (MgDevBatch *b, const char *bases, const int64_t *offsets, int nReads)
 {
   b->nReads = (U32) nReads;
   b->total = nReads ? (U64) offsets[nReads] : 0;
@@ -28,7 +28,7 @@ static void batchUpload (DevBatch *b, const char *bases, const int64_t *offsets,
       || mgStreamSynchronize (0)) fatal ("H2D");
 }
 
-static void batchFree (DevBatch *b) { mgDeviceFree (b->dPacked); mgDeviceFree (b->dOff); }
+void mgBatchFree (MgDevBatch *b) { mgDeviceFree (b->dPacked); mgDeviceFree (b->dOff); }
 
 /* ---------------------------------- modutils ---------------------------------- */
 
@@ -113,7 +113,7 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
     }
   U64 totLen = nSeq ? (U64) offsets[nSeq] : 0;
 
-  DevBatch b; batchUpload (&b, bases, offsets, nSeq);
+  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nSeq);
   U64 cap = b.total ? b.total : 1, n = 0;
   if (cap > ((U64) ref->size)) cap = ref->size;       /* more seeds than this cannot be stored anyway */
   void *dIx = 0, *dPos = 0, *dRid = 0;
@@ -131,7 +131,7 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
     }
   U32 *hIx = (U32 *) malloc ((size_t) (n + 1) * 4), *hPos = (U32 *) malloc ((size_t) (n + 1) * 4), *hRid = (U32 *) malloc ((size_t) (n + 1) * 4);
   if (n && (mgMemcpyD2H (hIx, dIx, n * 4, 0) || mgMemcpyD2H (hPos, dPos, n * 4, 0) || mgMemcpyD2H (hRid, dRid, n * 4, 0))) fatal ("D2H");
-  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); batchFree (&b);
+  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); mgBatchFree (&b);
 
   U32 idBase = (U32) ref->nSeq;
   for (U64 i = 0 ; i < n ; ++i)
@@ -170,7 +170,7 @@ static ssize_t gzCookieRead (void *c, char *buf, size_t n) { int r = gzread ((gz
 static ssize_t gzCookieWrite (void *c, const char *buf, size_t n) { int r = gzwrite ((gzFile) c, buf, (unsigned) n); return r <= 0 ? 0 : r; }
 static int gzCookieClose (void *c) { return gzclose ((gzFile) c) == Z_OK ? 0 : -1; }
 
-static FILE *tagOpen (const char *root, const char *tag, const char *mode)      /* utils.c:129-139 */
+FILE *mgTagOpen (const char *root, const char *tag, const char *mode)      /* utils.c:129-139 */
 {
   char *name = (char *) malloc (strlen (root) + strlen (tag) + 2);
   sprintf (name, "%s.%s", root, tag);
@@ -195,12 +195,12 @@ static void die1 (const char *fmt, const char *arg)
 typedef struct { int magic; char *base; int dim, size, max; } RefArrayHeader;     /* array.h:41-50, 32 bytes */
 #define REF_ARRAY_MAGIC 8918274                                                    /* array.h:56 */
 
-static int refArrayDim (int n)             /* allocated elements after n appends to arrayCreate (1024, U32): array.c:144-170,180-183 */
+int mgRefArrayDim (int first, int size, int n)      /* allocated elements after appending 0..n-1 to arrayCreate (first, size): array.c:144-170,180-183 */
 {
-  int dim = 1024;
+  int dim = first < 1 ? 1 : first;
   for (int i = 0 ; i < n ; ++i)
     if (i >= dim)
-      { if ((long) dim * 4 < (1 << 23)) dim *= 2; else dim += 1024 + ((1 << 23) / 4);
+      { if ((long) dim * size < (1 << 23)) dim *= 2; else dim += 1024 + ((1 << 23) / size);
         if (i >= dim) dim = i + 1;
       }
   return dim;
@@ -250,10 +250,10 @@ static int *refDictTable (char **names, int n, int *bitsOut)
 void mgReferenceWrite (MgReference *ref, const char *root)                       /* modmap.c:136-156 */
 {
   FILE *f;
-  if (!(f = tagOpen (root, "mod", "w"))) die1 ("failed to open %s.mod to write", root);
+  if (!(f = mgTagOpen (root, "mod", "w"))) die1 ("failed to open %s.mod to write", root);
   modsetWrite (ref->ms, f);
   fclose (f);
-  if (!(f = tagOpen (root, "ref", "w"))) die1 ("failed to open %s.ref to write", root);
+  if (!(f = mgTagOpen (root, "ref", "w"))) die1 ("failed to open %s.ref to write", root);
   const U32 size = ref->max, m = ref->ms->max + 1;
   WR ("RFMSHv1", 8, 1, "reference header");
   WR (&size, sizeof (U32), 1, "size");
@@ -266,7 +266,7 @@ void mgReferenceWrite (MgReference *ref, const char *root)                      
   WR (ref->loc, sizeof (U32), m, "loc");
   /* len: Array header + dim elements */
   RefArrayHeader ah; memset (&ah, 0, sizeof (ah));
-  ah.magic = REF_ARRAY_MAGIC; ah.dim = refArrayDim (ref->nSeq); ah.size = (int) sizeof (U32); ah.max = ref->nSeq;
+  ah.magic = REF_ARRAY_MAGIC; ah.dim = mgRefArrayDim (1024, (int) sizeof (U32), ref->nSeq); ah.size = (int) sizeof (U32); ah.max = ref->nSeq;
   U32 *lenBuf = (U32 *) calloc ((size_t) ah.dim, sizeof (U32));
   memcpy (lenBuf, ref->len, (size_t) ref->nSeq * sizeof (U32));
   WR (&ah, sizeof (ah), 1, "ref len");
@@ -291,10 +291,10 @@ void mgReferenceWrite (MgReference *ref, const char *root)                      
 MgReference *mgReferenceLoad (const char *root)                                  /* modmap.c:158-182 */
 {
   FILE *f;
-  if (!(f = tagOpen (root, "mod", "r"))) die1 ("failed to open %s.mod to read", root);
+  if (!(f = mgTagOpen (root, "mod", "r"))) die1 ("failed to open %s.mod to read", root);
   Modset *ms = modsetRead (f);
   fclose (f);
-  if (!(f = tagOpen (root, "ref", "r"))) die1 ("failed to open %s.ref to read", root);
+  if (!(f = mgTagOpen (root, "ref", "r"))) die1 ("failed to open %s.ref to read", root);
   char tag[8];
   RD (tag, 8, 1, "reference header");
   if (memcmp (tag, "RFMSHv1", 8)) die1 ("bad reference header%s", "");
@@ -366,7 +366,7 @@ int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets,
                     const char **names, FILE *out)
 {
   Modset *ms = ref->ms;
-  DevBatch b; batchUpload (&b, bases, offsets, nReads);
+  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
   U64 n = 0, guess = b.total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b.total) guess = b.total;
   if (guess < 1) guess = 1;
   void *dIx = 0, *dPos = 0, *dRid = 0;
@@ -380,7 +380,7 @@ int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets,
     }
   U32 *six = (U32 *) malloc ((size_t) (n + 1) * 4), *spos = (U32 *) malloc ((size_t) (n + 1) * 4), *srid = (U32 *) malloc ((size_t) (n + 1) * 4);
   if (n && (mgMemcpyD2H (six, dIx, n * 4, 0) || mgMemcpyD2H (spos, dPos, n * 4, 0) || mgMemcpyD2H (srid, dRid, n * 4, 0))) fatal ("D2H");
-  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); batchFree (&b);
+  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); mgBatchFree (&b);
   for (U64 i = 0 ; i < n ; ++i) spos[i] &= MG_POS_MASK;
 
   U64 at = 0;

@@ -16,6 +16,14 @@ int  mgHookMergeDevice (Modset *ms1, Modset *ms2);   /* modsetMerge with ms1 on 
 int  mgHookPruneDevice (Modset *ms, int lo, int hi);  /* modsetDepthPrune on the device; 0 = done */
 /* one GPU scan of one read for the iterator facade: *rec = malloc()ed {U64 kmer[n]; U32 posF[n]} */
 int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
+/* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */
+#define MG_HIDDEN __attribute__ ((visibility ("hidden")))
+typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } MgDevBatch;     /* host bytes -> 2-bit words in HBM */
+MG_HIDDEN void mgBatchUpload (MgDevBatch *b, const char *bases, const int64_t *offsets, int nReads);
+MG_HIDDEN void mgBatchFree (MgDevBatch *b);
+MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);   /* <root>.<tag> through gzip, as utils.c:107-139 */
+/* element count of the reference's Array after appending elements 0..n-1 (array.c:144-170,180-183) */
+MG_HIDDEN int mgRefArrayDim (int first, int size, int n);
 #ifdef __cplusplus
 }
 #endif

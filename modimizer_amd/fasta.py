@@ -45,3 +45,9 @@ def write_fasta(path, names, seqs, width=70):
             txt = "".join("ACGT"[b] for b in s) if not isinstance(s, str) else s
             for i in range(0, len(txt), width):
                 f.write(txt[i:i + width] + "\n")
+
+
+def read_fasta_list(path):
+    """the sequences of a FASTA file as a list of uint8 arrays"""
+    _, bases, offs = read_fasta(path)
+    return [bases[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]

@@ -104,6 +104,27 @@ int64_t orcQueryRead (OrcReference *ref, const char *readName, const uint8_t *s,
                       const char **refNames, FILE *f,
                       uint32_t *seedIndex, uint32_t *seedPos, int64_t seedCap);
 
+/* modasm.c:30-57,79-86: the long-read set that readsetFileRead + invBuild leave behind */
+typedef struct { int32_t len, nHit, nMiss, nCopy[4]; } OrcRead;
+typedef struct {
+  OrcModset *ms;
+  int nReads, capReads;
+  OrcRead  *reads;          /* [1..nReads]; entry 0 is burnt (modasm.c:95) */
+  uint64_t *hitStart;       /* hits of read i: [hitStart[i], hitStart[i+1]) */
+  uint32_t *hit;            /* modset index, top bit = forward */
+  uint16_t *dx;             /* distance to the previous hit of the read */
+  uint64_t  totHit, capHit;
+  uint64_t *invStart;       /* [max+2]: reads holding mod i at invSpace[invStart[i] ..] (depth[i] of them, none when saturated) */
+  uint32_t *invSpace;
+} OrcReadset;
+OrcReadset *orcReadsetCreate (OrcModset *ms);
+void orcReadsetDestroy (OrcReadset *rs);
+void orcReadsetBegin (OrcReadset *rs);                                           /* modasm.c:158 */
+void orcReadsetAddRead (OrcReadset *rs, const uint8_t *s, int64_t len);          /* modasm.c:161-188 */
+void orcReadsetFinish (OrcReadset *rs);                                          /* modasm.c:258-287 */
+void orcReadsetStats (const OrcReadset *rs, FILE *f);                            /* modasm.c:193-253 */
+int  orcReadsetWrite (const OrcReadset *rs, FILE *f);                            /* modasm.c:113-125 */
+
 /* seqhash.c:198-206 */
 const char *orcSeqString (uint64_t kmer, int len);
 

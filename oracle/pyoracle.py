@@ -22,7 +22,7 @@ I64P = C.POINTER(C.c_int64)
 def build(force=False):
     """make -C oracle (liboracle.so, and _ref when the reference tree is present)."""
     so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("orc_seqhash.c", "orc_modset.c", "oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("orc_seqhash.c", "orc_modset.c", "orc_readset.c", "oracle.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     need_ref = os.path.isdir(REF_TREE) and not os.path.exists(os.path.join(HERE, "_ref", "libmodref.so"))
     if stale or need_ref:
@@ -221,11 +221,77 @@ class Modset:
         _with_file(tmp, lambda f: L.orcModsetWriteText(self.p, f))
         return open(tmp).read()
 
+    def set_copy(self, c1, c2, cm):
+        """modutils -s (modutils.c:205-214): copy class from depth thresholds"""
+        c = self.p.contents
+        for u in range(1, c.max + 1):
+            d = c.depth[u]
+            cls = 0 if d < c1 else (1 if d < c2 else (2 if d < cm else 3))
+            c.info[u] = (c.info[u] | 3) if cls == 3 else ((c.info[u] & 0xfc) | cls)
+
     def write_mod(self, path):
         L = lib()
         L.orcModsetWrite.argtypes = [C.POINTER(OrcModset), C.c_void_p]
         L.orcModsetWrite.restype = C.c_int
         _with_file(path, lambda f: L.orcModsetWrite(self.p, f))
+
+
+class OrcRead(C.Structure):
+    _fields_ = [("len", C.c_int32), ("nHit", C.c_int32), ("nMiss", C.c_int32), ("nCopy", C.c_int32 * 4)]
+
+
+class OrcReadset(C.Structure):
+    _fields_ = [("ms", C.POINTER(OrcModset)), ("nReads", C.c_int), ("capReads", C.c_int),
+                ("reads", C.POINTER(OrcRead)), ("hitStart", C.POINTER(C.c_uint64)),
+                ("hit", C.POINTER(C.c_uint32)), ("dx", C.POINTER(C.c_uint16)),
+                ("totHit", C.c_uint64), ("capHit", C.c_uint64),
+                ("invStart", C.POINTER(C.c_uint64)), ("invSpace", C.POINTER(C.c_uint32))]
+
+
+class Readset:
+    """modasm.c read ingest restated (orc_readset.c): readsetFileRead + invBuild over reads in memory."""
+
+    def __init__(self, modset):
+        L = lib()
+        L.orcReadsetCreate.restype = C.POINTER(OrcReadset)
+        L.orcReadsetCreate.argtypes = [C.POINTER(OrcModset)]
+        for fn in ("orcReadsetDestroy", "orcReadsetBegin", "orcReadsetFinish"):
+            getattr(L, fn).argtypes = [C.POINTER(OrcReadset)]; getattr(L, fn).restype = None
+        L.orcReadsetAddRead.argtypes = [C.POINTER(OrcReadset), C.c_void_p, C.c_int64]; L.orcReadsetAddRead.restype = None
+        L.orcReadsetStats.argtypes = [C.POINTER(OrcReadset), C.c_void_p]; L.orcReadsetStats.restype = None
+        L.orcReadsetWrite.argtypes = [C.POINTER(OrcReadset), C.c_void_p]; L.orcReadsetWrite.restype = C.c_int
+        self.ms = modset
+        self.p = L.orcReadsetCreate(modset.p)
+
+    def read(self, seqs):
+        L = lib()
+        L.orcReadsetBegin(self.p)
+        for s in seqs:
+            s = np.ascontiguousarray(s, dtype=np.uint8)
+            L.orcReadsetAddRead(self.p, s.ctypes.data, len(s))
+        L.orcReadsetFinish(self.p)
+
+    def arrays(self):
+        r = self.p.contents
+        n, tot, m = r.nReads, int(r.totHit), self.ms.max
+        rd = [r.reads[i] for i in range(1, n + 1)]
+        as_np = lambda p, k, dt: np.ctypeslib.as_array(p, (max(k, 1),))[:k].astype(dt).copy()
+        return {"len": np.array([x.len for x in rd]), "nHit": np.array([x.nHit for x in rd]),
+                "nMiss": np.array([x.nMiss for x in rd]), "nCopy": np.array([list(x.nCopy) for x in rd]).reshape(n, 4),
+                "hitStart": as_np(r.hitStart, n + 2, np.uint64)[1:], "hit": as_np(r.hit, tot, np.uint32),
+                "dx": as_np(r.dx, tot, np.uint16), "totHit": tot,
+                "invStart": as_np(r.invStart, m + 2, np.uint64), "invSpace": as_np(r.invSpace, int(r.invStart[m + 1]), np.uint32)}
+
+    def stats_text(self, tmp):
+        _with_file(tmp, lambda f: lib().orcReadsetStats(self.p, f))
+        return open(tmp).read()
+
+    def write(self, path):
+        _with_file(path, lambda f: lib().orcReadsetWrite(self.p, f))
+
+    def close(self):
+        if self.p:
+            lib().orcReadsetDestroy(self.p); self.p = None
 
 
 class Reference:

@@ -250,6 +250,18 @@ def gen_seqio():
     os.remove(b)
 
 
+def gen_modasm():
+    """modasm's read ingest: a modset with copy classes (modutils -s), then modasm -m .. -f .. -S -w:
+    the stats it prints and its <stem>.mod + <stem>.readset files (gzip streams)."""
+    mu, ma = os.path.join(REFDIR, "modutils_ref"), os.path.join(REFDIR, "modasm_ref")
+    for tag, (k, w) in {"k21d16": (21, 16), "k17d31": (17, 31)}.items():
+        run([mu, "-c", "20", str(k), str(w), "17", "-a", "reads.fa", "-s", "2", "3", "5",
+             "-w", "asm_%s_src.mod" % tag])
+        out = run([ma, "-m", "asm_%s_src.mod" % tag, "-f", "reads2.fa", "-S", "-w", "asm_%s" % tag])
+        open(os.path.join(HERE, "asm_%s.stdout.txt" % tag), "w").write(strip_timing(out))
+        print("modasm", tag, [os.path.getsize(os.path.join(HERE, "asm_%s%s" % (tag, e))) for e in ("_src.mod", ".mod", ".readset")])
+
+
 def gen_modset_ops():
     """modsetMerge / modsetDepthPrune / modsetPack / modsetWrite through the reference library."""
     out = {}
@@ -322,6 +334,7 @@ if __name__ == "__main__":
     gen_modmap()
     gen_modmap_files()
     gen_modmap_many()
+    gen_modasm()
     make_seqio_inputs()
     gen_seqio()
     gen_modset_ops()
