@@ -102,6 +102,19 @@ __device__ __forceinline__ U64 mgLookback (U64 *desc, U64 tile, U64 count)
   if (lane == 0) mgDescStore (&desc[tile], MG_DESC_PREFIX, sum + count);
   return sum;
 }
+/* inclusive prefix sum over the 64 lanes of a wave with DPP only (no LDS traffic): Hillis-Steele inside the
+ * rows of 16 (row_shr 1,2,4,8), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31
+ * into rows 2 and 3 (row_bcast:31).  Lanes without a source add 0. */
+__device__ __forceinline__ U32 mgWaveInclusiveSum (U32 v)
+{
+  v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xf, 0xf, false);
+  v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x112, 0xf, 0xf, false);
+  v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x114, 0xf, 0xf, false);
+  v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x118, 0xf, 0xf, false);
+  v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x142, 0xa, 0xf, false);
+  v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x143, 0xc, 0xf, false);
+  return v;
+}
 #endif /* __HIPCC__ */
 
 /* launchers implemented in the .hip files */

@@ -341,10 +341,7 @@ void mgScanKernel (const MgScanArgs a)
 
       /* ---- Phase B: order the candidates ---- */
       const U32 cnt = (U32) __popcll (cand);
-      U32 incl = cnt;
-#pragma unroll
-      for (int off = 1 ; off < 64 ; off <<= 1)
-        { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
+      const U32 incl = mgWaveInclusiveSum (cnt);
       if (lane == 63) sWaveTotA[wave] = incl;
       __syncthreads ();                                                          /* (2) */
       U32 waveBase = 0, nc = 0;

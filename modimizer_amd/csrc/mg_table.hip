@@ -451,9 +451,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
       __syncthreads ();
       /* exclusive scan of the bin counts (two bins per thread) + reservation of the output runs */
       { U32 c0 = (U32) (2 * tid) < nBins ? sH[2 * tid] : 0, c1 = (U32) (2 * tid + 1) < nBins ? sH[2 * tid + 1] : 0;
-        U32 pair = c0 + c1, incl = pair;
-#pragma unroll
-        for (int off = 1 ; off < 64 ; off <<= 1) { U32 v = __shfl_up (incl, off); if (lane >= off) incl += v; }
+        const U32 pair = c0 + c1, incl = mgWaveInclusiveSum (pair);
         if (lane == 63) sWave[wave] = incl;
         __syncthreads ();
         U32 wb = 0;
