@@ -183,7 +183,7 @@ def main():
 def cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream):
     """The reference's own C path (oracle/_ref/ref_bench, built from the unmodified sources) timed
     single-threaded — its real execution model — on the first reads of the same workload."""
-    sample_mbp = float(os.environ.get("MODGPU_CPU_SAMPLE_MBP", "400"))
+    sample_mbp = float(os.environ.get("MODGPU_CPU_SAMPLE_MBP", "1200"))
     want = int(sample_mbp * 1e6)
     n = int(np.searchsorted(offsets, want, side="right")) - 1
     n = max(1, min(n, len(offsets) - 1))
