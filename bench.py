@@ -53,8 +53,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     L = mg.lib()
     mg.check(L.mgSetDevice(local_rank))
-    if world > 1:
+    # MODGPU_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, histogram all-reduce, barriers)
+    # with whatever WORLD_SIZE the launcher gave, even 1 — for checking that path on a one-GPU box
+    multi = world > 1 or os.environ.get("MODGPU_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     k, d, seed, bits = 21, 64, 17, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
@@ -89,7 +93,7 @@ def main():
         mg.check(L.mgModsetClear(ms, stream))
         mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads,
                                     C.byref(n_hash), stream))
-        if world > 1:
+        if multi:
             hist.zero_()
             mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), stream))
             dist.all_reduce(hist)
@@ -100,17 +104,17 @@ def main():
 
     L.mgProfileEnable(1)
     L.mgProfileReset()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -176,7 +180,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

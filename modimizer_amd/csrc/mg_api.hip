@@ -345,6 +345,7 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
   MG_HIP (hipMemsetAsync (t.counters, 0, 64, st));
   { MgStatus s0 = mgTableEnsure (&t, ms->max, st); if (s0) return s0; }   /* slots sized to the content; grows on demand */
   t.max = 0; t.syncedMax = 0;
+  t.baseZero = !ms->max;
   if (ms->max)
     { MG_HIP (hipMemcpyAsync (t.value, ms->value, ((size_t) ms->max + 1) * sizeof (U64), hipMemcpyHostToDevice, st));
       MG_HIP (hipMemcpyAsync (t.baseDepth, ms->depth, ((size_t) ms->max + 1) * sizeof (U16), hipMemcpyHostToDevice, st));
@@ -374,6 +375,7 @@ static MgStatus mgDevGet (Modset *ms, MgDev **out, hipStream_t st)
       if (last >= (ms->tableSize >> 2)) { mgSetError ("modset max %u beyond table capacity", last); return MG_ERR_CAPACITY; }
       MG_HIP (hipMemcpyAsync (d->t.value + first, ms->value + first, (size_t) (last - first + 1) * sizeof (U64), hipMemcpyHostToDevice, st));
       MG_HIP (hipMemcpyAsync (d->t.baseDepth + first, ms->depth + first, (size_t) (last - first + 1) * sizeof (U16), hipMemcpyHostToDevice, st));
+      d->t.baseZero = false;
       if ((s = mgTableLoadHost (&d->t, d->t.value, first, last, st))) return s;
       MG_HIP (hipStreamSynchronize (st));
       d->t.max = d->t.syncedMax = last;
@@ -413,7 +415,8 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
   if (d)
     { MgTable &t = d->t;
       mgTableForget (&t, st);          /* buckets are re-initialised by whoever writes them next (no 8 GB memset) */
-      if (t.syncedMax) MG_HIP (hipMemsetAsync (t.baseDepth, 0, ((size_t) t.syncedMax + 1) * sizeof (U16), st));
+      if (!t.baseZero) MG_HIP (hipMemsetAsync (t.baseDepth, 0, ((size_t) (t.max > t.syncedMax ? t.max : t.syncedMax) + 1) * sizeof (U16), st));
+      t.baseZero = true;
       t.max = t.syncedMax = 0;
       d->hostIndexMax = 0;
     }
@@ -465,6 +468,7 @@ extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
     MgStatus as = mgAddBatch (ms1, d, dV2, n2, dIdx, 0, false, st);
     if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }
     if (as) break;
+    t.baseZero = false;
     if (mgTableMergeApply (dIdx, dD2, dI2, n2, t.baseDepth, dI1, st)) break;
     if (hipStreamSynchronize (st)) break;
     /* bring the host mirror up to date wholesale: values of the new entries, all depths and info */
@@ -505,7 +509,8 @@ extern "C" int mgHookPruneDevice (Modset *ms, int lo, int hi)
     const U32 m = (U32) c[0];
     /* new arrays replace the old ones on both sides */
     if (m)
-      { if (hipMemcpy (t.value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToDevice) || hipMemcpy (t.baseDepth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToDevice)
+      { t.baseZero = false;
+        if (hipMemcpy (t.value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToDevice) || hipMemcpy (t.baseDepth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToDevice)
             || hipMemcpy (ms->value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToHost) || hipMemcpy (ms->depth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToHost)
             || hipMemcpy (ms->info + 1, dNewInfo + 1, m, hipMemcpyDeviceToHost)) break;
       }

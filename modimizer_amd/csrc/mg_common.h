@@ -142,6 +142,7 @@ struct MgTable {
   U32 *occ;            /* [NB] non-zero when the bucket may hold entries */
   U64 *value;          /* [size] device copy of ms->value */
   U16 *baseDepth;      /* [size] host depth at last sync */
+  bool baseZero;       /* baseDepth is known to be all zero (fresh or cleared set): the histogram skips its random loads */
   U32 size;            /* capacity in entries (ms->size) */
   U32 max;             /* entries known to the device table */
   U32 syncedMax;       /* entries whose value[] the host already has */

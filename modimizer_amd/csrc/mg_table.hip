@@ -275,18 +275,41 @@ void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U32 
   __shared__ U32 sBins[MG_HIST_LDS_BINS];
   for (int b = threadIdx.x ; b < MG_HIST_LDS_BINS ; b += blockDim.x) sBins[b] = 0;
   __syncthreads ();
-  U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
-  const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; s < nSlots ; s += stride)
-    { if (!occ[s >> log2R]) continue;
-      uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
-      if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
-      U32 idx = v.z & ~MG_ASSIGNED;
-      U32 d = (U32) baseDepth[idx] + v.w;
-      if (d > 0xffffu || d < v.w) d = 0xffffu;
-      if (d < MG_HIST_LDS_BINS) atomicAdd (&sBins[d], 1u);
-      else atomicAdd (&hist[d], 1ull);
+  /* a workgroup takes whole buckets (one occupancy test per bucket) and keeps four 16-byte loads per lane in
+     flight; whole waves run every step, so the two commonest bins (depth 1 and 2: sequencing errors) are counted
+     per wave with ballots instead of 64 colliding LDS atomics */
+  const U32 R = 1u << log2R, nBuckets = (U32) (nSlots >> log2R);
+  const int lane = threadIdx.x & 63;
+  U32 n1 = 0, n2 = 0;
+  for (U32 bk = blockIdx.x ; bk < nBuckets ; bk += gridDim.x)
+    { if (!occ[bk]) continue;
+      const MgSlot *base = slots + ((U64) bk << log2R);
+      for (U32 i0 = 0 ; i0 < R ; i0 += 4 * blockDim.x)
+        { uint4 v[4];
+#pragma unroll
+          for (int j = 0 ; j < 4 ; ++j)
+            { const U32 i = i0 + j * blockDim.x + threadIdx.x;
+              v[j] = i < R ? *reinterpret_cast<const uint4 *> (&base[i]) : make_uint4 (0, 0, 0, 0);
+            }
+#pragma unroll
+          for (int j = 0 ; j < 4 ; ++j)
+            { U32 d = 0; bool have = false;
+              if ((v[j].x | v[j].y) && mgIsAssigned (v[j].z))
+                { U32 idx = v[j].z & ~MG_ASSIGNED;
+                  d = (baseDepth ? (U32) baseDepth[idx] : 0u) + v[j].w;        /* baseDepth == 0: known to be all zero */
+                  if (d > 0xffffu || d < v[j].w) d = 0xffffu;
+                  have = true;
+                }
+              n1 += (U32) __popcll (__ballot (have && d == 1));
+              n2 += (U32) __popcll (__ballot (have && d == 2));
+              if (have && d != 1 && d != 2)
+                { if (d < MG_HIST_LDS_BINS) atomicAdd (&sBins[d], 1u);
+                  else atomicAdd (&hist[d], 1ull);
+                }
+            }
+        }
     }
+  if (lane == 0) { if (n1) atomicAdd (&sBins[1], n1); if (n2) atomicAdd (&sBins[2], n2); }
   __syncthreads ();
   for (int b = threadIdx.x ; b < MG_HIST_LDS_BINS ; b += blockDim.x)
     if (sBins[b]) atomicAdd (&hist[b], (unsigned long long) sBins[b]);
@@ -870,6 +893,7 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st)
 {
   if (!t->max) return MG_OK;
   MG_HIP (hipMemsetAsync (dDelta, 0, (size_t) t->max * sizeof (U16), st));
+  t->baseZero = false;                                   /* the fold below writes baseDepth */
   MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid (t->nSlots, 256, 8192)), dim3 (256), 0, st,
              t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, dDelta, t->max);
   MG_HIP (hipGetLastError ());
@@ -880,7 +904,7 @@ MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st)
 {
   if (!t->max) return MG_OK;
   MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->nSlots, 256, 2048)), dim3 (256), 0, st,
-             t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, (unsigned long long *) dHist);
+             t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseZero ? (const U16 *) 0 : t->baseDepth, (unsigned long long *) dHist);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
