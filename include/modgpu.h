@@ -83,7 +83,7 @@ Seqhash *seqhashRead (FILE *f) ;                                          /* seq
 void seqhashReport (Seqhash *sh, FILE *f) ;                               /* seqhash.c:55-56 */
 SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len) ;        /* seqhash.c:154-177 */
 bool modRCnext (SeqhashRCiterator *si, U64 *kmer, int *pos, bool *isF) ;  /* seqhash.c:179-196 */
-SeqhashRCiterator *minimizerRCiterator (Seqhash *sh, char *s, int len) ;  /* seqhash.c:83-108 */
+SeqhashRCiterator *minimizerRCiterator (Seqhash *sh, char *s, int len) ;  /* seqhash.c:83-108: one GPU pass, replayed */
 bool minimizerRCnext (SeqhashRCiterator *si, U64 *u, int *pos, bool *isF) ; /* seqhash.c:110-152 */
 char *seqString (U64 kmer, int len) ;                                     /* seqhash.c:198-206 */
 /* header-inline in the reference (seqhash.h:37,54-60); exported here as real symbols too */
@@ -169,6 +169,18 @@ MgStatus seqhashScanBatchDevice (const Seqhash *sh, const U32 *dPacked, U64 tota
  * modimizers, or -1 on error. */
 int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
                           U64 **kmer, int **pos, bool **isF, int64_t **survStart) ;
+
+/* minimizerRCiterator + minimizerRCnext (seqhash.c:83-152) run to exhaustion on every read of a batch:
+ * the (hash, pos | isF<<31) pairs successive minimizerRCnext calls return, reads in order, read r's at
+ * [dReadStart[r], dReadStart[r+1]) (dReadStart holds nReads+1 entries).  One wavefront per read walks the
+ * reference's chain of windows (see mg_minimizer.hip).  *n receives the total (also when it exceeds
+ * `capacity`: MG_ERR_CAPACITY, nothing written). */
+MgStatus seqhashMinimizerBatchDevice (const Seqhash *sh, const U32 *dPacked, U64 totalBases,
+                                      const U64 *dReadOffsets, U32 nReads,
+                                      U64 *dHash, U32 *dPosF, U64 *dReadStart, U64 capacity, U64 *n, void *stream) ;
+/* host buffers in, malloc()ed arrays out (as seqhashScanBatch); returns the number of minimizers, -1 on error */
+int64_t seqhashMinimizerBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
+                               U64 **hash, int **pos, bool **isF, int64_t **start) ;
 
 /* Device modset (modset.c:45-62 as a batch).  The device table is created on first use from the
  * host arrays of `ms` and lives until modsetDestroy / mgModsetDeviceRelease.

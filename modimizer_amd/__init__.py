@@ -67,7 +67,7 @@ EXPORTS = [
     "mgLastError", "mgDeviceCount", "mgSetDevice", "mgVersion", "mgDeviceAlloc", "mgDeviceFree",
     "mgMemcpyH2D", "mgMemcpyD2H", "mgMemsetD", "mgStreamSynchronize",
     "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice", "mgUploadPack",
-    "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch",
+    "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch", "seqhashMinimizerBatchDevice", "seqhashMinimizerBatch",
     "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgModsetDeviceRelease",
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
@@ -136,6 +136,8 @@ def lib():
     sig("mgScanWorkBytes", C.c_size_t, u64, u32, u64)
     sig("seqhashScanBatchDevice", i32, SH, vp, u64, vp, u32, vp, vp, vp, u64, vp, vp, vp)
     sig("seqhashScanBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
+    sig("seqhashMinimizerBatchDevice", i32, SH, vp, u64, vp, u32, vp, vp, vp, u64, U64P, vp)
+    sig("seqhashMinimizerBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
     sig("modsetAddBatchDevice", i32, MS, vp, u64, vp, i32, vp)
     sig("modsetFindBatchDevice", i32, MS, vp, u64, vp, vp)
     sig("modsetSyncToHost", i32, MS, i32); sig("mgModsetDeviceRelease", i32, MS)
@@ -258,6 +260,27 @@ def scan_batch(sh, bases, offsets):
     isf = take(pf, C.c_bool, n, np.uint8)
     st = take(ps, C.c_int64, n_reads + 1, np.int64)
     return kmer, pos, isf, st
+
+
+def minimizer_batch(sh, bases, offsets):
+    """seqhashMinimizerBatch: what minimizerRCnext returns for every read of a batch, reads in order.
+    Returns (hash u64[], pos i32[], isF u8[], start i64[nReads+1])."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_reads = len(offsets) - 1
+    pk, pp, pf, ps = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = L.seqhashMinimizerBatch(sh, bases.ctypes.data, offsets.ctypes.data, n_reads,
+                                C.byref(pk), C.byref(pp), C.byref(pf), C.byref(ps))
+    if n < 0:
+        raise ModgpuError("seqhashMinimizerBatch failed: " + L.mgLastError().decode())
+
+    def take(ptr, ctype, count, dtype):
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (max(count, 1),))[:count].astype(dtype, copy=True)
+        _libc.free(ptr)
+        return a
+    return (take(pk, C.c_uint64, n, np.uint64), take(pp, C.c_int, n, np.int32), take(pf, C.c_bool, n, np.uint8),
+            take(ps, C.c_int64, n_reads + 1, np.int64))
 
 
 class DeviceBuffer:

@@ -299,6 +299,98 @@ extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* minimizers (seqhash.c:83-152) */
+
+extern "C" MgStatus seqhashMinimizerBatchDevice (const Seqhash *sh, const U32 *dPacked, U64 totalBases,
+                                                 const U64 *dReadOffsets, U32 nReads,
+                                                 U64 *dHash, U32 *dPosF, U64 *dReadStart, U64 capacity,
+                                                 U64 *nOut, void *stream)
+{
+  MgStatus s = mgEnsureDevice (); if (s) return s;
+  if ((s = mgCheckHasher (sh))) return s;
+  (void) totalBases;
+  U64 total = 0;
+  s = mgLaunchMinimizers (mgMakeParams (sh), (U32) sh->w, dPacked, dReadOffsets, nReads, dHash, dPosF, dReadStart,
+                          capacity, &total, (hipStream_t) stream);
+  if (nOut) *nOut = total;
+  return s;
+}
+
+/* host buffers in, host arrays out; *startOut[r] .. [r+1] are read r's minimizers.  Returns their number, -1 on error. */
+static int64_t mgMinimizersHost (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
+                                 U64 **hashOut, U32 **posFOut, int64_t **startOut)
+{
+  if (mgEnsureDevice () || mgCheckHasher (sh)) return -1;
+  if (nReads < 0 || (nReads && (!readOffsets || readOffsets[0] != 0))) { mgSetError ("minimizer batch: bad read offsets"); return -1; }
+  const U64 total = nReads ? (U64) readOffsets[nReads] : 0;
+  const size_t nw = mgPackedWords (total);
+  U64 cap = total / ((U64) sh->w / 2 + 1) + total / 8 + (U64) nReads + 1024;
+  int64_t result = -1;
+  U64 *hH = 0; U32 *hP = 0; int64_t *hS = 0;
+  MgArena ar;
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { size_t need = al256 (nw * 4) + 2 * al256 (((size_t) nReads + 2) * 8) + al256 (cap * 8) + al256 (cap * 4) + 4096;
+      if (ar.reserve (need)) break;
+      ar.reset ();
+      U32 *dP = (U32 *) ar.take (nw * 4);
+      U64 *dOff = (U64 *) ar.take (((size_t) nReads + 2) * 8);
+      U64 *dStart = (U64 *) ar.take (((size_t) nReads + 2) * 8);
+      U64 *dH = (U64 *) ar.take (cap * 8);
+      U32 *dQ = (U32 *) ar.take (cap * 4);
+      if (mgUploadPack (bases, total, dP, 0)) break;
+      if (nReads && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+      U64 n = 0;
+      MgStatus s = seqhashMinimizerBatchDevice (sh, dP, total, dOff, (U32) nReads, dH, dQ, dStart, cap, &n, 0);
+      if (s == MG_ERR_CAPACITY && attempt == 0) { cap = n; continue; }
+      if (s) break;
+      hH = (U64 *) malloc ((n + 1) * 8); hP = (U32 *) malloc ((n + 1) * 4); hS = (int64_t *) malloc (((size_t) nReads + 1) * 8);
+      if (hipStreamSynchronize (0) != hipSuccess) break;
+      if (n && (hipMemcpy (hH, dH, n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy (hP, dQ, n * 4, hipMemcpyDeviceToHost) != hipSuccess)) break;
+      if (hipMemcpy (hS, dStart, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+      result = (int64_t) n;
+      break;
+    }
+  ar.release ();
+  if (result < 0)
+    { if (!gErr[0]) mgSetError ("minimizer batch: device failure");
+      free (hH); free (hP); free (hS); return -1;
+    }
+  *hashOut = hH; *posFOut = hP; *startOut = hS;
+  return result;
+}
+
+extern "C" int64_t seqhashMinimizerBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
+                                          U64 **hashOut, int **posOut, bool **isFOut, int64_t **startOut)
+{
+  U64 *hH = 0; U32 *hP = 0; int64_t *hS = 0;
+  int64_t n = mgMinimizersHost (sh, bases, readOffsets, nReads, &hH, &hP, &hS);
+  if (n < 0) return -1;
+  if (posOut) { int *p = (int *) malloc ((n + 1) * sizeof (int)); for (int64_t i = 0 ; i < n ; ++i) p[i] = (int) (hP[i] & MG_POS_MASK); *posOut = p; }
+  if (isFOut) { bool *f = (bool *) malloc ((n + 1) * sizeof (bool)); for (int64_t i = 0 ; i < n ; ++i) f[i] = (hP[i] & MG_FWD_BIT) != 0; *isFOut = f; }
+  if (hashOut) *hashOut = hH; else free (hH);
+  if (startOut) *startOut = hS; else free (hS);
+  free (hP);
+  return n;
+}
+
+/* one read for the iterator facade: *rec = malloc()ed {n hashes (U64), n posF (U32)} */
+extern "C" int mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut)
+{
+  *rec = 0; *nOut = 0;
+  if (len < sh->k) return mgEnsureDevice () ? -1 : 0;
+  int64_t off[2] = { 0, len };
+  U64 *hH = 0; U32 *hP = 0; int64_t *hS = 0;
+  int64_t n = mgMinimizersHost (sh, s, off, 1, &hH, &hP, &hS);
+  if (n < 0) return -1;
+  U64 *blk = (U64 *) malloc ((size_t) n * 12 + 16);
+  memcpy (blk, hH, (size_t) n * 8);
+  memcpy (blk + n, hP, (size_t) n * 4);
+  free (hH); free (hP); free (hS);
+  *rec = blk; *nOut = (U64) n;
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
 /* per-Modset device state                                                                    */
 
 struct MgDev {

@@ -134,6 +134,10 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
                             U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
                             U64 *dCount, void *dWork, hipStream_t st);
 
+/* minimizers (seqhash.c:83-152) of every read: per-read counts -> exclusive scan in dReadStart[nReads+1] -> write */
+MgStatus mgLaunchMinimizers (const MgHashParams &p, U32 w, const U32 *dPacked, const U64 *dReadOffsets, U32 nReads,
+                             U64 *dHash, U32 *dPosF, U64 *dReadStart, U64 capacity, U64 *totalOut, hipStream_t st);
+
 /* device modset table: NB = 2^log2NB buckets of R slots; see mg_table.hip */
 struct MgSlot { U64 key; U32 ord; U32 cnt; };      /* 16 bytes; key = kmer+1, 0 = empty */
 struct MgTable {

@@ -135,70 +135,39 @@ bool modRCnext (SeqhashRCiterator *si, U64 *kmer, int *pos, bool *isF)
 void mgSeqhashRCiteratorDestroy (SeqhashRCiterator *si)
 { free (si->hashBuf); free (si->fBuf); free (si); }
 
-/* minimizerRCiterator / minimizerRCnext (seqhash.c:83-152): no program in the reference calls
- * them, so they are not on the accelerated path; kept on the host for API completeness.  The
- * stream of canonical hashes is produced one k-mer at a time and the "window of w hashes that
- * restarts right after each reported minimum" logic of the reference is followed exactly,
- * including that the very first hash is never stored in the ring (seqhash.c:101). */
-static U64 stepHash (SeqhashRCiterator *si, bool *fwd)
-{
-  Seqhash *sh = si->sh;
-  if (si->s >= si->sEnd) return ~(U64) 0;
-  int b = *si->s & 3;
-  si->h = ((si->h << 2) & sh->mask) | (U64) b;
-  si->hRC = (si->hRC >> 2) | sh->patternRC[b];
-  U64 a = seqhash (sh, si->h), c = seqhash (sh, si->hRC);
-  *fwd = a < c;
-  return a < c ? a : c;
-}
-
+/* minimizerRCiterator / minimizerRCnext (seqhash.c:83-152): one GPU pass over the read
+ * (mg_minimizer.hip: a wavefront walks the reference's chain of windows), replayed like the
+ * modimizer iterator: the record block carries the returned hash values instead of k-mers. */
 SeqhashRCiterator *minimizerRCiterator (Seqhash *sh, char *s, int len)
 {
   SeqhashRCiterator *si = iterAlloc (sh, s, len);
-  si->hashBuf = (U64 *) xalloc ((size_t) sh->w * sizeof (U64), 1);
-  if (len < sh->k) { si->isDone = true; return si; }
-  for (int i = 0 ; i < sh->k ; ++i, ++si->s)
-    { int b = *si->s & 3;
-      si->h = (si->h << 2) | (U64) b;
-      si->hRC = (si->hRC >> 2) | sh->patternRC[b];
+  U64 *rec = 0, n = 0;
+  if (mgIterMinScan (sh, s, len, &rec, &n)) die ("minimizerRCiterator: GPU scan failed: %s", mgLastError ());
+  U64 *blk = (U64 *) xalloc ((size_t) (n + 1) * 8 + (size_t) n * 4 + 8, 0);
+  blk[0] = n;
+  if (n)
+    { memcpy (blk + 1, rec, (size_t) n * 8);
+      memcpy (blk + 1 + n, rec + n, (size_t) n * 4);
     }
-  U64 a = seqhash (sh, si->h), c = seqhash (sh, si->hRC);
-  si->fBuf[0] = a < c;
-  U64 best = a < c ? a : c;                /* slot 0 itself stays 0, as in the reference */
+  free (rec);
+  si->hashBuf = blk;
   si->iMin = 0;
-  for (int i = 1 ; i < sh->w ; ++i, ++si->s)
-    { si->hashBuf[i] = stepHash (si, &si->fBuf[i]);
-      if (si->hashBuf[i] < best) { best = si->hashBuf[i]; si->iMin = i; }
-    }
+  si->isDone = (n == 0);
   return si;
 }
 
 bool minimizerRCnext (SeqhashRCiterator *si, U64 *u, int *pos, bool *isF)
 {
   if (si->isDone) return false;
-  const int w = si->sh->w;
-  U64 out = si->hashBuf[si->iMin];
-  if (u) *u = out;
-  if (pos) *pos = si->base + si->iMin + (si->iMin < si->iStart ? w : 0);
-  if (isF) *isF = si->fBuf[si->iMin];
-  if (si->s >= si->sEnd) { si->isDone = true; return true; }
-
-  /* refill ring slots iStart..iMin (cyclically) with the next hashes */
-  int i = si->iStart;
-  for (;;)
-    { si->hashBuf[i] = stepHash (si, &si->fBuf[i]); ++si->s;
-      if (i == si->iMin) break;
-      if (++i == w) { i = 0; si->base += w; }
-    }
-  si->iStart = si->iMin + 1;
-  if (si->iStart == w) { si->iStart = 0; si->base += w; }
-
-  U64 bound; int pick;
-  if (si->hashBuf[si->iMin] != ~(U64) 0) { bound = ~(U64) 0; pick = si->iMin; }   /* full new window */
-  else { bound = out; pick = -1; }
-  for (i = 0 ; i < w ; ++i) if (si->hashBuf[i] < bound) { bound = si->hashBuf[i]; pick = i; }
-  si->iMin = pick;
-  if (pick < 0) si->isDone = true;
+  U64 n = si->hashBuf[0];
+  const U64 *hv = si->hashBuf + 1;
+  const U32 *pf = (const U32 *) (hv + n);
+  U64 i = (U64) (unsigned) si->iMin;
+  if (u) *u = hv[i];
+  if (pos) *pos = (int) (pf[i] & MG_POS_MASK);
+  if (isF) *isF = (pf[i] & MG_FWD_BIT) != 0;
+  if (++i >= n) si->isDone = true;
+  si->iMin = (int) i;
   return true;
 }
 

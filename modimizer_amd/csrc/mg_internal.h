@@ -16,6 +16,8 @@ int  mgHookMergeDevice (Modset *ms1, Modset *ms2);   /* modsetMerge with ms1 on 
 int  mgHookPruneDevice (Modset *ms, int lo, int hi);  /* modsetDepthPrune on the device; 0 = done */
 /* one GPU scan of one read for the iterator facade: *rec = malloc()ed {U64 kmer[n]; U32 posF[n]} */
 int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
+/* the same for the minimizer iterator: *rec = malloc()ed {U64 hash[n]; U32 posF[n]} */
+int  mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
 /* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */
 #define MG_HIDDEN __attribute__ ((visibility ("hidden")))
 typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } MgDevBatch;     /* host bytes -> 2-bit words in HBM */

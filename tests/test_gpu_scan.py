@@ -253,3 +253,63 @@ def test_upload_pack_multi_piece():
         mg.check(L.mgUploadPack(b.ctypes.data, n, d_w.ptr, None))
         got = d_w.to_numpy(np.uint32, L.mgPackedWords(n))
         assert np.array_equal(got, mg.pack_host(b)), n
+
+
+# ---- minimizers (seqhash.c:83-152): one wavefront per read walks the reference's chain of windows ----
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(9))
+def test_minimizer_iterator_vs_golden(ci):
+    """minimizerRCiterator / minimizerRCnext against the lists the reference produced (edge reads: empty,
+    len<k, len==k, homopolymers with all hashes equal, the hashBuf[0] case)"""
+    k, w, seed = util.scan_configs()[ci]
+    sh = mg.seqhashCreate(k, w, seed)
+    for name, bases, _, _, _ in util.scan_cases(ci):
+        m = util.minimizer_case(ci, name)
+        if m is None:
+            continue
+        x, y, z = mg.iterate(sh, bases, minimizer=True)
+        assert np.array_equal(x, m[0]) and np.array_equal(y, m[1]) and np.array_equal(z, m[2]), (ci, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,w,seed", [(21, 31, 17), (15, 5, 3), (31, 64, 17), (19, 100, 9), (12, 1, 2), (21, 2, 17)])
+def test_minimizer_batch_vs_oracle(k, w, seed):
+    """a ragged batch (empty, shorter than k, shorter than k+w, monotone runs, homopolymers, long reads)"""
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(k * 1000 + w)
+    reads = [np.zeros(0, np.uint8), rng.integers(0, 4, k - 1).astype(np.uint8), rng.integers(0, 4, k).astype(np.uint8),
+             rng.integers(0, 4, k + 1).astype(np.uint8), rng.integers(0, 4, k + w - 2).astype(np.uint8),
+             rng.integers(0, 4, k + w - 1).astype(np.uint8), rng.integers(0, 4, k + w).astype(np.uint8),
+             np.zeros(5 * w + k + 3, np.uint8), np.full(3 * w + k, 3, np.uint8), np.tile(np.array([0, 1], np.uint8), 4 * w + k),
+             np.tile(np.array([0, 1, 2, 3, 3, 2], np.uint8), 300)]
+    reads += [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(k, 6000, 60)]
+    reads += [rng.integers(0, 4, 200_000).astype(np.uint8)]
+    h = orc.Hasher(k, w, seed)
+    want = [h.minimizers(r) for r in reads]
+    sh = mg.seqhashCreate(k, w, seed)
+    bases, offs = util.concat_reads(reads)
+    hv, pos, isf, st = mg.minimizer_batch(sh, bases, offs)
+    assert st[0] == 0 and st[-1] == len(hv) == sum(len(x[0]) for x in want)
+    for r, (a, b, c) in enumerate(want):
+        s, e = st[r], st[r + 1]
+        assert np.array_equal(hv[s:e], a) and np.array_equal(pos[s:e], b) and np.array_equal(isf[s:e], c), r
+
+
+@pytest.mark.gpu
+def test_minimizer_batch_capacity_is_reported():
+    L = mg.lib()
+    sh = mg.seqhashCreate(21, 11, 17)
+    rng = np.random.default_rng(5)
+    bases = rng.integers(0, 4, 50_000).astype(np.uint8)
+    offs = np.array([0, 20_000, 50_000], np.int64)
+    hv, pos, isf, st = mg.minimizer_batch(sh, bases, offs)
+    n_true = len(hv)
+    packed = mg.pack_host(bases)
+    d_p = mg.DeviceBuffer.from_numpy(packed)
+    d_o = mg.DeviceBuffer.from_numpy(offs.astype(np.uint64))
+    d_h = mg.DeviceBuffer(8 * 16); d_q = mg.DeviceBuffer(4 * 16); d_s = mg.DeviceBuffer(8 * 3)
+    n = C.c_uint64()
+    rc = L.seqhashMinimizerBatchDevice(sh, d_p.ptr, len(bases), d_o.ptr, 2, d_h.ptr, d_q.ptr, d_s.ptr, 16, C.byref(n), None)
+    assert rc == 4 and n.value == n_true            # MG_ERR_CAPACITY
+    assert list(d_s.to_numpy(np.uint64, 3)) == [0, int(st[1]), n_true]

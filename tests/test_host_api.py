@@ -162,19 +162,6 @@ def test_modset_host_ops_vs_golden(golden_dir, tmp_path):
         L.modsetDestroy(ms)
 
 
-@pytest.mark.parametrize("ci", range(9))
-def test_minimizer_iterator_vs_golden(ci):
-    """minimizerRCiterator/minimizerRCnext (seqhash.c:83-152): host code, dead in the reference"""
-    k, w, seed = util.scan_configs()[ci]
-    sh = mg.seqhashCreate(k, w, seed)
-    for name, bases, _, _, _ in util.scan_cases(ci):
-        m = util.minimizer_case(ci, name)
-        if m is None:
-            continue
-        x, y, z = mg.iterate(sh, bases, minimizer=True)
-        assert np.array_equal(x, m[0]) and np.array_equal(y, m[1]) and np.array_equal(z, m[2]), (ci, name)
-
-
 def test_fasta_reader_matches_seqio_conventions(golden_dir):
     names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, "reads.fa"))
     assert names[-3:] == ["short", "exact21", "withN"] and offs[-1] == len(bases) and bases.max() <= 3
