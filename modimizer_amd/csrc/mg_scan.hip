@@ -363,16 +363,25 @@ void mgScanKernel (const MgScanArgs a)
          MG_CAND_ITERS x 64 candidates), keeps k-mer / position / rank in registers, and after ONE
          barrier (the four wave totals) writes them straight to the block's segment. */
       for (U32 rd = 0 ; rd < nRounds ; ++rd)
-        { const U32 lo = rd * MG_CAND_CAP, hi = lo + MG_CAND_CAP;
+        { const U32 lo = rd * MG_CAND_CAP;
           if (rd) __syncthreads ();                          /* previous round done with sCand / sWaveTotB */
-          { U64 c = cand; U32 o = myFirst;
-            while (c && o < hi)
-              { int t = __ffsll ((long long) c) - 1;
-                c &= c - 1;
-                if (o >= lo) sCand[o - lo] = (unsigned short) (tid * MG_POS_PER_THREAD + t);
-                ++o;
-              }
-          }
+          /* the lane's candidates, low half of the mask then high half: 32-bit bit tricks, one LDS store each.
+             o is the slot in this round's list; it wraps below lo, so "o < CAP" alone selects the round's entries
+             (a loop condition on o costs more than it saves when there is one round, the usual case). */
+          if (myFirst < lo + MG_CAND_CAP && myFirst + cnt > lo)
+            { U32 o = myFirst - lo;
+#pragma unroll
+              for (int half = 0 ; half < 2 ; ++half)
+                { U32 c = half ? (U32) (cand >> 32) : (U32) cand;
+                  const U32 base = (U32) tid * MG_POS_PER_THREAD + 32u * half;
+                  while (c)
+                    { const U32 t = (U32) __builtin_ctz (c);
+                      c &= c - 1;
+                      if (o < MG_CAND_CAP) sCand[o] = (unsigned short) (base + t);
+                      ++o;
+                    }
+                }
+            }
           __syncthreads ();                                                      /* (3) candidates listed */
           const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
           const U32 per = (((nHere + 3) / 4) + 63) & ~63u;   /* candidates per wave, multiple of 64 */
