@@ -213,7 +213,7 @@ __global__ __launch_bounds__ (MG_SCAN_THREADS)
 void mgScanKernel (const MgScanArgs a)
 {
   __shared__ __attribute__ ((aligned (16))) U32 sWords[MG_TILE_WORDS + 8];
-  __shared__ unsigned short sCand[MG_CAND_CAP];
+  __shared__ unsigned short sCand[MG_CAND_CAP + 2];          /* [MG_CAND_CAP]: where stores of other rounds' entries land */
   __shared__ U32 sRFirst[MG_SCAN_THREADS];
   __shared__ U32 sWaveTotA[MG_SCAN_THREADS / 64], sWaveTotB[MG_SCAN_THREADS / 64];
 
@@ -377,7 +377,7 @@ void mgScanKernel (const MgScanArgs a)
                   while (c)
                     { const U32 t = (U32) __builtin_ctz (c);
                       c &= c - 1;
-                      if (o < MG_CAND_CAP) sCand[o] = (unsigned short) (base + t);
+                      sCand[o < MG_CAND_CAP ? o : MG_CAND_CAP] = (unsigned short) (base + t);   /* no branch in the loop */
                       ++o;
                     }
                 }
