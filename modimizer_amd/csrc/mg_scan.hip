@@ -212,9 +212,11 @@ template <int MODE>
 __global__ __launch_bounds__ (MG_SCAN_THREADS)
 void mgScanKernel (const MgScanArgs a)
 {
-  __shared__ __attribute__ ((aligned (16))) U32 sWords[MG_TILE_WORDS + 8];
+  /* the tile's words and first-read table are double-buffered: a wave that is done with tile t stages tile t+1
+     while slower waves still read tile t (barrier (1) of t+1 is then the only meeting point between tiles) */
+  __shared__ __attribute__ ((aligned (16))) U32 sWordsBuf[2][MG_TILE_WORDS + 8];
   __shared__ unsigned short sCand[MG_CAND_CAP + 2];          /* [MG_CAND_CAP]: where stores of other rounds' entries land */
-  __shared__ U32 sRFirst[MG_SCAN_THREADS];
+  __shared__ U32 sRFirstBuf[2][MG_SCAN_THREADS];
   __shared__ U32 sWaveTotA[MG_SCAN_THREADS / 64], sWaveTotB[MG_SCAN_THREADS / 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,8 +240,10 @@ void mgScanKernel (const MgScanArgs a)
       nextFirstRead = a.tileInfo[tile + 1].firstRead;
     }
 
+  int buf = 0;
   while (tile < tileEnd)
-    { *reinterpret_cast<uint4 *> (&sWords[4 * tid]) = curV;
+    { U32 *sWords = sWordsBuf[buf]; U32 *sRFirst = sRFirstBuf[buf]; buf ^= 1;
+      *reinterpret_cast<uint4 *> (&sWords[4 * tid]) = curV;
       if (tid < 8) sWords[MG_TILE_WORDS + tid] = curHalo;
 
       const U64 tile0 = tile * (U64) MG_TILE_BASES;
@@ -433,7 +437,6 @@ void mgScanKernel (const MgScanArgs a)
               }
           found += total;
         }
-      __syncthreads ();                                                          /* (7) LDS free for the next tile */
       tile = nextTile;
       curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
     }
