@@ -11,8 +11,8 @@
 /* scan tiling: one workgroup walks tiles of the concatenated batch */
 #define MG_SCAN_THREADS   256
 #define MG_POS_PER_THREAD 64
-#define MG_TILE_BASES     (MG_SCAN_THREADS * MG_POS_PER_THREAD)   /* 16384 k-mer starts per tile */
-#define MG_TILE_WORDS     (MG_TILE_BASES / 16)                    /* 1024 packed words = 4 KiB  */
+#define MG_TILE_BASES     (64 * MG_POS_PER_THREAD)                /* 4096 k-mer starts per tile: one wavefront's */
+#define MG_TILE_WORDS     (MG_TILE_BASES / 16)                    /* 256 packed words = 1 KiB  */
 
 /* Hash parameters in the form the kernels use. */
 struct MgHashParams {

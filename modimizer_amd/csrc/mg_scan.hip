@@ -118,10 +118,11 @@ struct MgScanArgs {
   const U64 *readOff; U32 nReads;
   const MgTileInfo *tileInfo;
   U64 tileBegin, tileLimit;      /* this launch covers tiles [tileBegin, tileLimit) */
-  U64 tilesPerBlock;     /* block b owns tiles [b*tilesPerBlock, (b+1)*tilesPerBlock) */
+  U64 tilesPerWorker;    /* worker (wavefront) v owns tiles [v*tilesPerWorker, (v+1)*tilesPerWorker) */
+  U64 nWorkers;
   U64 segCap;            /* entries per output segment */
-  U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [gridDim.x * segCap] */
-  U64 *blockCount;       /* [gridDim.x] true number of modimizers each block found */
+  U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [nWorkers * segCap] */
+  U64 *blockCount;       /* [nWorkers] true number of modimizers each worker found */
   U32 fS, thresh;        /* fast path: factor1 << (32-B), 2^(32-m) */
   U32 debug;             /* dev only: bit0 = stop after phase B (timing ablation; output meaningless) */
 };
@@ -182,10 +183,20 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_MODE_ANY   0      /* any d: exact test in phase A via modular inverse */
 #define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
 #define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
-#define MG_CAND_CAP   1024   /* candidate list entries per round (LDS) */
-#define MG_CAND_ITERS (MG_CAND_CAP / MG_SCAN_THREADS)   /* 64-candidate steps per wave and round */
+#define MG_CAND_CAP   256    /* candidate list entries per round (LDS, per wavefront) */
+#define MG_CAND_ITERS (MG_CAND_CAP / 64)
+#define MG_WAVES      (MG_SCAN_THREADS / 64)
 
-/* One templated kernel.
+/* LDS written by some lanes of a wavefront and read by others of the same wavefront: DS operations of a
+ * wave complete in issue order, so all that is needed is that the compiler keeps the order */
+#define MG_WAVE_SYNC() do { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier (); \
+                            __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+/* One templated kernel; every WAVEFRONT is an independent worker.
+ *
+ * A worker owns a contiguous range of tiles (4096 k-mer starts each: 64 lanes x 64 starts) and its own
+ * output segment, so nothing in the kernel crosses a wavefront: no workgroup barrier, no shared counters
+ * (a workgroup is just four workers sharing a CU).  Per tile:
  *
  * Phase A  every lane owns 64 consecutive k-mer starts and produces a 64-bit candidate mask with
  *          no divergent work:
@@ -196,58 +207,57 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
  *                      last 16 bases of the forward k-mer and the first 16 bases, reverse-
  *                      complemented, of the reverse one.  With fS = factor1 << (32-B):
  *                      candidate  <=>  min (winF*fS, winR*fS) mod 2^32 < 2^(32-m)
- *                      (one v_alignbit + one 32-bit multiply per strand, a min and a compare):
- *                      a superset of the modimizers, about 2/d of the starts.
- * Phase B  candidates are compacted, in order, into an LDS list (rounds of MG_CAND_CAP).
- * Phase C  dense: one lane per candidate recomputes both full hashes from LDS, picks the strand
- *          (ties -> reverse, seqhash.c:66-67) and applies the exact test; wave ballots record it.
- * Phase D  ordered output: counts -> workgroup scan -> decoupled look-back across tiles ->
- *          surviving lanes write kmer / pos|isF / read.
+ *                      (one v_alignbit + one 32-bit multiply per strand, a min, a compare into VCC and an
+ *                      add-with-carry that shifts the bit into the mask): a superset of the modimizers,
+ *                      about 2/d of the starts.
+ * Phase B  a DPP prefix sum over the lanes' candidate counts orders the candidates; they are listed,
+ *          in order, in the wavefront's LDS list (rounds of MG_CAND_CAP).
+ * Phase C  dense: one lane per candidate recomputes both full hashes from the tile in LDS, picks the
+ *          strand (ties -> reverse, seqhash.c:66-67) and applies the exact test; a ballot ranks the
+ *          survivors, which go straight to the worker's segment: kmer / pos|isF / read.
  *
- * Latency: the next tile's ticket, metadata and packed words are fetched while the current tile
- * is processed (registers), so no global round trip sits on the per-tile critical path except
- * the look-back itself.
+ * Latency: the next tile's words, halo and metadata are fetched while the current tile is processed
+ * (registers), and the tile staging in LDS is double-buffered.
  */
 template <int MODE>
 __global__ __launch_bounds__ (MG_SCAN_THREADS)
 void mgScanKernel (const MgScanArgs a)
 {
-  /* the tile's words and first-read table are double-buffered: a wave that is done with tile t stages tile t+1
-     while slower waves still read tile t (barrier (1) of t+1 is then the only meeting point between tiles) */
-  __shared__ __attribute__ ((aligned (16))) U32 sWordsBuf[2][MG_TILE_WORDS + 8];
-  __shared__ unsigned short sCand[MG_CAND_CAP + 2];          /* [MG_CAND_CAP]: where stores of other rounds' entries land */
-  __shared__ U32 sRFirstBuf[2][MG_SCAN_THREADS];
-  __shared__ U32 sWaveTotA[MG_SCAN_THREADS / 64], sWaveTotB[MG_SCAN_THREADS / 64];
+  __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_WAVES][2][MG_TILE_WORDS + 8];
+  __shared__ unsigned short sCandAll[MG_WAVES][MG_CAND_CAP + 2];      /* [MG_CAND_CAP]: where stores of other rounds' entries land */
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const U64 worker = (U64) blockIdx.x * MG_WAVES + wave;
+  if (worker >= a.nWorkers) return;
+  unsigned short *sCand = sCandAll[wave];
   const MgHashParams &p = a.p;
   const int k = p.k, sh1 = p.shift1;
   const U64 f1 = p.factor1;
   const U64 dMask = (U64) (p.d - 1);
 
-  U64 tile = a.tileBegin + (U64) blockIdx.x * a.tilesPerBlock;
-  U64 tileEnd = tile + a.tilesPerBlock; if (tileEnd > a.tileLimit) tileEnd = a.tileLimit;
-  const U64 segBase = (U64) blockIdx.x * a.segCap;
-  U64 found = 0;                                   /* modimizers this block has found so far (uniform) */
+  U64 tile = a.tileBegin + worker * a.tilesPerWorker;
+  U64 tileEnd = tile + a.tilesPerWorker; if (tileEnd > a.tileLimit) tileEnd = a.tileLimit;
+  const U64 segBase = worker * a.segCap;
+  U64 found = 0;                                   /* modimizers this worker has found so far (uniform) */
   uint4 curV = make_uint4 (0, 0, 0, 0); U32 curHalo = 0;
   MgTileInfo ti, tiNext;
   ti.start = ti.end = 0; ti.firstRead = 0; tiNext = ti;
   U32 nextFirstRead = 0;
   if (tile < tileEnd)
-    { curV = mgLoadTileWords (a, tile, tid);
-      if (tid < 8) { U64 gh = tile * MG_TILE_WORDS + MG_TILE_WORDS + tid; curHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
+    { curV = mgLoadTileWords (a, tile, lane);
+      if (lane < 8) { U64 gh = tile * MG_TILE_WORDS + MG_TILE_WORDS + lane; curHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
       ti = a.tileInfo[tile];
       nextFirstRead = a.tileInfo[tile + 1].firstRead;
     }
 
   int buf = 0;
   while (tile < tileEnd)
-    { U32 *sWords = sWordsBuf[buf]; U32 *sRFirst = sRFirstBuf[buf]; buf ^= 1;
-      *reinterpret_cast<uint4 *> (&sWords[4 * tid]) = curV;
-      if (tid < 8) sWords[MG_TILE_WORDS + tid] = curHalo;
+    { U32 *sWords = sWordsAll[wave][buf]; buf ^= 1;
+      *reinterpret_cast<uint4 *> (&sWords[4 * lane]) = curV;
+      if (lane < 8) sWords[MG_TILE_WORDS + lane] = curHalo;
 
       const U64 tile0 = tile * (U64) MG_TILE_BASES;
-      const U64 p0 = tile0 + (U64) tid * MG_POS_PER_THREAD;
+      const U64 p0 = tile0 + (U64) lane * MG_POS_PER_THREAD;
       /* ---- which of the lane's 64 starts lie inside a read ---- */
       U64 valid = 0;
       U32 rFirst = ti.firstRead;
@@ -257,22 +267,21 @@ void mgScanKernel (const MgScanArgs a)
         { rFirst = mgReadOf (a.readOff, ti.firstRead, nextFirstRead, p0);
           valid = mgValidMask (a, p0, rFirst);
         }
-      sRFirst[tid] = rFirst;
-      __syncthreads ();                                                          /* (1) tile staged */
+      MG_WAVE_SYNC ();                                                           /* tile staged */
 
       /* prefetch the next tile (registers; consumed at the top of the next iteration) */
       const U64 nextTile = tile + 1;
       uint4 nextV = make_uint4 (0, 0, 0, 0); U32 nextHalo = 0; U32 nextNextFirst = 0;
       if (nextTile < tileEnd)
-        { nextV = mgLoadTileWords (a, nextTile, tid);
-          if (tid < 8) { U64 gh = nextTile * MG_TILE_WORDS + MG_TILE_WORDS + tid; nextHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
+        { nextV = mgLoadTileWords (a, nextTile, lane);
+          if (lane < 8) { U64 gh = nextTile * MG_TILE_WORDS + MG_TILE_WORDS + lane; nextHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
           tiNext = a.tileInfo[nextTile];
           nextNextFirst = a.tileInfo[nextTile + 1].firstRead;
         }
 
       /* ---- Phase A ---- */
       U32 w[6];
-      { uint2 h = *reinterpret_cast<const uint2 *> (&sWords[4 * tid + 4]);
+      { uint2 h = *reinterpret_cast<const uint2 *> (&sWords[4 * lane + 4]);
         w[0] = curV.x; w[1] = curV.y; w[2] = curV.z; w[3] = curV.w; w[4] = h.x; w[5] = h.y;
       }
       U64 cand;
@@ -346,29 +355,19 @@ void mgScanKernel (const MgScanArgs a)
       /* ---- Phase B: order the candidates ---- */
       const U32 cnt = (U32) __popcll (cand);
       const U32 incl = mgWaveInclusiveSum (cnt);
-      if (lane == 63) sWaveTotA[wave] = incl;
-      __syncthreads ();                                                          /* (2) */
-      U32 waveBase = 0, nc = 0;
-#pragma unroll
-      for (int i = 0 ; i < MG_SCAN_THREADS / 64 ; ++i)
-        { U32 v = sWaveTotA[i]; if (i < wave) waveBase += v; nc += v; }
-      const U32 myFirst = waveBase + incl - cnt;             /* ordinal of this lane's first candidate */
+      const U32 nc = (U32) __builtin_amdgcn_readlane ((int) incl, 63);
+      const U32 myFirst = incl - cnt;                        /* ordinal of this lane's first candidate */
       const U32 nRounds = (nc + MG_CAND_CAP - 1) / MG_CAND_CAP;
       if (a.debug & 1)                                      /* dev ablation: phases A+B only */
-        { __syncthreads ();
-          tile = nextTile; curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
+        { tile = nextTile; curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
           found += nc >> 20;
           continue;
         }
 
-      /* ---- Phases C+D, MG_CAND_CAP candidates per round ----
-         The round's candidates are split into four contiguous, 64-aligned ranges, one per wave, so a
-         wave's modimizers are contiguous in the output: it evaluates its range (at most
-         MG_CAND_ITERS x 64 candidates), keeps k-mer / position / rank in registers, and after ONE
-         barrier (the four wave totals) writes them straight to the block's segment. */
+      /* ---- Phase C, MG_CAND_CAP candidates per round ---- */
       for (U32 rd = 0 ; rd < nRounds ; ++rd)
         { const U32 lo = rd * MG_CAND_CAP;
-          if (rd) __syncthreads ();                          /* previous round done with sCand / sWaveTotB */
+          if (rd) MG_WAVE_SYNC ();                           /* previous round done with sCand */
           /* the lane's candidates, low half of the mask then high half: 32-bit bit tricks, one LDS store each.
              o is the slot in this round's list; it wraps below lo, so "o < CAP" alone selects the round's entries
              (a loop condition on o costs more than it saves when there is one round, the usual case). */
@@ -377,7 +376,7 @@ void mgScanKernel (const MgScanArgs a)
 #pragma unroll
               for (int half = 0 ; half < 2 ; ++half)
                 { U32 c = half ? (U32) (cand >> 32) : (U32) cand;
-                  const U32 base = (U32) tid * MG_POS_PER_THREAD + 32u * half;
+                  const U32 base = (U32) lane * MG_POS_PER_THREAD + 32u * half;
                   while (c)
                     { const U32 t = (U32) __builtin_ctz (c);
                       c &= c - 1;
@@ -386,18 +385,16 @@ void mgScanKernel (const MgScanArgs a)
                     }
                 }
             }
-          __syncthreads ();                                                      /* (3) candidates listed */
+          MG_WAVE_SYNC ();                                                       /* candidates listed */
           const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
-          const U32 per = (((nHere + 3) / 4) + 63) & ~63u;   /* candidates per wave, multiple of 64 */
-          const U32 wLo = wave * per;
-          U64 keepK[MG_CAND_ITERS]; U32 keepQ[MG_CAND_ITERS]; U32 keepR[MG_CAND_ITERS];
           U32 waveRun = 0;
 #pragma unroll
           for (int it = 0 ; it < MG_CAND_ITERS ; ++it)
-            { const U32 i = wLo + it * 64 + lane;
+            { if ((U32) it * 64 >= nHere) break;                                  /* uniform */
+              const U32 i = (U32) it * 64 + lane;
               bool surv = false, fwd = false;
               U64 F = 0; U32 q = 0;
-              if (it * 64 < (int) per && i < nHere && !(a.debug & 4))
+              if (i < nHere && !(a.debug & 4))
                 { q = sCand[i];
                   F = mgKmerAt (sWords, q, sh1);
                   U64 R = mgRevComp (F, sh1);
@@ -409,38 +406,26 @@ void mgScanKernel (const MgScanArgs a)
                   if (!fwd) F = R;
                 }
               const U64 bs = __ballot (surv);
-              keepK[it] = F;
-              keepQ[it] = q | (fwd ? MG_FWD_BIT : 0u);
-              keepR[it] = surv ? waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1)) : 0xffffffffu;
+              U32 r = (U32) __shfl ((int) rFirst, (int) (q >> 6));            /* first read of the owner lane's starts */
+              if (surv)
+                { const U64 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
+                  const U64 pos = tile0 + q;
+                  U64 rs = ti.start;
+                  if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
+                  if (o < a.segCap && !(a.debug & 2))
+                    { a.segKmer[segBase + o] = F;
+                      if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
+                      if (a.segRead) a.segRead[segBase + o] = r;
+                    }
+                }
               waveRun += (U32) __popcll (bs);
             }
-          if (lane == 0) sWaveTotB[wave] = waveRun;
-          __syncthreads ();                                                      /* (4) wave totals */
-          U32 before = 0, total = 0;
-#pragma unroll
-          for (int w = 0 ; w < MG_SCAN_THREADS / 64 ; ++w)
-            { U32 v = sWaveTotB[w]; if (w < wave) before += v; total += v; }
-#pragma unroll
-          for (int it = 0 ; it < MG_CAND_ITERS ; ++it)
-            if (keepR[it] != 0xffffffffu)
-              { const U64 o = found + before + keepR[it];
-                const U32 q = keepQ[it] & 0xffffu;
-                const U64 pos = tile0 + q;
-                U32 r = sRFirst[q >> 6];
-                U64 rs = ti.start;
-                if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
-                if (o < a.segCap && !(a.debug & 2))
-                  { a.segKmer[segBase + o] = keepK[it];
-                    if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (keepQ[it] & MG_FWD_BIT);
-                    if (a.segRead) a.segRead[segBase + o] = r;
-                  }
-              }
-          found += total;
+          found += waveRun;
         }
       tile = nextTile;
       curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
     }
-  if (tid == 0) a.blockCount[blockIdx.x] = found;
+  if (lane == 0) a.blockCount[worker] = found;
 }
 
 /* exclusive scan of the per-block counts (one workgroup): segStart[b], and
@@ -486,7 +471,7 @@ void mgSegScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 segCa
 }
 
 /* segments -> dense (read,pos)-ordered arrays; several workgroups per segment */
-#define MG_COMPACT_SPLIT 4
+#define MG_COMPACT_SPLIT 1
 __global__ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict__ segPosF,
                                     const U32 *__restrict__ segRead, U64 segCap,
                                     const U64 *__restrict__ blockCount, const U64 *__restrict__ segStart,
@@ -507,9 +492,9 @@ __global__ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *
 
 static inline U64 mgNumTiles (U64 totalBases) { return (totalBases + MG_TILE_BASES - 1) / MG_TILE_BASES; }
 
-/* Scan geometry: G workgroups, each owning tilesPerBlock consecutive tiles and one output segment. */
-struct MgScanGeom { U64 nTiles, tilesPerBlock; U32 nBlocks; U64 segCap; };
-#define MG_SCAN_MAX_BLOCKS 12288   /* measured: 2048 -> 4.63 ms, 6144 -> 4.16, 12288 -> 4.07 per 10 Gbp (6 workgroups/CU resident; more, shorter ranges balance the tail) */
+/* Scan geometry: G workers (wavefronts), each owning tilesPerBlock consecutive tiles and one output segment. */
+struct MgScanGeom { U64 nTiles, tilesPerBlock; U32 nBlocks; U64 segCap; };       /* nBlocks = number of workers = segments */
+#define MG_SCAN_MAX_BLOCKS 49152   /* workers per launch: many short ranges balance the tail (as workgroups: 2048 -> 4.63 ms, 12288 -> 4.07 per 10 Gbp) */
 
 static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
 {
@@ -583,11 +568,11 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   a.p = p; a.packed = dPacked; a.nWordsAlloc = (U64) mgPackedWords (totalBases); a.totalBases = totalBases;
   a.readOff = dReadOffsets; a.nReads = nReads; a.tileInfo = (const MgTileInfo *) dInfo;
   a.tileBegin = tile0; a.tileLimit = tile1;
-  a.tilesPerBlock = g.tilesPerBlock; a.segCap = g.segCap;
+  a.tilesPerWorker = g.tilesPerBlock; a.nWorkers = g.nBlocks; a.segCap = g.segCap;
   a.segKmer = segKmer; a.segPosF = dPosF ? segPosF : 0; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
   a.fS = 0; a.thresh = 0;
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
-  const unsigned grid = g.nBlocks;
+  const unsigned grid = (g.nBlocks + MG_WAVES - 1) / MG_WAVES;
   const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
   const int B = p.shift1 + p.dShift;
   static int forceGeneric = -1;
