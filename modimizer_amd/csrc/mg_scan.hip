@@ -226,7 +226,8 @@ void mgScanKernel (const MgScanArgs a)
   __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_WAVES][2][MG_TILE_WORDS + 8];
   __shared__ unsigned short sCandAll[MG_WAVES][MG_CAND_CAP + 2];      /* [MG_CAND_CAP]: where stores of other rounds' entries land */
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));   /* uniform: the worker's state lives in SGPRs */
   const U64 worker = (U64) blockIdx.x * MG_WAVES + wave;
   if (worker >= a.nWorkers) return;
   unsigned short *sCand = sCandAll[wave];
@@ -388,7 +389,7 @@ void mgScanKernel (const MgScanArgs a)
           MG_WAVE_SYNC ();                                                       /* candidates listed */
           const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
           U32 waveRun = 0;
-#pragma unroll
+#pragma unroll 1
           for (int it = 0 ; it < MG_CAND_ITERS ; ++it)
             { if ((U32) it * 64 >= nHere) break;                                  /* uniform */
               const U32 i = (U32) it * 64 + lane;
