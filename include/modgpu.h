@@ -332,6 +332,7 @@ MgStatus mgSynthReads (const U32 *dGenomePacked, U64 genomeBases,
  * returns, per kernel id in [0, mgProfileKernels()), its name, summed duration and launch count
  * since the last mgProfileReset (it synchronises the device to read the events). */
 void     mgProfileEnable (int on) ;
+void     mgProfileOnly (int kernelId) ;     /* >= 0: only that kernel is bracketed (an event pair costs a few microseconds of stream time per launch); -1: all */
 void     mgProfileReset (void) ;
 int      mgProfileKernels (void) ;
 MgStatus mgProfileGet (int id, const char **name, double *totalMs, U64 *launches) ;

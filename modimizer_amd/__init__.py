@@ -75,7 +75,7 @@ EXPORTS = [
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
-    "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
@@ -164,7 +164,7 @@ def lib():
     sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetClear", i32, MS, vp)
-    sig("mgProfileEnable", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)
+    sig("mgProfileEnable", None, i32); sig("mgProfileOnly", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)
     sig("mgProfileGet", i32, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), U64P)
     _lib = L
     return L

@@ -69,6 +69,7 @@ static const char *gKernelNames[MG_K_COUNT] = {
 struct MgProfRec { int id; hipEvent_t a, b; };
 static struct {
   bool on = false;
+  int only = -1;                 /* >= 0: bracket launches of this kernel id alone */
   MgProfRec rec[MG_PROF_POOL]; int used = 0, made = 0;
   double ms[MG_K_COUNT] = { 0 }; U64 n[MG_K_COUNT] = { 0 };
   int open = -1;
@@ -88,7 +89,7 @@ static void mgProfDrain (void)
 
 void mgProfBegin (int id, hipStream_t st)
 {
-  if (!gProf.on) return;
+  if (!gProf.on || (gProf.only >= 0 && id != gProf.only)) return;
   if (gProf.used == MG_PROF_POOL) mgProfDrain ();
   MgProfRec &r = gProf.rec[gProf.used];
   if (gProf.used >= gProf.made)
@@ -110,6 +111,7 @@ void mgProfEnd (int id, hipStream_t st)
 }
 
 extern "C" void mgProfileEnable (int on) { if (!on) mgProfDrain (); gProf.on = on != 0; }
+extern "C" void mgProfileOnly (int kernelId) { mgProfDrain (); gProf.only = (kernelId >= 0 && kernelId < MG_K_COUNT) ? kernelId : -1; }
 extern "C" void mgProfileReset (void)
 { mgProfDrain (); for (int i = 0 ; i < MG_K_COUNT ; ++i) { gProf.ms[i] = 0; gProf.n[i] = 0; } }
 extern "C" int mgProfileKernels (void) { return MG_K_COUNT; }
