@@ -452,22 +452,37 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
   __shared__ unsigned long long sBase[MG_PART_MAXBINS];
   __shared__ U32 sWave[MG_PART_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  U32 seg; U64 lo, hi;
-  if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
-  for (U64 sub = lo ; sub < hi ; sub += MG_PART_SUB)
+  /* A workgroup walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... sub-chunk by sub-chunk, and the elements
+     of the next sub-chunk are already on their way into registers while the current one is written out (one
+     workgroup fills a CU's LDS, so nothing else would hide that latency). */
+  U32 c = blockIdx.x, seg; U64 lo, hi;
+  bool have = mgChunkRange (segStart, chunkBase, nSeg, c, &seg, &lo, &hi);
+  U64 sub = have ? lo : 0;
+  U64 km[MG_PART_PER_THREAD]; U32 tk[MG_PART_PER_THREAD];
+  if (have)
+    { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
+#pragma unroll
+      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+        { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
+          km[j] = 0; tk[j] = 0;
+          if (i < subHi) { km[j] = kIn[i]; tk[j] = FIRST ? (U32) i : tIn[i]; }
+        }
+    }
+  while (have)
     { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
       const U32 cnt = (U32) (subHi - sub);
+      /* what comes after this sub-chunk */
+      U32 nc = c, nseg = seg; U64 nlo = lo, nhi = hi, nsub = sub + MG_PART_SUB; bool nhave = true;
+      if (nsub >= hi) { nc = c + gridDim.x; nhave = mgChunkRange (segStart, chunkBase, nSeg, nc, &nseg, &nlo, &nhi); nsub = nlo; }
       for (U32 b = tid ; b < nBins ; b += MG_PART_THREADS) sH[b] = 0;
       __syncthreads ();
-      U64 km[MG_PART_PER_THREAD]; U32 tk[MG_PART_PER_THREAD]; U32 dr[MG_PART_PER_THREAD];
+      U32 dr[MG_PART_PER_THREAD];
 #pragma unroll
       for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
         { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
           dr[j] = 0xffffffffu;
           if (i < subHi)
-            { km[j] = kIn[i];
-              tk[j] = FIRST ? (U32) i : tIn[i];
-              U32 d = mgDigit (km[j], g, shift, nBins - 1);
+            { U32 d = mgDigit (km[j], g, shift, nBins - 1);
               dr[j] = (d << 16) | atomicAdd (&sH[d], 1u);        /* rank within (sub-chunk, bin) */
             }
         }
@@ -497,6 +512,15 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
           { U32 d = dr[j] >> 16, p = sOff[d] + (dr[j] & 0xffffu);
             stK[p] = km[j]; stT[p] = tk[j]; stB[p] = (unsigned short) d;
           }
+      /* the registers are free: fetch the next sub-chunk */
+      if (nhave)
+        { const U64 nsubHi = nsub + MG_PART_SUB < nhi ? nsub + MG_PART_SUB : nhi;
+#pragma unroll
+          for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+            { U64 i = nsub + (U64) j * MG_PART_THREADS + tid;
+              if (i < nsubHi) { km[j] = kIn[i]; tk[j] = FIRST ? (U32) i : tIn[i]; }
+            }
+        }
       __syncthreads ();
       for (U32 p = tid ; p < cnt ; p += MG_PART_THREADS)
         { U32 d = stB[p];
@@ -505,6 +529,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
           tOut[at] = stT[p];
         }
       __syncthreads ();
+      c = nc; seg = nseg; lo = nlo; hi = nhi; sub = nsub; have = nhave;
     }
 }
 
@@ -755,12 +780,14 @@ static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const 
   MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkBase);
   unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
+  static int sgEnv = -1; if (sgEnv < 0) { const char *e = getenv ("MODGPU_SCATTER_GRID"); sgEnv = e ? atoi (e) : 0; }   /* dev knob */
+  unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
   MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
   if (first)
-    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (maxChunks), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (scatterGrid), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   else
-    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<false>, dim3 (maxChunks), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<false>, dim3 (scatterGrid), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
