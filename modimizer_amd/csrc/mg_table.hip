@@ -404,7 +404,17 @@ void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, int shift, U32 nBi
   if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
   for (U32 b = threadIdx.x ; b < nBins ; b += 256) sH[b] = 0;
   __syncthreads ();
-  for (U64 i = lo + threadIdx.x ; i < hi ; i += 256) atomicAdd (&sH[mgDigit (kIn[i], g, shift, nBins - 1)], 1u);
+  /* eight loads per lane in flight before the first LDS add */
+  for (U64 i0 = lo ; i0 < hi ; i0 += 8 * 256)
+    { U64 v[8];
+#pragma unroll
+      for (int j = 0 ; j < 8 ; ++j) { U64 i = i0 + (U64) j * 256 + threadIdx.x; v[j] = i < hi ? kIn[i] : 0; }
+#pragma unroll
+      for (int j = 0 ; j < 8 ; ++j)
+        { U64 i = i0 + (U64) j * 256 + threadIdx.x;
+          if (i < hi) atomicAdd (&sH[mgDigit (v[j], g, shift, nBins - 1)], 1u);
+        }
+    }
   __syncthreads ();
   for (U32 b = threadIdx.x ; b < nBins ; b += 256) if (sH[b]) atomicAdd (&binCount[(U64) seg * nBins + b], sH[b]);
 }
