@@ -400,23 +400,40 @@ void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, int shift, U32 nBi
                        U32 *__restrict__ binCount)
 {
   __shared__ U32 sH[MG_PART_MAXBINS];
-  U32 seg; U64 lo, hi;
-  if (!mgChunkRange (segStart, chunkBase, nSeg, blockIdx.x, &seg, &lo, &hi)) return;
+  /* a workgroup takes a contiguous run of chunks and adds its LDS counts to the global ones only when the
+     segment changes (one workgroup per chunk meant thousands of atomics on each of a few hundred addresses) */
+  const U32 nChunks = chunkBase[nSeg];
+  const U32 per = (nChunks + gridDim.x - 1) / gridDim.x;
+  U32 c = blockIdx.x * per;
+  const U32 cEnd = c + per < nChunks ? c + per : nChunks;
+  if (c >= cEnd) return;
   for (U32 b = threadIdx.x ; b < nBins ; b += 256) sH[b] = 0;
   __syncthreads ();
-  /* eight loads per lane in flight before the first LDS add */
-  for (U64 i0 = lo ; i0 < hi ; i0 += 8 * 256)
-    { U64 v[8];
+  U32 curSeg = 0xffffffffu;
+  for ( ; c < cEnd ; ++c)
+    { U32 seg; U64 lo, hi;
+      if (!mgChunkRange (segStart, chunkBase, nSeg, c, &seg, &lo, &hi)) break;
+      if (seg != curSeg && curSeg != 0xffffffffu)
+        { __syncthreads ();
+          for (U32 b = threadIdx.x ; b < nBins ; b += 256) { U32 v = sH[b]; if (v) { atomicAdd (&binCount[(U64) curSeg * nBins + b], v); sH[b] = 0; } }
+          __syncthreads ();
+        }
+      curSeg = seg;
+      /* eight loads per lane in flight before the first LDS add */
+      for (U64 i0 = lo ; i0 < hi ; i0 += 8 * 256)
+        { U64 v[8];
 #pragma unroll
-      for (int j = 0 ; j < 8 ; ++j) { U64 i = i0 + (U64) j * 256 + threadIdx.x; v[j] = i < hi ? kIn[i] : 0; }
+          for (int j = 0 ; j < 8 ; ++j) { U64 i = i0 + (U64) j * 256 + threadIdx.x; v[j] = i < hi ? kIn[i] : 0; }
 #pragma unroll
-      for (int j = 0 ; j < 8 ; ++j)
-        { U64 i = i0 + (U64) j * 256 + threadIdx.x;
-          if (i < hi) atomicAdd (&sH[mgDigit (v[j], g, shift, nBins - 1)], 1u);
+          for (int j = 0 ; j < 8 ; ++j)
+            { U64 i = i0 + (U64) j * 256 + threadIdx.x;
+              if (i < hi) atomicAdd (&sH[mgDigit (v[j], g, shift, nBins - 1)], 1u);
+            }
         }
     }
   __syncthreads ();
-  for (U32 b = threadIdx.x ; b < nBins ; b += 256) if (sH[b]) atomicAdd (&binCount[(U64) seg * nBins + b], sH[b]);
+  if (curSeg != 0xffffffffu)
+    for (U32 b = threadIdx.x ; b < nBins ; b += 256) if (sH[b]) atomicAdd (&binCount[(U64) curSeg * nBins + b], sH[b]);
 }
 
 /* per segment: binStart = segStart + exclusive scan of its bin counts; cursor = binStart */
@@ -792,7 +809,7 @@ static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const 
   unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
   static int sgEnv = -1; if (sgEnv < 0) { const char *e = getenv ("MODGPU_SCATTER_GRID"); sgEnv = e ? atoi (e) : 0; }   /* dev knob */
   unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
-  MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
+  MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks < 4096 ? maxChunks : 4096), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
   if (first)
     MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (scatterGrid), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
