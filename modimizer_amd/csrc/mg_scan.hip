@@ -399,11 +399,24 @@ void mgScanKernel (const MgScanArgs a)
                 { q = sCand[i];
                   F = mgKmerAt (sWords, q, sh1);
                   U64 R = mgRevComp (F, sh1);
-                  U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
-                  fwd = hF < hR;
-                  U64 h = fwd ? hF : hR;
-                  if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
-                  else                     surv = (h & dMask) == 0;
+                  if (MODE == MG_MODE_FAST)
+                    { /* hashes compared and tested where they sit in the products: no 64-bit shifts.  hash = P >> sh1,
+                         so hF < hR <=> (PF with its low sh1 bits cleared) < (PR likewise), and hash % 2^m == 0 <=>
+                         bits [sh1, sh1+m) of P are zero -- all inside the low word because sh1 + m <= 32 */
+                      const U64 PF = F * f1, PR = R * f1;
+                      const U32 keep = ~((1u << sh1) - 1u);
+                      const U64 cF = (PF & 0xffffffff00000000ull) | ((U32) PF & keep), cR = (PR & 0xffffffff00000000ull) | ((U32) PR & keep);
+                      fwd = cF < cR;
+                      const U32 lowWord = (U32) (fwd ? PF : PR);
+                      surv = (lowWord & ((U32) dMask << sh1)) == 0;
+                    }
+                  else
+                    { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
+                      fwd = hF < hR;
+                      U64 h = fwd ? hF : hR;
+                      if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
+                      else                     surv = (h & dMask) == 0;
+                    }
                   if (!fwd) F = R;
                 }
               const U64 bs = __ballot (surv);
