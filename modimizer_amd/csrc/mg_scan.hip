@@ -128,14 +128,14 @@ struct MgScanArgs {
 };
 
 /* which of this lane's 64 k-mer starts lie wholly inside a read (seqhash.c:162: len < k gives
- * nothing; the last start of a read is len-k) */
-__device__ __forceinline__ U64 mgValidMask (const MgScanArgs &a, U64 p0, U32 rFirst)
+ * nothing; the last start of a read is len-k).  off[r - rBase] is the start of read r: the global offsets
+ * (rBase 0) or the tile's copy of them in LDS. */
+__device__ __forceinline__ U64 mgValidMask (const U64 *off, U32 rBase, U32 nReads, int k, U64 p0, U32 rFirst)
 {
   U64 valid = 0;
-  const int k = a.p.k;
   U32 r = rFirst;
   for (;;)
-    { int64_t start = (int64_t) a.readOff[r], end = (int64_t) a.readOff[r + 1];
+    { int64_t start = (int64_t) off[r - rBase], end = (int64_t) off[r + 1 - rBase];
       int64_t lo = start > (int64_t) p0 ? start : (int64_t) p0;
       int64_t hi = end - k; if (hi > (int64_t) p0 + 63) hi = (int64_t) p0 + 63;
       if (hi >= lo)
@@ -143,7 +143,7 @@ __device__ __forceinline__ U64 mgValidMask (const MgScanArgs &a, U64 p0, U32 rFi
           U64 m = (n == 64) ? ~0ull : (((1ull << n) - 1) << (int) (lo - (int64_t) p0));
           valid |= m;
         }
-      if (end >= (int64_t) p0 + 64 || r + 1 >= a.nReads) break;
+      if (end >= (int64_t) p0 + 64 || r + 1 >= nReads) break;
       ++r;
     }
   return valid;
@@ -225,12 +225,14 @@ void mgScanKernel (const MgScanArgs a)
 {
   __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_WAVES][2][MG_TILE_WORDS + 8];
   __shared__ unsigned short sCandAll[MG_WAVES][MG_CAND_CAP + 2];      /* [MG_CAND_CAP]: where stores of other rounds' entries land */
+  __shared__ U64 sOffAll[MG_WAVES][64];                              /* read offsets of a tile that holds read boundaries */
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));   /* uniform: the worker's state lives in SGPRs */
   const U64 worker = (U64) blockIdx.x * MG_WAVES + wave;
   if (worker >= a.nWorkers) return;
   unsigned short *sCand = sCandAll[wave];
+  U64 *sOff = sOffAll[wave];
   const MgHashParams &p = a.p;
   const int k = p.k, sh1 = p.shift1;
   const U64 f1 = p.factor1;
@@ -263,12 +265,26 @@ void mgScanKernel (const MgScanArgs a)
       U64 valid = 0;
       U32 rFirst = ti.firstRead;
       const bool oneRead = ti.end >= tile0 + MG_TILE_BASES + (U64) k - 1;   /* tile + halo inside one read */
+      /* a tile with read boundaries: the offsets of its reads (first read of this tile .. first read of the next
+         tile, and one more) are fetched once, coalesced, into LDS, and the per-lane searches run there; only a
+         tile with more than 62 reads (reads under ~66 bases) searches the global array */
+      const bool offInLds = !oneRead && nextFirstRead - ti.firstRead + 2 <= 64;
+      if (offInLds)
+        { const U32 r = ti.firstRead + (U32) lane;
+          sOff[lane] = r <= a.nReads ? a.readOff[r] : ~0ull;
+        }
+      MG_WAVE_SYNC ();                                                           /* tile (and offsets) staged */
       if (oneRead) valid = ~0ull;
       else if (p0 < a.totalBases)
-        { rFirst = mgReadOf (a.readOff, ti.firstRead, nextFirstRead, p0);
-          valid = mgValidMask (a, p0, rFirst);
+        { if (offInLds)
+            { rFirst = ti.firstRead + mgReadOf (sOff, 0, nextFirstRead - ti.firstRead, p0);
+              valid = mgValidMask (sOff, ti.firstRead, a.nReads, k, p0, rFirst);
+            }
+          else
+            { rFirst = mgReadOf (a.readOff, ti.firstRead, nextFirstRead, p0);
+              valid = mgValidMask (a.readOff, 0, a.nReads, k, p0, rFirst);
+            }
         }
-      MG_WAVE_SYNC ();                                                           /* tile staged */
 
       /* prefetch the next tile (registers; consumed at the top of the next iteration) */
       const U64 nextTile = tile + 1;
@@ -425,7 +441,10 @@ void mgScanKernel (const MgScanArgs a)
                 { const U64 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
                   const U64 pos = tile0 + q;
                   U64 rs = ti.start;
-                  if (!oneRead) { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
+                  if (!oneRead)
+                    { if (offInLds) { while (sOff[r + 1 - ti.firstRead] <= pos) ++r; rs = sOff[r - ti.firstRead]; }
+                      else { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
+                    }
                   if (o < a.segCap && !(a.debug & 2))
                     { a.segKmer[segBase + o] = F;
                       if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
