@@ -658,15 +658,25 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               atomicAdd (&sCnt[at], 1u);
             }
           __syncthreads ();
-          for (U32 i = tid ; i < R ; i += T)
-            { unsigned long long k = sKey[i];
-              if (!k) continue;
-              U32 c = sCnt[i], ord = sOrd[i];
-              sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;               /* leave the image clean for the next bucket */
-              if (!c) continue;
-              U32 at = atomicAdd (&sN, 1u);
-              a.pK[lo + at] = k - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
-              if (!mgIsAssigned (ord) && !(a.debug & 1)) a.flags[0x7fffffffu - ord] = 1;
+          /* whole waves sweep together: a wave reserves room for its uniques with ONE add on the list counter
+             (a thousand lanes adding 1 to the same LDS word serialise) */
+          for (U32 i0 = 0 ; i0 < R ; i0 += T)
+            { const U32 i = i0 + tid;
+              unsigned long long k = i < R ? sKey[i] : 0;
+              U32 c = 0, ord = 0;
+              if (k) { c = sCnt[i]; ord = sOrd[i]; sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }   /* leave the image clean for the next bucket */
+              const bool emit = k && c;
+              const U64 m = __ballot (emit);
+              if (!m) continue;                                    /* uniform */
+              const int lane = tid & 63;
+              U32 base = 0;
+              if (lane == 0) base = atomicAdd (&sN, (U32) __popcll (m));
+              base = (U32) __shfl ((int) base, 0);
+              if (emit)
+                { const U32 at = base + (U32) __popcll (m & (((U64) 1 << lane) - 1));
+                  a.pK[lo + at] = k - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
+                  if (!mgIsAssigned (ord) && !(a.debug & 1)) a.flags[0x7fffffffu - ord] = 1;
+                }
             }
           __syncthreads ();
           if (tid == 0) { a.uniqCount[b] = sN; sN = 0; }
@@ -714,6 +724,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 }
               __syncthreads ();
             }
+          U32 myNew = 0;
           for (U32 i = tid ; i < nu ; i += T)
             { U64 km; U32 ord, c;
               if (i == tid) { km = ck; ord = co; c = cc; }
@@ -730,9 +741,15 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                   U64 idx = (U64) a.baseMax + 1 + rank;
                   sOrd[at] = idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
                   sCnt[at] = c;
-                  atomicAdd (&sNew, 1u);
+                  ++myNew;
                 }
             }
+          /* new entries of the bucket: summed inside the wave first (one LDS add per wave, not per entry) */
+          { U32 v = myNew;
+#pragma unroll
+            for (int off = 32 ; off ; off >>= 1) v += (U32) __shfl_xor ((int) v, off);
+            if ((tid & 63) == 0 && v) atomicAdd (&sNew, v);
+          }
           __syncthreads ();
           for (U32 i = tid ; i < R ; i += T)
             { unsigned long long k = sKey[i];
