@@ -70,6 +70,7 @@ MgReference *mgReferenceCreate (Modset *ms, U32 size)
 void mgReferenceDestroy (MgReference *ref)
 {
   if (!ref) return;
+  mgChainForget (ref);
   free (ref->depth); free (ref->loc); free (ref->rev);
   free (ref->index); free (ref->offset); free (ref->id);
   for (int i = 0 ; i < ref->nSeq ; ++i) free (ref->names[i]);
@@ -362,17 +363,18 @@ static void printM (const MgReference *ref, FILE *out, const char *name, const U
            n1 / (double) copy1);
 }
 
-int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
-                    const char **names, FILE *out)
+/* the long way: seed lists back on the host, tallies and chaining here (used when a read has more blocks
+ * than the device kernel keeps) */
+static int queryProcessHostChain (MgReference *ref, MgDevBatch *b, const int64_t *offsets, int nReads,
+                                  const char **names, FILE *out)
 {
   Modset *ms = ref->ms;
-  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
-  U64 n = 0, guess = b.total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b.total) guess = b.total;
+  U64 n = 0, guess = b->total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b->total) guess = b->total;
   if (guess < 1) guess = 1;
   void *dIx = 0, *dPos = 0, *dRid = 0;
   for (int attempt = 0 ; attempt < 2 ; ++attempt)
     { if (mgDeviceAlloc (&dIx, guess * 4) || mgDeviceAlloc (&dPos, guess * 4) || mgDeviceAlloc (&dRid, guess * 4)) fatal ("device alloc");
-      MgStatus s = mgQueryReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
+      MgStatus s = mgQueryReadsDevice (ms, (U32 *) b->dPacked, b->total, (U64 *) b->dOff, b->nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
       if (s == MG_OK) break;
       if (s == MG_ERR_CAPACITY && attempt == 0)
         { mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); guess = n; continue; }
@@ -380,7 +382,7 @@ int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets,
     }
   U32 *six = (U32 *) malloc ((size_t) (n + 1) * 4), *spos = (U32 *) malloc ((size_t) (n + 1) * 4), *srid = (U32 *) malloc ((size_t) (n + 1) * 4);
   if (n && (mgMemcpyD2H (six, dIx, n * 4, 0) || mgMemcpyD2H (spos, dPos, n * 4, 0) || mgMemcpyD2H (srid, dRid, n * 4, 0))) fatal ("D2H");
-  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); mgBatchFree (&b);
+  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid);
   for (U64 i = 0 ; i < n ; ++i) spos[i] &= MG_POS_MASK;
 
   U64 at = 0;
@@ -421,4 +423,39 @@ int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets,
     }
   free (six); free (spos); free (srid);
   return 0;
+}
+
+/* modmap.c:188-281.  Scan, lookup, the tallies of the "Q" line and the chaining into "M" blocks all run on the
+ * device (mg_chain.hip: one lane per read); the host formats the lines from a few integers per read and block. */
+#define MG_QUERY_MAXM 16
+int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
+                    const char **names, FILE *out)
+{
+  if (nReads <= 0) return 0;
+  if (modsetSyncToHost (ref->ms, 0)) fatal ("modsetSyncToHost");
+  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
+  MgChainQ *q = (MgChainQ *) malloc ((size_t) nReads * sizeof (MgChainQ));
+  MgChainM *m = (MgChainM *) malloc ((size_t) nReads * MG_QUERY_MAXM * sizeof (MgChainM));
+  static int hostChain = -1;
+  if (hostChain < 0) { const char *e = getenv ("MODGPU_QUERY_HOST_CHAIN"); hostChain = (e && *e == '1') ? 1 : 0; }   /* test knob */
+  int rc = hostChain ? 1 : mgChainQueryDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, q, m, MG_QUERY_MAXM);
+  if (rc < 0) fatal ("query");
+  if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
+  else
+    for (int r = 0 ; r < nReads ; ++r)
+      { const MgChainQ *qq = &q[r];
+        fprintf (out, "Q\t%s\t%llu\t%d miss, %d copy1, %d copy2, %d multi, %.2f hit\n",
+                 names[r], (unsigned long long) (offsets[r + 1] - offsets[r]), (int) qq->missed, (int) qq->copy1, (int) qq->copy2,
+                 (int) qq->copyM, ((int) qq->nSeeds - (int) qq->missed) / (double) ((int) qq->nSeeds));
+        for (U32 j = 0 ; j < qq->nM ; ++j)
+          { const MgChainM *e = &m[(size_t) r * MG_QUERY_MAXM + j];
+            fprintf (out, "M\t%s\t%d\t%d\t%d\t%s\t%d\t%d\t%d %d\t%.2f\t%.2f\n",
+                     names[r], (int) e->pos0, (int) e->posN, (int) (e->posN - e->pos0),
+                     ref->names[e->id0], (int) e->off0, (int) e->offN, e->n1, e->n2,
+                     (e->n1 + e->n2) / (double) e->span, e->n1 / (double) (int) qq->copy1);
+          }
+      }
+  free (q); free (m);
+  mgBatchFree (&b);
+  return rc;
 }

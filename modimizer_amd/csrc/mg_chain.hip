@@ -1,0 +1,173 @@
+/* mg_chain.hip — modmap's queryProcess (modmap.c:188-281) for a batch of reads, on the device:
+ * the seed list of every read (scan + lookup, mgQueryReadsDevice) and, new here, the tallies of the
+ * "Q" line and the chaining of seeds into "M" blocks (modmap.c:213-276).  The chaining is serial
+ * inside a read — every step looks at the block built so far — but reads are independent: one lane
+ * per read walks its seeds.  What comes back to the host is a few integers per read and per block;
+ * the host only formats the lines.
+ *
+ * The reference's rules, kept as they are (they decide what is printed):
+ *   - seeds that miss, and copy-M seeds, are skipped; a seed's place in the reference is its FIRST
+ *     occurrence, rev[loc[index]] (modmap.c:219-221);
+ *   - occurrence number 0 doubles as "no block open" (modmap.c:232);
+ *   - a block ends when the next seed is on another sequence, goes backwards along the block's
+ *     direction, or when the block's extent in the reference and in the read differ by more than 50
+ *     seeds (modmap.c:233-241); a copy-2 seed that would end the block is retried at its second
+ *     occurrence (modmap.c:242-254);
+ *   - a block is reported when it ENDS only if it holds more than two copy-1 seeds, and the block
+ *     still open at the end of the read only if it holds more than two copy-2 seeds (modmap.c:256,269).
+ */
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
+#include "mg_common.h"
+#include "mg_internal.h"
+
+struct MgRefDev { U8 *info; U32 *loc, *rev, *id, *offset; U32 msMax, refMax; };
+
+static std::mutex gRefLock;
+static std::unordered_map<const MgReference *, MgRefDev> gRefDev;
+
+static void mgRefDevFree (MgRefDev &d)
+{ (void) hipFree (d.info); (void) hipFree (d.loc); (void) hipFree (d.rev); (void) hipFree (d.id); (void) hipFree (d.offset); d = MgRefDev (); }
+
+extern "C" void mgChainForget (const MgReference *ref)
+{
+  std::lock_guard<std::mutex> g (gRefLock);
+  auto it = gRefDev.find (ref);
+  if (it != gRefDev.end ()) { mgRefDevFree (it->second); gRefDev.erase (it); }
+}
+
+/* device copies of what the chaining reads; rebuilt when the reference or its modset has grown */
+static MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
+{
+  std::lock_guard<std::mutex> g (gRefLock);
+  MgRefDev &d = gRefDev[ref];
+  const U32 msMax = ref->ms->max, refMax = ref->max;
+  if (d.info && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
+  mgRefDevFree (d);
+  const size_t m = (size_t) msMax + 1, n = refMax ? refMax : 1;
+  MG_HIP (hipMalloc ((void **) &d.info, m));
+  MG_HIP (hipMalloc ((void **) &d.loc, m * 4));
+  MG_HIP (hipMalloc ((void **) &d.rev, (n + 1) * 4));
+  MG_HIP (hipMalloc ((void **) &d.id, n * 4));
+  MG_HIP (hipMalloc ((void **) &d.offset, n * 4));
+  MG_HIP (hipMemcpy (d.info, ref->ms->info, m, hipMemcpyHostToDevice));
+  MG_HIP (hipMemcpy (d.loc, ref->loc, m * 4, hipMemcpyHostToDevice));
+  MG_HIP (hipMemset (d.rev, 0, (n + 1) * 4));
+  if (refMax)
+    { MG_HIP (hipMemcpy (d.rev, ref->rev, (size_t) refMax * 4, hipMemcpyHostToDevice));
+      MG_HIP (hipMemcpy (d.id, ref->id, (size_t) refMax * 4, hipMemcpyHostToDevice));
+      MG_HIP (hipMemcpy (d.offset, ref->offset, (size_t) refMax * 4, hipMemcpyHostToDevice));
+    }
+  d.msMax = msMax; d.refMax = refMax;
+  *out = d;
+  return MG_OK;
+}
+
+/* seedStart[r] = first seed of read r (seeds are in read order); seedStart[nReads] = nSeeds */
+__global__ void mgSeedStartKernel (const U32 *__restrict__ seedRead, U64 nSeeds, U32 nReads, U64 *__restrict__ seedStart)
+{
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i <= nSeeds ; i += stride)
+    { const U32 cur = i < nSeeds ? seedRead[i] : nReads;
+      const U32 prev = i ? seedRead[i - 1] + 1 : 0;            /* reads prev .. cur start here (empty ones included) */
+      for (U32 r = prev ; r <= cur && r <= nReads ; ++r) seedStart[r] = i;
+    }
+}
+
+__device__ __forceinline__ bool mgBlockEnds (const MgRefDev &d, U32 loc, U32 loc0, U32 locN, U32 i0, U32 iN, bool withUnset)
+{
+  if (withUnset && !loc0) return true;
+  if (d.id[loc] != d.id[loc0]) return true;
+  bool end = false;
+  if (loc0 < locN)
+    { if (loc < locN) end = true;
+      int dd = (int) (locN - loc0 - iN + i0); if (dd > 50 || dd < -50) end = true;
+    }
+  else if (loc0 > locN)
+    { if (loc > locN) end = true;
+      int dd = (int) (loc0 - locN - iN + i0); if (dd > 50 || dd < -50) end = true;
+    }
+  return end;
+}
+
+__global__ __launch_bounds__ (256)
+void mgChainKernel (const U32 *__restrict__ seedIx, const U32 *__restrict__ seedPos, const U64 *__restrict__ seedStart,
+                    U32 nReads, const MgRefDev d, MgChainQ *__restrict__ q, MgChainM *__restrict__ mRec, U32 maxM,
+                    U32 *__restrict__ overflow)
+{
+  const U32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nReads) return;
+  const U64 s0 = seedStart[r], s1 = seedStart[r + 1];
+  const U32 ns = (U32) (s1 - s0);
+  MgChainQ qq; qq.nSeeds = ns; qq.missed = 0; qq.copy1 = qq.copy2 = qq.copyM = 0; qq.nM = 0;
+  U32 loc0 = 0, locN = 0, i0 = 0, iN = 0;
+  int n1 = 0, n2 = 0;
+  MgChainM *mine = mRec + (U64) r * maxM;
+#define MG_EMIT() do { if (qq.nM < maxM) { MgChainM e; e.pos0 = seedPos[s0 + i0] & MG_POS_MASK; e.posN = seedPos[s0 + iN] & MG_POS_MASK; \
+      e.id0 = d.id[loc0]; e.off0 = d.offset[loc0]; e.offN = d.offset[locN]; e.n1 = n1; e.n2 = n2; \
+      e.span = locN > loc0 ? locN - loc0 : loc0 - locN; mine[qq.nM] = e; } else *overflow = 1; ++qq.nM; } while (0)
+  for (U32 i = 0 ; i < ns ; ++i)
+    { const U32 x = seedIx[s0 + i];
+      if (!x) { ++qq.missed; continue; }
+      const int c = d.info[x] & 3;
+      if (c == 1) ++qq.copy1; else if (c == 2) ++qq.copy2; else if (c == 3) ++qq.copyM;
+      if (c == 3) continue;
+      U32 loc = d.rev[d.loc[x]];
+      const bool is1 = c == 1;
+      bool end = mgBlockEnds (d, loc, loc0, locN, i0, iN, true);
+      if (end && loc0 && !is1)
+        { loc = d.rev[d.loc[x] + 1];
+          end = mgBlockEnds (d, loc, loc0, locN, i0, iN, false);
+        }
+      if (end)
+        { if (n1 > 2) MG_EMIT ();
+          n1 = n2 = 0; loc0 = loc; i0 = i;
+        }
+      if (is1) ++n1; else ++n2;
+      locN = loc; iN = i;
+    }
+  if (n2 > 2) MG_EMIT ();
+#undef MG_EMIT
+  q[r] = qq;
+}
+
+/* Q tallies and M blocks of every read of a device-resident batch.  hQ[nReads], hM[nReads*maxM] are host
+ * arrays filled here; returns 1 if some read had more than maxM blocks (the caller then does that batch the
+ * long way), 0 on success, -1 on error. */
+extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                   MgChainQ *hQ, MgChainM *hM, U32 maxM)
+{
+  Modset *ms = ref->ms;
+  MgRefDev d;
+  if (mgRefDevGet (ref, &d)) return -1;
+  U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
+  U32 *dIx = 0, *dPos = 0, *dRid = 0; U64 *dStart = 0; MgChainQ *dQ = 0; MgChainM *dM = 0; U32 *dOv = 0;
+  U64 n = 0;
+  int rc = -1;
+  do {
+    for (int attempt = 0 ; attempt < 2 ; ++attempt)
+      { if (hipMalloc ((void **) &dIx, guess * 4) || hipMalloc ((void **) &dPos, guess * 4) || hipMalloc ((void **) &dRid, guess * 4)) { attempt = 9; break; }
+        MgStatus s = mgQueryReadsDevice (ms, dPacked, totalBases, dReadOffsets, nReads, dIx, dPos, dRid, guess, &n, 0);
+        if (s == MG_OK) break;
+        (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); dIx = dPos = dRid = 0;
+        if (s == MG_ERR_CAPACITY && attempt == 0) { guess = n; continue; }
+        break;
+      }
+    if (!dIx) break;
+    if (hipMalloc ((void **) &dStart, ((size_t) nReads + 2) * 8) || hipMalloc ((void **) &dQ, (size_t) nReads * sizeof (MgChainQ))
+        || hipMalloc ((void **) &dM, (size_t) nReads * maxM * sizeof (MgChainM)) || hipMalloc ((void **) &dOv, 4)) break;
+    if (hipMemset (dOv, 0, 4)) break;
+    unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL (mgSeedStartKernel, dim3 (grid), dim3 (256), 0, 0, dRid, n, nReads, dStart);
+    hipLaunchKernelGGL (mgChainKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, d, dQ, dM, maxM, dOv);
+    if (hipGetLastError () != hipSuccess) break;
+    U32 ov = 0;
+    if (hipMemcpy (&ov, dOv, 4, hipMemcpyDeviceToHost) || hipMemcpy (hQ, dQ, (size_t) nReads * sizeof (MgChainQ), hipMemcpyDeviceToHost)
+        || hipMemcpy (hM, dM, (size_t) nReads * maxM * sizeof (MgChainM), hipMemcpyDeviceToHost)) break;
+    rc = ov ? 1 : 0;
+  } while (0);
+  (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dQ); (void) hipFree (dM); (void) hipFree (dOv);
+  if (rc < 0 && !mgLastError ()[0]) mgSetError ("query chaining on the device failed");
+  return rc;
+}

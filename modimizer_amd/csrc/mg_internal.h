@@ -24,6 +24,12 @@ typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } MgDevBatch;     
 MG_HIDDEN void mgBatchUpload (MgDevBatch *b, const char *bases, const int64_t *offsets, int nReads);
 MG_HIDDEN void mgBatchFree (MgDevBatch *b);
 MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);   /* <root>.<tag> through gzip, as utils.c:107-139 */
+/* queryProcess on the device (mg_chain.hip): per read the tallies of its "Q" line and its "M" blocks */
+typedef struct { U32 nSeeds, missed, copy1, copy2, copyM, nM; } MgChainQ;
+typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChainM;
+MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                   MgChainQ *hQ, MgChainM *hM, U32 maxM);
+MG_HIDDEN void mgChainForget (const MgReference *ref);      /* drop the device copies of the reference's arrays */
 /* element count of the reference's Array after appending elements 0..n-1 (array.c:144-170,180-183) */
 MG_HIDDEN int mgRefArrayDim (int first, int size, int n);
 #ifdef __cplusplus

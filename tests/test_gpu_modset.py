@@ -409,3 +409,54 @@ def test_merge_and_prune_on_device_vs_golden(golden_dir, tmp_path):
     d_v = mg.DeviceBuffer.from_numpy(vals); d_o = mg.DeviceBuffer(len(vals) * 4)
     mg.check(L.modsetFindBatchDevice(a, d_v.ptr, len(vals), d_o.ptr, None))
     assert np.array_equal(d_o.to_numpy(np.uint32, len(vals)), np.arange(1, len(vals) + 1, dtype=np.uint32))
+
+
+@pytest.mark.gpu
+def test_modmap_query_host_chain_path(golden_dir, tmp_path):
+    """the path taken when a read has more blocks than the device chaining keeps (seed lists chained on the
+    host): same lines.  Forced through MODGPU_QUERY_HOST_CHAIN=1 in a fresh process."""
+    import subprocess, sys
+    out = str(tmp_path / "mm.txt")
+    code = (
+        "import ctypes as C, os, modimizer_amd as mg\n"
+        "from modimizer_amd import fasta\n"
+        "L = mg.lib(); sh = mg.seqhashCreate(21, 64, 17); ms = mg.modsetCreate(sh, 20)\n"
+        "ref = L.mgReferenceCreate(ms, 1 << 26)\n"
+        "with mg.CFile(%r, 'w') as f:\n"
+        "    assert L.mgReferenceFastaRead(ref, %r, True, f) == 0\n"
+        "    assert L.mgQueryFile(ref, %r, f) == 0\n"
+    ) % (out, os.path.join(golden_dir, "ref.fa").encode(), os.path.join(golden_dir, "queries.fa").encode())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=util.ROOT,
+                       env=dict(os.environ, MODGPU_QUERY_HOST_CHAIN="1"))
+    assert r.returncode == 0, r.stderr[-800:]
+    assert open(out).read().splitlines() == util.golden_text("modmap_k21d64.stdout.txt").splitlines()[1:]
+
+
+@pytest.mark.gpu
+def test_modmap_query_many_blocks_overflow(tmp_path):
+    """a read stitched from 40 short pieces of the reference in shuffled order: more M blocks than the device
+    kernel keeps per read, so the batch goes the long way; both ways must print the same lines"""
+    import subprocess, sys
+    rng = np.random.default_rng(12)
+    g = rng.integers(0, 4, 400_000).astype(np.uint8)
+    pieces = [g[a:a + 3000] for a in rng.permutation(np.arange(0, 390_000, 9000))[:40]]
+    reads = [np.concatenate(pieces), g[1000:9000], np.concatenate(pieces[:5])]
+    fa_ref, fa_q = str(tmp_path / "ref.fa"), str(tmp_path / "q.fa")
+    fasta.write_fasta(fa_ref, ["chr"], [g]); fasta.write_fasta(fa_q, ["stitched", "plain", "five"], reads)
+    outs = []
+    for knob in ("0", "1"):
+        out = str(tmp_path / ("o%s.txt" % knob))
+        code = (
+            "import modimizer_amd as mg\n"
+            "L = mg.lib(); sh = mg.seqhashCreate(15, 8, 17); ms = mg.modsetCreate(sh, 20)\n"
+            "ref = L.mgReferenceCreate(ms, 1 << 26)\n"
+            "with mg.CFile(%r, 'w') as f:\n"
+            "    assert L.mgReferenceFastaRead(ref, %r, True, f) == 0\n"
+            "    assert L.mgQueryFile(ref, %r, f) == 0\n"
+        ) % (out, fa_ref.encode(), fa_q.encode())
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=util.ROOT,
+                           env=dict(os.environ, MODGPU_QUERY_HOST_CHAIN=knob))
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1]
+    assert sum(l.startswith("M\tstitched") for l in outs[0].splitlines()) > 16
