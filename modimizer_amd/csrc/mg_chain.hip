@@ -171,3 +171,104 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
   if (rc < 0 && !mgLastError ()[0]) mgSetError ("query chaining on the device failed");
   return rc;
 }
+
+/* ---------------------------------------------------------------------------------------- */
+/* modasm's readsetFileRead (modasm.c:161-188) for a batch of reads: per read the hits (modset index,
+ * top bit = forward), the 16-bit distance of each hit to the previous hit of the read, hit / miss counts,
+ * and per mod the number of hits.  One lane per read walks its seeds twice (count, then write at the
+ * offsets an exclusive scan of the counts gives). */
+
+template <bool WRITE>
+__global__ __launch_bounds__ (256)
+void mgReadsetKernel (const U32 *__restrict__ seedIx, const U32 *__restrict__ seedPosF, const U64 *__restrict__ seedStart, U32 nReads,
+                      U64 *__restrict__ hitStart, U32 *__restrict__ nMiss,
+                      U32 *__restrict__ hit, unsigned short *__restrict__ dx, U32 *__restrict__ depthCount)
+{
+  const U32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nReads) return;
+  const U64 s0 = seedStart[r], s1 = seedStart[r + 1];
+  U64 out = WRITE ? hitStart[r] : 0;
+  U32 miss = 0; int lastPos = 0;
+  for (U64 i = s0 ; i < s1 ; ++i)
+    { const U32 x = seedIx[i];
+      if (!x) { ++miss; continue; }
+      if (WRITE)
+        { const U32 pf = seedPosF[i];
+          const int pos = (int) (pf & MG_POS_MASK);
+          hit[out] = (pf & MG_FWD_BIT) ? (x | 0x80000000u) : x;                  /* modasm.c:171 */
+          dx[out] = (unsigned short) (pos - lastPos); lastPos = pos;             /* modasm.c:172 */
+          atomicAdd (&depthCount[x], 1u);                                        /* modasm.c:174, saturated by the caller */
+        }
+      ++out;
+    }
+  if (!WRITE) { hitStart[r] = out; nMiss[r] = miss; }
+}
+
+/* exclusive scan of n counts in place, a[n] = total (one workgroup) */
+__global__ __launch_bounds__ (1024)
+void mgChainScanKernel (U64 *__restrict__ a, U32 n)
+{
+  __shared__ U64 sPart[1024];
+  const int tid = threadIdx.x;
+  const U32 per = (n + 1023) / 1024;
+  U64 sum = 0;
+  for (U32 i = 0 ; i < per ; ++i) { U32 j = tid * per + i; if (j < n) sum += a[j]; }
+  sPart[tid] = sum;
+  __syncthreads ();
+  for (int off = 1 ; off < 1024 ; off <<= 1)
+    { U64 v = tid >= off ? sPart[tid - off] : 0;
+      __syncthreads ();
+      sPart[tid] += v;
+      __syncthreads ();
+    }
+  U64 run = sPart[tid] - sum;
+  for (U32 i = 0 ; i < per ; ++i) { U32 j = tid * per + i; if (j < n) { U64 c = a[j]; a[j] = run; run += c; } }
+  if (tid == 1023) a[n] = sPart[1023];
+}
+
+/* hHitStart[nReads+1], hNMiss[nReads], *hHit / *hDx malloc()ed here (totHit entries), hDepthCount[ms->max+1]
+ * (hits per mod, unsaturated).  Returns 0, -1 on error. */
+extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                     U64 *hHitStart, U32 *hNMiss, U32 **hHit, unsigned short **hDx, U32 *hDepthCount)
+{
+  *hHit = 0; *hDx = 0;
+  U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
+  U32 *dIx = 0, *dPos = 0, *dRid = 0, *dMiss = 0, *dHit = 0, *dDepth = 0; unsigned short *dDx = 0; U64 *dStart = 0, *dHitStart = 0;
+  U64 n = 0;
+  int rc = -1;
+  const size_t m = (size_t) ms->max + 1;
+  do {
+    for (int attempt = 0 ; attempt < 2 ; ++attempt)
+      { if (hipMalloc ((void **) &dIx, guess * 4) || hipMalloc ((void **) &dPos, guess * 4) || hipMalloc ((void **) &dRid, guess * 4)) break;
+        MgStatus s = mgQueryReadsDevice (ms, dPacked, totalBases, dReadOffsets, nReads, dIx, dPos, dRid, guess, &n, 0);
+        if (s == MG_OK) break;
+        (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); dIx = dPos = dRid = 0;
+        if (s == MG_ERR_CAPACITY && attempt == 0) { guess = n; continue; }
+        break;
+      }
+    if (!dIx) break;
+    if (hipMalloc ((void **) &dStart, ((size_t) nReads + 2) * 8) || hipMalloc ((void **) &dHitStart, ((size_t) nReads + 2) * 8)
+        || hipMalloc ((void **) &dMiss, ((size_t) nReads + 1) * 4) || hipMalloc ((void **) &dDepth, m * 4)) break;
+    if (hipMemset (dDepth, 0, m * 4)) break;
+    unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
+    const unsigned rgrid = (nReads + 255) / 256;
+    hipLaunchKernelGGL (mgSeedStartKernel, dim3 (grid), dim3 (256), 0, 0, dRid, n, nReads, dStart);
+    hipLaunchKernelGGL (mgReadsetKernel<false>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss,
+                        (U32 *) 0, (unsigned short *) 0, (U32 *) 0);
+    hipLaunchKernelGGL (mgChainScanKernel, dim3 (1), dim3 (1024), 0, 0, dHitStart, nReads);
+    U64 totHit = 0;
+    if (hipMemcpy (&totHit, dHitStart + nReads, 8, hipMemcpyDeviceToHost)) break;
+    if (hipMalloc ((void **) &dHit, (totHit + 1) * 4) || hipMalloc ((void **) &dDx, (totHit + 1) * 2)) break;
+    hipLaunchKernelGGL (mgReadsetKernel<true>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss, dHit, dDx, dDepth);
+    if (hipGetLastError () != hipSuccess) break;
+    *hHit = (U32 *) malloc ((size_t) (totHit + 1) * 4); *hDx = (unsigned short *) malloc ((size_t) (totHit + 1) * 2);
+    if (hipMemcpy (hHitStart, dHitStart, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) || hipMemcpy (hNMiss, dMiss, (size_t) nReads * 4, hipMemcpyDeviceToHost)
+        || (totHit && (hipMemcpy (*hHit, dHit, totHit * 4, hipMemcpyDeviceToHost) || hipMemcpy (*hDx, dDx, totHit * 2, hipMemcpyDeviceToHost)))
+        || hipMemcpy (hDepthCount, dDepth, m * 4, hipMemcpyDeviceToHost)) break;
+    rc = 0;
+  } while (0);
+  (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dHitStart);
+  (void) hipFree (dMiss); (void) hipFree (dHit); (void) hipFree (dDx); (void) hipFree (dDepth);
+  if (rc < 0) { free (*hHit); free (*hDx); *hHit = 0; *hDx = 0; if (!mgLastError ()[0]) mgSetError ("readset seeds on the device failed"); }
+  return rc;
+}

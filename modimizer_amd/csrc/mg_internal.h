@@ -29,7 +29,10 @@ typedef struct { U32 nSeeds, missed, copy1, copy2, copyM, nM; } MgChainQ;
 typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChainM;
 MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
                                    MgChainQ *hQ, MgChainM *hM, U32 maxM);
-MG_HIDDEN void mgChainForget (const MgReference *ref);      /* drop the device copies of the reference's arrays */
+MG_HIDDEN void mgChainForget (const MgReference *ref);
+/* readsetFileRead's per-read loop on the device (mg_chain.hip): hit lists, distances, counts, hits per mod */
+MG_HIDDEN int  mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                     U64 *hHitStart, U32 *hNMiss, U32 **hHit, unsigned short **hDx, U32 *hDepthCount);      /* drop the device copies of the reference's arrays */
 /* element count of the reference's Array after appending elements 0..n-1 (array.c:144-170,180-183) */
 MG_HIDDEN int mgRefArrayDim (int first, int size, int n);
 #ifdef __cplusplus

@@ -60,58 +60,44 @@ static void readsetBegin (MgReadset *rs)
   memset (rs->ms->depth, 0, ((size_t) rs->ms->max + 1) * sizeof (U16));
 }
 
-/* modasm.c:161-188 for a batch of reads: the seeds come back from the GPU in (read, position) order */
+/* modasm.c:161-188 for a batch of reads */
 static void readsetAddBatch (MgReadset *rs, const char *bases, const int64_t *offsets, int nReads)
 {
   Modset *ms = rs->ms;
   if (nReads <= 0) return;
   reserveReads (rs, nReads);
   MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
-  void *dIx = 0, *dPos = 0, *dRid = 0;
-  U64 n = 0, guess = b.total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b.total + 1) guess = b.total + 1;
-  for (int attempt = 0 ; attempt < 2 ; ++attempt)
-    { if (mgDeviceAlloc (&dIx, guess * 4) || mgDeviceAlloc (&dPos, guess * 4) || mgDeviceAlloc (&dRid, guess * 4)) fatal ("device alloc");
-      MgStatus s = mgQueryReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads,
-                                       (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
-      if (s == MG_OK) break;
-      if (s == MG_ERR_CAPACITY && n > guess && attempt == 0)
-        { mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); guess = n; continue; }
-      fatal ("read scan");
-    }
-  U32 *hIx = (U32 *) malloc ((size_t) (n + 1) * 4), *hPos = (U32 *) malloc ((size_t) (n + 1) * 4), *hRid = (U32 *) malloc ((size_t) (n + 1) * 4);
-  if (n && (mgMemcpyD2H (hIx, dIx, n * 4, 0) || mgMemcpyD2H (hPos, dPos, n * 4, 0) || mgMemcpyD2H (hRid, dRid, n * 4, 0))) fatal ("D2H");
-  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); mgBatchFree (&b);
-
+  /* scan, lookup, hit lists, distances and counts on the device (mg_chain.hip) */
+  U64 *hStart = (U64 *) malloc (((size_t) nReads + 1) * sizeof (U64));
+  U32 *hMiss = (U32 *) malloc (((size_t) nReads + 1) * sizeof (U32));
+  U32 *hDepth = (U32 *) malloc (((size_t) ms->max + 1) * sizeof (U32));
+  U32 *hHit = 0; U16 *hDx = 0;
+  if (mgReadsetSeedsDevice (ms, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, hStart, hMiss, &hHit, &hDx, hDepth)) fatal ("read scan");
+  mgBatchFree (&b);
+  const U64 n = hStart[nReads];
   if (rs->totHit + n + 1 > rs->capHit)
     { rs->capHit = (rs->totHit + n + 1) * 2;
       rs->hit = (U32 *) realloc (rs->hit, rs->capHit * sizeof (U32));
       rs->dx = (U16 *) realloc (rs->dx, rs->capHit * sizeof (U16));
     }
+  memcpy (rs->hit + rs->totHit, hHit, (size_t) n * sizeof (U32));
+  memcpy (rs->dx + rs->totHit, hDx, (size_t) n * sizeof (U16));
   const int first = rs->nReads + 1;                   /* reads are numbered from 1 (modasm.c:95) */
   for (int r = 0 ; r < nReads ; ++r)
-    { int id = first + r;
-      rs->len[id] = (int) (offsets[r + 1] - offsets[r]);
-      rs->nHit[id] = rs->nMiss[id] = 0;
-      memset (rs->nCopy[id], 0, sizeof (int[4]));
-    }
-  U64 i = 0;
-  for (int r = 0 ; r < nReads ; ++r)
     { const int id = first + r;
-      rs->hitStart[id] = rs->totHit;
-      int lastPos = 0;
-      for ( ; i < n && hRid[i] == (U32) r ; ++i)
-        { const U32 index = hIx[i];
-          if (!index) { ++rs->nMiss[id]; continue; }
-          const int pos = (int) (hPos[i] & MG_POS_MASK);
-          rs->hit[rs->totHit] = (hPos[i] & MG_FWD_BIT) ? (index | TOPBIT) : index;
-          rs->dx[rs->totHit] = (U16) (pos - lastPos); lastPos = pos;
-          ++rs->totHit; ++rs->nHit[id];
-          U16 *di = &ms->depth[index]; ++*di; if (!*di) *di = 0xffff;          /* modasm.c:174 */
-        }
+      rs->len[id] = (int) (offsets[r + 1] - offsets[r]);
+      rs->nHit[id] = (int) (hStart[r + 1] - hStart[r]);
+      rs->nMiss[id] = (int) hMiss[r];
+      memset (rs->nCopy[id], 0, sizeof (int[4]));
+      rs->hitStart[id] = rs->totHit + hStart[r];
     }
+  /* ++depth per hit with the wrap to 65535 (modasm.c:174): a saturating add of the hits per mod */
+  for (U32 i = 1 ; i <= ms->max ; ++i)
+    if (hDepth[i]) { U32 v = (U32) ms->depth[i] + hDepth[i]; ms->depth[i] = (U16) (v > 0xffffu ? 0xffffu : v); }
+  rs->totHit += n;
   rs->nReads += nReads;
   rs->hitStart[rs->nReads + 1] = rs->totHit;
-  free (hIx); free (hPos); free (hRid);
+  free (hStart); free (hMiss); free (hDepth); free (hHit); free (hDx);
 }
 
 /* invBuild (modasm.c:258-287): lists only for mods hit at least once and not saturated */
