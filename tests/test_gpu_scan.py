@@ -313,3 +313,14 @@ def test_minimizer_batch_capacity_is_reported():
     rc = L.seqhashMinimizerBatchDevice(sh, d_p.ptr, len(bases), d_o.ptr, 2, d_h.ptr, d_q.ptr, d_s.ptr, 16, C.byref(n), None)
     assert rc == 4 and n.value == n_true            # MG_ERR_CAPACITY
     assert list(d_s.to_numpy(np.uint64, 3)) == [0, int(st[1]), n_true]
+
+
+@pytest.mark.gpu
+def test_fuzz_small():
+    """tools/fuzz.py: random (k, d, seed) and ragged batches (reads around tile edges, homopolymer stretches),
+    scan / modset with its index[] layout / minimizers against the oracle"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "5", "120"], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "120 trials, 0 mismatches" in r.stdout, r.stdout[-500:]
