@@ -525,7 +525,7 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
 
 /* device forms of the whole-set passes, used when the modset lives on the device ------------- */
 static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            bool arenaLive, hipStream_t st);
+                            bool arenaLive, hipStream_t st, const MgHistReq *counted = 0);
 
 /* fold the pending device counts into baseDepth (afterwards baseDepth[i] IS depth[i]) */
 static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
@@ -656,12 +656,12 @@ static U64 mgAddChunkSize (void)
 #define MG_ADD_CHUNK (mgAddChunkSize ())
 
 static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            void *scratch, hipStream_t st)
+                            void *scratch, hipStream_t st, const MgHistReq *counted = 0)
 {
   MgTable &t = d->t;
   MgStatus s;
   MG_HIP (hipMemsetAsync (t.counters, 0, 16, st));
-  if ((s = mgTableAdd (&t, dKmer, n, withDepth, scratch, st))) return s;
+  if ((s = mgTableAdd (&t, dKmer, n, withDepth, scratch, st, counted))) return s;
   U64 c[2];
   MG_HIP (hipMemcpyAsync (c, t.counters, 16, hipMemcpyDeviceToHost, st));
   MG_HIP (hipStreamSynchronize (st));
@@ -680,7 +680,7 @@ static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
 /* arenaLive: dKmer itself lives in d->arena (mgAddReadsDevice), so the arena must not be reset
  * or reallocated; the caller reserved room for the temporaries taken here. */
 static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            bool arenaLive, hipStream_t st)
+                            bool arenaLive, hipStream_t st, const MgHistReq *counted)
 {
   if (!n) return MG_OK;
   U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
@@ -696,7 +696,8 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
   for (U64 off = 0 ; off < n && !s ; off += chunk)
     { U64 m = n - off < chunk ? n - off : chunk;
       if (off) s = mgTableEnsure (&d->t, m, st);
-      if (!s) s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, scratch, st);
+      if (!s) s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, scratch, st,
+                              (counted && n <= chunk) ? counted : 0);      /* the counts cover the whole batch */
     }
   return s;
 }
@@ -763,7 +764,7 @@ extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *st
 /* ---------------------------------------------------------------------------------------- */
 /* composite: scan a device-resident batch straight into the modset                           */
 
-struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; };
+struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; MgHistReq counted; };
 
 /* scan into arena buffers, growing once if the survivor guess was too small */
 static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked, U64 totalBases,
@@ -772,6 +773,13 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
 {
   U64 cap = mgSurvivorGuess (sh, totalBases);
   MgHashParams p = mgMakeParams (sh);
+  if (extraPerSurvivor)
+    { /* size the table now for the expected number of modimizers (N/d): the insert would do it anyway once the
+         count is known, and with the geometry fixed the compaction kernel can count for the first partition pass */
+      U64 expect = totalBases / (U64) (sh->w > 0 ? sh->w : 1) + 1;
+      if (expect > MG_ADD_CHUNK) expect = MG_ADD_CHUNK;
+      MgStatus es = mgTableEnsure (&d->t, expect, st); if (es) return es;
+    }
   for (int attempt = 0 ; attempt < 3 ; ++attempt)
     { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
       size_t need = al256 (cap * perS) + 4 * 4096 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
@@ -784,7 +792,13 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       b->rid = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
       b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads, cap));
       b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
-      if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st))) return s;
+      b->counted.log2NB = 0; b->counted.binCount = 0;
+      if (extraPerSurvivor)                           /* the survivors go into the modset: have the compaction count the first partition digit */
+        { b->counted.binCount = (U32 *) d->arena.take (512 * sizeof (U32));
+          b->counted.log2NB = d->t.log2NB;
+        }
+      if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
+                             b->counted.binCount ? &b->counted : 0))) return s;
       U64 c[MG_COUNT_WORDS];
       MG_HIP (hipMemcpyAsync (c, b->count, sizeof (c), hipMemcpyDeviceToHost, st));
       MG_HIP (hipStreamSynchronize (st));
@@ -806,7 +820,7 @@ extern "C" MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalB
   /* pos / isF / read are not needed by addSequence (modutils.c:24 passes 0 for isF and ignores pos) */
   if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, false, 4, &b, &n, st))) return s;
   if (nHash) *nHash = n;
-  return mgAddBatch (ms, d, b.kmer, n, 0, 1, true, st);
+  return mgAddBatch (ms, d, b.kmer, n, 0, 1, true, st, &b.counted);
 }
 
 /* mode 0: lookup only (modmap.c:202); mode 1: insert without depth (modmap.c:109) */
@@ -824,7 +838,7 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (n > capacity)
     { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
   if (mode == 0) s = mgTableFind (&d->t, b.kmer, n, dSeedIndex, st);
-  else s = mgAddBatch (ms, d, b.kmer, n, dSeedIndex, 0, true, st);
+  else s = mgAddBatch (ms, d, b.kmer, n, dSeedIndex, 0, true, st, &b.counted);
   if (s) return s;
   if (dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));
   if (dSeedRead) MG_HIP (hipMemcpyAsync (dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st));

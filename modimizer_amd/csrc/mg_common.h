@@ -115,7 +115,25 @@ __device__ __forceinline__ U32 mgWaveInclusiveSum (U32 v)
   v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x143, 0xc, 0xf, false);
   return v;
 }
+/* the modset table's hash of a k-mer (murmur-style remix): bucket = its top bits, home slot = its low bits */
+__device__ __forceinline__ U64 mgMix (U64 x)
+{
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
 #endif /* __HIPCC__ */
+
+/* The bucket id (log2NB bits) is split into a coarse digit (high bits, first partition pass) and a fine one. */
+static inline void mgPartSplit (int log2NB, int *hiB, int *loB)
+{ if (log2NB <= 9) { *hiB = log2NB; *loB = 0; } else { *loB = log2NB / 2; *hiB = log2NB - *loB; } }
+
+/* The first partition pass needs the number of modimizers per coarse digit.  The scan's compaction kernel
+ * reads every k-mer anyway, so it can count them on the way (its ALUs are idle: it is a copy): a caller that
+ * knows the table geometry asks for that with a request; log2NB says which geometry the counts are for. */
+struct MgHistReq { int log2NB; U32 *binCount; };          /* binCount: device, 512 entries, zeroed by the launcher */
+
 
 /* launchers implemented in the .hip files */
 MgStatus mgLaunchPack (const U8 *dBases, U64 nBases, U32 *dWords, hipStream_t st);
@@ -123,7 +141,7 @@ MgStatus mgLaunchUnpack (const U32 *dWords, U64 nBases, U8 *dBases, hipStream_t 
 MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                        const U64 *dReadOffsets, U32 nReads,
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                       U64 *dCount, void *dWork, hipStream_t st);
+                       U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0);
 
 U64      mgScanTiles (U64 totalBases);
 size_t   mgScanInfoBytes (U64 totalBases);
@@ -132,7 +150,7 @@ size_t   mgScanRangeWorkBytes (U64 nTilesRange, U64 capacity);
 MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                             const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
                             U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                            U64 *dCount, void *dWork, hipStream_t st);
+                            U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0);
 
 /* minimizers (seqhash.c:83-152) of every read: per-read counts -> exclusive scan in dReadStart[nReads+1] -> write */
 MgStatus mgLaunchMinimizers (const MgHashParams &p, U32 w, const U32 *dPacked, const U64 *dReadOffsets, U32 nReads,
@@ -161,7 +179,8 @@ MgStatus mgTableClean (MgTable *t, hipStream_t st);                      /* zero
 void     mgTableForget (MgTable *t, hipStream_t st);                     /* all buckets empty again (no memset of the slots) */
 size_t   mgTableAddScratchBytes (const MgTable *t, U64 n);
 bool     mgTableUseBuckets (const MgTable *t, U64 n);
-MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st);
+MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st,
+                     const MgHistReq *counted = 0);   /* counted: first-pass digit counts of exactly these n k-mers, if for this geometry */
 MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st);
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);

@@ -518,21 +518,46 @@ void mgSegScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 segCa
     }
 }
 
-/* segments -> dense (read,pos)-ordered arrays; several workgroups per segment */
-#define MG_COMPACT_SPLIT 1
-__global__ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict__ segPosF,
-                                    const U32 *__restrict__ segRead, U64 segCap,
-                                    const U64 *__restrict__ blockCount, const U64 *__restrict__ segStart,
-                                    U64 *__restrict__ outKmer, U32 *__restrict__ outPosF, U32 *__restrict__ outRead,
-                                    U64 capacity, const U64 *__restrict__ dCount)
+/* segments -> dense (read,pos)-ordered arrays.  A workgroup takes a run of consecutive segments.  With
+ * histBins != 0 it also counts, per coarse digit of the table bucket, the k-mers it copies (what the first
+ * partition pass of the modset build needs): a few ALU instructions per element in a kernel that only copies. */
+__global__ __launch_bounds__ (256)
+void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict__ segPosF,
+                         const U32 *__restrict__ segRead, U64 segCap, U32 nSegs,
+                         const U64 *__restrict__ blockCount, const U64 *__restrict__ segStart,
+                         U64 *__restrict__ outKmer, U32 *__restrict__ outPosF, U32 *__restrict__ outRead,
+                         U64 capacity, const U64 *__restrict__ dCount,
+                         int histLog2NB, int histShift, U32 histBins, U32 *__restrict__ histCount)
 {
+  __shared__ U32 sH[512];
   if (dCount[1]) return;                       /* overflow: the caller retries with the reported sizes */
-  const U32 b = blockIdx.x / MG_COMPACT_SPLIT, part = blockIdx.x % MG_COMPACT_SPLIT;
-  const U64 n = blockCount[b], dst = segStart[b], src = (U64) b * segCap;
-  for (U64 i = (U64) part * blockDim.x + threadIdx.x ; i < n ; i += (U64) MG_COMPACT_SPLIT * blockDim.x)
-    { outKmer[dst + i] = segKmer[src + i];
-      if (outPosF) outPosF[dst + i] = segPosF[src + i];
-      if (outRead) outRead[dst + i] = segRead[src + i];
+  if (histBins) { for (U32 b = threadIdx.x ; b < histBins ; b += 256) sH[b] = 0; __syncthreads (); }
+  const U32 per = (nSegs + gridDim.x - 1) / gridDim.x;
+  U32 sg = blockIdx.x * per;
+  const U32 sgEnd = sg + per < nSegs ? sg + per : nSegs;
+  for ( ; sg < sgEnd ; ++sg)
+    { const U64 n = blockCount[sg], dst = segStart[sg], src = (U64) sg * segCap;
+      for (U64 i0 = 0 ; i0 < n ; i0 += 4 * 256)            /* four loads per lane in flight */
+        { U64 km[4];
+#pragma unroll
+          for (int j = 0 ; j < 4 ; ++j) { const U64 i = i0 + (U64) j * 256 + threadIdx.x; km[j] = i < n ? segKmer[src + i] : 0; }
+#pragma unroll
+          for (int j = 0 ; j < 4 ; ++j)
+            { const U64 i = i0 + (U64) j * 256 + threadIdx.x;
+              if (i >= n) continue;
+              outKmer[dst + i] = km[j];
+              if (outPosF) outPosF[dst + i] = segPosF[src + i];
+              if (outRead) outRead[dst + i] = segRead[src + i];
+              if (histBins)
+                { const U32 bucket = histLog2NB ? (U32) (mgMix (km[j]) >> (64 - histLog2NB)) : 0u;
+                  atomicAdd (&sH[(bucket >> histShift) & (histBins - 1)], 1u);
+                }
+            }
+        }
+    }
+  if (histBins)
+    { __syncthreads ();
+      for (U32 b = threadIdx.x ; b < histBins ; b += 256) if (sH[b]) atomicAdd (&histCount[b], sH[b]);
     }
 }
 
@@ -599,9 +624,10 @@ size_t mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity)
 MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                             const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
                             U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                            U64 *dCount, void *dWork, hipStream_t st)
+                            U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist)
 {
   MG_HIP (hipMemsetAsync (dCount, 0, 4 * sizeof (U64), st));
+  if (hist && hist->binCount) MG_HIP (hipMemsetAsync (hist->binCount, 0, 512 * sizeof (U32), st));
   if (tile1 <= tile0 || !nReads) return MG_OK;
   MgScanGeom g = mgScanGeometryTiles (tile1 - tile0, capacity);
   char *wb = (char *) dWork;
@@ -639,8 +665,13 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   MG_HIP (hipGetLastError ());
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
   MG_HIP (hipGetLastError ());
-  MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (g.nBlocks * MG_COMPACT_SPLIT), dim3 (256), 0, st,
-             segKmer, a.segPosF, a.segRead, g.segCap, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount);
+  { int hiB = 0, loB = 0; U32 bins = 0;
+    if (hist && hist->binCount) { mgPartSplit (hist->log2NB, &hiB, &loB); bins = (U32) 1 << hiB; }
+    const unsigned cgrid = g.nBlocks < 4096 ? g.nBlocks : 4096;
+    MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (cgrid), dim3 (256), 0, st,
+               segKmer, a.segPosF, a.segRead, g.segCap, g.nBlocks, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount,
+               hist ? hist->log2NB : 0, loB, bins, hist ? hist->binCount : (U32 *) 0);
+  }
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -648,11 +679,11 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
 MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                        const U64 *dReadOffsets, U32 nReads,
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                       U64 *dCount, void *dWork, hipStream_t st)
+                       U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist)
 {
   const U64 nTiles = mgNumTiles (totalBases);
   char *info = (char *) dWork + mgScanRangeWorkBytes (nTiles, capacity);
   MgStatus s = mgScanPrepare (dReadOffsets, nReads, totalBases, info, st); if (s) return s;
   return mgLaunchScanRange (p, dPacked, totalBases, dReadOffsets, nReads, info, 0, nTiles,
-                            dKmer, dPosF, dReadId, capacity, dCount, dWork, st);
+                            dKmer, dPosF, dReadId, capacity, dCount, dWork, st, hist);
 }

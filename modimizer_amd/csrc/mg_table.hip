@@ -37,14 +37,6 @@
 __device__ __forceinline__ U32 mgToken (U64 o) { return 0x7fffffffu - (U32) o; }     /* 1..0x7fffffff */
 __device__ __forceinline__ bool mgIsAssigned (U32 v) { return (v & MG_ASSIGNED) != 0; }
 
-__device__ __forceinline__ U64 mgMix (U64 x)
-{
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
-  return x;
-}
-
 /* bucket geometry */
 struct MgGeom { U32 R, rMask; int log2NB; };
 __device__ __forceinline__ U32 mgBucketOf (U64 h, const MgGeom &g) { return g.log2NB ? (U32) (h >> (64 - g.log2NB)) : 0u; }
@@ -818,15 +810,17 @@ bool mgTableUseBuckets (const MgTable *t, U64 n)
 static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const U32 *tIn, U64 n,
                             const U64 *segStart, U32 nSeg, int shift, U32 nBins,
                             U64 *kOut, U32 *tOut, U64 *binStart, unsigned long long *cursor, U32 *binCount, U32 *chunkBase,
-                            hipStream_t st)
+                            hipStream_t st, const U32 *counted = 0)
 {
   MgGeom g = mgGeomOf (t);
-  MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
+  if (counted) MG_HIP (hipMemcpyAsync (binCount, counted, (size_t) nBins * sizeof (U32), hipMemcpyDeviceToDevice, st));   /* the compaction kernel counted them */
+  else MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkBase);
   unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
   static int sgEnv = -1; if (sgEnv < 0) { const char *e = getenv ("MODGPU_SCATTER_GRID"); sgEnv = e ? atoi (e) : 0; }   /* dev knob */
   unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
-  MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks < 4096 ? maxChunks : 4096), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
+  if (!counted)
+    MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks < 4096 ? maxChunks : 4096), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
   if (first)
     MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (scatterGrid), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
@@ -837,7 +831,8 @@ static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const 
 }
 
 /* insert a batch (ordinal order = array order); counters[0] = number of new entries afterwards */
-MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st)
+MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st,
+                     const MgHistReq *counted)
 {
   if (!n) return MG_OK;
   MgGeom g = mgGeomOf (t);
@@ -885,15 +880,16 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   /* split the bucket-id bits into a coarse digit (high) and a fine digit (low), each <= 9 bits */
   const int j = t->log2NB;
   int hiB, loB;
-  if (j <= 9) { hiB = j; loB = 0; } else { loB = j / 2; hiB = j - loB; }
+  mgPartSplit (j, &hiB, &loB);
+  const U32 *pre = (counted && counted->binCount && counted->log2NB == j) ? counted->binCount : 0;
   U64 segInit[2] = { 0, n };
   MG_HIP (hipMemcpyAsync (whole, segInit, 16, hipMemcpyHostToDevice, st));
   MgStatus s;
   const U64 *bucketStart = fineStart;
   if (!loB)
-    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s; }
+    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st, pre))) return s; }
   else
-    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st))) return s;
+    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st, pre))) return s;
       if ((s = mgPartPass (t, false, kA, tA, n, coarseStart, (U32) 1 << hiB, 0, (U32) 1 << loB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s;
     }
 
