@@ -271,7 +271,8 @@ int  mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offset
                       const char **names, bool isAdd, FILE *out) ;
 /* modmap.c:136-182: <root>.mod + <root>.ref in the reference's on-disk format (gzip streams, as its
  * fzopen writes them; gzip or plain accepted on read), interchangeable with modmap -w / -r.
- * mgReferenceLoad also creates the Modset (ref->ms, with its own Seqhash) as referenceRead does. */
+ * mgReferenceLoad also creates the Modset (ref->ms, with its own Seqhash) as referenceRead does; as in the
+ * reference, mgReferenceDestroy leaves ref->ms alone (modmap.c:66-72): the caller destroys it, and its hasher. */
 void mgReferenceWrite (MgReference *ref, const char *root) ;
 MgReference *mgReferenceLoad (const char *root) ;
 /* modmap.c:188-281: "Q" line and "M" lines for every read. */
@@ -300,7 +301,7 @@ int  mgReadsetRead (MgReadset *rs, const char *bases, const int64_t *offsets, in
 int  mgReadsetFileRead (MgReadset *rs, const char *filename) ;
 void mgReadsetStats (MgReadset *rs, FILE *out) ;                                            /* modasm.c:193-253 */
 void mgReadsetWrite (MgReadset *rs, const char *root) ;                                     /* modasm.c:108-126 */
-MgReadset *mgReadsetLoad (const char *root) ;                                               /* modasm.c:128-149 */
+MgReadset *mgReadsetLoad (const char *root) ;                                               /* modasm.c:128-149; creates rs->ms, which mgReadsetDestroy leaves to the caller (modasm.c:100-107) */
 
 /* The file front end (seqio.c:30-346 for FASTA / FASTQ text, plain or gzip, with the callers'
  * dna2indexConv + N->0 conversion): records are cut out of the text and converted by a pool of
