@@ -30,7 +30,8 @@
 #include <time.h>
 #include "modgpu.h"
 static double nowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
-#define TIMING(tag) do { if (getenv ("MODGPU_PARSE_TIMING")) { double t_ = nowS (); fprintf (stderr, "  [parse] %-10s %.3f s\n", tag, t_ - tLast); tLast = t_; } } while (0)
+static double gPhase[8]; static const char *gPhaseName[8];
+#define TIMING(slot, tag) do { double t_ = nowS (); gPhase[slot] += t_ - tLast; gPhaseName[slot] = tag; tLast = t_; } while (0)
 
 #define UNIT_BYTES ((size_t) 1 << 20)        /* raw text per conversion work unit */
 
@@ -200,6 +201,8 @@ void mgSeqClose (MgSeqReader *r)
   if (!r) return;
   closeInput (r); bigFree (r->buf, r->cap); free (r);
   bigFlush ();
+  if (getenv ("MODGPU_PARSE_TIMING"))          /* dev: where the parser's time went, summed over the batches */
+    { for (int i = 0 ; i < 8 ; ++i) if (gPhaseName[i]) { fprintf (stderr, "  [parse] %-8s %.3f s\n", gPhaseName[i], gPhase[i]); gPhase[i] = 0; } }
 }
 
 /* read until the window holds at least `want` unread bytes or the file ends (the buffer doubles as
@@ -246,10 +249,56 @@ static U64 countLines (const char *s, const char *e)
 /* ---- records cut out of the window ---- */
 typedef struct { size_t id, idLen, seq, seqEnd, end; } RawRec;      /* offsets into buf; [seq, seqEnd) is the text that holds the sequence */
 
-/* returns 1 and fills *rec when a whole record starts at `at`; 0 when the window ends inside it */
-static int cutFasta (MgSeqReader *r, size_t at, RawRec *rec, U64 line)
+/* FASTA record starts ('>' as the first byte of a line) of the unread window, found by the pool: each
+ * thread looks through slices of the text with memchr; the slices' finds are then strung together in order. */
+typedef struct { const char *buf; size_t lo, hi, slice, nSlices, next; size_t **found; size_t *nFound; } StartJob;
+static void *startWorker (void *arg)
 {
-  const char *b = r->buf, *end = r->buf + r->len;
+  StartJob *j = (StartJob *) arg;
+  for (;;)
+    { size_t k = __atomic_fetch_add (&j->next, 1, __ATOMIC_RELAXED);
+      if (k >= j->nSlices) break;
+      size_t a = j->lo + k * j->slice, b = a + j->slice < j->hi ? a + j->slice : j->hi;
+      size_t cap = 64, n = 0; size_t *v = (size_t *) malloc (cap * sizeof (size_t));
+      const char *p = j->buf + a, *e = j->buf + b;
+      while (p < e)
+        { const char *g = (const char *) memchr (p, '>', (size_t) (e - p));
+          if (!g) break;
+          if (g == j->buf + j->lo || g[-1] == '\n')
+            { if (n == cap) { cap *= 2; v = (size_t *) realloc (v, cap * sizeof (size_t)); }
+              v[n++] = (size_t) (g - j->buf);
+            }
+          p = g + 1;
+        }
+      j->found[k] = v; j->nFound[k] = n;
+    }
+  return 0;
+}
+static size_t findFastaStarts (MgSeqReader *r, size_t **startsOut)
+{
+  StartJob j; j.buf = r->buf; j.lo = r->pos; j.hi = r->len; j.slice = (size_t) 4 << 20; j.next = 0;
+  j.nSlices = (j.hi - j.lo + j.slice - 1) / j.slice;
+  j.found = (size_t **) calloc (j.nSlices + 1, sizeof (size_t *)); j.nFound = (size_t *) calloc (j.nSlices + 1, sizeof (size_t));
+  pthread_t th[32]; int started[32];
+  int nt = r->nThreads < (int) j.nSlices ? r->nThreads : (int) j.nSlices; if (nt < 1) nt = 1;
+  for (int i = 1 ; i < nt ; ++i) started[i] = pthread_create (&th[i], 0, startWorker, &j) == 0;
+  startWorker (&j);
+  for (int i = 1 ; i < nt ; ++i) if (started[i]) pthread_join (th[i], 0);
+  size_t n = 0;
+  for (size_t k = 0 ; k < j.nSlices ; ++k) n += j.nFound[k];
+  size_t *starts = (size_t *) malloc ((n + 1) * sizeof (size_t)), at = 0;
+  for (size_t k = 0 ; k < j.nSlices ; ++k)
+    { memcpy (starts + at, j.found[k], j.nFound[k] * sizeof (size_t)); at += j.nFound[k]; free (j.found[k]); }
+  free (j.found); free (j.nFound);
+  *startsOut = starts;
+  return n;
+}
+
+/* the record that starts at `at`, the next record starting at `next` (0: no later start in the window).
+ * Returns 1 and fills *rec when the record is whole; 0 when the window ends inside it. */
+static int cutFasta (MgSeqReader *r, size_t at, size_t next, RawRec *rec, U64 line)
+{
+  const char *b = r->buf, *end = r->buf + (next ? next : r->len);
   if (b[at] != '>') dieLine ("no initial > for FASTA record line %llu", line);
   const char *nl = (const char *) memchr (b + at, '\n', (size_t) (end - (b + at)));
   if (!nl) return 0;
@@ -257,13 +306,7 @@ static int cutFasta (MgSeqReader *r, size_t at, RawRec *rec, U64 line)
   while (p < nl && !isspace ((unsigned char) *p)) ++p;
   rec->id = at + 1; rec->idLen = (size_t) (p - (b + at + 1));
   rec->seq = (size_t) (nl + 1 - b);
-  const char *q = nl + 1;
-  for (;;)
-    { const char *g = (const char *) memchr (q, '>', (size_t) (end - q));
-      if (!g) break;
-      if (g[-1] == '\n') { rec->seqEnd = rec->end = (size_t) (g - b); return 1; }
-      q = g + 1;
-    }
+  if (next) { rec->seqEnd = rec->end = next; return 1; }
   if (!r->eof) return 0;
   if (end[-1] != '\n') return 0;             /* unterminated last line: the caller reports it */
   rec->seqEnd = rec->end = r->len;
@@ -330,8 +373,21 @@ static void *worker (void *arg)
             }
           else
             { char *t = j->dst + j->unitDst[u];
-              if (j->isFastq) { for ( ; s < e ; ++s) *t++ = (char) convTable[*s]; }
-              else for ( ; s < e ; ++s) { signed char c = convTable[*s]; if (c >= 0) *t++ = (char) c; }   /* no store for a dropped byte: the next unit's bytes start right there */
+              /* line by line: a line made of A C G T N only (either case) converts with arithmetic on whole vectors
+                 -- ((c >> 1) ^ (c >> 2)) & 3 sends A C G T to 0 1 2 3 and N to 0 -- anything else goes through the table */
+              while (s < e)
+                { const unsigned char *nl = (const unsigned char *) memchr (s, '\n', (size_t) (e - s));
+                  const unsigned char *le = nl ? nl : e;
+                  const size_t len = (size_t) (le - s);
+                  if (countKept (s, le) == len)
+                    { for (size_t i = 0 ; i < len ; ++i) t[i] = (char) (((s[i] >> 1) ^ (s[i] >> 2)) & 3);
+                      t += len;
+                    }
+                  else if (j->isFastq) { for ( ; s < le ; ++s) *t++ = (char) convTable[*s]; }
+                  else for ( ; s < le ; ++s) { signed char c = convTable[*s]; if (c >= 0) *t++ = (char) c; }   /* no store for a dropped byte */
+                  s = le;
+                  if (nl) { if (j->isFastq) *t++ = (char) convTable['\n']; ++s; }                         /* (a FASTQ unit never holds a newline) */
+                }
             }
         }
     }
@@ -364,19 +420,28 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   size_t want = (size_t) maxBases + (size_t) maxBases / 4 + ((size_t) 1 << 24);
   double tLast = nowS ();
   if (r->len - r->pos < want) refill (r, want);
-  TIMING ("refill");
+  TIMING (0, "read");
 
   RawRec *recs = 0; size_t nRec = 0, capRec = 0;
   size_t at = r->pos; U64 line = r->line; size_t rawSeq = 0;
+  size_t *starts = 0, nStarts = 0, si = 0;                       /* FASTA: where records start, found by the pool */
+  if (!r->isFastq) nStarts = findFastaStarts (r, &starts);
   while (at < r->len && (int64_t) rawSeq < maxBases)
     { RawRec rec;
-      int ok = r->isFastq ? cutFastq (r, at, &rec, line) : cutFasta (r, at, &rec, line);
+      int ok;
+      if (r->isFastq) ok = cutFastq (r, at, &rec, line);
+      else
+        { while (si < nStarts && starts[si] < at) ++si;
+          const size_t next = (si < nStarts && starts[si] == at && si + 1 < nStarts) ? starts[si + 1] : 0;
+          ok = cutFasta (r, at, next, &rec, line);
+        }
       if (!ok)
         { if (!r->eof)
             { if (nRec) break;                                   /* hand over what is whole; the rest next time */
               size_t have = r->len - r->pos;
               refill (r, have * 2 > want ? have * 2 : want);     /* one record larger than the window */
               at = r->pos;
+              if (!r->isFastq) { free (starts); nStarts = findFastaStarts (r, &starts); si = 0; }
               continue;
             }
           /* FASTA lines of this batch are only counted by the pool below: count here what was cut so far */
@@ -391,9 +456,10 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
       if (r->isFastq) line += 4;
       at = rec.end;
     }
+  free (starts);
   if (at >= r->len && r->eof) r->finished = 1;
   if (!nRec) { free (recs); r->pos = at; r->line = line; return 0; }
-  TIMING ("cut");
+  TIMING (1, "cut");
 
   /* units: raw ranges of at most UNIT_BYTES, never across records */
   size_t nUnits = 0;
@@ -414,7 +480,7 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   j.raw = r->buf; j.units = units; j.nUnits = nUnits; j.isFastq = r->isFastq;
   j.phase = 0;
   runJob (&j, r->nThreads);
-  TIMING ("count");
+  TIMING (2, "count");
 
   out->nSeq = (int) nRec;
   out->offsets = (int64_t *) malloc ((nRec + 1) * sizeof (int64_t));
@@ -431,10 +497,12 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   out->offsets[nRec] = (int64_t) total;
   out->total = (int64_t) total;
   out->basesCap = (int64_t) (total ? total : 1);
+  TIMING (4, "offsets");
   out->bases = (char *) bigAlloc ((size_t) out->basesCap);
+  TIMING (5, "alloc");
   j.phase = 1; j.dst = out->bases; j.unitDst = unitDst;
   runJob (&j, r->nThreads);
-  TIMING ("convert");
+  TIMING (3, "convert");
   free (unitDst); free (units); free (recs);
 
   r->pos = at; r->line = line; r->nSeq += nRec;
@@ -475,8 +543,11 @@ static int forEachBatch (const char *filename, int (*fn) (MgSeqBatch *, void *),
       pthread_t th;
       memset (&p.batch, 0, sizeof (p.batch)); p.n = 0;
       int threaded = pthread_create (&th, 0, prefetchMain, &p) == 0;
+      double tLast = nowS ();
       rc = fn (&cur, ctx);
+      TIMING (6, "consume");
       if (threaded) pthread_join (th, 0); else prefetchMain (&p);
+      TIMING (7, "wait");
       mgSeqBatchFree (&cur);
     }
   if (p.n > 0) mgSeqBatchFree (&p.batch);
