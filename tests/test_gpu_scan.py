@@ -317,10 +317,10 @@ def test_minimizer_batch_capacity_is_reported():
 
 @pytest.mark.gpu
 def test_fuzz_small():
-    """tools/fuzz.py: random (k, d, seed) and ragged batches (reads around tile edges, homopolymer stretches),
+    """tests/fuzz_gpu.py: random (k, d, seed) and ragged batches (reads around tile edges, homopolymer stretches),
     scan / modset with its index[] layout / minimizers against the oracle"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "5", "120"], capture_output=True, text=True, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "5", "120"], capture_output=True, text=True, cwd=root)
     assert r.returncode == 0, r.stderr[-500:]
     assert "120 trials, 0 mismatches" in r.stdout, r.stdout[-500:]
