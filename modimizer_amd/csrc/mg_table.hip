@@ -507,6 +507,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
         }
       __syncthreads ();
       /* exclusive scan of the bin counts (two bins per thread) + reservation of the output runs */
+      unsigned long long base0 = 0, base1 = 0;
       { U32 c0 = (U32) (2 * tid) < nBins ? sH[2 * tid] : 0, c1 = (U32) (2 * tid + 1) < nBins ? sH[2 * tid + 1] : 0;
         const U32 pair = c0 + c1, incl = mgWaveInclusiveSum (pair);
         if (lane == 63) sWave[wave] = incl;
@@ -515,13 +516,15 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
 #pragma unroll
         for (int w = 0 ; w < MG_PART_THREADS / 64 ; ++w) if (w < wave) wb += sWave[w];
         U32 ex = wb + incl - pair;
+        /* the two reservations are global atomics that return a value (a microsecond or two): they are issued here
+           and only waited for after the staging below, which does not need them */
         if ((U32) (2 * tid) < nBins)
           { sOff[2 * tid] = ex;
-            sBase[2 * tid] = c0 ? atomicAdd (&cursor[(U64) seg * nBins + 2 * tid], (unsigned long long) c0) : 0;
+            if (c0) base0 = atomicAdd (&cursor[(U64) seg * nBins + 2 * tid], (unsigned long long) c0);
           }
         if ((U32) (2 * tid + 1) < nBins)
           { sOff[2 * tid + 1] = ex + c0;
-            sBase[2 * tid + 1] = c1 ? atomicAdd (&cursor[(U64) seg * nBins + 2 * tid + 1], (unsigned long long) c1) : 0;
+            if (c1) base1 = atomicAdd (&cursor[(U64) seg * nBins + 2 * tid + 1], (unsigned long long) c1);
           }
       }
       __syncthreads ();
@@ -531,6 +534,8 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
           { U32 d = dr[j] >> 16, p = sOff[d] + (dr[j] & 0xffffu);
             stK[p] = km[j]; stT[p] = tk[j]; stB[p] = (unsigned short) d;
           }
+      if ((U32) (2 * tid) < nBins) sBase[2 * tid] = base0;
+      if ((U32) (2 * tid + 1) < nBins) sBase[2 * tid + 1] = base1;
       /* the registers are free: fetch the next sub-chunk */
       if (nhave)
         { const U64 nsubHi = nsub + MG_PART_SUB < nhi ? nsub + MG_PART_SUB : nhi;
