@@ -354,13 +354,15 @@ __global__ void mgIndexFinishKernel (U32 *__restrict__ index, U64 n)
 __device__ __forceinline__ U32 mgDigit (U64 km, const MgGeom &g, int shift, U32 binMask)
 { return (mgBucketOf (mgMix (km), g) >> shift) & binMask; }
 
-/* chunk -> (segment, range): segments are [segStart[s], segStart[s+1]); chunkBase[s] = first chunk of s */
+/* chunk -> (segment, range): segments are [segStart[s], segStart[s+1]); chunkBase[s] = first chunk of s,
+ * chunkBase[nSeg] = number of chunks, and behind that table (at MG_CHUNK_SEG_AT) the segment of every chunk, so
+ * that a workgroup moving to its next chunk does two rounds of loads, not a binary search of dependent ones */
+#define MG_CHUNK_SEG_AT (MG_PART_MAXBINS + 2)
 __device__ __forceinline__ bool mgChunkRange (const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                                               U32 chunk, U32 *seg, U64 *lo, U64 *hi)
 {
   if (chunk >= chunkBase[nSeg]) return false;
-  U32 a = 0, b = nSeg - 1;                       /* largest s with chunkBase[s] <= chunk */
-  while (a < b) { U32 m = a + (b - a + 1) / 2; if (chunkBase[m] <= chunk) a = m; else b = m - 1; }
+  const U32 a = chunkBase[MG_CHUNK_SEG_AT + chunk];
   *seg = a;
   *lo = segStart[a] + (U64) (chunk - chunkBase[a]) * MG_PART_CHUNK;
   U64 e = segStart[a + 1];
@@ -382,7 +384,11 @@ void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 *__rest
       sS[t] += v;
       __syncthreads ();
     }
-  if (t < nSeg) chunkBase[t] = sS[t] - c;
+  if (t < nSeg)
+    { const U32 first = sS[t] - c;
+      chunkBase[t] = first;
+      for (U32 i = 0 ; i < c ; ++i) chunkBase[MG_CHUNK_SEG_AT + first + i] = t;
+    }
   if (t == nSeg - 1) chunkBase[nSeg] = sS[t];
 }
 
@@ -789,7 +795,7 @@ size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
   size_t direct = mgAl (n * 4);
   size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
               + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3
-              + mgAl ((MG_PART_MAXBINS + 2) * 4) * 2;
+              + mgAl ((MG_PART_MAXBINS + 2) * 4) + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);
   return rank + (direct > part ? direct : part) + 4096;
 }
 
@@ -879,7 +885,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   unsigned long long *coarseCursor = (unsigned long long *) wb; wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
   U64 *whole = (U64 *) wb;                    wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
   U32 *coarseCount = (U32 *) wb;              wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
-  U32 *chunkBase = (U32 *) wb;                wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
+  U32 *chunkBase = (U32 *) wb;                wb += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);   /* + the segment of every chunk */
   (void) spare64;
 
   /* split the bucket-id bits into a coarse digit (high) and a fine digit (low), each <= 9 bits */
