@@ -620,6 +620,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
   if (tid == 0) sN = 0;
   U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
+  U32 occNow = a.occ[b];                          /* fetched one bucket ahead like the bounds: it gates a branch */
   U64 ck[MG_BUCKET_PREFETCH]; U32 ct[MG_BUCKET_PREFETCH];
 #pragma unroll
   for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
@@ -631,15 +632,17 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
       U64 nk[MG_BUCKET_PREFETCH]; U32 nt[MG_BUCKET_PREFETCH];
 #pragma unroll
       for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j) { nk[j] = 0; nt[j] = 0; }
+      U32 occNext = 0;
       if (b + 1 < bEnd)
         { nhi = a.bucketStart[b + 2];
+          occNext = a.occ[b + 1];
 #pragma unroll
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
             { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = a.pK[i]; nt[j] = a.pT[i]; } }
         }
       if (hi == lo) { if (tid == 0) a.uniqCount[b] = 0; }
       else
-        { if (a.occ[b])
+        { if (occNow)
             { for (U32 i = tid ; i < R ; i += T)
                 { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
                   sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z;
@@ -684,7 +687,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           __syncthreads ();
           if (tid == 0) { a.uniqCount[b] = sN; sN = 0; }
         }
-      lo = nlo; hi = nhi;
+      lo = nlo; hi = nhi; occNow = occNext;
 #pragma unroll
       for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j) { ck[j] = nk[j]; ct[j] = nt[j]; }
     }
@@ -705,14 +708,15 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
   if (tid == 0) sNew = 0;
   U32 nu = a.uniqCount[b];
+  U32 occNow = a.occ[b];                          /* one bucket ahead, like the counts */
   U64 lo = a.bucketStart[b];
   U64 ck = 0; U32 co = 0, cc = 0;
   if (tid < nu) { ck = a.pK[lo + tid]; co = a.pT[lo + tid]; cc = a.pC[lo + tid]; }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
-    { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0;
+    { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0, occNext = 0;
       if (b + 1 < bEnd)
-        { nnu = a.uniqCount[b + 1]; nlo = a.bucketStart[b + 1];
+        { nnu = a.uniqCount[b + 1]; nlo = a.bucketStart[b + 1]; occNext = a.occ[b + 1];
           if (tid < nnu) { nk = a.pK[nlo + tid]; no = a.pT[nlo + tid]; ncc = a.pC[nlo + tid]; }
         }
       if (nu)
@@ -720,7 +724,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           uint4 gv = make_uint4 (0, 0, 0, 0);
           const bool isNew0 = tid < nu && !mgIsAssigned (co);
           if (isNew0) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
-          if (a.occ[b])
+          if (occNow)
             { for (U32 i = tid ; i < R ; i += T)
                 { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
                   sKey[i] = ((unsigned long long) v.y << 32) | v.x; sOrd[i] = v.z; sCnt[i] = v.w;
@@ -763,7 +767,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           __syncthreads ();
           if (tid == 0 && sNew) { a.occ[b] += sNew; sNew = 0; }
         }
-      nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc;
+      nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc; occNow = occNext;
     }
 }
 
