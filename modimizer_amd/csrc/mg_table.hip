@@ -384,12 +384,16 @@ void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 *__rest
       sS[t] += v;
       __syncthreads ();
     }
-  if (t < nSeg)
-    { const U32 first = sS[t] - c;
-      chunkBase[t] = first;
-      for (U32 i = 0 ; i < c ; ++i) chunkBase[MG_CHUNK_SEG_AT + first + i] = t;
-    }
+  if (t < nSeg) chunkBase[t] = sS[t] - c;
   if (t == nSeg - 1) chunkBase[nSeg] = sS[t];
+  /* the segment of every chunk: all threads share the chunks; sS[] holds the inclusive prefix, so the segment
+     of chunk q is the first s with sS[s] > q */
+  const U32 total = sS[(nSeg ? nSeg : 1) - 1];
+  for (U32 q = t ; q < total ; q += MG_PART_MAXBINS)
+    { U32 a = 0, b = nSeg - 1;
+      while (a < b) { U32 m = (a + b) / 2; if (sS[m] > q) b = m; else a = m + 1; }
+      chunkBase[MG_CHUNK_SEG_AT + q] = a;
+    }
 }
 
 __global__ __launch_bounds__ (256)
