@@ -414,7 +414,7 @@ static void mgDevFree (MgDev *d)
   if (!d) return;
   if (d->built)
     { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
-      (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters);
+      (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters); (void) hipFree (d->t.liveHist);
     }
   d->arena.release ();
   delete d;
@@ -562,7 +562,7 @@ extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
     MgStatus as = mgAddBatch (ms1, d, dV2, n2, dIdx, 0, false, st);
     if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }
     if (as) break;
-    t.baseZero = false;
+    t.baseZero = false; t.liveHistValid = false;
     if (mgTableMergeApply (dIdx, dD2, dI2, n2, t.baseDepth, dI1, st)) break;
     if (hipStreamSynchronize (st)) break;
     /* bring the host mirror up to date wholesale: values of the new entries, all depths and info */
@@ -603,7 +603,7 @@ extern "C" int mgHookPruneDevice (Modset *ms, int lo, int hi)
     const U32 m = (U32) c[0];
     /* new arrays replace the old ones on both sides */
     if (m)
-      { t.baseZero = false;
+      { t.baseZero = false; t.liveHistValid = false;
         if (hipMemcpy (t.value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToDevice) || hipMemcpy (t.baseDepth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToDevice)
             || hipMemcpy (ms->value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToHost) || hipMemcpy (ms->depth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToHost)
             || hipMemcpy (ms->info + 1, dNewInfo + 1, m, hipMemcpyDeviceToHost)) break;

@@ -165,6 +165,8 @@ struct MgTable {
   U64 *value;          /* [size] device copy of ms->value */
   U16 *baseDepth;      /* [size] host depth at last sync */
   bool baseZero;       /* baseDepth is known to be all zero (fresh or cleared set): the histogram skips its random loads */
+  U64 *liveHist;       /* device U64[65536]: depth histogram kept by the merge kernel while liveHistValid */
+  bool liveHistValid;  /* the set was empty before its one bucketed add: liveHist is its depth histogram */
   U32 size;            /* capacity in entries (ms->size) */
   U32 max;             /* entries known to the device table */
   U32 syncedMax;       /* entries whose value[] the host already has */

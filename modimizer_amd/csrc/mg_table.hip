@@ -582,6 +582,7 @@ struct MgBucketArgs {
   int withDepth;
   U64 *counters;
   int debug;                       /* dev ablation (MODGPU_BUCKET_DEBUG): 1 = no flag stores; results are wrong */
+  unsigned long long *liveHist;    /* != 0: the merge kernel also counts the final depths of the entries it writes */
 };
 
 extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
@@ -608,6 +609,7 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
  * bucket is processed, and the LDS image is kept all-zero between buckets by clearing exactly the
  * slots the closing sweep visits (no 64 KiB re-zeroing per bucket). */
 #define MG_BUCKET_PREFETCH 2
+#define MG_LIVE_BINS 256              /* depths below this are counted in LDS by the merge kernel's live histogram */
 
 /* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
 __global__ __launch_bounds__ (1024)
@@ -711,6 +713,9 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   if (b >= bEnd) return;
   for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
   if (tid == 0) sNew = 0;
+  U32 *sLive = sCnt + R + 4;                       /* MG_LIVE_BINS small-depth bins (behind sNew) */
+  for (U32 i = tid ; i < MG_LIVE_BINS ; i += T) sLive[i] = 0;
+  U32 n1 = 0, n2 = 0;                              /* depth 1 and 2, the commonest, counted per wave */
   U32 nu = a.uniqCount[b];
   U32 occNow = a.occ[b];                          /* one bucket ahead, like the counts */
   U64 lo = a.bucketStart[b];
@@ -762,16 +767,33 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
             if ((tid & 63) == 0 && v) atomicAdd (&sNew, v);
           }
           __syncthreads ();
-          for (U32 i = tid ; i < R ; i += T)
-            { unsigned long long k = sKey[i];
-              uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
-              *reinterpret_cast<uint4 *> (&a.slots[(U64) b * R + i]) = v;
-              if (k) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+          for (U32 i0 = 0 ; i0 < R ; i0 += T)
+            { const U32 i = i0 + tid;
+              unsigned long long k = 0; U32 dep = 0;
+              if (i < R)
+                { k = sKey[i];
+                  uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
+                  *reinterpret_cast<uint4 *> (&a.slots[(U64) b * R + i]) = v;
+                  dep = v.w > 0xffffu ? 0xffffu : v.w;
+                  if (k) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+                }
+              if (a.liveHist)                                  /* uniform: depths of a set built by this one add */
+                { n1 += (U32) __popcll (__ballot (k && dep == 1));
+                  n2 += (U32) __popcll (__ballot (k && dep == 2));
+                  if (k && dep != 1 && dep != 2)
+                    { if (dep < MG_LIVE_BINS) atomicAdd (&sLive[dep], 1u); else atomicAdd (&a.liveHist[dep], 1ull); }
+                }
             }
           __syncthreads ();
           if (tid == 0 && sNew) { a.occ[b] += sNew; sNew = 0; }
         }
       nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc; occNow = occNext;
+    }
+  if (a.liveHist)
+    { __syncthreads ();
+      if ((tid & 63) == 0) { if (n1) atomicAdd (&sLive[1], n1); if (n2) atomicAdd (&sLive[2], n2); }
+      __syncthreads ();
+      for (U32 i = tid ; i < MG_LIVE_BINS ; i += T) if (sLive[i]) atomicAdd (&a.liveHist[i], (unsigned long long) sLive[i]);
     }
 }
 
@@ -854,6 +876,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
                      const MgHistReq *counted)
 {
   if (!n) return MG_OK;
+  t->liveHistValid = false;                          /* set again below if this add is the set's only one */
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
@@ -919,7 +942,16 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
   a.counters = t->counters;
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_BUCKET_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = dbg; }
-  const size_t lds = (size_t) t->R * 16 + 16;
+  /* depth histogram on the fly: possible when this add builds the whole set (empty before, no host depths) */
+  const bool track = t->max == 0 && t->baseZero;
+  a.liveHist = 0;
+  if (track)
+    { if (!t->liveHist) MG_HIP (hipMalloc ((void **) &t->liveHist, 65536 * sizeof (U64)));
+      MG_HIP (hipMemsetAsync (t->liveHist, 0, 65536 * sizeof (U64), st));
+      a.liveHist = (unsigned long long *) t->liveHist;
+    }
+  t->liveHistValid = track;
+  const size_t lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
   if (lds > 48 * 1024)
     { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -968,6 +1000,7 @@ MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipSt
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st)
 {
   if (last < first) return MG_OK;
+  t->liveHistValid = false;
   { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
   MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
              t->slots, mgGeomOf (t), dValue, first, last, t->occ, t->counters);
@@ -980,15 +1013,25 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st)
   if (!t->max) return MG_OK;
   MG_HIP (hipMemsetAsync (dDelta, 0, (size_t) t->max * sizeof (U16), st));
   t->baseZero = false;                                   /* the fold below writes baseDepth */
+  t->liveHistValid = false;
   MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid (t->nSlots, 256, 8192)), dim3 (256), 0, st,
              t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, dDelta, t->max);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
 
+/* dHist[i] += live[i] */
+__global__ void mgHistAddKernel (const U64 *__restrict__ live, unsigned long long *__restrict__ hist)
+{ U32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < 65536 && live[i]) atomicAdd (&hist[i], (unsigned long long) live[i]); }
+
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st)
 {
   if (!t->max) return MG_OK;
+  if (t->liveHistValid && t->liveHist)                 /* the merge kernel kept it while it built the set */
+    { MG_LAUNCH (MG_K_TABLE_HIST, st, mgHistAddKernel, dim3 (256), dim3 (256), 0, st, t->liveHist, (unsigned long long *) dHist);
+      MG_HIP (hipGetLastError ());
+      return MG_OK;
+    }
   MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->nSlots, 256, 2048)), dim3 (256), 0, st,
              t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseZero ? (const U16 *) 0 : t->baseDepth, (unsigned long long *) dHist);
   MG_HIP (hipGetLastError ());
@@ -1074,6 +1117,7 @@ void mgTableForget (MgTable *t, hipStream_t st)
 {
   (void) hipMemsetAsync (t->occ, 0, ((size_t) 1 << t->log2NB) * sizeof (U32), st);
   t->dirty = true;               /* no memset of the slots: a bucket is defined once something wrote all of it */
+  t->liveHistValid = false;
 }
 
 MgStatus mgTableClean (MgTable *t, hipStream_t st)
