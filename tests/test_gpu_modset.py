@@ -460,3 +460,42 @@ def test_modmap_query_many_blocks_overflow(tmp_path):
         outs.append(open(out).read())
     assert outs[0] == outs[1]
     assert sum(l.startswith("M\tstitched") for l in outs[0].splitlines()) > 16
+
+
+@pytest.mark.gpu
+def test_histogram_kept_by_the_build(tmp_path):
+    """a set built by one add from empty keeps its depth histogram while it is built (merge kernel): depths 1, 2,
+    mid-range, above the LDS bins, and saturated at 65535; a second add falls back to the table pass"""
+    L = mg.lib()
+    k, w, bits = 15, 1, 22
+    rng = np.random.default_rng(21)
+    g = rng.integers(0, 4, 40_000).astype(np.uint8)
+    reads = [np.zeros(70_000, np.uint8)]                                   # one k-mer 69 986 times -> 65535
+    reads += [g[:30_000]] * 1 + [g[:20_000]] * 2 + [g[:5_000]] * 300       # depths 1, 3, 303
+    reads += [np.tile(g[100:140], 12)]                                     # short repeats
+    bases, offs = util.concat_reads(reads)
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    oms = po.Modset(oh, bits)
+    for r in reads:
+        oms.add_sequence(r)
+    ms = mg.modsetCreate(sh, bits)
+    mg.add_sequence_batch(ms, bases, offs)
+    d_h = mg.DeviceBuffer(65536 * 8)
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+    want = oms.histogram()
+    assert want[65535] >= 1 and want[303:].sum() > 10 and want[1] > 0
+    assert np.array_equal(d_h.to_numpy(np.uint64, 65536), want)
+    # a second add: the table pass takes over
+    mg.add_sequence_batch(ms, bases[:30_000], np.array([0, 30_000], np.int64))
+    oms.add_sequence(bases[:30_000])
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+    assert np.array_equal(d_h.to_numpy(np.uint64, 65536), oms.histogram())
+    # cleared and rebuilt: kept again
+    mg.check(L.mgModsetClear(ms, None))
+    mg.add_sequence_batch(ms, bases, offs)
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+    assert np.array_equal(d_h.to_numpy(np.uint64, 65536), want)
+    L.modsetDestroy(ms); oms.close()
