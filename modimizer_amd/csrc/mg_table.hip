@@ -1133,7 +1133,9 @@ MgStatus mgTableClean (MgTable *t, hipStream_t st)
 /* slots needed so that `entries` fit at load <= 0.6 */
 static int mgLog2SlotsFor (const MgTable *t, U64 entries)
 {
-  U64 need = entries + entries * 2 / 3 + 1;          /* entries / 0.6 */
+  static int loadPct = -1;
+  if (loadPct < 0) { const char *e = getenv ("MODGPU_TABLE_LOAD"); loadPct = e && atoi (e) >= 10 && atoi (e) <= 150 ? atoi (e) : 60; }   /* dev knob (above 100: experiments only) */
+  U64 need = entries * 100 / (U64) loadPct + 1;      /* entries / 0.6 by default */
   int lg = mgLog2 (need);
   if (lg < 16) lg = 16;
   if (lg > t->maxLog2Slots) lg = t->maxLog2Slots;
