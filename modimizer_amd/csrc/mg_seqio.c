@@ -14,8 +14,8 @@
  *   - a last record that is not closed by a newline is reported ("incomplete sequence record line
  *     N") and not returned (seqio.c:213-217).
  * Unlike the reference (one record at a time, one thread) a batch of records is cut out of the
- * text serially (memchr) and converted by a pool of threads; batches stream, so memory is bounded
- * by the batch size, not by the file.
+ * text and converted by a pool of threads (only the last record of a window, which may be unfinished,
+ * is cut serially); batches stream, so memory is bounded by the batch size, not by the file.
  */
 #define _GNU_SOURCE
 #include <ctype.h>
@@ -336,6 +336,168 @@ static int cutFastq (MgSeqReader *r, size_t at, RawRec *rec, U64 line)
   return 1;
 }
 
+
+/* ---- records cut by the pool ----
+ * FASTQ: the pool lists the line ends of the window (slices of text, memchr), a record is then four
+ * consecutive lines, so every record can be delimited and checked on its own.  FASTA: the record
+ * starts are known (findFastaStarts), a record runs up to the next start.  What the pool cannot
+ * decide (the last, possibly unfinished, record of the window) is left to cutFasta / cutFastq. */
+static void runPool (int n, void *(*fn) (void *), void *arg)
+{
+  pthread_t th[32]; int started[32];
+  if (n > 32) n = 32;
+  for (int i = 1 ; i < n ; ++i) started[i] = pthread_create (&th[i], 0, fn, arg) == 0;
+  fn (arg);
+  for (int i = 1 ; i < n ; ++i) if (started[i]) pthread_join (th[i], 0);
+}
+
+typedef struct { const char *buf; size_t lo, hi, slice, nSlices, next; U32 **found; size_t *nFound, *prefix; } LineJob;
+static void *lineWorker (void *arg)
+{
+  LineJob *j = (LineJob *) arg;
+  for (;;)
+    { size_t k = __atomic_fetch_add (&j->next, 1, __ATOMIC_RELAXED);
+      if (k >= j->nSlices) break;
+      size_t a = j->lo + k * j->slice, b = a + j->slice < j->hi ? a + j->slice : j->hi;
+      size_t cap = (b - a) / 64 + 16, n = 0; U32 *v = (U32 *) malloc (cap * sizeof (U32));
+      const char *p = j->buf + a, *e = j->buf + b;
+      while (p < e)
+        { const char *g = (const char *) memchr (p, '\n', (size_t) (e - p));
+          if (!g) break;
+          if (n == cap) { cap *= 2; v = (U32 *) realloc (v, cap * sizeof (U32)); }
+          v[n++] = (U32) ((size_t) (g - j->buf) - j->lo);
+          p = g + 1;
+        }
+      j->found[k] = v; j->nFound[k] = n;
+    }
+  return 0;
+}
+/* a walk over the listed line ends, in order */
+typedef struct { const LineJob *j; size_t s, k; } LineCursor;
+static void lineSeek (LineCursor *c, const LineJob *j, size_t line)
+{
+  size_t lo = 0, hi = j->nSlices;                   /* the slice with prefix[s] <= line < prefix[s+1] */
+  while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (j->prefix[mid] <= line) lo = mid; else hi = mid; }
+  c->j = j; c->s = lo; c->k = line - j->prefix[lo];
+}
+static inline size_t lineNext (LineCursor *c)
+{
+  while (c->k >= c->j->nFound[c->s]) { ++c->s; c->k = 0; }
+  return c->j->lo + c->j->found[c->s][c->k++];
+}
+
+enum { CUT_OK = 0, CUT_NO_AT, CUT_NO_PLUS, CUT_QUAL };
+typedef struct {
+  const char *buf; const LineJob *lines; const size_t *starts;     /* FASTQ: lines; FASTA: starts */
+  size_t at0; RawRec *recs; size_t nCand, grain, next;
+  pthread_mutex_t mu; size_t errRec; int errKind;
+} CutJob;
+static void cutFail (CutJob *j, size_t i, int kind)
+{
+  pthread_mutex_lock (&j->mu);
+  if (i < j->errRec) { j->errRec = i; j->errKind = kind; }
+  pthread_mutex_unlock (&j->mu);
+}
+static void *cutWorker (void *arg)
+{
+  CutJob *j = (CutJob *) arg;
+  const char *b = j->buf;
+  for (;;)
+    { size_t i0 = __atomic_fetch_add (&j->next, j->grain, __ATOMIC_RELAXED);
+      if (i0 >= j->nCand) break;
+      size_t i1 = i0 + j->grain < j->nCand ? i0 + j->grain : j->nCand;
+      if (j->lines)
+        { LineCursor c; size_t at = j->at0;
+          if (i0) { lineSeek (&c, j->lines, 4 * i0 - 1); at = lineNext (&c) + 1; } else lineSeek (&c, j->lines, 0);
+          for (size_t i = i0 ; i < i1 ; ++i)
+            { const size_t l1 = lineNext (&c), l2 = lineNext (&c), l3 = lineNext (&c), l4 = lineNext (&c);
+              RawRec *rec = &j->recs[i];
+              if (b[at] != '@') cutFail (j, i, CUT_NO_AT);
+              else if (b[l2 + 1] != '+') cutFail (j, i, CUT_NO_PLUS);
+              else if (l4 - (l3 + 1) != l2 - (l1 + 1)) cutFail (j, i, CUT_QUAL);
+              const char *p = b + at + 1;
+              while (p < b + l1 && !isspace ((unsigned char) *p)) ++p;
+              rec->id = at + 1; rec->idLen = (size_t) (p - (b + at + 1));
+              rec->seq = l1 + 1; rec->seqEnd = l2; rec->end = l4 + 1;
+              at = l4 + 1;
+            }
+        }
+      else
+        for (size_t i = i0 ; i < i1 ; ++i)
+          { const size_t at = j->starts[i], next = j->starts[i + 1];
+            const char *nl = (const char *) memchr (b + at, '\n', next - at);   /* there is one: the next start follows a line end */
+            const char *p = b + at + 1;
+            while (p < nl && !isspace ((unsigned char) *p)) ++p;
+            RawRec *rec = &j->recs[i];
+            rec->id = at + 1; rec->idLen = (size_t) (p - (b + at + 1));
+            rec->seq = (size_t) (nl + 1 - b); rec->seqEnd = rec->end = next;
+          }
+    }
+  return 0;
+}
+
+/* Whole records from position *at of the window on, cut by the pool and appended to *recs, until
+ * *rawSeq reaches maxBases or the window holds no further whole record that the pool can delimit.
+ * Returns how many were appended; *at, *rawSeq, *line move as the serial loop would move them.
+ * FASTQ looks at a bounded stretch of text per call (about what maxBases needs), so call it again
+ * while it makes progress. */
+static size_t cutByPool (MgSeqReader *r, int64_t maxBases, const size_t *starts, size_t nStarts,
+                         RawRec **recs, size_t *nRec, size_t *capRec, size_t *at, size_t *rawSeq, U64 *line)
+{
+  CutJob cj; memset (&cj, 0, sizeof (cj));
+  LineJob lj; memset (&lj, 0, sizeof (lj));
+  cj.buf = r->buf; cj.at0 = *at; cj.errRec = (size_t) -1;
+  size_t si = 0;
+  if (*at >= r->len || (int64_t) *rawSeq >= maxBases) return 0;
+  if (r->isFastq)
+    { const size_t need = (size_t) (maxBases - (int64_t) *rawSeq);
+      size_t span = need < ((size_t) 1 << 29) ? 4 * need + 65536 : (size_t) 0xfff00000u;   /* line ends are kept as 32-bit offsets */
+      lj.buf = r->buf; lj.lo = *at; lj.hi = r->len - *at > span ? *at + span : r->len; lj.slice = (size_t) 4 << 20;
+      lj.nSlices = (lj.hi - lj.lo + lj.slice - 1) / lj.slice;
+      lj.found = (U32 **) calloc (lj.nSlices, sizeof (U32 *)); lj.nFound = (size_t *) calloc (lj.nSlices, sizeof (size_t));
+      lj.prefix = (size_t *) calloc (lj.nSlices + 1, sizeof (size_t));
+      runPool (r->nThreads < (int) lj.nSlices ? r->nThreads : (int) lj.nSlices, lineWorker, &lj);
+      for (size_t k = 0 ; k < lj.nSlices ; ++k) lj.prefix[k + 1] = lj.prefix[k] + lj.nFound[k];
+      cj.lines = &lj; cj.nCand = lj.prefix[lj.nSlices] / 4;
+    }
+  else
+    { while (si < nStarts && starts[si] < *at) ++si;
+      if (si + 1 >= nStarts || starts[si] != *at) return 0;
+      cj.starts = starts + si; cj.nCand = nStarts - 1 - si;
+    }
+  size_t taken = 0;
+  if (cj.nCand)
+    { RawRec *cand = (RawRec *) malloc (cj.nCand * sizeof (RawRec));
+      cj.recs = cand; cj.grain = cj.nCand / ((size_t) r->nThreads * 16) + 1;
+      pthread_mutex_init (&cj.mu, 0);
+      runPool (r->nThreads, cutWorker, &cj);
+      pthread_mutex_destroy (&cj.mu);
+      while (taken < cj.nCand && (int64_t) *rawSeq < maxBases)
+        { if (taken == cj.errRec)
+            { const U64 l = *line + 4 * (U64) taken;
+              if (cj.errKind == CUT_NO_AT) dieLine ("no initial @ for FASTQ record line %llu", l);
+              if (cj.errKind == CUT_NO_PLUS) dieLine ("missing + FASTQ line %llu", l + 2);
+              dieLine ("qual not same length as seq line %llu", l + 3);
+            }
+          *rawSeq += cand[taken].seqEnd - cand[taken].seq;
+          ++taken;
+        }
+      if (taken)
+        { *at = cand[taken - 1].end;
+          if (r->isFastq) *line += 4 * (U64) taken;
+          if (!*recs) { *recs = cand; *capRec = cj.nCand; *nRec = taken; cand = 0; }       /* the usual case: one call per batch */
+          else
+            { if (*nRec + taken > *capRec) { *capRec = (*nRec + taken) * 2; *recs = (RawRec *) realloc (*recs, *capRec * sizeof (RawRec)); }
+              memcpy (*recs + *nRec, cand, taken * sizeof (RawRec));
+              *nRec += taken;
+            }
+        }
+      free (cand);
+    }
+  if (lj.found) { for (size_t k = 0 ; k < lj.nSlices ; ++k) free (lj.found[k]); free (lj.found); free (lj.nFound); free (lj.prefix); }
+  return taken;
+}
+
 /* ---- parallel conversion ----
  * Two passes over the raw text, both by the pool: count what each unit keeps (FASTA only; a FASTQ
  * line keeps every byte), then, the destinations being known, convert straight into the batch. */
@@ -344,6 +506,7 @@ typedef struct {
   const char *raw; Unit *units; size_t nUnits, grain; int isFastq;
   size_t next;
   char *dst; const size_t *unitDst;                               /* second pass */
+  const RawRec *recs; char **names;                               /* second pass: the unit that opens a record copies its id */
   int phase;
 } Job;
 
@@ -373,6 +536,8 @@ static void *worker (void *arg)
             }
           else
             { char *t = j->dst + j->unitDst[u];
+              const RawRec *rc = &j->recs[un->rec];
+              if (un->from == rc->seq) { memcpy (j->names[un->rec], j->raw + rc->id, rc->idLen); j->names[un->rec][rc->idLen] = 0; }
               /* line by line: a line made of A C G T N only (either case) converts with arithmetic on whole vectors
                  -- ((c >> 1) ^ (c >> 2)) & 3 sends A C G T to 0 1 2 3 and N to 0 -- anything else goes through the table */
               while (s < e)
@@ -426,6 +591,7 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   size_t at = r->pos; U64 line = r->line; size_t rawSeq = 0;
   size_t *starts = 0, nStarts = 0, si = 0;                       /* FASTA: where records start, found by the pool */
   if (!r->isFastq) nStarts = findFastaStarts (r, &starts);
+  while (cutByPool (r, maxBases, starts, nStarts, &recs, &nRec, &capRec, &at, &rawSeq, &line)) ;
   while (at < r->len && (int64_t) rawSeq < maxBases)
     { RawRec rec;
       int ok;
@@ -462,15 +628,15 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   TIMING (1, "cut");
 
   /* units: raw ranges of at most UNIT_BYTES, never across records */
-  size_t nUnits = 0;
-  for (size_t i = 0 ; i < nRec ; ++i) nUnits += (recs[i].seqEnd - recs[i].seq) / UNIT_BYTES + 1;
+  size_t nUnits = 0, nameBytes = 0;
+  for (size_t i = 0 ; i < nRec ; ++i) { nUnits += (recs[i].seqEnd - recs[i].seq) / UNIT_BYTES + 1; nameBytes += recs[i].idLen + 1; }
   Unit *units = (Unit *) malloc (nUnits * sizeof (Unit));
   size_t u = 0;
   for (size_t i = 0 ; i < nRec ; ++i)
     { size_t s = recs[i].seq;
       do
         { size_t e = s + UNIT_BYTES < recs[i].seqEnd ? s + UNIT_BYTES : recs[i].seqEnd;
-          units[u].from = s; units[u].to = e; units[u].rec = (int) i; units[u].outLen = 0; units[u].lines = 0; ++u;
+          units[u].from = s; units[u].to = e; units[u].rec = (int) i; units[u].outLen = r->isFastq ? e - s : 0; units[u].lines = 0; ++u;
           s = e;
         }
       while (s < recs[i].seqEnd);
@@ -479,20 +645,20 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   Job j; memset (&j, 0, sizeof (j));
   j.raw = r->buf; j.units = units; j.nUnits = nUnits; j.isFastq = r->isFastq;
   j.phase = 0;
-  runJob (&j, r->nThreads);
+  if (!r->isFastq) runJob (&j, r->nThreads);                     /* a FASTQ line keeps every byte: nothing to count */
   TIMING (2, "count");
 
   out->nSeq = (int) nRec;
   out->offsets = (int64_t *) malloc ((nRec + 1) * sizeof (int64_t));
   out->names = (char **) malloc (nRec * sizeof (char *));
   size_t *unitDst = (size_t *) malloc (nUnits * sizeof (size_t));
+  char *nameArena = (char *) malloc (nameBytes);                 /* one block for all ids: names[0] is its start */
   size_t total = 0; u = 0;
   for (size_t i = 0 ; i < nRec ; ++i)
     { out->offsets[i] = (int64_t) total;
       while (u < nUnits && units[u].rec == (int) i) { unitDst[u] = total; total += units[u].outLen; line += units[u].lines; ++u; }
       if (!r->isFastq) ++line;                                   /* the header line */
-      out->names[i] = (char *) malloc (recs[i].idLen + 1);
-      memcpy (out->names[i], r->buf + recs[i].id, recs[i].idLen); out->names[i][recs[i].idLen] = 0;
+      out->names[i] = nameArena; nameArena += recs[i].idLen + 1; /* filled by the pool, with the bases */
     }
   out->offsets[nRec] = (int64_t) total;
   out->total = (int64_t) total;
@@ -500,7 +666,7 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   TIMING (4, "offsets");
   out->bases = (char *) bigAlloc ((size_t) out->basesCap);
   TIMING (5, "alloc");
-  j.phase = 1; j.dst = out->bases; j.unitDst = unitDst;
+  j.phase = 1; j.dst = out->bases; j.unitDst = unitDst; j.recs = recs; j.names = out->names;
   runJob (&j, r->nThreads);
   TIMING (3, "convert");
   free (unitDst); free (units); free (recs);
@@ -512,7 +678,7 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
 void mgSeqBatchFree (MgSeqBatch *b)
 {
   if (!b) return;
-  for (int i = 0 ; i < b->nSeq ; ++i) free (b->names[i]);
+  if (b->names && b->nSeq > 0) free (b->names[0]);               /* the ids share one block */
   free (b->names); free (b->offsets); bigFree (b->bases, (size_t) b->basesCap);
   memset (b, 0, sizeof (*b));
 }

@@ -125,6 +125,40 @@ def test_large_record_and_many_small(tmp_path):
         assert all(np.array_equal(a, b) for a, b in zip(seqs[1:], small))
 
 
+def test_many_short_fastq_records_across_slices(tmp_path, capfd):
+    """records cut by the pool: line ends listed per 4 MiB slice, a record = four lines; a bad record
+    deep in the file is reported with its line number, an unfinished last record is left out"""
+    rng = np.random.default_rng(5)
+    n = 60_000
+    lens = rng.integers(0, 260, n)
+    letters = np.frombuffer(b"ACGTN", np.uint8)
+    seqs = [letters[rng.integers(0, 5, int(l))] for l in lens]
+    path = tmp_path / "short.fq"
+    with open(path, "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b"@q%d extra words\n" % i + s.tobytes() + b"\n+\n" + b"I" * len(s) + b"\n")
+        f.write(b"@tail\nACGT\n+\nII")                          # no closing newline
+    assert os.path.getsize(path) > 3 * (4 << 20)
+    conv = np.zeros(256, np.uint8); conv[ord("C")] = 1; conv[ord("G")] = 2; conv[ord("T")] = 3
+    for max_bases, threads in ((1 << 40, 8), (1_000_000, 5), (1 << 40, 1)):
+        names, got = parse_file(str(path), max_bases, threads)
+        assert "incomplete sequence record line %d" % (4 * n + 4) in capfd.readouterr().err
+        assert len(got) == n and names[0] == "q0" and names[-1] == "q%d" % (n - 1)
+        assert all(np.array_equal(a, conv[b]) for a, b in zip(got, seqs))
+    # the same file with record 41 234 broken
+    bad = 41_234
+    with open(path, "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b"@q%d\n" % i + s.tobytes() + (b"\n-\n" if i == bad else b"\n+\n") + b"I" * len(s) + b"\n")
+    code = ("import ctypes as C, modimizer_amd as mg; L = mg.lib(); r = L.mgSeqOpen(%r.encode()); "
+            "b = mg.MgSeqBatch()\nwhile L.mgSeqNextBatch(r, 2_000_000, C.byref(b)): print(b.nSeq, flush=True)" % str(path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=util.ROOT,
+                       env=dict(os.environ, MODGPU_NO_TORCH="1", MODGPU_PARSE_THREADS="6"))
+    assert r.returncode == 255 and ("FATAL ERROR: missing + FASTQ line %d" % (4 * bad + 3)) in r.stderr
+    taken = sum(int(x) for x in r.stdout.split())
+    assert 0 < taken <= bad                                       # whole batches before the bad record were handed over
+
+
 # ------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu

@@ -1,0 +1,48 @@
+#!/bin/bash
+# dev: the text parser (mg_seqio.c) under AddressSanitizer + UBSan on the CPU, over the golden text files
+# and a generated short-read FASTQ file.  usage: bash tools/asan_seqio.sh
+set -e
+cd "$(dirname "$0")/.."
+B=gpurun_out/asan; mkdir -p $B
+cat > $B/main.c <<'EOC'
+#include <stdio.h>
+#include <stdlib.h>
+#include "modgpu.h"
+/* the parser's callers live in other units: not exercised here */
+int64_t mgAddSequenceBatch (Modset *ms, const char *b, const int64_t *o, int n) { (void) ms; (void) b; (void) o; (void) n; return 0; }
+int mgReferenceRead (MgReference *r, const char *b, const int64_t *o, int n, const char **nm, bool a, FILE *f) { (void) r; (void) b; (void) o; (void) n; (void) nm; (void) a; (void) f; return 0; }
+int mgQueryProcess (MgReference *r, const char *b, const int64_t *o, int n, const char **nm, FILE *f) { (void) r; (void) b; (void) o; (void) n; (void) nm; (void) f; return 0; }
+int main (int argc, char **argv)
+{
+  for (int a = 2 ; a < argc ; ++a)
+    { MgSeqReader *r = mgSeqOpen (argv[a]); if (!r) continue;
+      MgSeqBatch b; unsigned long long sum = 0, ids = 0, n = 0;
+      while (mgSeqNextBatch (r, atoll (argv[1]), &b))
+        { for (int i = 0 ; i < b.nSeq ; ++i) { for (const char *p = b.names[i] ; *p ; ++p) ids = ids * 31 + (unsigned char) *p; ids = ids * 31 + (unsigned long long) (b.offsets[i + 1] - b.offsets[i]); }
+          for (int64_t i = 0 ; i < b.total ; ++i) sum = sum * 131 + (unsigned char) b.bases[i];
+          n += b.nSeq; mgSeqBatchFree (&b);
+        }
+      mgSeqClose (r);
+      printf ("%s: %llu records, checksums %llx %llx\n", argv[a], n, ids, sum);
+    }
+  return 0;
+}
+EOC
+gcc -g -O1 -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Imodimizer_amd/csrc \
+    $B/main.c modimizer_amd/csrc/mg_seqio.c -o $B/seqio_asan -lz -lpthread
+python3 - <<'EOP'
+import numpy as np
+rng = np.random.default_rng(2)
+with open("gpurun_out/asan/short.fq", "wb") as f:
+    for i in range(120000):
+        l = int(rng.integers(0, 200)); s = np.frombuffer(b"ACGTNacgtRY", np.uint8)[rng.integers(0, 11, l)].tobytes()
+        f.write(b"@r%d x\n" % i + s + b"\n+\n" + b"I" * l + b"\n")
+    f.write(b"@cut\nACG")
+EOP
+G=tests/golden
+for mb in 3000 777777 1000000000; do
+  for t in 1 7; do
+    MODGPU_PARSE_THREADS=$t $B/seqio_asan $mb $G/mixed.fa $G/mixed.fa.gz $G/mixed.fq $G/unterminated.fa $G/many.fa $B/short.fq 2>&1 | md5sum
+  done
+done
+echo "(all six digests above must be equal)"

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""dev probe: short-read FASTQ file -> modset end to end (k=31 d=4 as BASELINE config 5)"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import modimizer_amd as mg
+n_reads = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 4_000_000
+path = "/dev/shm/probe.fq"
+rng = np.random.default_rng(1)
+letters = np.frombuffer(b"ACGT", np.uint8)
+rec = 150
+seqs = letters[rng.integers(0, 4, (n_reads, rec))]
+hdr = np.frombuffer(b"@r\n", np.uint8); plus = np.frombuffer(b"\n+\n", np.uint8); q = np.full((n_reads, rec), ord("I"), np.uint8); nl = np.full((n_reads, 1), 10, np.uint8)
+block = np.concatenate([np.tile(hdr, (n_reads, 1)), seqs, np.tile(plus, (n_reads, 1)), q, nl], axis=1)
+block.tofile(path); size = os.path.getsize(path); del block, seqs, q
+L = mg.lib()
+for threads in (1, 16):
+    os.environ["MODGPU_PARSE_THREADS"] = str(threads)
+    t0 = time.time(); r = L.mgSeqOpen(path.encode()); b = mg.MgSeqBatch(); tot = 0
+    while L.mgSeqNextBatch(r, 512_000_000, C.byref(b)):
+        tot += b.total; L.mgSeqBatchFree(C.byref(b))
+    L.mgSeqClose(r); dt = time.time() - t0
+    print("FASTQ parse, %2d threads: %.2f s  %.2f GB/s text  %.2f Gbp/s" % (threads, dt, size / dt / 1e9, tot / dt / 1e9))
+del os.environ["MODGPU_PARSE_THREADS"]
+if L.mgDeviceCount() > 0:
+    sh = mg.seqhashCreate(31, 4, 17); ms = mg.modsetCreate(sh, 30)
+    for rep in range(2):
+        L.mgModsetClear(ms, None); t0 = time.time()
+        with mg.CFile("/dev/null", "w") as f:
+            assert L.mgAddSequenceFile(ms, path.encode(), f) == 0
+        dt = time.time() - t0
+        print("FASTQ file -> modset: %.2f s  %.2f Gbp/s (max %d)" % (dt, n_reads * rec / dt / 1e9, ms.contents.max))
+os.remove(path)
