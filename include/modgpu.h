@@ -303,7 +303,7 @@ void mgReadsetStats (MgReadset *rs, FILE *out) ;                                
 void mgReadsetWrite (MgReadset *rs, const char *root) ;                                     /* modasm.c:108-126 */
 MgReadset *mgReadsetLoad (const char *root) ;                                               /* modasm.c:128-149; creates rs->ms, which mgReadsetDestroy leaves to the caller (modasm.c:100-107) */
 
-/* The file front end (seqio.c:30-346 for FASTA / FASTQ text, plain or gzip, with the callers'
+/* The file front end (seqio.c:30-346 for FASTA / FASTQ text, plain, gzip or blocked gzip, with the callers'
  * dna2indexConv + N->0 conversion): records are cut out of the text and converted by a pool of
  * threads, a batch at a time.  bases hold 0..3 (FASTQ keeps other bytes as (char)-2, as the
  * reference does); offsets[nSeq+1]; names = the record ids. */

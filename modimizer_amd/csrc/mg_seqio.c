@@ -1,4 +1,4 @@
-/* mg_seqio.c — the front end of the hot path: FASTA / FASTQ text (plain or gzip) -> bases 0..3.
+/* mg_seqio.c — the front end of the hot path: FASTA / FASTQ text (plain, gzip, blocked gzip) -> bases 0..3.
  *
  * Restates what the reference's callers get from seqIOopenRead + seqIOread (seqio.c:30-110,187-346)
  * with dna2indexConv after their N->0 patch (seqio.c:643-652, modutils.c:39, modmap.c:97):
@@ -36,8 +36,10 @@ static double gPhase[8]; static const char *gPhaseName[8];
 #define UNIT_BYTES ((size_t) 1 << 20)        /* raw text per conversion work unit */
 
 struct MgSeqReader {
-  gzFile gz;                                 /* gzip stream, or 0: plain text read straight from fd */
+  gzFile gz;                                 /* gzip stream, or 0: plain text (or BGZF blocks) read straight from fd */
   int fd;
+  int bgzf; size_t bgzfOff;                  /* blocked gzip: file offset of the next block */
+  char *cbuf; size_t ccap;                   /* blocked gzip: compressed bytes being taken apart */
   size_t fileSize, consumed;                 /* plain regular file: its size, and bytes read so far */
   char *buf; size_t cap, len, pos;           /* raw text window: [pos, len) not yet consumed */
   int eof, isFastq, finished;
@@ -114,10 +116,127 @@ static int threadCount (void)
   return (int) n;
 }
 
+static void runPool (int n, void *(*fn) (void *), void *arg);
+static int threadCount (void);
+
+/* ---- blocked gzip (BGZF: bgzip, htslib) ----
+ * A gzip file made of members of at most 64 KiB, each carrying its compressed length in a 'BC' extra
+ * field and, like every gzip member, its CRC and uncompressed length at its end.  zlib reads such a file
+ * as any other (which is what the reference does, seqio.c:33-40, one thread); here the members of a
+ * stretch of the file are inflated by the pool, each straight to its place in the text window.
+ * A member that is not a BGZF block hands the rest of the file to zlib's stream reader. */
+typedef struct { size_t cOff, cLen, uOff, uLen; } BgBlock;
+typedef struct { const unsigned char *src; char *dst; const BgBlock *blocks; size_t n, next; int bad; } BgJob;
+
+static size_t bgzfBlockSize (const unsigned char *p, size_t avail, size_t *payloadOff)     /* 0: not a block header */
+{
+  if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || p[3] != 4) return 0;
+  const size_t xlen = (size_t) p[10] | ((size_t) p[11] << 8);
+  if (avail < 12 + xlen) return 0;
+  for (size_t at = 12 ; at + 4 <= 12 + xlen ; )
+    { const size_t len = (size_t) p[at + 2] | ((size_t) p[at + 3] << 8);
+      if (p[at] == 'B' && p[at + 1] == 'C' && len == 2 && at + 6 <= 12 + xlen)
+        { *payloadOff = 12 + xlen; return ((size_t) p[at + 4] | ((size_t) p[at + 5] << 8)) + 1; }
+      at += 4 + len;
+    }
+  return 0;
+}
+
+static void *bgzfWorker (void *arg)
+{
+  BgJob *j = (BgJob *) arg;
+  z_stream zs; memset (&zs, 0, sizeof (zs));
+  if (inflateInit2 (&zs, -15) != Z_OK) { j->bad = 1; return 0; }
+  for (;;)
+    { size_t b0 = __atomic_fetch_add (&j->next, 16, __ATOMIC_RELAXED);
+      if (b0 >= j->n) break;
+      size_t b1 = b0 + 16 < j->n ? b0 + 16 : j->n;
+      for (size_t b = b0 ; b < b1 ; ++b)
+        { const BgBlock *k = &j->blocks[b];
+          const unsigned char *blk = j->src + k->cOff;
+          size_t pay = 0; (void) bgzfBlockSize (blk, k->cLen, &pay);
+          inflateReset (&zs);
+          zs.next_in = (Bytef *) (blk + pay); zs.avail_in = (uInt) (k->cLen - pay - 8);
+          zs.next_out = (Bytef *) (j->dst + k->uOff); zs.avail_out = (uInt) k->uLen;
+          const int rc = inflate (&zs, Z_FINISH);
+          const unsigned char *t = blk + k->cLen - 8;
+          const U32 crc = (U32) t[0] | ((U32) t[1] << 8) | ((U32) t[2] << 16) | ((U32) t[3] << 24);
+          if (rc != Z_STREAM_END || zs.total_out != k->uLen || zs.avail_in != 0
+              || (U32) crc32 (crc32 (0L, Z_NULL, 0), (const Bytef *) (j->dst + k->uOff), (uInt) k->uLen) != crc)
+            __atomic_store_n (&j->bad, 1, __ATOMIC_RELAXED);
+        }
+    }
+  inflateEnd (&zs);
+  return 0;
+}
+
+static void bgzfToStream (MgSeqReader *r)          /* the rest of the file is ordinary gzip: zlib's reader takes over */
+{
+  r->bgzf = 0;
+  (void) lseek (r->fd, (off_t) r->bgzfOff, SEEK_SET);
+  r->gz = gzdopen (r->fd, "r");
+  if (!r->gz) { fprintf (stderr, "FATAL ERROR: gzip stream at offset %zu\n", r->bgzfOff); exit (-1); }
+  gzbuffer (r->gz, 1 << 20);
+}
+
+/* whole blocks, as many as fit in `room` (at least 64 KiB), inflated into dst; 0 at the end of the file */
+static size_t bgzfRead (MgSeqReader *r, char *dst, size_t room)
+{
+  for (;;)
+    { size_t want = room / 3 + ((size_t) 128 << 10);                /* compressed bytes to look at */
+      if (want > ((size_t) 512 << 20)) want = (size_t) 512 << 20;
+      if (want > r->ccap) { free (r->cbuf); r->cbuf = (char *) malloc (want); r->ccap = want; }
+      size_t have = 0;
+      while (have < want)
+        { ssize_t g = pread (r->fd, r->cbuf + have, want - have, (off_t) (r->bgzfOff + have));
+          if (g <= 0) break;
+          have += (size_t) g;
+        }
+      if (!have) return 0;
+      const unsigned char *c = (const unsigned char *) r->cbuf;
+      size_t cap = 1024, n = 0, cAt = 0, uAt = 0; int foreign = 0;
+      BgBlock *blocks = (BgBlock *) malloc (cap * sizeof (BgBlock));
+      while (cAt < have)
+        { size_t pay = 0; const size_t len = bgzfBlockSize (c + cAt, have - cAt, &pay);
+          if (!len)
+            { if (have - cAt >= 18 + 65536 || have < want) foreign = 1;     /* a whole header is in view and it is not a block's */
+              break;
+            }
+          if (cAt + len > have) { if (have < want) foreign = 1; break; }    /* the file ends inside the block: zlib reports it */
+          if (len < pay + 8 + 2) { foreign = 1; break; }
+          const unsigned char *t = c + cAt + len - 4;
+          const size_t uLen = (size_t) t[0] | ((size_t) t[1] << 8) | ((size_t) t[2] << 16) | ((size_t) t[3] << 24);
+          if (uLen > 65536) { foreign = 1; break; }
+          if (uAt + uLen > room) break;
+          if (n == cap) { cap *= 2; blocks = (BgBlock *) realloc (blocks, cap * sizeof (BgBlock)); }
+          blocks[n].cOff = cAt; blocks[n].cLen = len; blocks[n].uOff = uAt; blocks[n].uLen = uLen; ++n;
+          cAt += len; uAt += uLen;
+        }
+      if (n)
+        { BgJob j; j.src = c; j.dst = dst; j.blocks = blocks; j.n = n; j.next = 0; j.bad = 0;
+          int nt = r->nThreads > 0 ? r->nThreads : threadCount ();
+          if ((size_t) nt > n / 16 + 1) nt = (int) (n / 16 + 1);
+          runPool (nt, bgzfWorker, &j);
+          if (j.bad) { fprintf (stderr, "FATAL ERROR: corrupt BGZF block near file offset %zu\n", r->bgzfOff); exit (-1); }
+        }
+      free (blocks);
+      r->bgzfOff += cAt;
+      if (foreign && !uAt) { bgzfToStream (r); int got = gzread (r->gz, dst, (unsigned) (room > ((size_t) 1 << 30) ? (size_t) 1 << 30 : room)); return got > 0 ? (size_t) got : 0; }
+      if (uAt) return uAt;
+      if (!cAt) { fprintf (stderr, "FATAL ERROR: BGZF block at file offset %zu does not fit the window\n", r->bgzfOff); exit (-1); }   /* (the caller keeps 64 KiB free) */
+      /* only empty blocks (bgzip's end marker, possibly in mid-file after cat): look further */
+    }
+}
+
 static size_t readSome (MgSeqReader *r, char *dst, size_t room)
 {
+  if (r->bgzf) return bgzfRead (r, dst, room);
   if (room > ((size_t) 1 << 30)) room = (size_t) 1 << 30;
-  if (r->gz) { int got = gzread (r->gz, dst, (unsigned) room); return got > 0 ? (size_t) got : 0; }
+  if (r->gz)
+    { int got = gzread (r->gz, dst, (unsigned) room);
+      if (got < 0) { int e = 0; fprintf (stderr, "gzip read error: %s -- input ends here\n", gzerror (r->gz, &e)); }   /* the reference ends silently */
+      return got > 0 ? (size_t) got : 0;
+    }
   ssize_t got = read (r->fd, dst, room);
   if (got > 0) r->consumed += (size_t) got;
   return got > 0 ? (size_t) got : 0;
@@ -154,7 +273,7 @@ static size_t readParallel (MgSeqReader *r, char *dst, size_t n)
   return j.got;
 }
 
-static void closeInput (MgSeqReader *r) { if (r->gz) gzclose (r->gz); else close (r->fd); }
+static void closeInput (MgSeqReader *r) { if (r->gz) gzclose (r->gz); else close (r->fd); free (r->cbuf); r->cbuf = 0; }
 
 MgSeqReader *mgSeqOpen (const char *filename)
 {
@@ -165,17 +284,21 @@ MgSeqReader *mgSeqOpen (const char *filename)
   if (fd < 0) return 0;
   unsigned char magic[2] = { 0, 0 };
   gzFile gz = 0;
-  if (pread (fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b))   /* gzip, or not seekable: let zlib decide */
+  unsigned char head[64]; size_t pay = 0; int bgzf = 0;
+  { ssize_t g = pread (fd, head, sizeof (head), 0); if (g >= 18 && bgzfBlockSize (head, (size_t) g, &pay)) bgzf = 1; }
+  if (bgzf) ;                                                                    /* blocked gzip: inflated by the pool */
+  else if (pread (fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b))   /* gzip, or not seekable: let zlib decide */
     { gz = gzdopen (fd, "r");
       if (!gz) { close (fd); return 0; }
       gzbuffer (gz, 1 << 20);
     }
   MgSeqReader *r = (MgSeqReader *) calloc (1, sizeof (MgSeqReader));
   pthread_mutex_lock (&bigMu); ++bigReaders; pthread_mutex_unlock (&bigMu);
-  r->gz = gz; r->fd = fd;
+  r->gz = gz; r->fd = fd; r->bgzf = bgzf;
+  r->nThreads = threadCount ();
   r->cap = (size_t) 1 << 24;                                     /* seqio.c:36 */
   { struct stat st;                                              /* plain file: the window it will need is known */
-    if (!gz && fstat (fd, &st) == 0 && S_ISREG (st.st_mode)) r->fileSize = (size_t) st.st_size;
+    if (!gz && !bgzf && fstat (fd, &st) == 0 && S_ISREG (st.st_mode)) r->fileSize = (size_t) st.st_size;
   }
   r->buf = (char *) bigAlloc (r->cap);
   r->len = readSome (r, r->buf, r->cap);
@@ -229,11 +352,13 @@ static void refill (MgSeqReader *r, size_t want)
       if (got < n || r->consumed >= r->fileSize) { r->eof = (r->consumed >= r->fileSize || got < n); }
     }
   while (r->len < want && !r->eof)
-    { if (r->len == r->cap)
-        { char *grown = (char *) bigAlloc (r->cap * 2);
+    { if (r->len == r->cap || (r->bgzf && r->cap - r->len < 65536))      /* a BGZF block inflates to up to 64 KiB */
+        { size_t cap2 = r->cap * 2, lim = (size_t) 1 << 30;      /* straight to what is wanted (pages are only touched as they fill), 1 GiB at a time */
+          if (want > cap2) cap2 = want < lim ? want : (cap2 > lim ? cap2 : lim);
+          char *grown = (char *) bigAlloc (cap2);
           memcpy (grown, r->buf, r->len);
           bigFree (r->buf, r->cap);
-          r->buf = grown; r->cap *= 2;
+          r->buf = grown; r->cap = cap2;
         }
       size_t room = r->cap - r->len;
       if (room > want - r->len && want - r->len >= ((size_t) 1 << 20)) room = want - r->len;

@@ -159,6 +159,62 @@ def test_many_short_fastq_records_across_slices(tmp_path, capfd):
     assert 0 < taken <= bad                                       # whole batches before the bad record were handed over
 
 
+def bgzf_bytes(data, block, eof=True):
+    """blocked gzip as bgzip writes it: members of `block` text bytes with the 'BC' extra field, then the empty end marker"""
+    import struct
+    import zlib
+    out = []
+    for i in range(0, len(data), block):
+        ch = data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        pay = c.compress(ch) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(pay) + 25) + pay
+                   + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    if eof:
+        out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("fname", ["mixed.fa", "mixed.fq", "many.fa"])
+def test_blocked_gzip_is_read_like_the_text(fname, golden_dir, tmp_path):
+    """BGZF members are inflated by the pool; the result is what zlib's stream reader (the reference's path) gives"""
+    import gzip
+    raw = open(os.path.join(golden_dir, fname), "rb").read()
+    want = parse_file(os.path.join(golden_dir, fname), 1 << 40, 1)
+    path = str(tmp_path / "x.gz")
+
+    def same(got):
+        return got[0] == want[0] and all(np.array_equal(a, b) for a, b in zip(got[1], want[1]))
+    for block in (65280, 999, 37):
+        open(path, "wb").write(bgzf_bytes(raw, block))
+        assert same(parse_file(path, 1 << 40, 4)) and same(parse_file(path, 3000, 3))
+    # blocks + an end marker in mid-file + more blocks + an ordinary gzip member: zlib's reader takes over there
+    half = raw.index(b"\n", len(raw) // 2) + 1
+    open(path, "wb").write(bgzf_bytes(raw[:half], 4000) + bgzf_bytes(raw[half:half + 100], 50, eof=False) + gzip.compress(raw[half + 100:]))
+    assert same(parse_file(path, 1 << 40, 4))
+
+
+def test_blocked_gzip_large_and_corrupt(tmp_path):
+    rng = np.random.default_rng(9)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    reads = letters[rng.integers(0, 4, (150_000, 120))]
+    text = b"".join(b">r%d\n" % i + reads[i].tobytes() + b"\n" for i in range(len(reads)))    # 19 MB: several windows
+    blob = bgzf_bytes(text, 65280)
+    path = tmp_path / "big.fa.gz"
+    path.write_bytes(blob)
+    names, seqs = parse_file(str(path), 1 << 40, 8)
+    assert len(seqs) == len(reads) and names[-1] == "r%d" % (len(reads) - 1)
+    conv = np.zeros(256, np.uint8); conv[ord("C")] = 1; conv[ord("G")] = 2; conv[ord("T")] = 3
+    assert np.array_equal(np.concatenate(seqs), conv[reads].ravel())
+    bad = bytearray(blob); bad[len(blob) // 2] ^= 0x55
+    path.write_bytes(bytes(bad))
+    code = ("import ctypes as C, modimizer_amd as mg; L = mg.lib(); r = L.mgSeqOpen(%r.encode()); "
+            "b = mg.MgSeqBatch()\nwhile L.mgSeqNextBatch(r, 1 << 40, C.byref(b)): pass" % str(path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=util.ROOT,
+                       env=dict(os.environ, MODGPU_NO_TORCH="1"))
+    assert r.returncode != 0 and "FATAL ERROR" in r.stderr
+
+
 # ------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu

@@ -38,11 +38,18 @@ with open("gpurun_out/asan/short.fq", "wb") as f:
         l = int(rng.integers(0, 200)); s = np.frombuffer(b"ACGTNacgtRY", np.uint8)[rng.integers(0, 11, l)].tobytes()
         f.write(b"@r%d x\n" % i + s + b"\n+\n" + b"I" * l + b"\n")
     f.write(b"@cut\nACG")
+import struct, zlib
+raw = open("gpurun_out/asan/short.fq", "rb").read()
+with open("gpurun_out/asan/short.fq.bgz", "wb") as f:                 # the same text as blocked gzip
+    for i in range(0, len(raw), 60000):
+        ch = raw[i:i + 60000]; c = zlib.compressobj(1, zlib.DEFLATED, -15); pay = c.compress(ch) + c.flush()
+        f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(pay) + 25) + pay + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
 EOP
 G=tests/golden
 for mb in 3000 777777 1000000000; do
   for t in 1 7; do
-    MODGPU_PARSE_THREADS=$t $B/seqio_asan $mb $G/mixed.fa $G/mixed.fa.gz $G/mixed.fq $G/unterminated.fa $G/many.fa $B/short.fq 2>&1 | md5sum
+    MODGPU_PARSE_THREADS=$t $B/seqio_asan $mb $G/mixed.fa $G/mixed.fa.gz $G/mixed.fq $G/unterminated.fa $G/many.fa $B/short.fq $B/short.fq.bgz 2>&1 | md5sum
   done
 done
 echo "(all six digests above must be equal)"

@@ -30,4 +30,21 @@ if L.mgDeviceCount() > 0:
             assert L.mgAddSequenceFile(ms, path.encode(), f) == 0
         dt = time.time() - t0
         print("FASTQ file -> modset: %.2f s  %.2f Gbp/s (max %d)" % (dt, n_reads * rec / dt / 1e9, ms.contents.max))
+# the same text as ordinary gzip (one zlib stream, the reference's path) and as blocked gzip (inflated by the pool)
+import gzip, struct, zlib
+raw = open(path, "rb").read()[: 300 * (1 << 20)]
+raw = raw[: raw.rindex(b"\n@r\n") + 1]
+open(path + ".gz", "wb").write(gzip.compress(raw, 1))
+with open(path + ".bgz", "wb") as f:
+    for i in range(0, len(raw), 65280):
+        ch = raw[i:i + 65280]; c = zlib.compressobj(1, zlib.DEFLATED, -15); pay = c.compress(ch) + c.flush()
+        f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(pay) + 25) + pay + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+for ext in (".gz", ".bgz"):
+    t0 = time.time(); r = L.mgSeqOpen((path + ext).encode()); b = mg.MgSeqBatch(); tot = 0
+    while L.mgSeqNextBatch(r, 512_000_000, C.byref(b)):
+        tot += b.total; L.mgSeqBatchFree(C.byref(b))
+    L.mgSeqClose(r); dt = time.time() - t0
+    print("FASTQ%s parse: %.2f s  %.2f GB/s text  %.2f Gbp/s  (%d MB compressed)" % (ext, dt, len(raw) / dt / 1e9, tot / dt / 1e9, os.path.getsize(path + ext) >> 20))
+    os.remove(path + ext)
 os.remove(path)
