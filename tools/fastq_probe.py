@@ -23,11 +23,12 @@ for threads in (1, 16):
     print("FASTQ parse, %2d threads: %.2f s  %.2f GB/s text  %.2f Gbp/s" % (threads, dt, size / dt / 1e9, tot / dt / 1e9))
 del os.environ["MODGPU_PARSE_THREADS"]
 if L.mgDeviceCount() > 0:
-    sh = mg.seqhashCreate(31, 4, 17); ms = mg.modsetCreate(sh, 30)
+    sh = mg.seqhashCreate(31, 4, 17); ms = mg.modsetCreate(sh, 32)
     for rep in range(2):
         L.mgModsetClear(ms, None); t0 = time.time()
         with mg.CFile("/dev/null", "w") as f:
-            assert L.mgAddSequenceFile(ms, path.encode(), f) == 0
+            rc = L.mgAddSequenceFile(ms, path.encode(), f)
+            assert rc == 0, L.mgLastError().decode()
         dt = time.time() - t0
         print("FASTQ file -> modset: %.2f s  %.2f Gbp/s (max %d)" % (dt, n_reads * rec / dt / 1e9, ms.contents.max))
 # the same text as ordinary gzip (one zlib stream, the reference's path) and as blocked gzip (inflated by the pool)
