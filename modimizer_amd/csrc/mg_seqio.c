@@ -698,6 +698,55 @@ static void runJob (Job *j, int nThreads)
   else worker (j);
 }
 
+/* ---- per-record bookkeeping by the pool ---- */
+typedef struct { size_t units, nameBytes, bases, lines; } BookRun;       /* sums of a run of records, then their prefixes */
+typedef struct {
+  const RawRec *recs; size_t nRec, nRuns, next; int isFastq, phase;
+  BookRun *run; Unit *units; char **names; char *nameArena; int64_t *offsets; size_t *unitDst;
+} Book;
+static void *bookWorker (void *arg)
+{
+  Book *b = (Book *) arg;
+  for (;;)
+    { const size_t c = __atomic_fetch_add (&b->next, 1, __ATOMIC_RELAXED);
+      if (c >= b->nRuns) break;
+      const size_t i0 = b->nRec * c / b->nRuns, i1 = b->nRec * (c + 1) / b->nRuns;
+      BookRun *rn = &b->run[c];
+      if (b->phase == 0)                                          /* units and id bytes of the run */
+        { size_t nu = 0, nb = 0;
+          for (size_t i = i0 ; i < i1 ; ++i) { nu += (b->recs[i].seqEnd - b->recs[i].seq) / UNIT_BYTES + 1; nb += b->recs[i].idLen + 1; }
+          rn->units = nu; rn->nameBytes = nb;
+        }
+      else if (b->phase == 1)                                     /* the run's units and id slots */
+        { size_t u = rn->units; char *nm = b->nameArena + rn->nameBytes;
+          for (size_t i = i0 ; i < i1 ; ++i)
+            { size_t s = b->recs[i].seq;
+              do
+                { size_t e = s + UNIT_BYTES < b->recs[i].seqEnd ? s + UNIT_BYTES : b->recs[i].seqEnd;
+                  Unit *un = &b->units[u++];
+                  un->from = s; un->to = e; un->rec = (int) i; un->outLen = b->isFastq ? e - s : 0; un->lines = 0;
+                  s = e;
+                }
+              while (s < b->recs[i].seqEnd);
+              b->names[i] = nm; nm += b->recs[i].idLen + 1;
+            }
+        }
+      else if (b->phase == 2)                                     /* what the run's units keep */
+        { size_t nb = 0, nl = 0;
+          for (size_t u = rn->units ; u < rn[1].units ; ++u) { nb += b->units[u].outLen; nl += b->units[u].lines; }
+          rn->bases = nb; rn->lines = nl;
+        }
+      else                                                        /* where the run's records and units go */
+        { size_t u = rn->units, total = rn->bases;
+          for (size_t i = i0 ; i < i1 ; ++i)
+            { b->offsets[i] = (int64_t) total;
+              while (u < rn[1].units && b->units[u].rec == (int) i) { b->unitDst[u] = total; total += b->units[u].outLen; ++u; }
+            }
+        }
+    }
+  return 0;
+}
+
 /* Next batch of whole records: at least one, and no more once `maxBases` sequence characters have
  * been taken.  Returns the number of records (0 at the end of the file). */
 int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
@@ -753,38 +802,42 @@ int mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out)
   TIMING (1, "cut");
 
   /* units: raw ranges of at most UNIT_BYTES, never across records */
+  /* per-record bookkeeping, by the pool over contiguous runs of records: sums per run, a serial prefix over the
+     (few) runs, then every run fills its own part -- units and id slots first, output offsets after the count */
+  Book bk; memset (&bk, 0, sizeof (bk));
+  bk.recs = recs; bk.nRec = nRec; bk.isFastq = r->isFastq;
+  bk.nRuns = (size_t) r->nThreads * 4 < nRec ? (size_t) r->nThreads * 4 : (nRec < 1 ? 1 : nRec);
+  if (nRec < 4096) bk.nRuns = 1;
+  bk.run = (BookRun *) calloc (bk.nRuns + 1, sizeof (BookRun));
+  const int bookThreads = bk.nRuns > 1 ? r->nThreads : 1;
+  bk.phase = 0; bk.next = 0; runPool (bookThreads, bookWorker, &bk);
   size_t nUnits = 0, nameBytes = 0;
-  for (size_t i = 0 ; i < nRec ; ++i) { nUnits += (recs[i].seqEnd - recs[i].seq) / UNIT_BYTES + 1; nameBytes += recs[i].idLen + 1; }
-  Unit *units = (Unit *) malloc (nUnits * sizeof (Unit));
-  size_t u = 0;
-  for (size_t i = 0 ; i < nRec ; ++i)
-    { size_t s = recs[i].seq;
-      do
-        { size_t e = s + UNIT_BYTES < recs[i].seqEnd ? s + UNIT_BYTES : recs[i].seqEnd;
-          units[u].from = s; units[u].to = e; units[u].rec = (int) i; units[u].outLen = r->isFastq ? e - s : 0; units[u].lines = 0; ++u;
-          s = e;
-        }
-      while (s < recs[i].seqEnd);
+  for (size_t c = 0 ; c < bk.nRuns ; ++c)
+    { size_t nu = bk.run[c].units, nb = bk.run[c].nameBytes;
+      bk.run[c].units = nUnits; bk.run[c].nameBytes = nameBytes; nUnits += nu; nameBytes += nb;
     }
-  nUnits = u;
+  bk.run[bk.nRuns].units = nUnits;
+  Unit *units = (Unit *) malloc ((nUnits ? nUnits : 1) * sizeof (Unit));
+  out->nSeq = (int) nRec;
+  out->offsets = (int64_t *) malloc ((nRec + 1) * sizeof (int64_t));
+  out->names = (char **) malloc (nRec * sizeof (char *));
+  size_t *unitDst = (size_t *) malloc ((nUnits ? nUnits : 1) * sizeof (size_t));
+  bk.units = units; bk.names = out->names; bk.offsets = out->offsets; bk.unitDst = unitDst;
+  bk.nameArena = (char *) malloc (nameBytes ? nameBytes : 1);    /* one block for all ids (names[0] is its start), filled by the pool with the bases */
+  bk.phase = 1; bk.next = 0; runPool (bookThreads, bookWorker, &bk);
   Job j; memset (&j, 0, sizeof (j));
   j.raw = r->buf; j.units = units; j.nUnits = nUnits; j.isFastq = r->isFastq;
   j.phase = 0;
   if (!r->isFastq) runJob (&j, r->nThreads);                     /* a FASTQ line keeps every byte: nothing to count */
   TIMING (2, "count");
 
-  out->nSeq = (int) nRec;
-  out->offsets = (int64_t *) malloc ((nRec + 1) * sizeof (int64_t));
-  out->names = (char **) malloc (nRec * sizeof (char *));
-  size_t *unitDst = (size_t *) malloc (nUnits * sizeof (size_t));
-  char *nameArena = (char *) malloc (nameBytes);                 /* one block for all ids: names[0] is its start */
-  size_t total = 0; u = 0;
-  for (size_t i = 0 ; i < nRec ; ++i)
-    { out->offsets[i] = (int64_t) total;
-      while (u < nUnits && units[u].rec == (int) i) { unitDst[u] = total; total += units[u].outLen; line += units[u].lines; ++u; }
-      if (!r->isFastq) ++line;                                   /* the header line */
-      out->names[i] = nameArena; nameArena += recs[i].idLen + 1; /* filled by the pool, with the bases */
-    }
+  bk.phase = 2; bk.next = 0; runPool (bookThreads, bookWorker, &bk);
+  size_t total = 0;
+  for (size_t c = 0 ; c < bk.nRuns ; ++c)
+    { size_t nb = bk.run[c].bases; bk.run[c].bases = total; total += nb; line += bk.run[c].lines; }
+  if (!r->isFastq) line += nRec;                                 /* the header lines */
+  bk.phase = 3; bk.next = 0; runPool (bookThreads, bookWorker, &bk);
+  free (bk.run);
   out->offsets[nRec] = (int64_t) total;
   out->total = (int64_t) total;
   out->basesCap = (int64_t) (total ? total : 1);
