@@ -61,6 +61,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL writes its version banner to stdout (C stdio, block-buffered on a pipe) when the communicator
+        # comes up: bring it up and push the banner out now, so that rank 0's JSON line is the last line of stdout
+        dist.barrier()
+        torch.cuda.synchronize()
+        C.CDLL(None).fflush(None)
 
     k, d, seed, bits = 21, 64, 17, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
     gbp = float(os.environ.get("MODGPU_BENCH_GBP", "10"))
@@ -202,6 +207,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream)
 
+    if multi:
+        dist.barrier()                    # every rank is done (and silent) before the line goes out
+        C.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:
