@@ -704,6 +704,9 @@ typedef struct {
   const RawRec *recs; size_t nRec, nRuns, next; int isFastq, phase;
   BookRun *run; Unit *units; char **names; char *nameArena; int64_t *offsets; size_t *unitDst;
 } Book;
+/* units a record of `len` raw sequence bytes is cut into: ceil (len / UNIT_BYTES), and one (empty) unit for an empty
+ * record -- exactly what the do/while of phase 1 creates (an exact multiple of UNIT_BYTES must not count one more) */
+static inline size_t unitsOf (size_t len) { return len ? (len + UNIT_BYTES - 1) / UNIT_BYTES : 1; }
 static void *bookWorker (void *arg)
 {
   Book *b = (Book *) arg;
@@ -714,7 +717,7 @@ static void *bookWorker (void *arg)
       BookRun *rn = &b->run[c];
       if (b->phase == 0)                                          /* units and id bytes of the run */
         { size_t nu = 0, nb = 0;
-          for (size_t i = i0 ; i < i1 ; ++i) { nu += (b->recs[i].seqEnd - b->recs[i].seq) / UNIT_BYTES + 1; nb += b->recs[i].idLen + 1; }
+          for (size_t i = i0 ; i < i1 ; ++i) { nu += unitsOf (b->recs[i].seqEnd - b->recs[i].seq); nb += b->recs[i].idLen + 1; }
           rn->units = nu; rn->nameBytes = nb;
         }
       else if (b->phase == 1)                                     /* the run's units and id slots */

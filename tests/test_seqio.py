@@ -125,6 +125,35 @@ def test_large_record_and_many_small(tmp_path):
         assert all(np.array_equal(a, b) for a, b in zip(seqs[1:], small))
 
 
+@pytest.mark.parametrize("fastq", [False, True])
+def test_records_whose_text_is_a_multiple_of_the_work_unit(fastq, tmp_path):
+    """raw sequence text of exactly 1 MiB and 2 MiB (the conversion work unit, mg_seqio.c UNIT_BYTES): the unit
+    count of the bookkeeping pass must equal the units the cutting pass creates (a surplus unit was read
+    uninitialised: wild reads in the conversion workers)"""
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    mib = 1 << 20
+    path = tmp_path / ("mult.fq" if fastq else "mult.fa")
+    want = []
+    with open(path, "wb") as f:
+        if fastq:
+            for i, n in enumerate((mib, 5, 2 * mib, mib - 1, mib + 1, 0)):
+                s = rng.integers(0, 4, n).astype(np.uint8)
+                want.append(s)
+                f.write(b"@q%d\n" % i + letters[s].tobytes() + b"\n+\n" + b"I" * n + b"\n")
+        else:
+            # FASTA: the raw text includes the newlines: 16384 lines of 63 bases + newline = 1 MiB exactly
+            for i, lines in enumerate((16384, 3, 32768, 16383, 16385)):
+                s = rng.integers(0, 4, lines * 63).astype(np.uint8)
+                want.append(s)
+                f.write(b">r%d\n" % i)
+                f.write(b"".join(letters[s[j:j + 63]].tobytes() + b"\n" for j in range(0, len(s), 63)))
+    for max_bases, threads in ((1 << 40, 4), (1 << 40, 1), (100, 3)):
+        names, got = parse_file(str(path), max_bases, threads)
+        assert len(got) == len(want)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
 def test_many_short_fastq_records_across_slices(tmp_path, capfd):
     """records cut by the pool: line ends listed per 4 MiB slice, a record = four lines; a bad record
     deep in the file is reported with its line number, an unfinished last record is left out"""

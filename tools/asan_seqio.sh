@@ -45,11 +45,20 @@ with open("gpurun_out/asan/short.fq.bgz", "wb") as f:                 # the same
         ch = raw[i:i + 60000]; c = zlib.compressobj(1, zlib.DEFLATED, -15); pay = c.compress(ch) + c.flush()
         f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(pay) + 25) + pay + struct.pack("<II", zlib.crc32(ch), len(ch)))
     f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+# records whose raw sequence text is an exact multiple of the 1 MiB conversion unit (FASTA: newlines included)
+L = np.frombuffer(b"ACGT", np.uint8)
+with open("gpurun_out/asan/mult.fa", "wb") as f:
+    for i, lines in enumerate((16384, 3, 32768, 16383)):
+        s = L[rng.integers(0, 4, lines * 63)]
+        f.write(b">m%d\n" % i + b"".join(s[j:j + 63].tobytes() + b"\n" for j in range(0, len(s), 63)))
+with open("gpurun_out/asan/mult.fq", "wb") as f:
+    for i, n in enumerate((1 << 20, 7, 2 << 20, (1 << 20) + 1)):
+        f.write(b"@m%d\n" % i + L[rng.integers(0, 4, n)].tobytes() + b"\n+\n" + b"I" * n + b"\n")
 EOP
 G=tests/golden
 for mb in 3000 777777 1000000000; do
   for t in 1 7; do
-    MODGPU_PARSE_THREADS=$t $B/seqio_asan $mb $G/mixed.fa $G/mixed.fa.gz $G/mixed.fq $G/unterminated.fa $G/many.fa $B/short.fq $B/short.fq.bgz 2>&1 | md5sum
+    MODGPU_PARSE_THREADS=$t $B/seqio_asan $mb $G/mixed.fa $G/mixed.fa.gz $G/mixed.fq $G/unterminated.fa $G/many.fa $B/short.fq $B/short.fq.bgz $B/mult.fa $B/mult.fq 2>&1 | md5sum
   done
 done
 echo "(all six digests above must be equal)"
