@@ -4,55 +4,256 @@
 One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM:
 clear the modset (what modsetCreate's calloc is to the reference), scan every read for modimizers
 (seqhash.c:154-196) and insert them with depth counting (modset.c:45-62 + modutils.c:19-31).
-With N > 1 each rank owns its own contiguous block of reads (weak scaling) and builds its own
-modset; the 65536-bin depth histograms are summed with an RCCL all-reduce (BASELINE.json config 4).
 
-Workload at N=1: BASELINE.json configs[1] — 10 Gbp ONT-like reads (log-normal lengths, N50 20 kb,
-5 % substitutions, 30x of a 333 Mbp genome), k=21 d=64 seed 17, table bits 30.
-Environment overrides (for quick runs): MODGPU_BENCH_GBP, MODGPU_BENCH_BITS, MODGPU_CPU_SAMPLE_MBP.
+Workloads (BASELINE.json configs; SURVEY §8(d) sizes):
+  N = 1   configs[1]: 10 Gbp ONT-like reads (log-normal lengths, N50 20 kb, 5 % substitutions, 30x of a 333 Mbp
+          genome), k=21 d=64 seed 17, table bits 30.
+  N > 1   configs[3]: the 100 Gbp ONT set cut into contiguous blocks of 12.5 Gbp of reads, one block per GPU (rank r
+          owns block r; with N < 8 the first N blocks), all drawn from the same 3.33 Gbp genome; per-GPU modset build
+          + one RCCL all-reduce of the 65536-bin depth histogram per step.  Weak scaling: 12.5 Gbp per GPU at every N.
+  other_configs (N = 1, after the headline): configs[2] (modmap: 3 Gbp reference modset, 90 Gbp of reads queried in
+          10 Gbp batches) and configs[4] (depth histogram of 50x 150 b reads, k=31 d=4), each with its own roofline.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]   (N>1 via torch.distributed.run)
+Launch: python bench.py [--gpus N --steps K --warmup W]
+  --gpus N > 1 without WORLD_SIZE in the environment: this process starts N ranks (torch.distributed.run, one per GPU)
+  BEFORE anything touches the GPU and passes their output through; under torch.distributed.run it is a rank itself.
+Environment overrides (for quick runs): MODGPU_BENCH_GBP, MODGPU_BENCH_BITS, MODGPU_CPU_SAMPLE_MBP,
+MODGPU_BENCH_FORCE_DIST=1 (run the N>1 code path at whatever world size, even 1).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
 import time
-
-import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only does dmabuf IPC (RCCL needs it)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+# integer issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md,
+# "Wave scheduling"), at the 2.4 GHz peak clock
+VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    args = ap.parse_args()
+    ap.add_argument("--no-other", action="store_true", help="skip configs 3 and 5 (other_configs)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch path only: gloo ranks, a tiny host-side modset each, the histogram all-reduce (no GPU)")
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(args):
+    """--gpus N from a plain `python bench.py`: N ranks as children of this process, which has not imported torch
+    or touched HIP (a process that has initialised the GPU must never be replaced or forked into ranks)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.dry_launch:
+        return dry_rank(args)
+    return gpu_rank(args)
+
+
+# ------------------------------------------------------------------------------------------------
+# --dry-launch: what a rank does around the GPU work, on CPU (gloo)
+
+def dry_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MODGPU_NO_TORCH"] = "0"
+    import modimizer_amd as mg
+    from modimizer_amd import synth
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = mg.lib()
+    sh = mg.seqhashCreate(21, 64, 17)
+    ms = mg.modsetCreate(sh, 20)
+    # the rank's "block": 3000 + 100*rank pseudo k-mers with repeats, through the reference's scalar insert
+    # (modset.c:45-62 + modutils.c:26 on the host arrays: nothing here needs a device)
+    n = 3000 + 100 * rank
+    kmers = synth.splitmix64(np.arange(n, dtype=np.uint64) % np.uint64(1000 + 10 * rank) + np.uint64(rank << 20)) & np.uint64((1 << 42) - 1)
+    for km in kmers:
+        ix = L.modsetIndexFind(ms, int(km), 1)
+        dd = (int(ms.contents.depth[ix]) + 1) & 0xffff
+        ms.contents.depth[ix] = dd if dd else 0xffff
+    depth = np.ctypeslib.as_array(ms.contents.depth, (ms.contents.max + 1,))[1:]
+    local = torch.from_numpy(np.bincount(depth, minlength=65536).astype(np.int64))
+    hist = local.clone()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hist.copy_(local); dist.all_reduce(hist)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([int(local.sum()), n], dtype=torch.int64); dist.all_reduce(tot)
+    if rank == 0:
+        print(json.dumps({"metric": "Gbp/s hashed+sketched (k=21,d=64)", "dry_launch": True, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "backend": "gloo",
+                          "histogram_entries": int(hist.sum()), "entries_all_ranks": int(tot[0]),
+                          "kmers_all_ranks": int(tot[1]), "ms_per_step": round(float(tmax) / max(args.steps, 1) * 1e3, 3)}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# the real thing
+
+class Ctx:
+    pass
+
+
+def read_profile(L, mg):
+    out = {}
+    for i in range(L.mgProfileKernels()):
+        name = C.c_char_p(); ms_tot = C.c_double(); n = C.c_uint64()
+        mg.check(L.mgProfileGet(i, C.byref(name), C.byref(ms_tot), C.byref(n)))
+        if n.value:
+            out[name.value.decode()] = (ms_tot.value, n.value, i)
+    return out
+
+
+def make_reads(cx, total, genome, genome_bases, plan_seed, err, err_seed, plan=None):
+    """device-resident packed reads drawn from `genome` (device, packed): returns (reads, d_offsets, offsets, n_reads)"""
+    import numpy as np
+    torch, L, mg, synth = cx.torch, cx.L, cx.mg, cx.synth
+    starts, offsets, strands = plan if plan is not None else synth.ont_read_plan(total, genome_bases, seed=plan_seed)
+    n_reads = len(starts)
+    d_starts = torch.from_numpy(starts.view(np.int64)).to(cx.dev)
+    d_offsets = torch.from_numpy(offsets.view(np.int64)).to(cx.dev)
+    d_strands = torch.from_numpy(strands).to(cx.dev)
+    reads = torch.empty(L.mgPackedWords(total), dtype=torch.int32, device=cx.dev)
+    mg.check(L.mgSynthReads(genome.data_ptr(), genome_bases, d_starts.data_ptr(), d_offsets.data_ptr(),
+                            d_strands.data_ptr(), n_reads, total, err, err_seed, reads.data_ptr(), cx.stream))
+    torch.cuda.synchronize()
+    return reads, d_offsets, offsets, n_reads
+
+
+def make_genome(cx, genome_bases, seed):
+    genome = cx.torch.empty(cx.L.mgPackedWords(genome_bases), dtype=cx.torch.int32, device=cx.dev)
+    cx.mg.check(cx.L.mgSynthGenome(genome.data_ptr(), genome_bases, seed, cx.stream))
+    return genome
+
+
+def alg_bytes_table(total, S, entries, d, slots):
+    """algorithmic bytes per launch: SURVEY §8(d)'s per-unit figures x the units a launch processes"""
+    return {
+        "mgScanKernel": (0.25 + 8.0 / d) * total,    # 2-bit read + the 8-byte k-mer per modimizer (this path needs no pos)
+        "mgSegCompactKernel": 16.0 * S,              # kmer read + written
+        "mgPartHistKernel": 8.0 * S,
+        "mgPartScatterKernel": 24.0 * S,             # (kmer 8 + ordinal 4) read and written, per pass
+        "mgBucketDedupKernel": 12.0 * S + 16.0 * entries,
+        "mgRankAssignKernel": 9.0 * S + 8.0 * entries,
+        "mgBucketMergeKernel": 16.0 * entries + 16.0 * slots,   # uniques in, table buckets out
+        "mgTableInsertKernel": 16.0 * S,
+        "mgTableFindKernel": 24.0 * S,               # kmer 8 read + one 16-byte slot probed + (index) 4 written ~ SURVEY's 24*S
+    }
+
+
+def time_steps(cx, step, steps, warmup, multi):
+    """W untimed warm-up steps (every launch bracketed: the per-kernel table and the dominant kernel), then exactly
+    K steps between barrier + synchronize on both sides with only the dominant kernel bracketed (an event pair costs
+    a few microseconds of stream time per launch).  Returns (seconds, events of the dominant kernel, per-kernel table)."""
+    torch, dist, L, mg = cx.torch, cx.dist, cx.L, cx.mg
+    L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    warm = read_profile(L, mg)
+    dom_id = max(warm.values(), key=lambda v: v[0])[2] if warm else -1
+    L.mgProfileReset(); L.mgProfileOnly(dom_id)
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if multi:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cx.dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern = read_profile(L, mg)
+    # one more step, outside the timed region, with every launch bracketed: the per-kernel table
+    L.mgProfileOnly(-1); L.mgProfileReset()
+    step()
+    torch.cuda.synchronize()
+    table = read_profile(L, mg)
+    L.mgProfileEnable(0)
+    return dt, kern, table
+
+
+def roofline_of(kern, table, alg_bytes, tag, extra=None):
+    if not kern:
+        return None
+    dom = max(kern.items(), key=lambda kv: kv[1][0])[0]
+    avg_ms = kern[dom][0] / kern[dom][1]
+    ab = alg_bytes.get(dom, 0.0)
+    ach = ab / (avg_ms * 1e-3) / 1e9
+    traffic, tfrom = None, None
+    tpath = os.path.join(HERE, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch from an EARLIER rocprofv3 run
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom, {}).get(tag)
+            if traffic is not None:
+                tfrom = "profiles/traffic.json (%s; separate rocprofv3 --pmc passes of an earlier run of this command, not this run)" % tj.get("_from", "round profile")
+        except Exception:
+            traffic = None
+    r = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": tfrom,
+         "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": ab,
+         "kernels_ms_per_step": {k: round(v[0], 4) for k, v in sorted(table.items())},
+         "kernels_ms_per_step_from": "one extra step after the timed region, every launch bracketed"}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def gpu_rank(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
     import modimizer_amd as mg
     from modimizer_amd import synth
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    L = mg.lib()
+    cx = Ctx()
+    cx.torch, cx.dist, cx.mg, cx.synth = torch, dist, mg, synth
+    cx.dev = torch.device("cuda", local_rank)
+    cx.L = L = mg.lib()
     mg.check(L.mgSetDevice(local_rank))
     # MODGPU_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, histogram all-reduce, barriers)
     # with whatever WORLD_SIZE the launcher gave, even 1 — for checking that path on a one-GPU box
@@ -60,7 +261,7 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=cx.dev)
         # RCCL writes its version banner to stdout (C stdio, block-buffered on a pipe) when the communicator
         # comes up: bring it up and push the banner out now, so that rank 0's JSON line is the last line of stdout
         dist.barrier()
@@ -68,31 +269,25 @@ def main():
         C.CDLL(None).fflush(None)
 
     k, d, seed, bits = 21, 64, 17, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
-    gbp = float(os.environ.get("MODGPU_BENCH_GBP", "10"))
+    # config 2 at N = 1; one 12.5 Gbp block of config 4's 100 Gbp set per GPU otherwise
+    gbp = float(os.environ.get("MODGPU_BENCH_GBP", "12.5" if multi else "10"))
     total = int(gbp * 1e9)
-    genome_bases = max(int(total / 30), 1_000_000)
+    blocks = 8 if multi else 1                                   # the config-4 set is always the 8-block one
+    genome_bases = max(int(total * blocks / 30), 1_000_000)
     err = 0.05
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cx.stream = stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ---- synthetic reads, generated in HBM -------------------------------------------------
     t_gen = time.time()
-    starts, offsets, strands = synth.ont_read_plan(total, genome_bases, seed=1000 + rank)
-    n_reads = len(starts)
-    genome = torch.empty(L.mgPackedWords(genome_bases), dtype=torch.int32, device=dev)
-    mg.check(L.mgSynthGenome(genome.data_ptr(), genome_bases, 12345, stream))
-    d_starts = torch.from_numpy(starts.view(np.int64)).to(dev)
-    d_offsets = torch.from_numpy(offsets.view(np.int64)).to(dev)
-    d_strands = torch.from_numpy(strands).to(dev)
-    reads = torch.empty(L.mgPackedWords(total), dtype=torch.int32, device=dev)
-    mg.check(L.mgSynthReads(genome.data_ptr(), genome_bases, d_starts.data_ptr(), d_offsets.data_ptr(),
-                            d_strands.data_ptr(), n_reads, total, err, 777 + rank, reads.data_ptr(), stream))
-    torch.cuda.synchronize()
+    genome = make_genome(cx, genome_bases, 12345)
+    reads, d_offsets, offsets, n_reads = make_reads(cx, total, genome, genome_bases, 1000 + rank, err, 777 + rank)
     del genome
     t_gen = time.time() - t_gen
 
     sh = mg.seqhashCreate(k, d, seed)
     ms = mg.modsetCreate(sh, bits)
-    hist = torch.zeros(65536, dtype=torch.int64, device=dev)
+    hist = torch.zeros(65536, dtype=torch.int64, device=cx.dev)
+    local_hist = torch.zeros(65536, dtype=torch.int64, device=cx.dev)
     n_hash = C.c_uint64(0)
 
     def step():
@@ -104,108 +299,99 @@ def main():
             mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), stream))
             dist.all_reduce(hist)
 
-    def read_profile():
-        out = {}
-        for i in range(L.mgProfileKernels()):
-            name = C.c_char_p(); ms_tot = C.c_double(); n = C.c_uint64()
-            mg.check(L.mgProfileGet(i, C.byref(name), C.byref(ms_tot), C.byref(n)))
-            if n.value:
-                out[name.value.decode()] = (ms_tot.value, n.value, i)
-        return out
-
-    # Warm-up steps run with every kernel launch bracketed by HIP events (on the launch stream): that gives the
-    # per-kernel table and says which kernel dominates.  An event pair costs a few microseconds of stream time per
-    # launch (25 launches a step), so in the timed region only the dominant kernel is bracketed.
-    L.mgProfileOnly(-1)
-    L.mgProfileEnable(1)
-    L.mgProfileReset()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    warm = read_profile()
-    warm_steps = args.warmup
-    dom_id = max(warm.values(), key=lambda v: v[0])[2] if warm else -1
-
-    L.mgProfileReset()
-    L.mgProfileOnly(dom_id)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # ---- HIP-event timings over the timed region -> roofline of the dominant kernel ---------
-    kern = read_profile()
-    # one more step, outside the timed region, with every launch bracketed: the per-kernel table
-    L.mgProfileOnly(-1)
-    L.mgProfileReset()
-    step()
-    torch.cuda.synchronize()
-    warm = read_profile()
-    warm_steps = 1
-    L.mgProfileEnable(0)
+    dt, kern, table = time_steps(cx, step, args.steps, args.warmup, multi)
     S = n_hash.value
     entries = ms.contents.max
-    alg_bytes = {                                   # algorithmic bytes per launch
-        "mgScanKernel": (0.25 + 12.0 / d) * total,  # 2-bit read + (kmer 8 + pos 4) per modimizer
-        "mgSegCompactKernel": 16.0 * S,             # kmer read + written
-        "mgPartHistKernel": 8.0 * S,
-        "mgPartScatterKernel": 24.0 * S,            # (kmer 8 + ordinal 4) read and written, per pass
-        "mgBucketDedupKernel": 12.0 * S + 16.0 * entries,
-        "mgRankAssignKernel": 9.0 * S + 8.0 * entries,
-        "mgBucketMergeKernel": 16.0 * entries + 16.0 * entries / 0.6,   # uniques in, table buckets out
-        "mgTableInsertKernel": 16.0 * S,
-    }
-    dom = max(kern.items(), key=lambda kv: kv[1][0])[0] if kern else None
-    roofline = None
-    if dom:
-        avg_ms = kern[dom][0] / kern[dom][1]
-        ach = alg_bytes.get(dom, 0.0) / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(HERE, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tpath):
+    slots = float(L.mgModsetDeviceSlots(ms))
+    alg = alg_bytes_table(total, S, entries, d, slots)
+
+    # the scan's two bounds (SURVEY §8(d) asks for both): HBM bytes and integer issue
+    scan_ms = table.get("mgScanKernel", (0, 1))[0] / max(table.get("mgScanKernel", (0, 1))[1], 1)
+    starts = float(total)
+    alu = None
+    if scan_ms:
+        ipath = os.path.join(HERE, "profiles", "scan_issue.json")     # SQ_INSTS_VALU etc. of mgScanKernel from a --pmc pass
+        valu_per_start, src = None, None
+        if os.path.exists(ipath):
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("%g" % gbp)
+                ij = json.load(open(ipath)); valu_per_start = ij.get("valu_per_start"); src = ij.get("_from")
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_bytes_per_launch": alg_bytes.get(dom),
-                    "kernels_ms_per_step": ({kname: round(v[0] / warm_steps, 4) for kname, v in sorted(warm.items())}
-                                            if warm_steps and dom_id >= 0 else
-                                            {kname: round(v[0] / args.steps, 4) for kname, v in sorted(kern.items())}),
-                    "kernels_ms_per_step_from": "one extra step after the timed region, every launch bracketed" if warm_steps and dom_id >= 0 else "timed steps"}
+                pass
+        floor7 = 7.0 * starts / 64 / VALU_WAVE_INSTS_PER_S * 1e3      # the 7-instruction candidate filter alone
+        alu = {"valu_per_start": valu_per_start, "valu_per_start_from": src,
+               "filter_floor_valu_per_start": 7, "floor_ms": round(floor7, 3),
+               "issue_peak_wave_insts_per_s": VALU_WAVE_INSTS_PER_S,
+               "issue_frac": (round(valu_per_start * starts / 64 / VALU_WAVE_INSTS_PER_S / (scan_ms * 1e-3), 3)
+                              if valu_per_start else None),
+               "scan_ms": round(scan_ms, 4)}
+    extra = {"alu": alu,
+             "scan_bytes": {"this_path_8B_per_modimizer": alg["mgScanKernel"],
+                            "survey_12B_per_modimizer": (0.25 + 12.0 / d) * total,
+                            "read_only_0.25B_per_base": 0.25 * total,
+                            "scan_GBps_this_path": round(alg["mgScanKernel"] / (scan_ms * 1e-3) / 1e9, 1) if scan_ms else None,
+                            "scan_read_only_frac": round(0.25 * total / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if scan_ms else None},
+             "whole_step": {"bytes_per_base": 0.25 + 28.0 / d,
+                            "GBps": round((0.25 + 28.0 / d) * total * args.steps / dt / 1e9, 1),
+                            "frac": round((0.25 + 28.0 / d) * total * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)}}
+    roofline = roofline_of(kern, table, alg, "%g" % gbp, extra)
 
     value = world * total * args.steps / dt / 1e9
+    scan_step_ms = sum(v[0] for kname, v in table.items() if kname in ("mgScanKernel", "mgSegScanKernel", "mgSegCompactKernel", "mgTileInfoKernel"))
     out = {
         "metric": "Gbp/s hashed+sketched (k=21,d=64)", "value": round(value, 3), "unit": "Gbp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%g Gbp per GPU synthetic ONT-like reads (log-normal N50 20 kb, 5%% subs, 30x of a %d Mbp genome), "
-                               "k=21 d=64 seed=17, seqhash scan + modset build (table bits %d)%s"
-                               % (gbp, genome_bases // 1_000_000, bits,
-                                  ", per-GPU build + RCCL all-reduce of the depth histogram" if world > 1 else ""),
+        "config": {"workload": ("BASELINE config 4: block %s of the 100 Gbp synthetic ONT set (8 contiguous blocks of %g Gbp of reads from one "
+                                "%d Mbp genome, log-normal N50 20 kb, 5%% subs), one block per GPU, k=21 d=64 seed=17, per-GPU seqhash scan + "
+                                "modset build (table bits %d) + RCCL all-reduce of the depth histogram"
+                                % ("r on rank r" if world > 1 else "0", gbp, genome_bases // 1_000_000, bits)) if multi else
+                               ("BASELINE config 2: %g Gbp synthetic ONT-like reads (log-normal N50 20 kb, 5%% subs, 30x of a %d Mbp genome), "
+                                "k=21 d=64 seed=17, seqhash scan + modset build (table bits %d)" % (gbp, genome_bases // 1_000_000, bits)),
                    "reads_per_gpu": n_reads, "bases_per_gpu": total, "modimizers_per_gpu": S,
                    "modset_entries": entries, "k": k, "d": d, "table_bits": bits,
                    "parallelism": "reads sharded x%d, modset per GPU" % world},
         "roofline": roofline,
+        "scan_only": {"ms": round(scan_step_ms, 4), "Gbp_per_s": round(total / (scan_step_ms * 1e-3) / 1e9, 1) if scan_step_ms else None,
+                      "what": "tile info + scan + segment scan + compaction (dense (read,pos)-ordered k-mers out), by HIP events"},
         "setup_s": round(t_gen, 2),
     }
 
+    if multi:
+        # the collective by itself, and a check of what it produced
+        local_hist.zero_()
+        mg.check(L.modsetDepthHistogramDevice(ms, local_hist.data_ptr(), stream))
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            hist.copy_(local_hist); dist.all_reduce(hist)
+        torch.cuda.synchronize(); dist.barrier()
+        ar_ms = (time.perf_counter() - t0) / reps * 1e3
+        sums = torch.tensor([int(local_hist.sum().item()), entries], dtype=torch.int64, device=cx.dev)
+        dist.all_reduce(sums)
+        ok = int(hist.sum().item()) == int(sums[0].item()) and int(sums[0].item()) == int(sums[1].item())
+        if world == 1:
+            ok = ok and bool(torch.equal(hist, local_hist))
+        out["collective"] = {"what": "all_reduce(SUM) of the 65536 x int64 depth histogram (512 KiB) over RCCL",
+                             "allreduce_ms": round(ar_ms, 4), "histogram_entries": int(hist.sum().item()),
+                             "entries_all_ranks": int(sums[1].item()), "matches_local_sums": ok}
+
     # ---- CPU baseline (rank 0, N=1 only): the compiled reference on a bounded sample ---------
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream)
+        out["cpu_baseline"] = cpu_baseline(cx, reads, offsets, k, d, seed)
+
+    L.modsetDestroy(ms)
+    del reads, d_offsets
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not multi and not args.no_other:
+        other = {}
+        for name, fn in (("c5", bench_c5), ("c3", bench_c3)):
+            try:
+                other[name] = fn(cx, args)
+            except Exception as e:                                # the headline line must still go out
+                other[name] = {"error": str(e)[:300]}
+        out["other_configs"] = other
 
     if multi:
         dist.barrier()                    # every rank is done (and silent) before the line goes out
@@ -216,28 +402,163 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream):
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 5 and 3 (N = 1)
+
+def bench_c5(cx, args):
+    """configs[4]: modutils depth histogram on 50x synthetic Illumina 150 b reads, k=31 d=4 (20 Mbp genome,
+    6 666 667 reads, 0.5 % substitutions, table bits 28).  Step = clear + scan + build + depth histogram (modutils.c:19-63)."""
+    torch, L, mg, synth = cx.torch, cx.L, cx.mg, cx.synth
+    k, d, bits = 31, 4, 28
+    scale = float(os.environ.get("MODGPU_BENCH_C5_SCALE", "1"))
+    genome_bases = int(20_000_000 * scale)
+    n_reads = int(6_666_667 * scale)
+    total = n_reads * 150
+    genome = make_genome(cx, genome_bases, 555)
+    plan = synth.fixed_read_plan(n_reads, 150, genome_bases, 556)
+    reads, d_offsets, offsets, _ = make_reads(cx, total, genome, genome_bases, 0, 0.005, 557, plan=plan)
+    del genome
+    sh = mg.seqhashCreate(k, d, 17)
+    ms = mg.modsetCreate(sh, bits)
+    hist = torch.zeros(65536, dtype=torch.int64, device=cx.dev)
+    n_hash = C.c_uint64(0)
+
+    def step():
+        mg.check(L.mgModsetClear(ms, cx.stream))
+        mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads, C.byref(n_hash), cx.stream))
+        hist.zero_()
+        mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), cx.stream))
+
+    steps = max(3, min(args.steps, 10))
+    dt, kern, table = time_steps(cx, step, steps, 1, False)
+    S, entries = n_hash.value, ms.contents.max
+    alg = alg_bytes_table(total, S, entries, d, float(L.mgModsetDeviceSlots(ms)))
+    h = hist.cpu().numpy()
+    res = {"workload": "BASELINE config 5: %d x 150 b reads (50x of a %d Mbp genome, 0.5%% subs), k=31 d=4 seed=17, table bits %d: "
+                       "seqhash scan + modset build + depth histogram" % (n_reads, genome_bases // 1_000_000, bits),
+           "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "bases": total, "modimizers": S, "modset_entries": entries,
+           "histogram": {"entries": int(h.sum()), "depth_sum_le_modimizers": bool(int((h * range(65536)).sum()) <= S),
+                         "mode_depth": int(h[1:].argmax()) + 1},
+           "whole_step": {"bytes_per_base": 0.25 + 28.0 / d, "GBps": round((0.25 + 28.0 / d) * total * steps / dt / 1e9, 1),
+                          "frac": round((0.25 + 28.0 / d) * total * steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+           "roofline": roofline_of(kern, table, alg, "c5")}
+    L.modsetDestroy(ms)
+    del reads, d_offsets
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_c3(cx, args):
+    """configs[2]: modmap — a 3 Gbp synthetic reference (24 sequences of 125 Mbp, table bits 28, modmap.c:93-134 insert
+    loop) queried with 30x = 90 Gbp of ONT-like reads in batches of 10 Gbp (modmap.c:197-206 lookup loop: one seed
+    (index,pos) per modimizer incl. misses).  Timed: the query batches (scan + lookup), reads resident in HBM."""
+    import numpy as np
+    torch, L, mg, synth = cx.torch, cx.L, cx.mg, cx.synth
+    k, d, bits = 21, 64, 28
+    scale = float(os.environ.get("MODGPU_BENCH_C3_SCALE", "1"))
+    n_seq = 24
+    seq_len = int(125_000_000 * scale)
+    genome_bases = n_seq * seq_len
+    batch = int(float(os.environ.get("MODGPU_BENCH_C3_BATCH_GBP", "10")) * 1e9 * min(scale * 4, 1.0))
+    n_batches = int(os.environ.get("MODGPU_BENCH_C3_BATCHES", "9"))
+    genome = make_genome(cx, genome_bases, 333)
+    ref_off = torch.arange(0, n_seq + 1, dtype=torch.int64, device=cx.dev) * seq_len
+    sh = mg.seqhashCreate(k, d, 17)
+    ms = mg.modsetCreate(sh, bits)
+    cap = int(genome_bases / d * 1.3) + (1 << 16)
+    s_idx = torch.empty(cap, dtype=torch.int32, device=cx.dev)
+    s_pos = torch.empty(cap, dtype=torch.int32, device=cx.dev)
+    s_rd = torch.empty(cap, dtype=torch.int32, device=cx.dev)
+    n_seeds = C.c_uint64(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mg.check(L.mgInsertReadsDevice(ms, genome.data_ptr(), genome_bases, ref_off.data_ptr(), n_seq,
+                                   s_idx.data_ptr(), s_pos.data_ptr(), s_rd.data_ptr(), cap, C.byref(n_seeds), cx.stream))
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    ref_occ, ref_entries = n_seeds.value, ms.contents.max
+    del s_idx, s_pos, s_rd
+    torch.cuda.empty_cache()
+
+    qcap = int(batch / d * 1.3) + (1 << 16)
+    q_idx = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
+    q_pos = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
+    q_rd = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
+    L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
+    tot_bases = tot_seeds = tot_hits = 0
+    t_query = 0.0
+    first_table = None
+    for b in range(n_batches):
+        reads, d_offsets, offsets, n_reads = make_reads(cx, batch, genome, genome_bases, 4000 + b, 0.05, 5000 + b)
+        if b == 0:                                               # warm-up of the arena and the kernels, untimed
+            mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
+                                          q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
+            torch.cuda.synchronize()
+            L.mgProfileReset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
+                                      q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
+        torch.cuda.synchronize()
+        t_query += time.perf_counter() - t0
+        tot_bases += batch; tot_seeds += n_seeds.value
+        tot_hits += int((q_idx[:n_seeds.value] != 0).sum().item())
+        del reads, d_offsets
+    table = read_profile(L, mg)
+    L.mgProfileEnable(0)
+    per_batch = {kname: (v[0] / n_batches, 1, v[2]) for kname, v in table.items()}
+    S = tot_seeds / n_batches
+    alg = alg_bytes_table(batch, S, ref_entries, d, float(L.mgModsetDeviceSlots(ms)))
+    alg["mgScanKernel"] = (0.25 + 16.0 / d) * batch              # this path writes kmer 8 + pos 4 + read 4 per modimizer
+    alg["mgSegCompactKernel"] = 32.0 * S
+    kern = {kname: (v[0], v[1], v[2]) for kname, v in table.items()}
+    res = {"workload": "BASELINE config 3: modmap, reference %d x %d Mbp = %.1f Gbp (table bits %d, %d occurrences, %d modset entries), "
+                       "%d query batches of %g Gbp ONT-like reads from it (5%% subs): scan + lookup, seeds (index,pos,read) out"
+                       % (n_seq, seq_len // 1_000_000, genome_bases / 1e9, bits, ref_occ, ref_entries, n_batches, batch / 1e9),
+           "value": round(tot_bases / t_query / 1e9, 2), "unit": "Gbp/s", "ms_per_batch": round(t_query / n_batches * 1e3, 3),
+           "query_bases": tot_bases, "seeds": tot_seeds, "seed_hit_fraction": round(tot_hits / max(tot_seeds, 1), 4),
+           "reference_build_s": round(t_ref, 3), "reference_build_Gbp_per_s": round(genome_bases / t_ref / 1e9, 1),
+           "whole_batch": {"bytes_per_base": 0.25 + 36.0 / d, "GBps": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9, 1),
+                           "frac": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9 / HBM_PEAK_GBS, 4),
+                           "note": "0.25 B/base read + per seed: 12 B written by the scan + 24 B lookup (kmer 8, one 16-byte slot, wait index 4 out)"},
+           "roofline": roofline_of(kern, per_batch, alg, "c3")}
+    L.modsetDestroy(ms)
+    del genome, q_idx, q_pos, q_rd
+    torch.cuda.empty_cache()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+
+def cpu_baseline(cx, reads, offsets, k, d, seed):
     """The reference's own C path (oracle/_ref/ref_bench, built from the unmodified sources) timed
-    single-threaded — its real execution model — on the first reads of the same workload."""
+    single-threaded — its real execution model — on the first reads of the same workload; and, so that the GPU is not
+    flattered, the same sample sharded over every host core with private modsets merged in block order
+    (modsetMerge semantics, modset.c:106-128) by oracle/cpu_bench (this repo's C restatement, pthreads)."""
+    import numpy as np
+    torch, L, mg = cx.torch, cx.L, cx.mg
     sample_mbp = float(os.environ.get("MODGPU_CPU_SAMPLE_MBP", "1200"))
     want = int(sample_mbp * 1e6)
     n = int(np.searchsorted(offsets, want, side="right")) - 1
     n = max(1, min(n, len(offsets) - 1))
     nb = int(offsets[n])
-    d_bytes = torch.empty(nb, dtype=torch.uint8, device=dev)
-    mg.check(L.mgUnpackDevice(reads.data_ptr(), nb, d_bytes.data_ptr(), stream))
+    d_bytes = torch.empty(nb, dtype=torch.uint8, device=cx.dev)
+    mg.check(L.mgUnpackDevice(reads.data_ptr(), nb, d_bytes.data_ptr(), cx.stream))
     torch.cuda.synchronize()
     h_bytes = d_bytes.cpu().numpy()
     del d_bytes
     off = offsets[:n + 1].astype(np.int64)
     sample_desc = "first %d reads (%.0f Mbp) of the same workload, single thread, table bits 28" % (n, nb / 1e6)
     ref_bench = os.path.join(HERE, "oracle", "_ref", "ref_bench")
+    cpu_bench = os.path.join(HERE, "oracle", "cpu_bench")
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(shm, "modgpu_cpu_sample_%d.bin" % os.getpid())
+    res = None
     try:
+        with open(path, "wb") as f:
+            np.array([n, nb], np.uint64).tofile(f); off.tofile(f); h_bytes.tofile(f)
         if os.path.exists(ref_bench):
-            with open(path, "wb") as f:
-                np.array([n, nb], np.uint64).tofile(f); off.tofile(f); h_bytes.tofile(f)
             try:
                 r = subprocess.run([ref_bench, path, str(k), str(d), str(seed), "28"],
                                    capture_output=True, text=True, timeout=900)
@@ -247,61 +568,28 @@ def cpu_baseline(L, mg, torch, dev, reads, offsets, k, d, seed, stream):
                            "kind": "reference", "sample": sample_desc,
                            "scan_only_gbps": round(j["scan_mbps"] / 1e3, 5),
                            "host_cores_online": os.cpu_count()}
-                    try:
-                        res["all_cores_port"] = all_cores_port(h_bytes, off, k, d, seed)
-                    except Exception as e:      # informational only
-                        res["all_cores_port"] = {"error": str(e)[:200]}
-                    return res
             except Exception:
-                pass
+                res = None
+        if res is None:
+            # fall back to this repo's C restatement of the same path
+            from oracle import pyoracle as po
+            oh = po.Hasher(k, d, seed)
+            oms = po.Modset(oh, 28)
+            t0 = time.perf_counter()
+            po.lib().orcScanMany(C.byref(oh.c), h_bytes.ctypes.data, off.ctypes.data, n, oms.p)
+            dt = time.perf_counter() - t0
+            res = {"value": round(nb / dt / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
+                   "sample": sample_desc, "host_cores_online": os.cpu_count()}
+        if os.path.exists(cpu_bench):
+            try:
+                r = subprocess.run([cpu_bench, path, str(k), str(d), str(seed), "28"], capture_output=True, text=True, timeout=900)
+                res["all_cores"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+            except Exception as e:                  # informational only
+                res["all_cores"] = {"error": str(e)[:200]}
     finally:
         if os.path.exists(path):
             os.remove(path)
-    # fall back to this repo's C restatement of the same path
-    from oracle import pyoracle as po
-    oh = po.Hasher(k, d, seed)
-    oms = po.Modset(oh, 28)
-    t0 = time.perf_counter()
-    po.lib().orcScanMany(C.byref(oh.c), h_bytes.ctypes.data, off.ctypes.data, n, oms.p)
-    dt = time.perf_counter() - t0
-    return {"value": round(nb / dt / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": sample_desc, "host_cores_online": os.cpu_count()}
-
-
-def all_cores_port(h_bytes, off, k, d, seed):
-    """Informational, so the GPU is not flattered by a single-thread baseline: this repo's C restatement
-    (oracle/, kind "port") with the sample's reads sharded over every host core, each thread building a
-    PRIVATE modset (no merge step, which favours the CPU).  The reference itself has no threading."""
-    import threading
-    from oracle import pyoracle as po
-    n = len(off) - 1
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:                                        # the box may cap CPU time below the core count (cgroup v2 cpu.max)
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            avail = max(1, min(avail, int(quota) // int(period)))
-    except Exception:
-        pass
-    T = max(1, min(avail, 64, n))
-    hashers = [po.Hasher(k, d, seed) for _ in range(T)]
-    sets = [po.Modset(hashers[t], 24) for t in range(T)]
-    bounds = [n * t // T for t in range(T + 1)]
-    lib = po.lib()
-
-    def work(t):
-        lo, hi = bounds[t], bounds[t + 1]
-        sub = np.ascontiguousarray(off[lo:hi + 1] - off[lo])
-        base = h_bytes[int(off[lo]):int(off[hi])]
-        lib.orcScanMany(C.byref(hashers[t].c), base.ctypes.data, sub.ctypes.data, hi - lo, sets[t].p)
-    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-    t0 = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t0
-    return {"value": round(int(off[-1]) / dt / 1e9, 4), "unit": "Gbp/s", "threads": T, "kind": "port",
-            "note": "private per-thread modsets (table bits 24), no merge"}
+    return res
 
 
 if __name__ == "__main__":

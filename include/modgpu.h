@@ -4,12 +4,20 @@
  *
  *  (1) the reference's own seqhash.h / modset.h API with identical signatures and struct layouts,
  *      so modmap/modutils-style callers link against this library unchanged
- *      (reference seqhash.h:36-60, modset.h:30-42; struct layouts seqhash.h:15-34, modset.h:17-28);
+ *      (reference seqhash.h:36-60, modset.h:30-69; struct layouts seqhash.h:15-34, modset.h:17-28).
+ *      A caller built inside the reference tree keeps including the reference's own modset.h (its
+ *      unmodified modutils.c / modmap.c link against libmodgpu.so as they are: oracle/Makefile builds
+ *      them that way and tests/test_dropin.py runs them); a caller without the reference tree gets
+ *      the same declarations, header-inline helpers included, from modgpu_compat.h.
  *
- *  (2) batch entry points that carry the GPU path: whole batches of reads are scanned, the
+ *  (2) this file: batch entry points that carry the GPU path: whole batches of reads are scanned, the
  *      modimizers compacted in (read,pos) order, and inserted into / looked up in a device-resident
  *      modset table.  These replace the per-read loops of the reference callers
  *      (modutils.c:19-31, modmap.c:106-118, modmap.c:197-206).
+ *
+ * Using (2) next to the reference's headers: include the reference's modset.h FIRST, then this file.
+ * It notices (MS_MINOR is a macro of modset.h:49; or define MODGPU_WITH_REFERENCE_HEADERS) and takes
+ * Seqhash / Modset / U8..U64 from there instead of declaring them again.
  *
  * Error behaviour follows the reference: invalid parameters and capacity overflow print
  * "FATAL ERROR: ..." and exit(-1) (utils.c:19-30) in layer (1); layer (2) functions return a
@@ -24,83 +32,23 @@
 #include <stdbool.h>
 #include <stddef.h>
 
+#if defined (MODGPU_WITH_REFERENCE_HEADERS) || defined (MS_MINOR)
+/* layer 1 comes from the reference's modset.h + seqhash.h + utils.h, already included */
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-typedef uint8_t  U8;
-typedef uint16_t U16;
-typedef uint32_t U32;
-typedef uint64_t U64;
-
-/* ------------------------------------------------------------------------------------------
- * Layer 1: reference-compatible types (layouts are ABI: reference callers touch the fields).
- * ------------------------------------------------------------------------------------------ */
-
-/* seqhash.h:15-23 — 80 bytes, written raw into .mod files (seqhash.c:41-44) */
-typedef struct {
-  int seed ;
-  int k ;
-  int w ;
-  U64 mask ;
-  int shift1, shift2 ;
-  U64 factor1, factor2 ;
-  U64 patternRC[4] ;
-} Seqhash ;
-
-/* seqhash.h:25-34.  hashBuf and fBuf are free()-able heap blocks and the iterator itself is a
- * free()-able block, because the reference's destroy is header-inlined into callers
- * (seqhash.h:54-55).  This library keeps the precomputed modimizers of the read behind hashBuf. */
-typedef struct {
-  Seqhash *sh ;
-  char *s, *sEnd ;
-  U64 h, hRC ;
-  U64 *hashBuf ;
-  bool *fBuf ;
-  int base ;
-  int iStart, iMin ;
-  bool isDone ;
-} SeqhashRCiterator ;
-
-/* modset.h:17-28 — transparent: callers read/write index/value/depth/info/max directly */
-typedef struct {
-  Seqhash *hasher ;
-  int tableBits ;
-  U32 size ;
-  U64 tableSize ;
-  U64 tableMask ;
-  U32 *index ;
-  U64 *value ;
-  U16 *depth ;
-  U8  *info ;
-  U32 max ;
-} Modset ;
-
-/* seqhash.h:36-60 */
-Seqhash *seqhashCreate (int k, int w, int seed) ;                         /* seqhash.c:20-37 */
-void seqhashWrite (Seqhash *sh, FILE *f) ;                                /* seqhash.c:41-44 */
-Seqhash *seqhashRead (FILE *f) ;                                          /* seqhash.c:46-53 */
-void seqhashReport (Seqhash *sh, FILE *f) ;                               /* seqhash.c:55-56 */
-SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len) ;        /* seqhash.c:154-177 */
-bool modRCnext (SeqhashRCiterator *si, U64 *kmer, int *pos, bool *isF) ;  /* seqhash.c:179-196 */
-SeqhashRCiterator *minimizerRCiterator (Seqhash *sh, char *s, int len) ;  /* seqhash.c:83-108: one GPU pass, replayed */
-bool minimizerRCnext (SeqhashRCiterator *si, U64 *u, int *pos, bool *isF) ; /* seqhash.c:110-152 */
-char *seqString (U64 kmer, int len) ;                                     /* seqhash.c:198-206 */
-/* header-inline in the reference (seqhash.h:37,54-60); exported here as real symbols too */
-void mgSeqhashDestroy (Seqhash *sh) ;
+void mgSeqhashDestroy (Seqhash *sh) ;                       /* real symbols for the reference's header-inline destroys */
 void mgSeqhashRCiteratorDestroy (SeqhashRCiterator *si) ;
-static inline U64 seqhash (Seqhash *sh, U64 k) { return ((k * sh->factor1) >> sh->shift1) ; }
+#ifdef __cplusplus
+}
+#endif
+#else
+#include "modgpu_compat.h"
+#endif
 
-/* modset.h:30-42 */
-Modset *modsetCreate (Seqhash *sh, int bits, U32 size) ;                  /* modset.c:15-31 */
-void modsetDestroy (Modset *ms) ;                                         /* modset.c:33-34 */
-void modsetWrite (Modset *ms, FILE *f) ;                                  /* modset.c:79-88 */
-Modset *modsetRead (FILE *f) ;                                            /* modset.c:90-104 */
-U32 modsetIndexFind (Modset *ms, U64 kmer, int isAdd) ;                   /* modset.c:45-62 */
-void modsetSummary (Modset *ms, FILE *f) ;                                /* modset.c:130-153 */
-bool modsetPack (Modset *ms) ;                                            /* modset.c:36-43 */
-void modsetDepthPrune (Modset *ms, int min, int max) ;                    /* modset.c:64-77 */
-bool modsetMerge (Modset *ms1, Modset *ms2) ;                             /* modset.c:106-128 */
+#ifdef __cplusplus
+extern "C" {
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * Layer 2: batch / device entry points (the GPU hot path).
@@ -209,6 +157,9 @@ void     mgModsetHostChanged (Modset *ms) ;
  * Clears the device table (if any), ms->max, and the host index[]/depth[]/info[] of used entries. */
 MgStatus mgModsetClear (Modset *ms, void *stream) ;
 
+/* Slots of the device table behind ms (0 when there is none): what bench.py prices the bucket image with. */
+U64 mgModsetDeviceSlots (Modset *ms) ;
+
 /* modutils.c:53-63 on the device: dHist[65536] (U64) += histogram of depth[1..max], where depth is
  * the host depth at last sync plus pending device counts, saturated at 65535. */
 MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist65536, void *stream) ;
@@ -278,6 +229,10 @@ MgReference *mgReferenceLoad (const char *root) ;
 /* modmap.c:188-281: "Q" line and "M" lines for every read. */
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
                      const char **names, FILE *out) ;
+/* modmap's -v toggle (modmap.c:23,348): with it on, mgQueryProcess / mgQueryFile also print the per-seed lines of
+ * modmap.c:218-229 ("  <pos>\t<seq> <offset>[\t<seq2> <offset2>]", to stdout as the reference's printf does,
+ * before the M line a seed closes); the seed lists then come back to the host and are chained there. */
+void mgSetVerbose (int on) ;
 
 /* modasm's long-read set (modasm.c:30-57,79-86) as readsetFileRead + invBuild leave it:
  * per read its length, hit / miss counts and copy-class tallies; the hits (modset index, bit 31 =

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmodgpu.so")
+LIB_PATH = os.environ.get("MODGPU_LIB") or os.path.join(_HERE, "libmodgpu.so")   # MODGPU_LIB: a variant build (tools/ablate_*.sh)
 CSRC = os.path.join(_HERE, "csrc")
 
 U64P = C.POINTER(C.c_uint64)
@@ -75,14 +75,14 @@ EXPORTS = [
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
-    "mgModsetMergeArrays", "mgModsetClear", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
 def build(force=False):
     """Compile libmodgpu.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".c", ".h"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "modgpu.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "modgpu.h")); srcs.append(os.path.join(_HERE, "..", "include", "modgpu_compat.h"))
     stale = force or not os.path.exists(LIB_PATH) or \
         any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
@@ -163,7 +163,7 @@ def lib():
     sig("mgQueryFile", i32, vp, C.c_char_p, vp)
     sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
-    sig("mgModsetClear", i32, MS, vp)
+    sig("mgModsetClear", i32, MS, vp); sig("mgModsetDeviceSlots", u64, MS); sig("mgSetVerbose", None, i32)
     sig("mgProfileEnable", None, i32); sig("mgProfileOnly", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)
     sig("mgProfileGet", i32, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), U64P)
     _lib = L

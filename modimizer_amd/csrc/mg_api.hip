@@ -512,6 +512,7 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
       if (!t.baseZero) MG_HIP (hipMemsetAsync (t.baseDepth, 0, ((size_t) (t.max > t.syncedMax ? t.max : t.syncedMax) + 1) * sizeof (U16), st));
       t.baseZero = true;
       t.max = t.syncedMax = 0;
+      t.pendingDepth = false;
       d->hostIndexMax = 0;
     }
   if (hostIndexed) memset (ms->index, 0, ms->tableSize * sizeof (U32));
@@ -638,7 +639,9 @@ extern "C" void mgHookNeedHost (Modset *ms, int wantIndex)
 {
   MgDev *d = mgDevLookup (ms);
   if (!d) return;
-  if (d->t.syncedMax == d->t.max && (!wantIndex || d->hostIndexMax >= d->t.max)) return;
+  /* current when no entry, no index slot and no depth count is pending on the device (a batch that only re-hits
+     existing k-mers leaves max alone but not depth[], which callers read and bump directly: modutils.c:26) */
+  if (!d->t.pendingDepth && d->t.syncedMax == d->t.max && (!wantIndex || d->hostIndexMax >= d->t.max)) return;
   mgHookNeedHostAll (ms, wantIndex);
 }
 extern "C" int mgHookHasDevice (Modset *ms) { return mgDevLookup (ms) != 0; }
@@ -753,6 +756,8 @@ extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
     }
   return MG_OK;
 }
+
+extern "C" U64 mgModsetDeviceSlots (Modset *ms) { MgDev *d = mgDevLookup (ms); return d && d->built ? d->t.nSlots : 0; }
 
 extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *stream)
 {

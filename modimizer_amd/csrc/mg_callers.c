@@ -105,13 +105,29 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
   /* names: the reference die()s on a duplicate name (modmap.c:102) */
   ref->names = (char **) realloc (ref->names, (size_t) (ref->nSeq + nSeq) * sizeof (char *));
   ref->len = (U32 *) realloc (ref->len, (size_t) (ref->nSeq + nSeq) * sizeof (U32));
-  for (int i = 0 ; i < nSeq ; ++i)
-    { for (int j = 0 ; j < ref->nSeq + i ; ++j)
-        if (!strcmp (ref->names[j], names[i]))
-          { fprintf (stderr, "FATAL ERROR: duplicate ref sequence name %s\n", names[i]); exit (-1); }
-      ref->names[ref->nSeq + i] = strdup (names[i]);
-      ref->len[ref->nSeq + i] = (U32) (offsets[i + 1] - offsets[i]);
-    }
+  { /* an open-addressed set of the names seen so far (the reference keeps them in a DICT): a fragmented assembly
+       has 1e5 - 1e6 contigs, so no pairwise comparison */
+    const size_t all = (size_t) ref->nSeq + (size_t) nSeq;
+    size_t cap = 16; while (cap < 4 * all) cap *= 2;
+    int *slot = (int *) calloc (cap, sizeof (int));                       /* 1 + position in ref->names; 0 = empty */
+    for (size_t i = 0 ; i < all ; ++i)
+      { const char *nm = i < (size_t) ref->nSeq ? ref->names[i] : names[i - ref->nSeq];
+        U64 h = 0xcbf29ce484222325ull;
+        for (const unsigned char *c = (const unsigned char *) nm ; *c ; ++c) h = (h ^ *c) * 0x100000001b3ull;
+        size_t at = (size_t) (h ^ (h >> 29)) & (cap - 1);
+        while (slot[at])
+          { if (!strcmp (ref->names[slot[at] - 1], nm))
+              { fprintf (stderr, "FATAL ERROR: duplicate ref sequence name %s\n", nm); exit (-1); }
+            at = (at + 1) & (cap - 1);
+          }
+        slot[at] = (int) i + 1;
+        if (i >= (size_t) ref->nSeq)
+          { ref->names[i] = strdup (nm);
+            ref->len[i] = (U32) (offsets[i - ref->nSeq + 1] - offsets[i - ref->nSeq]);
+          }
+      }
+    free (slot);
+  }
   U64 totLen = nSeq ? (U64) offsets[nSeq] : 0;
 
   MgDevBatch b; mgBatchUpload (&b, bases, offsets, nSeq);
@@ -365,6 +381,9 @@ static void printM (const MgReference *ref, FILE *out, const char *name, const U
 
 /* the long way: seed lists back on the host, tallies and chaining here (used when a read has more blocks
  * than the device kernel keeps) */
+static int gVerbose = 0;                          /* modmap's global isVerbose (modmap.c:23), toggled by -v (modmap.c:348) */
+void mgSetVerbose (int on) { gVerbose = on != 0; }
+
 static int queryProcessHostChain (MgReference *ref, MgDevBatch *b, const int64_t *offsets, int nReads,
                                   const char **names, FILE *out)
 {
@@ -407,6 +426,14 @@ static int queryProcessHostChain (MgReference *ref, MgDevBatch *b, const int64_t
           if (!x || (ms->info[x] & 3) == 3) continue;
           U32 loc = ref->rev[ref->loc[x]];
           bool is1 = (ms->info[x] & 3) == 1;
+          if (gVerbose)                                         /* modmap.c:218-229: printf, i.e. stdout whatever outFile is */
+            { if (is1) printf ("  %6d\t%s %d\n", (int) ps[i], ref->names[ref->id[loc]], (int) ref->offset[loc]);
+              else
+                { U32 loc2 = ref->rev[ref->loc[x] + 1];
+                  printf ("  %6d\t%s %d\t%s %d\n", (int) ps[i], ref->names[ref->id[loc]], (int) ref->offset[loc],
+                          ref->names[ref->id[loc2]], (int) ref->offset[loc2]);
+                }
+            }
           bool end = blockEnds (ref, loc, loc0, locN, i0, iN, true);
           if (end && loc0 && !is1)
             { loc = ref->rev[ref->loc[x] + 1];
@@ -438,7 +465,7 @@ int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets,
   MgChainM *m = (MgChainM *) malloc ((size_t) nReads * MG_QUERY_MAXM * sizeof (MgChainM));
   static int hostChain = -1;
   if (hostChain < 0) { const char *e = getenv ("MODGPU_QUERY_HOST_CHAIN"); hostChain = (e && *e == '1') ? 1 : 0; }   /* test knob */
-  int rc = hostChain ? 1 : mgChainQueryDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, q, m, MG_QUERY_MAXM);
+  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, q, m, MG_QUERY_MAXM);
   if (rc < 0) fatal ("query");
   if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
   else

@@ -61,47 +61,6 @@ __device__ __forceinline__ U64 mgRevComp (U64 f, int shift1)
   return (~x) >> shift1;
 }
 
-/* 64-bit tile descriptor for the ordered single-pass compaction (decoupled look-back):
- * bits 63..62 status, bits 61..0 value.  Published and polled with agent-scope relaxed atomics
- * (one naturally aligned 8-byte granule carries both data and tag, so no separate flag). */
-#define MG_DESC_INVALID   0ull
-#define MG_DESC_AGGREGATE 1ull
-#define MG_DESC_PREFIX    2ull
-__device__ __forceinline__ void mgDescStore (U64 *d, U64 status, U64 v)
-{ __hip_atomic_store (d, (status << 62) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ U64 mgDescLoad (const U64 *d)
-{ return __hip_atomic_load (d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-/* Exclusive prefix of `count` over all earlier tiles; publishes this tile's aggregate/prefix.
- * Called by every lane of wave 0 of the workgroup (count is tile-uniform); returns the same value
- * in every lane.  Tiles are handed out by an atomic ticket, so every predecessor has started. */
-__device__ __forceinline__ U64 mgLookback (U64 *desc, U64 tile, U64 count)
-{
-  const int lane = threadIdx.x & 63;
-  if (tile == 0)
-    { if (lane == 0) mgDescStore (&desc[0], MG_DESC_PREFIX, count);
-      return 0;
-    }
-  if (lane == 0) mgDescStore (&desc[tile], MG_DESC_AGGREGATE, count);
-  U64 sum = 0;
-  int64_t top = (int64_t) tile - 1;
-  for (;;)
-    { int64_t j = top - lane;
-      U64 v = (MG_DESC_PREFIX << 62);            /* lanes before tile 0 act as a zero prefix */
-      if (j >= 0)
-        { do { v = mgDescLoad (&desc[j]); } while ((v >> 62) == MG_DESC_INVALID); }
-      unsigned long long isPrefix = __ballot ((v >> 62) == MG_DESC_PREFIX);
-      U64 val = v & 0x3fffffffffffffffull;
-      int first = isPrefix ? __ffsll ((long long) isPrefix) - 1 : 63;   /* nearest predecessor with a prefix */
-      U64 contrib = (lane <= first) ? val : 0;
-      for (int off = 32 ; off ; off >>= 1) contrib += __shfl_xor (contrib, off);
-      sum += contrib;
-      if (isPrefix) break;
-      top -= 64;
-    }
-  if (lane == 0) mgDescStore (&desc[tile], MG_DESC_PREFIX, sum + count);
-  return sum;
-}
 /* inclusive prefix sum over the 64 lanes of a wave with DPP only (no LDS traffic): Hillis-Steele inside the
  * rows of 16 (row_shr 1,2,4,8), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31
  * into rows 2 and 3 (row_bcast:31).  Lanes without a source add 0. */
@@ -171,6 +130,7 @@ struct MgTable {
   U32 max;             /* entries known to the device table */
   U32 syncedMax;       /* entries whose value[] the host already has */
   U64 *counters;       /* device U64[8]: 0 = new entries of the last add, 1 = bucket overflow */
+  bool pendingDepth;   /* an add with depth counting ran since the counts were last folded into baseDepth / the host's depth[] */
   bool dirty;          /* buckets with occ == 0 hold undefined bytes (never zeroed): see mgTableClean */
   int  maxLog2Slots;   /* tableBits - 1: the size at which load <= 0.5 for the largest legal set */
   U32  wantR;          /* preferred slots per bucket */

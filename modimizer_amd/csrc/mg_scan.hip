@@ -7,16 +7,16 @@
  * is 0 mod d.  Output order is (read, pos), exactly the order the reference's loops see.
  *
  * Work decomposition (MI355X-first, not one wave per read): the batch is one concatenated 2-bit
- * stream cut into tiles of 16384 k-mer starts, so short reads (150 b) and chromosomes (125 Mb)
- * load-balance alike.  Each 256-thread workgroup owns a CONTIGUOUS range of tiles and appends the
- * modimizers it finds, in order, to its own segment of the output; there is no inter-workgroup
- * protocol at all (a first version handed tiles out by an atomic ticket and ordered the output by
- * decoupled look-back: at > 50 M tiles/s both the single ticket word and the descriptor polling
- * saturated and capped the kernel near 0.8 Tbp/s).  Per-block counts are scanned by a one-block
- * kernel and the segments are copied into the dense (read,pos)-ordered arrays by a streaming
- * compaction kernel (12 B read + 12 B written per modimizer).
- * A tile's 4 KiB of packed bases are fetched with one 16-byte load per lane one tile ahead
- * (registers) and staged in LDS (+ a (k-1)-base halo); each lane owns 64 consecutive k-mer starts.
+ * stream cut into tiles of 4096 k-mer starts (MG_TILE_BASES: 64 lanes x 64 starts, 1 KiB of packed bases),
+ * so short reads (150 b) and chromosomes (125 Mb) load-balance alike.  Every WAVEFRONT is an independent
+ * worker: it owns a contiguous range of tiles and appends the modimizers it finds, in order, to its own
+ * segment of a staging buffer; nothing crosses a wavefront (no workgroup barrier, no shared counter, no
+ * inter-workgroup protocol: a first version handed tiles out by an atomic ticket and ordered the output
+ * by decoupled look-back; at > 50 M tiles/s both the single ticket word and the descriptor polling
+ * saturated and capped the kernel near 0.8 Tbp/s).  The per-worker counts are scanned by a one-block
+ * kernel and the segments are copied into the dense (read,pos)-ordered arrays by a streaming compaction
+ * kernel.  A tile's 1 KiB is fetched one tile ahead with one 16-byte load per lane (registers) and staged,
+ * double-buffered, in the wavefront's LDS with a (k-1)-base halo; each lane owns 64 consecutive k-mer starts.
  */
 #include <stdlib.h>
 #include "mg_common.h"
@@ -124,7 +124,9 @@ struct MgScanArgs {
   U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [nWorkers * segCap] */
   U64 *blockCount;       /* [nWorkers] true number of modimizers each worker found */
   U32 fS, thresh;        /* fast path: factor1 << (32-B), 2^(32-m) */
-  U32 debug;             /* dev only: bit0 = stop after phase B (timing ablation; output meaningless) */
+#ifdef MG_ABLATE
+  U32 debug;             /* ablation builds only (tools/ablate_scan.sh): bit0 = stop after phase B, bit1 = no stores, bit2 = no evaluation */
+#endif
 };
 
 /* which of this lane's 64 k-mer starts lie wholly inside a read (seqhash.c:162: len < k gives
@@ -186,6 +188,11 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_CAND_CAP   256    /* candidate list entries per round (LDS, per wavefront) */
 #define MG_CAND_ITERS (MG_CAND_CAP / 64)
 #define MG_WAVES      (MG_SCAN_THREADS / 64)
+#ifdef MG_ABLATE
+#define MG_ABLATE_AND(x) && (x)
+#else
+#define MG_ABLATE_AND(x)
+#endif
 
 /* LDS written by some lanes of a wavefront and read by others of the same wavefront: DS operations of a
  * wave complete in issue order, so all that is needed is that the compiler keeps the order */
@@ -375,11 +382,13 @@ void mgScanKernel (const MgScanArgs a)
       const U32 nc = (U32) __builtin_amdgcn_readlane ((int) incl, 63);
       const U32 myFirst = incl - cnt;                        /* ordinal of this lane's first candidate */
       const U32 nRounds = (nc + MG_CAND_CAP - 1) / MG_CAND_CAP;
-      if (a.debug & 1)                                      /* dev ablation: phases A+B only */
+#ifdef MG_ABLATE
+      if (a.debug & 1)                                      /* phases A+B only (output meaningless) */
         { tile = nextTile; curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
           found += nc >> 20;
           continue;
         }
+#endif
 
       /* ---- Phase C, MG_CAND_CAP candidates per round ---- */
       for (U32 rd = 0 ; rd < nRounds ; ++rd)
@@ -411,7 +420,7 @@ void mgScanKernel (const MgScanArgs a)
               const U32 i = (U32) it * 64 + lane;
               bool surv = false, fwd = false;
               U64 F = 0; U32 q = 0;
-              if (i < nHere && !(a.debug & 4))
+              if (i < nHere MG_ABLATE_AND (!(a.debug & 4)))
                 { q = sCand[i];
                   F = mgKmerAt (sWords, q, sh1);
                   U64 R = mgRevComp (F, sh1);
@@ -445,7 +454,7 @@ void mgScanKernel (const MgScanArgs a)
                     { if (offInLds) { while (sOff[r + 1 - ti.firstRead] <= pos) ++r; rs = sOff[r - ti.firstRead]; }
                       else { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
                     }
-                  if (o < a.segCap && !(a.debug & 2))
+                  if (o < a.segCap MG_ABLATE_AND (!(a.debug & 2)))
                     { a.segKmer[segBase + o] = F;
                       if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
                       if (a.segRead) a.segRead[segBase + o] = r;
@@ -575,8 +584,8 @@ static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
   g.nTiles = nTiles;
   static long maxBlocks = -1;
   if (maxBlocks < 0)
-    { const char *e = getenv ("MODGPU_SCAN_GRID");           /* dev knob */
-      maxBlocks = e && atol (e) > 0 ? atol (e) : MG_SCAN_MAX_BLOCKS;
+    { const char *e = getenv ("MODGPU_SCAN_GRID");           /* test knob */
+      maxBlocks = e && atol (e) > 0 ? atol (e) : MG_SCAN_MAX_BLOCKS;   /* read once; tests use it to put several tiles in a worker's range */
     }
   U64 want = g.nTiles < (U64) maxBlocks ? g.nTiles : (U64) maxBlocks;
   if (!want) want = 1;
@@ -645,7 +654,9 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   a.tilesPerWorker = g.tilesPerBlock; a.nWorkers = g.nBlocks; a.segCap = g.segCap;
   a.segKmer = segKmer; a.segPosF = dPosF ? segPosF : 0; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
   a.fS = 0; a.thresh = 0;
+#ifdef MG_ABLATE
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
+#endif
   const unsigned grid = (g.nBlocks + MG_WAVES - 1) / MG_WAVES;
   const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
   const int B = p.shift1 + p.dShift;

@@ -34,6 +34,11 @@
 #include "mg_common.h"
 
 #define MG_ASSIGNED 0x80000000u
+#ifdef MG_ABLATE
+#define MG_ABLATE_AND(x) && (x)
+#else
+#define MG_ABLATE_AND(x)
+#endif
 __device__ __forceinline__ U32 mgToken (U64 o) { return 0x7fffffffu - (U32) o; }     /* 1..0x7fffffff */
 __device__ __forceinline__ bool mgIsAssigned (U32 v) { return (v & MG_ASSIGNED) != 0; }
 
@@ -581,7 +586,9 @@ struct MgBucketArgs {
   const MgRankGrp *grp; U32 baseMax; U32 size;
   int withDepth;
   U64 *counters;
-  int debug;                       /* dev ablation (MODGPU_BUCKET_DEBUG): 1 = no flag stores; results are wrong */
+#ifdef MG_ABLATE
+  int debug;                       /* ablation builds only (MODGPU_BUCKET_DEBUG): 1 = no flag stores; results are wrong */
+#endif
   unsigned long long *liveHist;    /* != 0: the merge kernel also counts the final depths of the entries it writes */
 };
 
@@ -687,7 +694,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (emit)
                 { const U32 at = base + (U32) __popcll (m & (((U64) 1 << lane) - 1));
                   a.pK[lo + at] = k - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
-                  if (!mgIsAssigned (ord) && !(a.debug & 1)) a.flags[0x7fffffffu - ord] = 1;
+                  if (!mgIsAssigned (ord) MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - ord] = 1;
                 }
             }
           __syncthreads ();
@@ -877,6 +884,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
 {
   if (!n) return MG_OK;
   t->liveHistValid = false;                          /* set again below if this add is the set's only one */
+  if (withDepth) t->pendingDepth = true;
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
@@ -941,7 +949,9 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
   a.counters = t->counters;
+#ifdef MG_ABLATE
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_BUCKET_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = dbg; }
+#endif
   /* depth histogram on the fly: possible when this add builds the whole set (empty before, no host depths) */
   const bool track = t->max == 0 && t->baseZero;
   a.liveHist = 0;
@@ -1013,6 +1023,7 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st)
   if (!t->max) return MG_OK;
   MG_HIP (hipMemsetAsync (dDelta, 0, (size_t) t->max * sizeof (U16), st));
   t->baseZero = false;                                   /* the fold below writes baseDepth */
+  t->pendingDepth = false;
   t->liveHistValid = false;
   MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid (t->nSlots, 256, 8192)), dim3 (256), 0, st,
              t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, dDelta, t->max);

@@ -28,29 +28,49 @@ def allreduce_histogram(hist_tensor):
 
 
 def merge_modsets_in_rank_order(ms, lib):
-    """Exact global modset from per-rank modsets built over CONTIGUOUS blocks of reads: every rank's
-    (value, depth, info) arrays are gathered and folded into rank 0's modset in rank order with
-    modsetMerge semantics (modset.c:106-128).  Because the blocks are contiguous, first-occurrence
-    index order and saturated depths equal those of the single-stream build.  Returns on rank 0 the
-    merged Modset* (ms itself); other ranks return None.  Uses only torch.distributed object/tensor
-    collectives, so it runs over RCCL or gloo alike."""
-    import ctypes as C
+    """Exact global modset from per-rank modsets built over CONTIGUOUS blocks of reads: rank by rank, in rank
+    order, a rank's (value, depth, info) arrays travel to rank 0 as three tensors (point-to-point send/recv: RCCL
+    over xGMI with device tensors, gloo with host tensors) and are folded into rank 0's modset with modsetMerge
+    semantics (modset.c:106-128).  Because the blocks are contiguous, first-occurrence index order and saturated
+    depths equal those of the single-stream build.  Only one rank's arrays are in flight at a time, so rank 0
+    needs room for its own set plus one more, whatever the world size.  Returns on rank 0 the merged Modset*
+    (ms itself); other ranks return None."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     if hasattr(lib, "modsetSyncToHost"):
         lib.modsetSyncToHost(ms, 0)
     m = ms.contents
     n = m.max
-    mine = (np.ctypeslib.as_array(m.value, (n + 1,)).copy(), np.ctypeslib.as_array(m.depth, (n + 1,)).copy(),
-            np.ctypeslib.as_array(m.info, (n + 1,)).copy())
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(mine, gathered, dst=0)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[rank] = n
+    dist.all_reduce(counts)                                   # everybody learns every rank's entry count
+    counts = counts.cpu().tolist()
     if rank != 0:
+        v = torch.from_numpy(np.ctypeslib.as_array(m.value, (n + 1,)).view(np.int64).copy()).to(dev)
+        d = torch.from_numpy(np.ctypeslib.as_array(m.depth, (n + 1,)).view(np.int16).copy()).to(dev)
+        i = torch.from_numpy(np.ctypeslib.as_array(m.info, (n + 1,)).copy()).to(dev)
+        for r in range(1, world):                             # rank order: wait for one's turn
+            if r == rank:
+                for t in (v, d, i):
+                    dist.send(t, dst=0)
+            dist.barrier()
         return None
     for r in range(1, world):
-        v, d, i = (np.ascontiguousarray(a) for a in gathered[r])
-        ok = lib.mgModsetMergeArrays(ms, v.ctypes.data, d.ctypes.data, i.ctypes.data, len(v) - 1)
+        nr = int(counts[r])
+        v = torch.empty(nr + 1, dtype=torch.int64, device=dev)
+        d = torch.empty(nr + 1, dtype=torch.int16, device=dev)
+        i = torch.empty(nr + 1, dtype=torch.uint8, device=dev)
+        for t in (v, d, i):
+            dist.recv(t, src=r)
+        hv = np.ascontiguousarray(v.cpu().numpy().view(np.uint64))
+        hd = np.ascontiguousarray(d.cpu().numpy().view(np.uint16))
+        hi = np.ascontiguousarray(i.cpu().numpy())
+        ok = lib.mgModsetMergeArrays(ms, hv.ctypes.data, hd.ctypes.data, hi.ctypes.data, nr)
+        del v, d, i
+        dist.barrier()
         if not ok:
             raise RuntimeError("modsets of different hashers cannot be merged")
     return ms

@@ -160,6 +160,15 @@ def gen_modmap():
               sum(l.startswith("Q\t") for l in out.splitlines()), "Q lines")
 
 
+def gen_modmap_verbose():
+    """modmap -v: the per-seed lines of modmap.c:218-229 (printf, interleaved with the Q / M lines on stdout)"""
+    mm = os.path.join(REFDIR, "modmap_ref")
+    for tag, (k, w) in {"k21d64": (21, 64), "k15d8": (15, 8)}.items():
+        out = run([mm, "-K", str(k), "-W", str(w), "-S", "17", "-B", "20", "-v", "-f", "ref.fa", "-q", "queries.fa"])
+        open(os.path.join(HERE, "modmap_%s.verbose.stdout.txt" % tag), "w").write(strip_timing(out))
+        print("modmap -v", tag, sum(l.startswith("  ") and "\t" in l for l in out.splitlines()), "seed lines")
+
+
 def gen_modmap_files():
     """modmap -f ref.fa -w stem, then -r stem -q queries.fa: the reference's own .mod/.ref pair (gzip
     streams, utils.c:107-127) and what it prints when it reads them back."""
@@ -332,6 +341,7 @@ if __name__ == "__main__":
     gen_modutils()
     make_modmap_inputs()
     gen_modmap()
+    gen_modmap_verbose()
     gen_modmap_files()
     gen_modmap_many()
     gen_modasm()

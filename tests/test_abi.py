@@ -1,4 +1,4 @@
-"""The C-ABI boundary: libmodgpu.so loads, exports every symbol include/modgpu.h declares, keeps the
+"""The C-ABI boundary: libmodgpu.so loads, exports every symbol include/modgpu.h and modgpu_compat.h declare, keeps the
 reference's struct layouts, and fails loudly (no CPU fallback) when there is no HIP device."""
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
-    src = open(os.path.join(ROOT, "include", "modgpu.h")).read()
+    src = open(os.path.join(ROOT, "include", "modgpu.h")).read() + open(os.path.join(ROOT, "include", "modgpu_compat.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set()
     for m in re.finditer(r"^[A-Za-z_][\w \t\*]*?[\s\*]([A-Za-z_]\w*)\s*\([^;{]*\)\s*;", src, flags=re.M):

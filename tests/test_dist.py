@@ -1,14 +1,17 @@
 """The N>1 path on CPU: world_size-2 gloo.  Reads are sharded in contiguous blocks, each rank
 builds its own modset (here with the oracle, since there is no GPU in this container) and the
 depth histograms are summed with one all-reduce — the collective bench.py runs over RCCL."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -141,3 +144,36 @@ def test_rank_order_merge_equals_single_stream_gloo_world2():
         oms.add_sequence(bases[int(offsets[r]):int(offsets[r + 1])])
     assert len(v) - 1 == oms.max
     assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(dep[1:], oms.depths()[1:])
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) starts two ranks itself, before anything touches
+    a GPU; --dry-launch runs what a rank does around the GPU work on CPU: process group (gloo), a small modset per
+    rank through the scalar host API, the histogram all-reduce, MAX-over-ranks timing, one JSON line from rank 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1                                  # one line, from rank 0 only
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["dry_launch"] is True and j["steps"] == 3
+    assert j["kmers_all_ranks"] == 3000 + 3100             # both ranks' blocks took part
+    assert j["histogram_entries"] == j["entries_all_ranks"] == 1000 + 1010   # the all-reduced histogram holds every entry of every rank
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_on_one_gpu():
+    """the N > 1 code path of bench.py (RCCL process group, per-step histogram + all-reduce, barriers, collective
+    timing) at world size 1: the all-reduced histogram is the rank's own modsetDepthHistogramDevice result"""
+    env = dict(os.environ, MODGPU_BENCH_FORCE_DIST="1", MODGPU_BENCH_GBP="0.3", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-other"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and "config 4" in j["config"]["workload"]
+    c = j["collective"]
+    assert c["matches_local_sums"] is True and c["histogram_entries"] == j["config"]["modset_entries"] > 0
+    assert j["roofline"]["kernel"] and j["roofline"]["alu"]["floor_ms"] > 0

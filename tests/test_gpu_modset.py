@@ -129,6 +129,28 @@ def test_host_scalar_and_device_batches_interleave():
     assert_same_modset(ms, oms, bits)
 
 
+def test_depth_is_current_after_a_batch_that_adds_no_entry():
+    """the same reads added a second time leave max alone: the scalar lookup must still hand back an index whose
+    ms->depth[] is current, because callers read and bump depth[index] themselves (modutils.c:26)"""
+    L = mg.lib()
+    k, w, bits = 21, 16, 20
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b1 = synth_batch(80_000, 20_000, 31)
+    km = util.oracle_scan_batch(oh, *b1)[0]
+    ms = mg.modsetCreate(sh, bits)
+    mg.add_sequence_batch(ms, *b1)
+    mg.check(L.modsetSyncToHost(ms, 1))                          # everything current: value[], depth[], index[]
+    oms, _ = oracle_build(oh, bits, [b1, b1])
+    max1 = ms.contents.max
+    mg.add_sequence_batch(ms, *b1)                               # only re-hits: no new entry
+    assert ms.contents.max == max1
+    ix = L.modsetIndexFind(ms, int(km[0]), 0)                    # scalar API: must bring depth[] up to date
+    assert ix == oms.find(km[0], False)
+    assert int(ms.contents.depth[ix]) == int(oms.depths()[ix])
+    assert_same_modset(ms, oms, bits)
+    L.modsetDestroy(ms)
+
+
 def test_histogram_clear_and_capacity(tmp_path):
     L = mg.lib()
     k, w, bits = 21, 4, 22

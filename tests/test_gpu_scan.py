@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 import util
 
 pytestmark = pytest.mark.gpu
-TILE = 16384
+TILE = 4096            # MG_TILE_BASES (mg_common.h): k-mer starts per tile = one wavefront-worker's unit
 
 
 def assert_batch_equal(sh, oh, reads):
@@ -51,16 +51,59 @@ def test_random_ragged_batches(k, w, seed):
 
 
 def test_tile_boundaries():
-    """reads that start/end exactly at, just before and just after 16384-base tile edges"""
+    """reads that start / end exactly at, just before and just after the 4096-base tile edges, and whose last
+    k-mer (start len-k) falls on either side of an edge: 4096-1, 4096, 4096+1, 4096+k-1 and neighbours"""
     k, w = 21, 8
     sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
     rng = np.random.default_rng(1)
-    lens = [TILE - k + 1, k - 1, TILE, 1, TILE - 1, 2, TILE + k - 1, TILE - 20, 20, 21, 22, 3 * TILE + 5, 19, TILE // 2, TILE // 2]
+    lens = [TILE - k + 1, k - 1, TILE, 1, TILE - 1, 2, TILE + k - 1, TILE - 20, 20, 21, 22, 3 * TILE + 5, 19, TILE // 2, TILE // 2,
+            TILE + 1, TILE - 1, TILE + k, TILE + k - 2, 2 * TILE - k, 2 * TILE + k - 1, k, TILE - k, TILE - k - 1, TILE - k + 2]
     reads = [rng.integers(0, 4, L).astype(np.uint8) for L in lens]
     assert_batch_equal(sh, oh, reads)
-    # a batch that ends exactly on a tile edge, and one base short / over
-    for total in (TILE, TILE - 1, TILE + 1, 2 * TILE, 64, 63, 65):
+    # a batch that ends exactly on a tile edge, and one base short / over; one read per case
+    for total in (TILE, TILE - 1, TILE + 1, TILE + k - 1, TILE + k - 2, TILE + k, 2 * TILE, 64, 63, 65, 4 * TILE + k - 1):
         assert_batch_equal(sh, oh, [rng.integers(0, 4, total).astype(np.uint8)])
+    # every read boundary position around one tile edge, with the d = 1 hasher (every start is a modimizer) and with
+    # the filtering kernel (k=21 d=64) on a read pair swept across the edge
+    for kk, ww in ((5, 1), (21, 64), (31, 4)):
+        sh2 = mg.seqhashCreate(kk, ww, 17); oh2 = po.Hasher(kk, ww, 17)
+        body = rng.integers(0, 4, 3 * TILE).astype(np.uint8)
+        for cut in list(range(TILE - kk - 1, TILE + kk + 2)) + [2 * TILE - 1, 2 * TILE, 2 * TILE + 1]:
+            assert_batch_equal(sh2, oh2, [body[:cut], body[cut:]])
+
+
+WORKER_RANGE_CODE = r"""
+import numpy as np, sys
+sys.path.insert(0, "tests")
+import modimizer_amd as mg
+from oracle import pyoracle as po
+import util
+TILE = 4096
+rng = np.random.default_rng(7)
+for k, w in ((21, 64), (21, 8), (31, 4), (19, 31)):
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    # 3 workers over 11+ tiles: ranges of 4 tiles; reads ending exactly at, one before and one after the range edges
+    # (4*TILE, 8*TILE), reads spanning a range edge, and a run of short reads across one
+    lens = [4 * TILE, 4 * TILE - 1, 1, 4 * TILE + k - 1, TILE - k + 1, 3 * TILE]
+    for reads in ([rng.integers(0, 4, L).astype(np.uint8) for L in lens],
+                  [rng.integers(0, 4, 4 * TILE - 100).astype(np.uint8)] + [rng.integers(0, 4, int(L)).astype(np.uint8) for L in rng.integers(0, 60, 40)]
+                  + [rng.integers(0, 4, 7 * TILE).astype(np.uint8)],
+                  [rng.integers(0, 4, 12 * TILE + 17).astype(np.uint8)]):
+        bases, offs = util.concat_reads(reads)
+        km, pos, isf, st = mg.scan_batch(sh, bases, offs)
+        ek, ep, ef, est = util.oracle_scan_batch(oh, bases, offs)
+        assert np.array_equal(st, est) and np.array_equal(km, ek) and np.array_equal(pos, ep) and np.array_equal(isf, ef), (k, w)
+print("ok")
+"""
+
+
+def test_worker_range_boundaries():
+    """MODGPU_SCAN_GRID=3: three wavefront-workers, each owning a RANGE of consecutive tiles and its own output segment;
+    reads that end on, straddle and crowd the range edges (a small batch otherwise gets one tile per worker)"""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, "-c", WORKER_RANGE_CODE], capture_output=True, text=True, cwd=util.ROOT,
+                       env=dict(os.environ, MODGPU_SCAN_GRID="3"), timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
 
 
 def test_many_short_reads():
