@@ -311,18 +311,20 @@ def gpu_rank(args):
     alu = None
     if scan_ms:
         ipath = os.path.join(HERE, "profiles", "scan_issue.json")     # SQ_INSTS_VALU etc. of mgScanKernel from a --pmc pass
-        valu_per_start, src = None, None
+        valu_per_start, src, peak = None, None, VALU_WAVE_INSTS_PER_S
         if os.path.exists(ipath):
             try:
                 ij = json.load(open(ipath)); valu_per_start = ij.get("valu_per_start"); src = ij.get("_from")
+                peak = ij.get("measured_int_valu_peak_wave_insts_per_s", peak)     # tools/ubench.hip: 37.6 T integer lane-ops/s
             except Exception:
                 pass
-        floor7 = 7.0 * starts / 64 / VALU_WAVE_INSTS_PER_S * 1e3      # the 7-instruction candidate filter alone
+        floor7 = 7.0 * starts / 64 / peak * 1e3                        # the 7-instruction candidate filter alone
         alu = {"valu_per_start": valu_per_start, "valu_per_start_from": src,
                "filter_floor_valu_per_start": 7, "floor_ms": round(floor7, 3),
-               "issue_peak_wave_insts_per_s": VALU_WAVE_INSTS_PER_S,
-               "issue_frac": (round(valu_per_start * starts / 64 / VALU_WAVE_INSTS_PER_S / (scan_ms * 1e-3), 3)
-                              if valu_per_start else None),
+               "issue_peak_wave_insts_per_s": peak,
+               "issue_peak_from": "measured integer VALU rate (v_mul_lo_u32 / v_alignbit / v_min / v_add chains, tools/ubench.hip); "
+                                  "the fp32 datasheet rate would be %.3g" % VALU_WAVE_INSTS_PER_S,
+               "issue_frac": (round(valu_per_start * starts / 64 / peak / (scan_ms * 1e-3), 3) if valu_per_start else None),
                "scan_ms": round(scan_ms, 4)}
     extra = {"alu": alu,
              "scan_bytes": {"this_path_8B_per_modimizer": alg["mgScanKernel"],

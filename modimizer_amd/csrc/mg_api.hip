@@ -772,9 +772,13 @@ extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *st
 struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; MgHistReq counted; };
 
 /* scan into arena buffers, growing once if the survivor guess was too small */
+/* outPosF / outRid (with room for outCap entries): the caller's own arrays; when they are large enough for the scan's
+ * capacity the compaction writes pos / read straight into them (a device-to-device copy of 1.2 GB per 10 Gbp batch
+ * took longer than the scan itself) */
 static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked, U64 totalBases,
                                  const U64 *dReadOffsets, U32 nReads, bool wantPos, size_t extraPerSurvivor,
-                                 MgScanBufs *b, U64 *nOut, hipStream_t st)
+                                 MgScanBufs *b, U64 *nOut, hipStream_t st,
+                                 U32 *outPosF = 0, U32 *outRid = 0, U64 outCap = 0)
 {
   U64 cap = mgSurvivorGuess (sh, totalBases);
   MgHashParams p = mgMakeParams (sh);
@@ -793,8 +797,9 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       d->arena.reset ();
       b->cap = cap;
       b->kmer = (U64 *) d->arena.take (cap * 8);
-      b->posF = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
-      b->rid = wantPos ? (U32 *) d->arena.take (cap * 4) : 0;
+      const bool direct = wantPos && outPosF && outRid && outCap >= cap;
+      b->posF = !wantPos ? 0 : (direct ? outPosF : (U32 *) d->arena.take (cap * 4));
+      b->rid = !wantPos ? 0 : (direct ? outRid : (U32 *) d->arena.take (cap * 4));
       b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads, cap));
       b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
       b->counted.log2NB = 0; b->counted.binCount = 0;
@@ -838,15 +843,16 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (nSeeds) *nSeeds = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
-  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st))) return s;
+  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st,
+                            dSeedPosF, dSeedRead, capacity))) return s;
   if (nSeeds) *nSeeds = n;
   if (n > capacity)
     { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
   if (mode == 0) s = mgTableFind (&d->t, b.kmer, n, dSeedIndex, st);
   else s = mgAddBatch (ms, d, b.kmer, n, dSeedIndex, 0, true, st, &b.counted);
   if (s) return s;
-  if (dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));
-  if (dSeedRead) MG_HIP (hipMemcpyAsync (dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st));
+  if (dSeedPosF && b.posF != dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));
+  if (dSeedRead && b.rid != dSeedRead) MG_HIP (hipMemcpyAsync (dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st));
   MG_HIP (hipStreamSynchronize (st));
   return MG_OK;
 }

@@ -177,10 +177,7 @@ if host:
     assert L.mgQueryFile(ref, os.path.join(gd, "queries.fa").encode(), out) == 0
 else:
     def load(p):
-        names, seqs = fasta.read_fasta(p)
-        import numpy as np
-        from tests import util
-        b, o = util.concat_reads(seqs)
+        names, b, o = fasta.read_fasta(p)
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         return b, o, arr, len(names)
     b, o, arr, n = load(os.path.join(gd, "ref.fa"))

@@ -1,0 +1,201 @@
+"""BASELINE configs 3 and 5 at their full sizes on the GPU, through the C ABI.
+
+The oracle cannot build a 3 Gbp reference or sketch 1 Gbp of short reads in seconds, so at full size the checks are
+(i) bit-exact comparisons with the oracle on a sample it does finish quickly, tied to the full-size result by a
+property of the reference's algorithm — indices are handed out in order of first occurrence (modset.c:57), so the
+modset of a PREFIX of the input is a prefix of the modset of the whole input — and (ii) size-independent properties
+(histogram sums, every seed of a sampled read against a host-side dictionary of the GPU-built value[] array, Q-line
+tallies against the seeds).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import modimizer_amd as mg
+from modimizer_amd import synth
+from oracle import pyoracle as po
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def device_reads(L, genome_bases, genome_seed, plan, err, err_seed, keep_genome=False):
+    starts, offs, strands = plan
+    total = int(offs[-1])
+    d_g = mg.DeviceBuffer(L.mgPackedWords(genome_bases) * 4)
+    mg.check(L.mgSynthGenome(d_g.ptr, genome_bases, genome_seed, None))
+    d_s = mg.DeviceBuffer.from_numpy(starts); d_of = mg.DeviceBuffer.from_numpy(offs); d_st = mg.DeviceBuffer.from_numpy(strands)
+    d_r = mg.DeviceBuffer(L.mgPackedWords(total) * 4)
+    mg.check(L.mgSynthReads(d_g.ptr, genome_bases, d_s.ptr, d_of.ptr, d_st.ptr, len(starts), total, err, err_seed, d_r.ptr, None))
+    mg.check(L.mgStreamSynchronize(None))
+    if not keep_genome:
+        d_g.free()
+    return d_r, d_of, (d_g if keep_genome else None)
+
+
+def unpack_range(L, d_packed, first_base, n_bases):
+    """bases [first_base, first_base + n_bases) of a packed device stream as host bytes (first_base a multiple of 16)"""
+    assert first_base % 16 == 0
+    d_b = mg.DeviceBuffer(max(n_bases, 16))
+    src = C.c_void_p(d_packed.ptr.value + first_base // 4)
+    mg.check(L.mgUnpackDevice(src, n_bases, d_b.ptr, None))
+    out = d_b.to_numpy(np.uint8, n_bases)
+    d_b.free()
+    return out
+
+
+def test_config5_full_size_depth_histogram():
+    """50x of a 20 Mbp genome as 6 666 667 reads of 150 b, k=31 d=4, table bits 28 (modutils.c:19-63): the whole set on
+    the GPU; the first 20 000 reads also through the oracle, bit-exact, and as a prefix of the full-size modset"""
+    L = mg.lib()
+    k, w, bits = 31, 4, 28
+    G, n_reads, rl = 20_000_000, 6_666_667, 150
+    plan = synth.fixed_read_plan(n_reads, rl, G, 556)
+    total = n_reads * rl
+    d_r, d_of, _ = device_reads(L, G, 555, plan, 0.005, 557)
+    sh = mg.seqhashCreate(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    n = C.c_uint64()
+    mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, C.byref(n), None))
+    S, U = n.value, ms.contents.max
+    assert 0.18 < S / total < 0.22 and 0 < U < S and U < (1 << 26) - 1            # ~N/5 modimizers; under the table's capacity (modset.c:58)
+    d_h = mg.DeviceBuffer(65536 * 8)
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+    h = d_h.to_numpy(np.uint64, 65536)
+    assert int(h.sum()) == U and h[0] == 0
+    assert h[65535] == 0 and int((h * np.arange(65536, dtype=np.uint64)).sum()) == S     # 50x: nothing saturates; depth sum == hash count
+    # 50x coverage at 0.5 % errors: a peak of error k-mers at depth 1 and a genomic mode well above it
+    genomic_mode = int(h[5:200].argmax()) + 5
+    assert h[1] > h[2] > h[3] and 15 <= genomic_mode <= 60
+
+    # the first 20 000 reads: host mirror of the generator, the oracle, and the product on that prefix alone
+    m = 20_000
+    genome = synth.iid_bases(G, 555)
+    sub_plan = (plan[0][:m], plan[1][:m + 1], plan[2][:m])
+    host = synth.reads_from_genome(genome, *sub_plan, 0.005, 557)
+    assert np.array_equal(host, unpack_range(L, d_r, 0, m * rl))                     # device generator == host mirror
+    oh = po.Hasher(k, w, 17); oms = po.Modset(oh, 24)
+    offs = sub_plan[1].astype(np.int64)
+    tot = sum(oms.add_sequence(host[offs[r]:offs[r + 1]]) for r in range(m))
+    ms2 = mg.modsetCreate(sh, 24)
+    n2 = C.c_uint64()
+    mg.check(L.mgAddReadsDevice(ms2, d_r.ptr, m * rl, d_of.ptr, m, C.byref(n2), None))
+    assert n2.value == tot
+    mg.check(L.modsetSyncToHost(ms2, 0))
+    v2, dep2, _ = mg.modset_arrays(ms2)
+    assert ms2.contents.max == oms.max and np.array_equal(v2[1:], oms.values()[1:]) and np.array_equal(dep2[1:], oms.depths()[1:])
+    # prefix property: the full-size set starts with exactly these entries, in this order, with depths at least as large
+    mg.check(L.modsetSyncToHost(ms, 0))
+    vf = np.ctypeslib.as_array(ms.contents.value, (U + 1,))
+    df = np.ctypeslib.as_array(ms.contents.depth, (U + 1,))
+    assert np.array_equal(vf[1:oms.max + 1], oms.values()[1:])
+    assert np.all(df[1:oms.max + 1] >= oms.depths()[1:])
+    assert len(np.unique(vf[1:])) == U
+    assert int(df[1:].astype(np.int64).sum()) == S
+    L.modsetDestroy(ms); L.modsetDestroy(ms2)
+    d_r.free(); d_of.free(); d_h.free()
+
+
+def test_config3_full_size_reference_and_queries(tmp_path):
+    """a 3 Gbp reference in 24 sequences of 125 Mbp (table bits 28; its occurrences stay under modmap's 1 << 26 cap,
+    modmap.c:111,363) built by mgReferenceRead; a 10 Gbp batch of ONT-like reads from it queried on the device"""
+    L = mg.lib()
+    k, w, bits = 21, 64, 28
+    n_seq, seq_len = 24, 125_000_000
+    G = n_seq * seq_len
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    d_g = mg.DeviceBuffer(L.mgPackedWords(G) * 4)
+    mg.check(L.mgSynthGenome(d_g.ptr, G, 333, None))
+    genome = unpack_range(L, d_g, 0, G)                                  # 3 GB of host bytes, as a FASTA parser would hold them
+    assert np.array_equal(genome[:100_000], synth.iid_bases(100_000, 333))
+    ref_off = (np.arange(n_seq + 1, dtype=np.int64) * seq_len)
+    names = (C.c_char_p * n_seq)(*[b"chr%d" % (i + 1) for i in range(n_seq)])
+    ref = L.mgReferenceCreate(ms, 1 << 26)                              # modmap.c:363
+    out = str(tmp_path / "ref.txt")
+    with mg.CFile(out, "w") as f:
+        assert L.mgReferenceRead(ref, genome.ctypes.data, ref_off.ctypes.data, n_seq, names, True, f) == 0
+    R = C.cast(ref, C.POINTER(mg.MgReference)).contents
+    U, occ = ms.contents.max, R.max
+    lines = open(out).read().splitlines()
+    assert lines[0] == "  %d hashes from %d reference sequences, total length %d" % (occ, n_seq, G)
+    c1, c2, cM = (int(x) for x in re.match(r"\s+(\d+) copy 1, (\d+) copy 2, (\d+) multiple", lines[1]).groups())
+    assert c1 + c2 + cM == U and occ < (1 << 26) and abs(occ / (G / 64.0) - 1) < 0.01
+    assert c1 > 0.99 * U                                               # a random genome: almost every modimizer is single copy
+    # prefix property against the oracle: the first 40 Mbp of chr1 alone
+    m = 40_000_000
+    oms = po.Modset(oh, 22)
+    oms.add_sequence(genome[:m])
+    v = np.ctypeslib.as_array(ms.contents.value, (U + 1,))
+    assert np.array_equal(v[1:oms.max + 1], oms.values()[1:])
+    # occurrences of chr1's prefix: (index, offset, id) are the oracle's modimizers in order (modmap.c:112-116)
+    ek, ep, ef = oh.scan(genome[:m])
+    n0 = len(ek)
+    r_index = np.ctypeslib.as_array(R.index, (occ,)); r_off = np.ctypeslib.as_array(R.offset, (occ,)); r_id = np.ctypeslib.as_array(R.id, (occ,))
+    assert np.array_equal(r_off[:n0], ep.astype(np.uint32)) and not r_id[:n0].any()
+    assert np.array_equal(v[r_index[:n0]], ek)
+    # per-sequence occurrence counts add up, ids are sorted (sequences in order)
+    assert np.all(np.diff(r_id.astype(np.int64)) >= 0) and r_id[-1] == n_seq - 1
+    del genome
+
+    # ---- a 10 Gbp batch of queries, device resident --------------------------------------------------
+    total = 10_000_000_000
+    plan = synth.ont_read_plan(total, G, 4000)
+    n_reads = len(plan[0])
+    d_s = mg.DeviceBuffer.from_numpy(plan[0]); d_of = mg.DeviceBuffer.from_numpy(plan[1]); d_st = mg.DeviceBuffer.from_numpy(plan[2])
+    d_r = mg.DeviceBuffer(L.mgPackedWords(total) * 4)
+    mg.check(L.mgSynthReads(d_g.ptr, G, d_s.ptr, d_of.ptr, d_st.ptr, n_reads, total, 0.05, 5000, d_r.ptr, None))
+    cap = int(total / w * 1.3) + (1 << 16)
+    d_ix = mg.DeviceBuffer(cap * 4); d_ps = mg.DeviceBuffer(cap * 4); d_rd = mg.DeviceBuffer(cap * 4)
+    ns = C.c_uint64()
+    mg.check(L.mgQueryReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, d_ix.ptr, d_ps.ptr, d_rd.ptr, cap, C.byref(ns), None))
+    S = ns.value
+    assert abs(S / (total / 64.0) - 1) < 0.01
+    s_ix = d_ix.to_numpy(np.uint32, S); s_ps = d_ps.to_numpy(np.uint32, S); s_rd = d_rd.to_numpy(np.uint32, S)
+    assert np.all(np.diff(s_rd.astype(np.int64)) >= 0) and s_rd[-1] < n_reads and s_ix.max() <= U
+    hit = float((s_ix != 0).mean())
+    assert 0.30 < hit < 0.40                                            # (1 - 0.05)^21 = 0.34 of the k-mers survive 5 % substitutions
+    first = np.searchsorted(s_rd, np.arange(n_reads + 1))               # seeds of read r: [first[r], first[r+1])
+    # sampled reads against the oracle: positions, strands, and the index of every k-mer via a dictionary of value[]
+    order = np.argsort(v[1:], kind="stable")
+    vs = v[1:][order]
+    rng = np.random.default_rng(5)
+    offs = plan[1].astype(np.int64)
+    sample = np.concatenate([[0, n_reads - 1], rng.integers(0, n_reads, 998)])
+    for r in sample:
+        a, b = int(offs[r]), int(offs[r + 1])
+        a16 = a - a % 16
+        bases = unpack_range(L, d_r, a16, b - a16)[a - a16:]
+        ek, ep, ef = oh.scan(bases)
+        lo, hi = int(first[r]), int(first[r + 1])
+        assert hi - lo == len(ek), r
+        assert np.array_equal(s_ps[lo:hi] & mg.MG_POS_MASK, ep.astype(np.uint32)) and np.array_equal((s_ps[lo:hi] >> 31).astype(np.uint8), ef)
+        at = np.searchsorted(vs, ek)
+        at[at >= len(vs)] = 0
+        want = np.where(vs[at] == ek, order[at] + 1, 0).astype(np.uint32)
+        assert np.array_equal(s_ix[lo:hi], want), r
+    # Q lines (modmap.c:208-211) of the first 1500 reads from host bytes: tallies == what the device seeds say
+    nq = 1500
+    qb = unpack_range(L, d_r, 0, int(offs[nq]))
+    qn = (C.c_char_p * nq)(*[b"q%d" % i for i in range(nq)])
+    qout = str(tmp_path / "q.txt")
+    with mg.CFile(qout, "w") as f:
+        assert L.mgQueryProcess(ref, qb.ctypes.data, offs[:nq + 1].ctypes.data, nq, qn, f) == 0
+    info = np.ctypeslib.as_array(ms.contents.info, (U + 1,))
+    qlines = [l for l in open(qout).read().splitlines() if l.startswith("Q\t")]
+    assert len(qlines) == nq
+    for r, l in enumerate(qlines):
+        nm, ln, rest = l.split("\t")[1:4]
+        miss, k1, k2, kM = (int(x) for x in re.match(r"(\d+) miss, (\d+) copy1, (\d+) copy2, (\d+) multi", rest).groups())
+        ix = s_ix[first[r]:first[r + 1]]
+        cls = info[ix[ix != 0]] & 3
+        assert int(ln) == offs[r + 1] - offs[r] and miss == int((ix == 0).sum())
+        assert (k1, k2, kM) == (int((cls == 1).sum()), int((cls == 2).sum()), int((cls == 3).sum()))
+    L.mgReferenceDestroy(ref)
+    L.modsetDestroy(ms)
+    for d in (d_g, d_r, d_s, d_of, d_st, d_ix, d_ps, d_rd):
+        d.free()
