@@ -427,6 +427,7 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
     { mgSetError ("device modset supports table bits 20..32 (got %d)", ms->tableBits); return MG_ERR_ARG; }
   memset (&t, 0, sizeof (t));
   t.maxLog2Slots = ms->tableBits - 1;                 /* load <= 0.5 at the largest legal fill */
+  t.kbits = 2 * ms->hasher->k;
   t.wantR = 4096;                                      /* 64 KiB of LDS per bucket, 1024-thread workgroups (measured best) */
   { const char *e = getenv ("MODGPU_BUCKET_R"); if (e && atoi (e) >= 256) t.wantR = (U32) atoi (e); }
   t.size = ms->size;
@@ -802,10 +803,10 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       b->rid = !wantPos ? 0 : (direct ? outRid : (U32 *) d->arena.take (cap * 4));
       b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads, cap));
       b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
-      b->counted.log2NB = 0; b->counted.binCount = 0;
+      b->counted.log2NB = 0; b->counted.kbits = 64; b->counted.binCount = 0;
       if (extraPerSurvivor)                           /* the survivors go into the modset: have the compaction count the first partition digit */
         { b->counted.binCount = (U32 *) d->arena.take (512 * sizeof (U32));
-          b->counted.log2NB = d->t.log2NB;
+          b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
         }
       if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
                              b->counted.binCount ? &b->counted : 0))) return s;

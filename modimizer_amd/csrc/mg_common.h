@@ -74,14 +74,28 @@ __device__ __forceinline__ U32 mgWaveInclusiveSum (U32 v)
   v += (U32) __builtin_amdgcn_update_dpp (0, (int) v, 0x143, 0xc, 0xf, false);
   return v;
 }
-/* the modset table's hash of a k-mer (murmur-style remix): bucket = its top bits, home slot = its low bits */
-__device__ __forceinline__ U64 mgMix (U64 x)
+/* The modset table's hash of a k-mer: a BIJECTION of the 2k-bit k-mer onto 2k-bit values (odd multipliers and
+ * xor-shifts, all invertible modulo 2^(2k)), murmur-style.  Bucket = its top log2NB bits, home slot = its low bits, and
+ * the table stores the mixed value itself (+1) as the key: being a bijection it identifies the k-mer, and a k-mer's
+ * bucket digits are a prefix of its key -- which lets the partition passes drop the digits a bin already implies and
+ * carry the first-occurrence ordinal in the freed bits of one 8-byte element (see mg_table.hip). */
+struct MgGeom { U32 R, rMask; int log2NB; int kbits; };      /* kbits = 2k */
+__device__ __forceinline__ U64 mgMixK (U64 x, int b)
 {
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
+  const U64 mask = b >= 64 ? ~0ull : (((U64) 1 << b) - 1);
+  const int h = (b + 1) >> 1;
+  x ^= x >> h; x = (x * 0xff51afd7ed558ccdull) & mask;
+  x ^= x >> h; x = (x * 0xc4ceb9fe1a85ec53ull) & mask;
+  x ^= x >> h;
   return x;
 }
+__device__ __forceinline__ U32 mgBucketOfM (U64 m, const MgGeom &g)
+{
+  if (!g.log2NB) return 0u;
+  const int s = g.kbits - g.log2NB;
+  return s >= 0 ? (U32) (m >> s) : ((U32) m << (-s));
+}
+__device__ __forceinline__ U32 mgHomeOfM (U64 m, const MgGeom &g) { return (U32) m & g.rMask; }
 #endif /* __HIPCC__ */
 
 /* The bucket id (log2NB bits) is split into a coarse digit (high bits, first partition pass) and a fine one. */
@@ -91,7 +105,7 @@ static inline void mgPartSplit (int log2NB, int *hiB, int *loB)
 /* The first partition pass needs the number of modimizers per coarse digit.  The scan's compaction kernel
  * reads every k-mer anyway, so it can count them on the way (its ALUs are idle: it is a copy): a caller that
  * knows the table geometry asks for that with a request; log2NB says which geometry the counts are for. */
-struct MgHistReq { int log2NB; U32 *binCount; };          /* binCount: device, 512 entries, zeroed by the launcher */
+struct MgHistReq { int log2NB; int kbits; U32 *binCount; };   /* binCount: device, 512 entries, zeroed by the launcher; kbits = 2k (the table hash is over 2k bits) */
 
 
 /* launchers implemented in the .hip files */
@@ -120,6 +134,7 @@ struct MgSlot { U64 key; U32 ord; U32 cnt; };      /* 16 bytes; key = kmer+1, 0 
 struct MgTable {
   MgSlot *slots; U64 nSlots;
   U32 R; int log2NB;
+  int kbits;           /* 2k: width of the k-mers this table holds (and of its hash) */
   U32 *occ;            /* [NB] non-zero when the bucket may hold entries */
   U64 *value;          /* [size] device copy of ms->value */
   U16 *baseDepth;      /* [size] host depth at last sync */

@@ -536,7 +536,7 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
                          const U64 *__restrict__ blockCount, const U64 *__restrict__ segStart,
                          U64 *__restrict__ outKmer, U32 *__restrict__ outPosF, U32 *__restrict__ outRead,
                          U64 capacity, const U64 *__restrict__ dCount,
-                         int histLog2NB, int histShift, U32 histBins, U32 *__restrict__ histCount)
+                         int histLog2NB, int histKbits, int histShift, U32 histBins, U32 *__restrict__ histCount)
 {
   __shared__ U32 sH[512];
   if (dCount[1]) return;                       /* overflow: the caller retries with the reported sizes */
@@ -558,7 +558,8 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
               if (outPosF) outPosF[dst + i] = segPosF[src + i];
               if (outRead) outRead[dst + i] = segRead[src + i];
               if (histBins)
-                { const U32 bucket = histLog2NB ? (U32) (mgMix (km[j]) >> (64 - histLog2NB)) : 0u;
+                { MgGeom hg; hg.R = 0; hg.rMask = 0; hg.log2NB = histLog2NB; hg.kbits = histKbits;
+                  const U32 bucket = mgBucketOfM (mgMixK (km[j], histKbits), hg);
                   atomicAdd (&sH[(bucket >> histShift) & (histBins - 1)], 1u);
                 }
             }
@@ -681,7 +682,7 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
     const unsigned cgrid = g.nBlocks < 4096 ? g.nBlocks : 4096;
     MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (cgrid), dim3 (256), 0, st,
                segKmer, a.segPosF, a.segRead, g.segCap, g.nBlocks, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount,
-               hist ? hist->log2NB : 0, loB, bins, hist ? hist->binCount : (U32 *) 0);
+               hist ? hist->log2NB : 0, hist ? hist->kbits : 64, loB, bins, hist ? hist->binCount : (U32 *) 0);
   }
   MG_HIP (hipGetLastError ());
   return MG_OK;

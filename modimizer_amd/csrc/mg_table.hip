@@ -8,9 +8,10 @@
  * Layout.  The device table is not the reference's index[] array (with a power-of-two modulus d
  * every primary slot of that table has its low log2(d) bits zero, because the hash that picks the
  * slot is the hash that was just tested to be 0 mod d; that layout is only materialised on
- * request by mgReplayIndexKernel).  Here: NB buckets of R slots of 16 bytes {kmer+1, ord, cnt};
- * a k-mer's bucket is the top bits of a 64-bit remix, its home slot the low bits, and linear
- * probing wraps INSIDE the bucket, so a bucket is a self-contained little table that fits LDS.
+ * request by mgReplayIndexKernel).  Here: NB buckets of R slots of 16 bytes {mix(kmer)+1, ord, cnt},
+ * where mix is a bijection of the 2k-bit k-mers (mgMixK); a k-mer's bucket is the top bits of its mixed
+ * value, its home slot the low bits, and linear probing wraps INSIDE the bucket, so a bucket is a
+ * self-contained little table that fits LDS.
  * ord: 0 = none, bit 31 set = assigned index, otherwise a transient first-occurrence token.
  *
  * Two build paths, same table, same results:
@@ -42,10 +43,7 @@
 __device__ __forceinline__ U32 mgToken (U64 o) { return 0x7fffffffu - (U32) o; }     /* 1..0x7fffffff */
 __device__ __forceinline__ bool mgIsAssigned (U32 v) { return (v & MG_ASSIGNED) != 0; }
 
-/* bucket geometry */
-struct MgGeom { U32 R, rMask; int log2NB; };
-__device__ __forceinline__ U32 mgBucketOf (U64 h, const MgGeom &g) { return g.log2NB ? (U32) (h >> (64 - g.log2NB)) : 0u; }
-__device__ __forceinline__ U32 mgHomeOf (U64 h, const MgGeom &g) { return (U32) h & g.rMask; }
+/* bucket geometry: MgGeom, mgMixK, mgBucketOfM, mgHomeOfM in mg_common.h */
 
 /* counters[]: 0 = new entries this call, 1 = bucket overflow flag */
 
@@ -58,10 +56,9 @@ __global__ void mgTableInsertKernel (MgSlot *__restrict__ slots, MgGeom g, const
   U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; o < n ; o += stride)
-    { const U64 km = kmer[o], key = km + 1;
-      const U64 h = mgMix (km);
-      const U64 base = (U64) mgBucketOf (h, g) * g.R;
-      U32 at = mgHomeOf (h, g);
+    { const U64 m = mgMixK (kmer[o], g.kbits), key = m + 1;
+      const U64 base = (U64) mgBucketOfM (m, g) * g.R;
+      U32 at = mgHomeOfM (m, g);
       bool ok = false;
       for (U32 probes = 0 ; probes < g.R ; ++probes)
         { U64 cur = slots[base + at].key;          /* plain load: a stale "empty" is repaired by the CAS */
@@ -192,11 +189,11 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
 
 __device__ __forceinline__ U32 mgProbeFind (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, const MgGeom &g, U64 km)
 {
-  const U64 key = km + 1, h = mgMix (km);
-  const U32 bkt = mgBucketOf (h, g);
+  const U64 m = mgMixK (km, g.kbits), key = m + 1;
+  const U32 bkt = mgBucketOfM (m, g);
   if (!occ[bkt]) return 0;                         /* never written: its bytes are undefined */
   const U64 base = (U64) bkt * g.R;
-  U32 at = mgHomeOf (h, g);
+  U32 at = mgHomeOfM (m, g);
   for (U32 probes = 0 ; probes < g.R ; ++probes)
     { U64 cur = slots[base + at].key;
       if (cur == key) { U32 v = slots[base + at].ord; return mgIsAssigned (v) ? (v & ~MG_ASSIGNED) : 0; }
@@ -221,10 +218,10 @@ __global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, MgGeom g, const U
   U64 i = (U64) first + (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; i <= last ; i += stride)
-    { const U64 km = value[i], key = km + 1, h = mgMix (km);
-      const U32 b = mgBucketOf (h, g);
+    { const U64 m = mgMixK (value[i], g.kbits), key = m + 1;
+      const U32 b = mgBucketOfM (m, g);
       const U64 base = (U64) b * g.R;
-      U32 at = mgHomeOf (h, g);
+      U32 at = mgHomeOfM (m, g);
       bool placed = false, dup = false;
       for (U32 probes = 0 ; probes < g.R ; ++probes)
         { U64 cur = slots[base + at].key;
@@ -355,9 +352,26 @@ __global__ void mgIndexFinishKernel (U32 *__restrict__ index, U64 n)
 #define MG_PART_CHUNK 16384          /* elements per workgroup pass */
 #define MG_PART_MAXBINS 512
 
-/* digit of element = bits [shift, shift+bits) of its bucket id */
-__device__ __forceinline__ U32 mgDigit (U64 km, const MgGeom &g, int shift, U32 binMask)
-{ return (mgBucketOf (mgMix (km), g) >> shift) & binMask; }
+/* What a partition pass reads and writes.  The first pass reads the dense k-mers (an element's ordinal is its
+ * position) and mixes them; from then on everything is in mixed space.  Two element formats:
+ *   wide    8 bytes of mixed k-mer + 4 bytes of ordinal (separate arrays): any k, any batch size;
+ *   packed  one 8-byte word (rem << ordBits) | ordinal, where rem = the mixed k-mer WITHOUT its coarse digit (the
+ *           bin the element sits in implies those hiB bits: the mix is a bijection and the bucket id is a prefix of
+ *           it) and ordBits = bits of the batch's largest ordinal.  Fits when 2k - hiB + ordBits <= 64, e.g. k = 21
+ *           with 2^28 modimizers: 34 + 28 bits.  A third less traffic in both passes and in the dedup kernel. */
+#define MG_EL_DENSE  0      /* input of the first pass: k-mers, ordinal = index */
+#define MG_EL_WIDE   1      /* (mixed k-mer, ordinal) */
+#define MG_EL_PACKED 2      /* (rem << ordBits) | ordinal */
+struct MgPartFmt { int ordBits, remBits, loB; };      /* remBits = 2k - hiB; loB = bits of the fine digit */
+
+/* digit of an element = bits [shift, shift+log2(nBins)) of its bucket id */
+template <int MODE>
+__device__ __forceinline__ U32 mgDigitOf (U64 x, const MgGeom &g, const MgPartFmt &f, int shift, U32 binMask)
+{
+  if (MODE == MG_EL_DENSE)  return (mgBucketOfM (mgMixK (x, g.kbits), g) >> shift) & binMask;
+  if (MODE == MG_EL_WIDE)   return (mgBucketOfM (x, g) >> shift) & binMask;
+  return (U32) (x >> (f.ordBits + f.remBits - f.loB)) & binMask;      /* packed: only ever asked for the fine digit, the top loB bits of rem */
+}
 
 /* chunk -> (segment, range): segments are [segStart[s], segStart[s+1]); chunkBase[s] = first chunk of s,
  * chunkBase[nSeg] = number of chunks, and behind that table (at MG_CHUNK_SEG_AT) the segment of every chunk, so
@@ -401,8 +415,9 @@ void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 *__rest
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__ (256)
-void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, int shift, U32 nBins,
+void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, MgPartFmt f, int shift, U32 nBins,
                        const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                        U32 *__restrict__ binCount)
 {
@@ -434,7 +449,7 @@ void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, int shift, U32 nBi
 #pragma unroll
           for (int j = 0 ; j < 8 ; ++j)
             { U64 i = i0 + (U64) j * 256 + threadIdx.x;
-              if (i < hi) atomicAdd (&sH[mgDigit (v[j], g, shift, nBins - 1)], 1u);
+              if (i < hi) atomicAdd (&sH[mgDigitOf<MODE> (v[j], g, f, shift, nBins - 1)], 1u);
             }
         }
     }
@@ -473,19 +488,21 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
 #define MG_PART_SUB 8192
 #define MG_PART_THREADS 1024
 #define MG_PART_PER_THREAD (MG_PART_SUB / MG_PART_THREADS)
-template <bool FIRST>     /* FIRST: input ordinal is the element's position */
+template <int INMODE, bool PACKOUT>     /* INMODE: what kIn holds; PACKOUT: one packed word out, otherwise (mixed k-mer, ordinal) */
 __global__ __launch_bounds__ (MG_PART_THREADS)
-void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, MgGeom g, int shift, U32 nBins,
+void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, MgGeom g, MgPartFmt f, int shift, U32 nBins,
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                           unsigned long long *__restrict__ cursor, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
 {
+  constexpr bool WIDE = !PACKOUT;
   __shared__ U64 stK[MG_PART_SUB];
-  __shared__ U32 stT[MG_PART_SUB];
+  __shared__ U32 stT[WIDE ? MG_PART_SUB : 1];
   __shared__ unsigned short stB[MG_PART_SUB];
   __shared__ U32 sH[MG_PART_MAXBINS], sOff[MG_PART_MAXBINS];
   __shared__ unsigned long long sBase[MG_PART_MAXBINS];
   __shared__ U32 sWave[MG_PART_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const U64 remMask = f.remBits >= 64 ? ~0ull : (((U64) 1 << f.remBits) - 1);
   /* A workgroup walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... sub-chunk by sub-chunk, and the elements
      of the next sub-chunk are already on their way into registers while the current one is written out (one
      workgroup fills a CU's LDS, so nothing else would hide that latency). */
@@ -499,7 +516,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
       for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
         { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
           km[j] = 0; tk[j] = 0;
-          if (i < subHi) { km[j] = kIn[i]; tk[j] = FIRST ? (U32) i : tIn[i]; }
+          if (i < subHi) { km[j] = kIn[i]; if (INMODE == MG_EL_WIDE) tk[j] = tIn[i]; }
         }
     }
   while (have)
@@ -516,8 +533,11 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
         { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
           dr[j] = 0xffffffffu;
           if (i < subHi)
-            { U32 d = mgDigit (km[j], g, shift, nBins - 1);
+            { if (INMODE == MG_EL_DENSE)                         /* into mixed space, once */
+                { km[j] = mgMixK (km[j], g.kbits); tk[j] = (U32) i; }
+              U32 d = mgDigitOf<(INMODE == MG_EL_DENSE ? MG_EL_WIDE : INMODE)> (km[j], g, f, shift, nBins - 1);
               dr[j] = (d << 16) | atomicAdd (&sH[d], 1u);        /* rank within (sub-chunk, bin) */
+              if (INMODE == MG_EL_DENSE && PACKOUT) km[j] = ((km[j] & remMask) << f.ordBits) | (U64) tk[j];
             }
         }
       __syncthreads ();
@@ -547,7 +567,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
       for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
         if (dr[j] != 0xffffffffu)
           { U32 d = dr[j] >> 16, p = sOff[d] + (dr[j] & 0xffffu);
-            stK[p] = km[j]; stT[p] = tk[j]; stB[p] = (unsigned short) d;
+            stK[p] = km[j]; if (WIDE) stT[p] = tk[j]; stB[p] = (unsigned short) d;
           }
       if ((U32) (2 * tid) < nBins) sBase[2 * tid] = base0;
       if ((U32) (2 * tid + 1) < nBins) sBase[2 * tid + 1] = base1;
@@ -557,7 +577,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
 #pragma unroll
           for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
             { U64 i = nsub + (U64) j * MG_PART_THREADS + tid;
-              if (i < nsubHi) { km[j] = kIn[i]; tk[j] = FIRST ? (U32) i : tIn[i]; }
+              if (i < nsubHi) { km[j] = kIn[i]; if (INMODE == MG_EL_WIDE) tk[j] = tIn[i]; }
             }
         }
       __syncthreads ();
@@ -565,7 +585,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
         { U32 d = stB[p];
           U64 at = sBase[d] + (p - sOff[d]);
           kOut[at] = stK[p];
-          tOut[at] = stT[p];
+          if (WIDE) tOut[at] = stT[p];
         }
       __syncthreads ();
       c = nc; seg = nseg; lo = nlo; hi = nhi; sub = nsub; have = nhave;
@@ -579,7 +599,9 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
 struct MgBucketArgs {
   MgSlot *slots; MgGeom g; U32 nBuckets;
   const U64 *bucketStart;          /* [NB+1] ranges into pK/pT/pC */
-  U64 *pK; U32 *pT; U32 *pC;       /* in: occurrences (kmer, ordinal); out (in place): uniques (kmer, ord field, count) */
+  U64 *pK; U32 *pT; U32 *pC;       /* in: occurrences, wide (mixed k-mer in pK, ordinal in pT) or packed (pK alone); out (in place over
+                                      pK, and in pT / pC): uniques (mixed k-mer, ord field, count) */
+  MgPartFmt f;                     /* packed format */
   U32 *uniqCount;                  /* [NB] */
   U32 *occ;                        /* [NB] entries per bucket */
   unsigned char *flags;            /* [n] first occurrence of a k-mer new to the table */
@@ -619,6 +641,18 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
 #define MG_LIVE_BINS 256              /* depths below this are counted in LDS by the merge kernel's live histogram */
 
 /* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
+/* one occurrence of bucket b -> (mixed k-mer, ordinal) */
+template <bool PACKED>
+__device__ __forceinline__ void mgOccurrence (const MgBucketArgs &a, U32 b, U64 x, U32 t, U64 *m, U32 *ord)
+{
+  if (PACKED)
+    { *ord = (U32) (x & (((U64) 1 << a.f.ordBits) - 1));
+      *m = ((U64) (b >> a.f.loB) << a.f.remBits) | (x >> a.f.ordBits);     /* the bin's coarse digit in front of rem */
+    }
+  else { *m = x; *ord = t; }
+}
+
+template <bool PACKED>
 __global__ __launch_bounds__ (1024)
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
@@ -637,7 +671,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   U64 ck[MG_BUCKET_PREFETCH]; U32 ct[MG_BUCKET_PREFETCH];
 #pragma unroll
   for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (i < hi) { ck[j] = a.pK[i]; ct[j] = a.pT[i]; } }
+    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (i < hi) { ck[j] = a.pK[i]; if (!PACKED) ct[j] = a.pT[i]; } }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
     { /* fetch the next bucket while this one is processed */
@@ -651,7 +685,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           occNext = a.occ[b + 1];
 #pragma unroll
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-            { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = a.pK[i]; nt[j] = a.pT[i]; } }
+            { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = a.pK[i]; if (!PACKED) nt[j] = a.pT[i]; } }
         }
       if (hi == lo) { if (tid == 0) a.uniqCount[b] = 0; }
       else
@@ -665,15 +699,16 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #pragma unroll
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
             if (lo + (U64) j * T + tid < hi)
-              { U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (ck[j]), a.g), ck[j] + 1);
+              { U64 m; U32 ord; mgOccurrence<PACKED> (a, b, ck[j], ct[j], &m, &ord);
+                U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
                 if (at == R) a.counters[1] = 1;
-                else { atomicMax (&sOrd[at], mgToken (ct[j])); atomicAdd (&sCnt[at], 1u); }
+                else { atomicMax (&sOrd[at], mgToken (ord)); atomicAdd (&sCnt[at], 1u); }
               }
           for (U64 i = lo + (U64) MG_BUCKET_PREFETCH * T + tid ; i < hi ; i += T)
-            { const U64 km = a.pK[i];
-              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
+            { U64 m; U32 ord; mgOccurrence<PACKED> (a, b, a.pK[i], PACKED ? 0u : a.pT[i], &m, &ord);
+              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
               if (at == R) { a.counters[1] = 1; continue; }
-              atomicMax (&sOrd[at], mgToken (a.pT[i]));          /* assigned entries (bit 31) stay as they are */
+              atomicMax (&sOrd[at], mgToken (ord));              /* assigned entries (bit 31) stay as they are */
               atomicAdd (&sCnt[at], 1u);
             }
           __syncthreads ();
@@ -753,7 +788,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (i == tid) { km = ck; ord = co; c = cc; }
               else { km = a.pK[lo + i]; ord = a.pT[lo + i]; c = a.pC[lo + i]; }
               if (!a.withDepth) c = 0;
-              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOf (mgMix (km), a.g), km + 1);
+              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
               if (at == R) { a.counters[1] = 1; continue; }
               if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
               else
@@ -811,7 +846,7 @@ static inline unsigned mgGrid (U64 n, unsigned per = 256, unsigned cap = 16384)
 { U64 b = (n + per - 1) / per; if (b > cap) b = cap; if (b < 1) b = 1; return (unsigned) b; }
 static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
 static inline int mgLog2 (U64 x) { int l = 0; while (((U64) 1 << l) < x) ++l; return l; }
-static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.rMask = t->R - 1; g.log2NB = t->log2NB; return g; }
+static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.rMask = t->R - 1; g.log2NB = t->log2NB; g.kbits = t->kbits; return g; }
 
 #define MG_RANK_UNITS 8192           /* waves that share the ordered flag count */
 static inline U64 mgRankRowsPerUnit (U64 n, U32 *nBlocks)
@@ -854,8 +889,9 @@ bool mgTableUseBuckets (const MgTable *t, U64 n)
   return n >= t->nSlots / 16;           /* streaming every touched bucket twice beats ~100 ps/modimizer of atomics */
 }
 
-/* one partition pass: nSeg segments of kIn -> nBins bins each */
-static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const U32 *tIn, U64 n,
+/* one partition pass: nSeg segments of kIn -> nBins bins each.  inMode: what kIn holds (MG_EL_*); packed: the format
+ * of the output (and, after the first pass, of the input) */
+static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgPartFmt &f, const U64 *kIn, const U32 *tIn, U64 n,
                             const U64 *segStart, U32 nSeg, int shift, U32 nBins,
                             U64 *kOut, U32 *tOut, U64 *binStart, unsigned long long *cursor, U32 *binCount, U32 *chunkBase,
                             hipStream_t st, const U32 *counted = 0)
@@ -867,13 +903,22 @@ static MgStatus mgPartPass (const MgTable *t, bool first, const U64 *kIn, const 
   unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
   static int sgEnv = -1; if (sgEnv < 0) { const char *e = getenv ("MODGPU_SCATTER_GRID"); sgEnv = e ? atoi (e) : 0; }   /* dev knob */
   unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
+  const dim3 hg (maxChunks < 4096 ? maxChunks : 4096), sg (scatterGrid);
   if (!counted)
-    MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel, dim3 (maxChunks < 4096 ? maxChunks : 4096), dim3 (256), 0, st, kIn, g, shift, nBins, segStart, chunkBase, nSeg, binCount);
+    { if (inMode == MG_EL_DENSE)
+        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_DENSE>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, binCount);
+      else if (inMode == MG_EL_WIDE)
+        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_WIDE>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, binCount);
+      else
+        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_PACKED>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, binCount);
+    }
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
-  if (first)
-    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<true>, dim3 (scatterGrid), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
-  else
-    MG_LAUNCH (MG_K_PART_SCATTER, st, mgPartScatterKernel<false>, dim3 (scatterGrid), dim3 (MG_PART_THREADS), 0, st, kIn, tIn, g, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut);
+#define MG_SCATTER(IN, PK) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK>), sg, dim3 (MG_PART_THREADS), 0, st, \
+                                      kIn, tIn, g, f, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut)
+  if (inMode == MG_EL_DENSE) { if (packed) MG_SCATTER (MG_EL_DENSE, true); else MG_SCATTER (MG_EL_DENSE, false); }
+  else if (inMode == MG_EL_WIDE) MG_SCATTER (MG_EL_WIDE, false);
+  else MG_SCATTER (MG_EL_PACKED, true);
+#undef MG_SCATTER
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -931,16 +976,21 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   const int j = t->log2NB;
   int hiB, loB;
   mgPartSplit (j, &hiB, &loB);
-  const U32 *pre = (counted && counted->binCount && counted->log2NB == j) ? counted->binCount : 0;
+  const U32 *pre = (counted && counted->binCount && counted->log2NB == j && counted->kbits == t->kbits) ? counted->binCount : 0;
   U64 segInit[2] = { 0, n };
   MG_HIP (hipMemcpyAsync (whole, segInit, 16, hipMemcpyHostToDevice, st));
+  /* element format: one packed 8-byte word when the mixed k-mer without its coarse digit and the ordinal fit in 64 bits */
+  MgPartFmt f;
+  f.ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1; f.remBits = t->kbits - hiB; f.loB = loB;
+  static int packEnv = -1; if (packEnv < 0) { const char *e = getenv ("MODGPU_PART_PACKED"); packEnv = e ? atoi (e) : 1; }   /* test knob: 0 forces the wide format */
+  const bool packed = packEnv && t->kbits >= j + 4 && f.remBits + f.ordBits <= 64;
   MgStatus s;
   const U64 *bucketStart = fineStart;
   if (!loB)
-    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st, pre))) return s; }
+    { if ((s = mgPartPass (t, MG_EL_DENSE, packed, f, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st, pre))) return s; }
   else
-    { if ((s = mgPartPass (t, true, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st, pre))) return s;
-      if ((s = mgPartPass (t, false, kA, tA, n, coarseStart, (U32) 1 << hiB, 0, (U32) 1 << loB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s;
+    { if ((s = mgPartPass (t, MG_EL_DENSE, packed, f, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st, pre))) return s;
+      if ((s = mgPartPass (t, packed ? MG_EL_PACKED : MG_EL_WIDE, packed, f, kA, tA, n, coarseStart, (U32) 1 << hiB, 0, (U32) 1 << loB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s;
     }
 
   MG_HIP (hipMemsetAsync (flags, 0, n, st));
@@ -948,7 +998,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
-  a.counters = t->counters;
+  a.counters = t->counters; a.f = f;
 #ifdef MG_ABLATE
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_BUCKET_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = dbg; }
 #endif
@@ -963,7 +1013,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   t->liveHistValid = track;
   const size_t lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
   if (lds > 48 * 1024)
-    { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
   static int bThreadsEnv = -1;
@@ -972,7 +1023,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
   U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
-  MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
+  if (packed) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel<true>, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
+  else        MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel<false>, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
   MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nRankBlocks), dim3 (256), 0, st,
@@ -987,7 +1039,7 @@ __global__ void mgMarkOccKernel (MgGeom g, const U64 *__restrict__ kmer, U64 n, 
   U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for ( ; o < n ; o += stride)
-    { U32 b = mgBucketOf (mgMix (kmer[o]), g);
+    { U32 b = mgBucketOfM (mgMixK (kmer[o], g.kbits), g);
       if (!occ[b]) occ[b] = 1;
     }
 }
@@ -1088,10 +1140,10 @@ __global__ void mgRehashKernel (const MgSlot *__restrict__ oldSlots, U64 oldN, c
       uint4 v = *reinterpret_cast<const uint4 *> (&oldSlots[s]);
       if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
       const unsigned long long key = ((unsigned long long) v.y << 32) | v.x;
-      const U64 h = mgMix (key - 1);
-      const U32 b = mgBucketOf (h, g);
+      const U64 m = key - 1;                                  /* the key IS the mixed k-mer: no re-hash needed to re-place it */
+      const U32 b = mgBucketOfM (m, g);
       const U64 base = (U64) b * g.R;
-      U32 at = mgHomeOf (h, g);
+      U32 at = mgHomeOfM (m, g);
       bool placed = false;
       for (U32 probes = 0 ; probes < g.R ; ++probes)
         { if (slots[base + at].key == 0 && atomicCAS ((unsigned long long *) &slots[base + at].key, 0ull, key) == 0) { placed = true; break; }
