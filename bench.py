@@ -389,6 +389,8 @@ def gpu_rank(args):
     if rank == 0 and world == 1 and not multi and not args.no_other:
         other = {}
         for name, fn in (("c5", bench_c5), ("c3", bench_c3)):
+            if name not in os.environ.get("MODGPU_BENCH_OTHER", "c5,c3").split(","):      # dev: run a subset
+                continue
             try:
                 other[name] = fn(cx, args)
             except Exception as e:                                # the headline line must still go out
@@ -490,7 +492,7 @@ def bench_c3(cx, args):
     L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
     tot_bases = tot_seeds = tot_hits = 0
     t_query = 0.0
-    first_table = None
+    per = []
     for b in range(n_batches):
         reads, d_offsets, offsets, n_reads = make_reads(cx, batch, genome, genome_bases, 4000 + b, 0.05, 5000 + b)
         if b == 0:                                               # warm-up of the arena and the kernels, untimed
@@ -503,7 +505,7 @@ def bench_c3(cx, args):
         mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
                                       q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
         torch.cuda.synchronize()
-        t_query += time.perf_counter() - t0
+        t_query += time.perf_counter() - t0; per.append(round((time.perf_counter() - t0) * 1e3, 2))
         tot_bases += batch; tot_seeds += n_seeds.value
         tot_hits += int((q_idx[:n_seeds.value] != 0).sum().item())
         del reads, d_offsets
@@ -519,7 +521,7 @@ def bench_c3(cx, args):
                        "%d query batches of %g Gbp ONT-like reads from it (5%% subs): scan + lookup, seeds (index,pos,read) out"
                        % (n_seq, seq_len // 1_000_000, genome_bases / 1e9, bits, ref_occ, ref_entries, n_batches, batch / 1e9),
            "value": round(tot_bases / t_query / 1e9, 2), "unit": "Gbp/s", "ms_per_batch": round(t_query / n_batches * 1e3, 3),
-           "query_bases": tot_bases, "seeds": tot_seeds, "seed_hit_fraction": round(tot_hits / max(tot_seeds, 1), 4),
+           "ms_each_batch": per, "query_bases": tot_bases, "seeds": tot_seeds, "seed_hit_fraction": round(tot_hits / max(tot_seeds, 1), 4),
            "reference_build_s": round(t_ref, 3), "reference_build_Gbp_per_s": round(genome_bases / t_ref / 1e9, 1),
            "whole_batch": {"bytes_per_base": 0.25 + 36.0 / d, "GBps": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9, 1),
                            "frac": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9 / HBM_PEAK_GBS, 4),

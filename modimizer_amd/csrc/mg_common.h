@@ -53,14 +53,21 @@ __device__ __forceinline__ bool mgDivisible (U64 x, const MgHashParams &p)
   return ((x >> p.dShift) * p.dOddInv) <= p.dOddLim;
 }
 
-/* reverse complement of a k-mer held in the low 2k bits */
-__device__ __forceinline__ U64 mgRevComp (U64 f, int shift1)
+/* reverse complement of 16 bases in one word: reverse the bit order, swap the two bits of every base back, complement.
+ * After the bit reversal the swap-and-complement is one three-input bit operation on (x << 1, x >> 1, 0x55555555):
+ * out = mask ? ~(x >> 1) : ~(x << 1), truth table 0x27 */
+__device__ __forceinline__ U32 mgRevComp16 (U32 w)
 {
-  U64 x = __brevll (f);
-  x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
-  return (~x) >> shift1;
+  const U32 x = __brev (w);
+  return __builtin_amdgcn_bitop3_b32 (x << 1, x >> 1, 0x55555555u, 0x27);
 }
 
+/* reverse complement of a k-mer held in the low 2k bits: the two words swap places, each reverse-complemented */
+__device__ __forceinline__ U64 mgRevComp (U64 f, int shift1)
+{
+  const U64 x = ((U64) mgRevComp16 ((U32) f) << 32) | mgRevComp16 ((U32) (f >> 32));
+  return x >> shift1;
+}
 /* inclusive prefix sum over the 64 lanes of a wave with DPP only (no LDS traffic): Hillis-Steele inside the
  * rows of 16 (row_shr 1,2,4,8), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31
  * into rows 2 and 3 (row_bcast:31).  Lanes without a source add 0. */

@@ -151,13 +151,6 @@ __device__ __forceinline__ U64 mgValidMask (const U64 *off, U32 rBase, U32 nRead
   return valid;
 }
 
-__device__ __forceinline__ U32 mgRevComp16 (U32 w)
-{
-  U32 x = __brev (w);
-  x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
-  return ~x;
-}
-
 __device__ __forceinline__ uint4 mgLoadTileWords (const MgScanArgs &a, U64 tile, int tid)
 {
   U64 g = tile * MG_TILE_WORDS + 4 * (U64) tid;
@@ -321,7 +314,7 @@ void mgScanKernel (const MgScanArgs a)
           for (int j = 0 ; j < 6 ; ++j) rw[j] = mgRevComp16 (w[j]);
           const U32 fS = a.fS, thresh = a.thresh;
           U32 acc = 0, candLo = 0;
-#pragma unroll 1
+#pragma unroll
           for (int chunk = 0 ; chunk < 4 ; ++chunk)
             { const U32 f0 = fw[0], f1w = fw[1], r0 = rw[0], r1 = rw[1];
               fw[0] = fw[1]; fw[1] = fw[2]; fw[2] = fw[3]; fw[3] = fw[4]; fw[4] = fw[5];
