@@ -154,18 +154,8 @@ static MgStatus mgCheckHasher (const Seqhash *sh)
 
 extern "C" size_t mgPackedWords (U64 nBases) { return (size_t) ((nBases + 15) / 16) + MG_PACK_PAD; }
 
-extern "C" void mgPackHost (const char *bases, U64 nBases, U32 *words)
-{
-  U64 nw = (nBases + 15) / 16;
-  for (U64 i = 0 ; i < nw ; ++i)
-    { U32 w = 0;
-      U64 b0 = i * 16;
-      int m = (nBases - b0 >= 16) ? 16 : (int) (nBases - b0);
-      for (int j = 0 ; j < m ; ++j) w |= (U32) (bases[b0 + j] & 3) << (30 - 2 * j);
-      words[i] = w;
-    }
-  for (int j = 0 ; j < MG_PACK_PAD ; ++j) words[nw + j] = 0;
-}
+/* mgPackHost, mgPackWords: mg_pack.c */
+extern "C" void mgPackWords (const char *bases, U64 nBases, U32 *words);
 
 extern "C" MgStatus mgPackDevice (const U8 *dBases, U64 nBases, U32 *dWords, void *stream)
 { MgStatus s = mgEnsureDevice (); if (s) return s; return mgLaunchPack (dBases, nBases, dWords, (hipStream_t) stream); }
@@ -213,32 +203,85 @@ static U64 mgSurvivorGuess (const Seqhash *sh, U64 totalBases)
   return g < totalBases ? g : totalBases;
 }
 
-/* Host bytes (one base per byte) -> 2-bit packed words in HBM: the bytes cross PCIe as they are, in
- * pieces through two device staging buffers, and K1 packs them on the device (a single host thread
- * packs at only ~3.6 GB/s, far below the link). */
+/* Host bytes (one base per byte) -> 2-bit packed words in HBM.  The bytes are packed ON THE HOST by a team of
+ * threads (mg_pack.c: 128 bases per AVX2 step) into two pinned staging buffers, piece by piece, and each piece goes
+ * across PCIe as packed words (a quarter of the bytes) with an asynchronous copy that overlaps the packing of the
+ * next piece.  (Before: the bytes crossed as they were and were packed on the device: 1 byte per base on the link.) */
+#include <pthread.h>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+#define MG_UP_PIECE ((U64) 128 << 20)                 /* bases per piece (a multiple of 16): 32 MiB of packed words */
+static struct MgUpStage { U32 *pin[2] = { 0, 0 }; hipEvent_t done[2]; bool ready = false; std::mutex lock; } gUp;
+
+static int mgHostThreads (void)
+{
+  static int n = 0;
+  if (n) return n;
+  const char *e = getenv ("MODGPU_PACK_THREADS");
+  long v = e ? atol (e) : 0;
+  if (v <= 0)
+    { v = sysconf (_SC_NPROCESSORS_ONLN);
+      cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
+      FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");                 /* a cgroup CPU quota caps what threads can get */
+      if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < v) v = c; } fclose (q); }
+    }
+  if (!e) v = v / 2;                                   /* measured (16-CPU quota): 8 packers keep the link busy, 16 starve the thread that issues the copies */
+  if (v < 1) v = 1;
+  if (v > 16) v = 16;
+  return n = (int) v;
+}
+
 extern "C" MgStatus mgUploadPack (const char *bases, U64 nBases, U32 *dPacked, void *stream)
 {
   MgStatus s = mgEnsureDevice (); if (s) return s;
   hipStream_t st = (hipStream_t) stream;
   if (!nBases) { MG_HIP (hipMemsetAsync (dPacked, 0, mgPackedWords (0) * 4, st)); return MG_OK; }
-  const U64 piece = (U64) 64 << 20;                      /* bases per piece, a multiple of 16 */
-  U8 *dStage[2] = { 0, 0 };
-  const U64 stageBytes = nBases < piece ? ((nBases + 15) & ~(U64) 15) : piece;
-  MG_HIP (hipMalloc ((void **) &dStage[0], stageBytes));
-  if (nBases > piece) MG_HIP (hipMalloc ((void **) &dStage[1], stageBytes));
-  hipEvent_t done[2]; MG_HIP (hipEventCreate (&done[0])); MG_HIP (hipEventCreate (&done[1]));
-  int i = 0;
-  for (U64 off = 0 ; off < nBases && !s ; off += piece, i ^= 1)
-    { U64 len = nBases - off < piece ? nBases - off : piece;
-      if (off >= 2 * piece) MG_HIP (hipEventSynchronize (done[i]));       /* the pack that last read this stage */
-      MG_HIP (hipMemcpyAsync (dStage[i], bases + off, len, hipMemcpyHostToDevice, st));
-      s = mgLaunchPack (dStage[i], len, dPacked + off / 16, st);           /* also zeroes the pad words after the piece */
-      MG_HIP (hipEventRecord (done[i], st));
+  std::lock_guard<std::mutex> g (gUp.lock);
+  if (!gUp.ready)
+    { for (int i = 0 ; i < 2 ; ++i)
+        { MG_HIP (hipHostMalloc ((void **) &gUp.pin[i], (MG_UP_PIECE / 16 + MG_PACK_PAD) * 4, hipHostMallocDefault));
+          MG_HIP (hipEventCreateWithFlags (&gUp.done[i], hipEventDisableTiming));
+        }
+      gUp.ready = true;
     }
+  const U64 nPieces = (nBases + MG_UP_PIECE - 1) / MG_UP_PIECE;
+  int T = mgHostThreads ();
+  if (nBases < ((U64) 1 << 20)) T = 1;
+  pthread_barrier_t bar;
+  pthread_barrier_init (&bar, 0, (unsigned) T);
+  /* every thread packs its share of every piece; thread 0 also waits for the staging buffer to be free before a
+     piece and sends the piece off after it */
+  volatile int failed = 0;
+  auto work = [&] (int t)
+    { for (U64 p = 0 ; p < nPieces ; ++p)
+        { const U64 off = p * MG_UP_PIECE, len = nBases - off < MG_UP_PIECE ? nBases - off : MG_UP_PIECE;
+          U32 *buf = gUp.pin[p & 1];
+          if (t == 0 && p >= 2 && hipEventSynchronize (gUp.done[p & 1]) != hipSuccess) failed = 1;    /* the copy that last read this buffer */
+          pthread_barrier_wait (&bar);
+          const U64 words = (len + 15) / 16, per = ((words + T - 1) / T + 7) & ~(U64) 7;               /* whole words per thread, a multiple of 8 */
+          const U64 w0 = per * (U64) t < words ? per * (U64) t : words, w1 = w0 + per < words ? w0 + per : words;
+          if (w1 > w0)
+            { const U64 b0 = w0 * 16, b1 = w1 * 16 < len ? w1 * 16 : len;
+              mgPackWords (bases + off + b0, b1 - b0, buf + w0);
+            }
+          pthread_barrier_wait (&bar);
+          if (t == 0)
+            { U64 n = words;
+              if (p + 1 == nPieces) { for (int j = 0 ; j < MG_PACK_PAD ; ++j) buf[words + j] = 0; n += MG_PACK_PAD; }   /* the pad words after the stream */
+              if (hipMemcpyAsync (dPacked + off / 16, buf, n * 4, hipMemcpyHostToDevice, st) != hipSuccess
+                  || hipEventRecord (gUp.done[p & 1], st) != hipSuccess) failed = 1;
+            }
+        }
+    };
+  std::vector<std::thread> th;
+  for (int t = 1 ; t < T ; ++t) th.emplace_back (work, t);
+  work (0);
+  for (auto &x : th) x.join ();
+  pthread_barrier_destroy (&bar);
+  if (failed) return mgHipFail (hipGetLastError (), "mgUploadPack");
   MG_HIP (hipStreamSynchronize (st));
-  (void) hipEventDestroy (done[0]); (void) hipEventDestroy (done[1]);
-  (void) hipFree (dStage[0]); if (dStage[1]) (void) hipFree (dStage[1]);
-  return s;
+  return MG_OK;
 }
 
 extern "C" int64_t seqhashScanBatch (const Seqhash *sh, const char *bases, const int64_t *readOffsets, int nReads,
@@ -873,23 +916,41 @@ extern "C" MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 tot
 /* ---------------------------------------------------------------------------------------- */
 /* host-buffer mirrors of the reference callers' loops                                        */
 
+/* grow-only device buffers for the host-buffer entry points (a hipMalloc + hipFree of a gigabyte per call costs
+ * milliseconds): the packed reads and their offsets of the batch in flight */
+static struct MgHostBatchBufs { U32 *dP = 0; size_t words = 0; U64 *dOff = 0; size_t offs = 0; std::mutex lock; } gHb;
+static double mgNowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads)
 {
   if (mgEnsureDevice ()) return -1;
   if (nReads <= 0) return 0;
+  static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_UPLOAD_TIMING"); timing = e && *e == '1'; }   /* dev */
+  std::lock_guard<std::mutex> g (gHb.lock);
   U64 total = (U64) readOffsets[nReads];
   size_t nw = mgPackedWords (total);
-  U32 *dP = 0; U64 *dOff = 0;
-  int64_t res = -1;
-  if (hipMalloc ((void **) &dP, nw * 4) == hipSuccess && hipMalloc ((void **) &dOff, ((size_t) nReads + 1) * 8) == hipSuccess
-      && mgUploadPack (bases, total, dP, 0) == MG_OK
-      && hipMemcpy (dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess)
-    { U64 nHash = 0;
-      if (mgAddReadsDevice (ms, dP, total, dOff, (U32) nReads, &nHash, 0) == MG_OK) res = (int64_t) nHash;
+  if (nw > gHb.words)
+    { if (gHb.dP) (void) hipFree (gHb.dP);
+      gHb.dP = 0; gHb.words = 0;
+      if (hipMalloc ((void **) &gHb.dP, (nw + nw / 8) * 4) != hipSuccess) { mgSetError ("mgAddSequenceBatch: device allocation failed"); return -1; }
+      gHb.words = nw + nw / 8;
     }
-  else mgSetError ("mgAddSequenceBatch: device allocation or copy failed");
-  if (dP) (void) hipFree (dP);
-  if (dOff) (void) hipFree (dOff);
+  if ((size_t) nReads + 1 > gHb.offs)
+    { if (gHb.dOff) (void) hipFree (gHb.dOff);
+      gHb.dOff = 0; gHb.offs = 0;
+      if (hipMalloc ((void **) &gHb.dOff, ((size_t) nReads + 1) * 2 * 8) != hipSuccess) { mgSetError ("mgAddSequenceBatch: device allocation failed"); return -1; }
+      gHb.offs = ((size_t) nReads + 1) * 2;
+    }
+  int64_t res = -1;
+  const double t0 = mgNowS ();
+  if (hipMemcpyAsync (gHb.dOff, readOffsets, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice, 0) == hipSuccess
+      && mgUploadPack (bases, total, gHb.dP, 0) == MG_OK)
+    { const double t1 = mgNowS ();
+      U64 nHash = 0;
+      if (mgAddReadsDevice (ms, gHb.dP, total, gHb.dOff, (U32) nReads, &nHash, 0) == MG_OK) res = (int64_t) nHash;
+      if (timing) fprintf (stderr, "mgAddSequenceBatch: %.3f Gbp  pack+upload %.2f ms  scan+build %.2f ms\n", total / 1e9, (t1 - t0) * 1e3, (mgNowS () - t1) * 1e3);
+    }
+  else mgSetError ("mgAddSequenceBatch: copy to the device failed");
   return res;
 }
 
