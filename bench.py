@@ -383,6 +383,12 @@ def gpu_rank(args):
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(cx, reads, offsets, k, d, seed)
 
+    if rank == 0 and world == 1 and not multi and not args.no_cpu:
+        try:
+            out["end_to_end"] = end_to_end(cx, reads, offsets, k, d, seed)
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)[:300]}
+
     L.modsetDestroy(ms)
     del reads, d_offsets
     torch.cuda.empty_cache()
@@ -486,29 +492,36 @@ def bench_c3(cx, args):
     torch.cuda.empty_cache()
 
     qcap = int(batch / d * 1.3) + (1 << 16)
-    q_idx = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
     q_pos = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
     q_rd = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
-    L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
-    tot_bases = tot_seeds = tot_hits = 0
-    t_query = 0.0
-    per = []
+    # all query batches are generated first (22 GB of packed reads in HBM) and then queried back to back, as a
+    # streaming caller would: nothing else touches the GPU or keeps the host busy between two timed calls
+    batches = []
     for b in range(n_batches):
         reads, d_offsets, offsets, n_reads = make_reads(cx, batch, genome, genome_bases, 4000 + b, 0.05, 5000 + b)
-        if b == 0:                                               # warm-up of the arena and the kernels, untimed
-            mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
-                                          q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
-            torch.cuda.synchronize()
-            L.mgProfileReset()
-        torch.cuda.synchronize()
+        batches.append((reads, d_offsets, n_reads, torch.empty(qcap, dtype=torch.int32, device=cx.dev)))
+    L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
+    reads, d_offsets, n_reads, q_idx = batches[0]                # warm-up of the arena and the kernels, untimed
+    mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
+                                  q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
+    torch.cuda.synchronize()
+    L.mgProfileReset()
+    tot_bases = tot_seeds = tot_hits = 0
+    per, seeds_each = [], []
+    torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    for reads, d_offsets, n_reads, q_idx in batches:
         t0 = time.perf_counter()
         mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
                                       q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
-        torch.cuda.synchronize()
-        t_query += time.perf_counter() - t0; per.append(round((time.perf_counter() - t0) * 1e3, 2))
+        per.append(round((time.perf_counter() - t0) * 1e3, 2))      # the call returns when its seeds are complete (it synchronises)
+        seeds_each.append(n_seeds.value)
         tot_bases += batch; tot_seeds += n_seeds.value
-        tot_hits += int((q_idx[:n_seeds.value] != 0).sum().item())
-        del reads, d_offsets
+    torch.cuda.synchronize()
+    t_query = time.perf_counter() - t_all
+    for (reads, d_offsets, n_reads, q_idx), ns in zip(batches, seeds_each):
+        tot_hits += int((q_idx[:ns] != 0).sum().item())
+    del batches, reads, d_offsets, q_idx
     table = read_profile(L, mg)
     L.mgProfileEnable(0)
     per_batch = {kname: (v[0] / n_batches, 1, v[2]) for kname, v in table.items()}
@@ -528,12 +541,75 @@ def bench_c3(cx, args):
                            "note": "0.25 B/base read + per seed: 12 B written by the scan + 24 B lookup (kmer 8, one 16-byte slot, wait index 4 out)"},
            "roofline": roofline_of(kern, per_batch, alg, "c3")}
     L.modsetDestroy(ms)
-    del genome, q_idx, q_pos, q_rd
+    del genome, q_pos, q_rd
     torch.cuda.empty_cache()
     return res
 
 
 # ------------------------------------------------------------------------------------------------
+
+def end_to_end(cx, reads, offsets, k, d, seed):
+    """PCIe- and parser-inclusive rates of the host entry points on a sample of the same reads (never `value`):
+    mgAddSequenceBatch from host bytes (one base per byte, as the reference's iterator takes them: packed to 2 bits on the
+    host, pinned staging, H2D, scan, build) and mgAddSequenceFile from an 80-column FASTA file in /dev/shm (parse pool
+    -> pack -> H2D -> scan -> build, the next batch parsed while the GPU works on the current one)."""
+    import numpy as np
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    res = {}
+    want = int(float(os.environ.get("MODGPU_E2E_GBP", "2")) * 1e9)
+    n = max(1, min(int(np.searchsorted(offsets, want, side="right")) - 1, len(offsets) - 1))
+    nb = int(offsets[n])
+    d_bytes = torch.empty(nb, dtype=torch.uint8, device=cx.dev)
+    mg.check(L.mgUnpackDevice(reads.data_ptr(), nb, d_bytes.data_ptr(), cx.stream))
+    torch.cuda.synchronize()
+    h = d_bytes.cpu().numpy(); del d_bytes
+    off = offsets[:n + 1].astype(np.int64)
+    sh = mg.seqhashCreate(k, d, seed); ms = mg.modsetCreate(sh, 28)
+    best = None
+    for it in range(3):                                   # the first call sets up the pinned staging and the device buffers
+        mg.check(L.mgModsetClear(ms, None))
+        t0 = time.perf_counter()
+        nh = L.mgAddSequenceBatch(ms, h.ctypes.data, off.ctypes.data, n)
+        dt = time.perf_counter() - t0
+        if nh < 0:
+            raise RuntimeError(L.mgLastError().decode())
+        if it:
+            best = dt if best is None else min(best, dt)
+    res["host_bytes"] = {"entry": "mgAddSequenceBatch", "Gbp_per_s": round(nb / best / 1e9, 1), "bases": nb,
+                         "what": "1 byte per base in pageable host memory -> 2-bit pack on host threads -> pinned staging -> H2D -> scan -> build"}
+    # FASTA file, 80 columns, of the first ~1 Gbp
+    m = max(1, min(int(np.searchsorted(offsets, want // 2, side="right")) - 1, n))
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(shm, "modgpu_e2e_%d.fa" % os.getpid())
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    try:
+        with open(path, "wb") as f:
+            for r in range(m):
+                s_ = letters[h[int(off[r]):int(off[r + 1])]]
+                pad = (-len(s_)) % 80
+                t_ = np.concatenate([s_, np.zeros(pad, np.uint8)]).reshape(-1, 80)
+                t_ = np.concatenate([t_, np.full((len(t_), 1), 10, np.uint8)], axis=1).ravel()
+                f.write(b">r%d\n" % r); f.write(t_[t_ != 0].tobytes())
+        fb = int(off[m])
+        best = None
+        for it in range(3):
+            mg.check(L.mgModsetClear(ms, None))
+            t0 = time.perf_counter()
+            with mg.CFile(os.devnull, "w") as fo:
+                rc = L.mgAddSequenceFile(ms, path.encode(), fo)
+            dt = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError("mgAddSequenceFile failed")
+            if it:
+                best = dt if best is None else min(best, dt)
+        res["fasta_file"] = {"entry": "mgAddSequenceFile", "Gbp_per_s": round(fb / best / 1e9, 2), "bases": fb, "file_bytes": os.path.getsize(path),
+                             "what": "80-column FASTA in the page cache -> parser threads -> pack -> H2D -> scan -> build"}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    L.modsetDestroy(ms)
+    return res
+
 
 def cpu_baseline(cx, reads, offsets, k, d, seed):
     """The reference's own C path (oracle/_ref/ref_bench, built from the unmodified sources) timed

@@ -441,6 +441,8 @@ extern "C" int mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U6
 struct MgDev {
   MgTable t;
   MgArena arena;
+  U64 *hPin;               /* pinned host words the per-call counters come back into: a device-to-host copy into pageable memory
+                              goes through the runtime's staging path, whose wake-up was seen to take 10 - 25 ms now and then */
   U32 hostIndexMax;        /* entries 1..hostIndexMax are present in the host index[] table */
   bool built;
 };
@@ -455,6 +457,7 @@ static MgDev *mgDevLookup (const Modset *ms)
 static void mgDevFree (MgDev *d)
 {
   if (!d) return;
+  if (d->hPin) (void) hipHostFree (d->hPin);
   if (d->built)
     { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
       (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters); (void) hipFree (d->t.liveHist);
@@ -503,7 +506,8 @@ static MgStatus mgDevGet (Modset *ms, MgDev **out, hipStream_t st)
   if ((s = mgCheckHasher (ms->hasher))) return s;
   MgDev *d = mgDevLookup (ms);
   if (!d)
-    { d = new MgDev (); d->built = false; d->hostIndexMax = 0;
+    { d = new MgDev (); d->built = false; d->hostIndexMax = 0; d->hPin = 0;
+      if (hipHostMalloc ((void **) &d->hPin, 256, hipHostMallocDefault) != hipSuccess) { delete d; return mgHipFail (hipGetLastError (), "hipHostMalloc"); }
       if ((s = mgDevBuild (ms, d, st))) { mgDevFree (d); return s; }
       std::lock_guard<std::mutex> g (gRegLock); gReg[ms] = d; mgLiveDeviceModsets = (int) gReg.size ();
     }
@@ -709,8 +713,8 @@ static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
   MgStatus s;
   MG_HIP (hipMemsetAsync (t.counters, 0, 16, st));
   if ((s = mgTableAdd (&t, dKmer, n, withDepth, scratch, st, counted))) return s;
-  U64 c[2];
-  MG_HIP (hipMemcpyAsync (c, t.counters, 16, hipMemcpyDeviceToHost, st));
+  volatile U64 *c = d->hPin;
+  MG_HIP (hipMemcpyAsync (d->hPin, t.counters, 16, hipMemcpyDeviceToHost, st));
   MG_HIP (hipStreamSynchronize (st));
   U64 newMax = (U64) t.max + c[0];
   if (c[1] || newMax >= t.size)
@@ -853,8 +857,8 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
         }
       if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
                              b->counted.binCount ? &b->counted : 0))) return s;
-      U64 c[MG_COUNT_WORDS];
-      MG_HIP (hipMemcpyAsync (c, b->count, sizeof (c), hipMemcpyDeviceToHost, st));
+      volatile U64 *c = d->hPin + 8;
+      MG_HIP (hipMemcpyAsync (d->hPin + 8, b->count, MG_COUNT_WORDS * sizeof (U64), hipMemcpyDeviceToHost, st));
       MG_HIP (hipStreamSynchronize (st));
       if (!c[1] && c[0] <= cap) { *nOut = c[0]; return MG_OK; }
       cap = c[3];
@@ -887,8 +891,11 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (nSeeds) *nSeeds = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
+  static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_SEED_TIMING"); timing = e && *e == '1'; }   /* dev */
+  struct timespec q0, q1, q2; if (timing) clock_gettime (CLOCK_MONOTONIC, &q0);
   if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st,
                             dSeedPosF, dSeedRead, capacity))) return s;
+  if (timing) clock_gettime (CLOCK_MONOTONIC, &q1);
   if (nSeeds) *nSeeds = n;
   if (n > capacity)
     { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
@@ -898,6 +905,11 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (dSeedPosF && b.posF != dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));
   if (dSeedRead && b.rid != dSeedRead) MG_HIP (hipMemcpyAsync (dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st));
   MG_HIP (hipStreamSynchronize (st));
+  if (timing)
+    { clock_gettime (CLOCK_MONOTONIC, &q2);
+      fprintf (stderr, "mgSeedReads: scan+count %.2f ms, lookup+sync %.2f ms\n", (q1.tv_sec - q0.tv_sec) * 1e3 + (q1.tv_nsec - q0.tv_nsec) * 1e-6,
+               (q2.tv_sec - q1.tv_sec) * 1e3 + (q2.tv_nsec - q1.tv_nsec) * 1e-6);
+    }
   return MG_OK;
 }
 

@@ -1,10 +1,8 @@
 #!/bin/bash
-# dev: time prebuilt library variants (tools/variants/*.so) with the bench, interleaved
-cp modimizer_amd/libmodgpu.so /tmp/libmodgpu.keep
+# dev: time prebuilt library variants (tools/variants/<name>/libmodgpu.so, chosen with MODGPU_LIB) with the bench,
+# interleaved on one box (boxes differ by a few per cent).  usage: ab_variants.sh [bench env assignments...]
 for rep in 1 2 3; do
-for f in tools/variants/*.so; do
-  cp $f modimizer_amd/libmodgpu.so
-  python bench.py --steps 5 --warmup 1 --no-cpu 2>/dev/null | python tools/kern_ms.py "$(basename $f)" | grep -o "^.*ms/step\|'mgBucket[A-Za-z]*': [0-9.]*\|'mgPartScatterKernel': [0-9.]*" | tr '\n' ' '; echo
+for d in tools/variants/*/; do
+  env "$@" MODGPU_LIB=$PWD/${d}libmodgpu.so python bench.py --steps 5 --warmup 1 --no-cpu --no-other 2>/dev/null | python tools/kern_ms.py "$(basename $d)" | grep -o "^.*ms/step\|'mgBucket[A-Za-z]*': [0-9.]*\|'mgPartScatterKernel': [0-9.]*\|'mgScanKernel': [0-9.]*" | tr '\n' ' '; echo
 done
 done
-cp /tmp/libmodgpu.keep modimizer_amd/libmodgpu.so
