@@ -167,7 +167,7 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
         { const U64 o = (row + j) * 64 + lane;
           const bool in = (row + j < rEnd) && (o < n);
           f[j] = in && (flags[o] & 1);
-          km[j] = in ? kmer[o] : 0;
+          km[j] = in ? __builtin_nontemporal_load (&kmer[o]) : 0;
         }
 #pragma unroll
       for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
@@ -178,7 +178,7 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
           if (f[j])
             { U64 idx = (U64) baseMax + 1 + run + (U32) __popcll (bits & below);
               if (idx < size)
-                { value[idx] = km[j];
+                { __builtin_nontemporal_store (km[j], &value[idx]);
                   if (DIRECT) slots[slotId[o]].ord = (U32) idx | MG_ASSIGNED;
                 }
             }
@@ -671,7 +671,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   U64 ck[MG_BUCKET_PREFETCH]; U32 ct[MG_BUCKET_PREFETCH];
 #pragma unroll
   for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (i < hi) { ck[j] = a.pK[i]; if (!PACKED) ct[j] = a.pT[i]; } }
+    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (i < hi) { ck[j] = __builtin_nontemporal_load (&a.pK[i]); if (!PACKED) ct[j] = __builtin_nontemporal_load (&a.pT[i]); } }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
     { /* fetch the next bucket while this one is processed */
@@ -685,7 +685,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           occNext = a.occ[b + 1];
 #pragma unroll
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-            { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = a.pK[i]; if (!PACKED) nt[j] = a.pT[i]; } }
+            { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = __builtin_nontemporal_load (&a.pK[i]); if (!PACKED) nt[j] = __builtin_nontemporal_load (&a.pT[i]); } }
         }
       if (hi == lo) { if (tid == 0) a.uniqCount[b] = 0; }
       else
@@ -728,7 +728,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               base = (U32) __shfl ((int) base, 0);
               if (emit)
                 { const U32 at = base + (U32) __popcll (m & (((U64) 1 << lane) - 1));
-                  a.pK[lo + at] = k - 1; a.pT[lo + at] = ord; a.pC[lo + at] = c;
+                  __builtin_nontemporal_store ((U64) (k - 1), &a.pK[lo + at]); __builtin_nontemporal_store (ord, &a.pT[lo + at]); __builtin_nontemporal_store (c, &a.pC[lo + at]);
                   if (!mgIsAssigned (ord) MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - ord] = 1;
                 }
             }
@@ -762,13 +762,13 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   U32 occNow = a.occ[b];                          /* one bucket ahead, like the counts */
   U64 lo = a.bucketStart[b];
   U64 ck = 0; U32 co = 0, cc = 0;
-  if (tid < nu) { ck = a.pK[lo + tid]; co = a.pT[lo + tid]; cc = a.pC[lo + tid]; }
+  if (tid < nu) { ck = __builtin_nontemporal_load (&a.pK[lo + tid]); co = __builtin_nontemporal_load (&a.pT[lo + tid]); cc = __builtin_nontemporal_load (&a.pC[lo + tid]); }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
     { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0, occNext = 0;
       if (b + 1 < bEnd)
         { nnu = a.uniqCount[b + 1]; nlo = a.bucketStart[b + 1]; occNext = a.occ[b + 1];
-          if (tid < nnu) { nk = a.pK[nlo + tid]; no = a.pT[nlo + tid]; ncc = a.pC[nlo + tid]; }
+          if (tid < nnu) { nk = __builtin_nontemporal_load (&a.pK[nlo + tid]); no = __builtin_nontemporal_load (&a.pT[nlo + tid]); ncc = __builtin_nontemporal_load (&a.pC[nlo + tid]); }
         }
       if (nu)
         { /* the rank record of this lane's first unique: in flight while the bucket image is set up */
@@ -786,7 +786,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           for (U32 i = tid ; i < nu ; i += T)
             { U64 km; U32 ord, c;
               if (i == tid) { km = ck; ord = co; c = cc; }
-              else { km = a.pK[lo + i]; ord = a.pT[lo + i]; c = a.pC[lo + i]; }
+              else { km = __builtin_nontemporal_load (&a.pK[lo + i]); ord = __builtin_nontemporal_load (&a.pT[lo + i]); c = __builtin_nontemporal_load (&a.pC[lo + i]); }
               if (!a.withDepth) c = 0;
               U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
               if (at == R) { a.counters[1] = 1; continue; }
