@@ -556,7 +556,7 @@ def end_to_end(cx, reads, offsets, k, d, seed):
     import numpy as np
     torch, L, mg = cx.torch, cx.L, cx.mg
     res = {}
-    want = int(float(os.environ.get("MODGPU_E2E_GBP", "2")) * 1e9)
+    want = int(float(os.environ.get("MODGPU_E2E_GBP", "4")) * 1e9)
     n = max(1, min(int(np.searchsorted(offsets, want, side="right")) - 1, len(offsets) - 1))
     nb = int(offsets[n])
     d_bytes = torch.empty(nb, dtype=torch.uint8, device=cx.dev)
