@@ -651,6 +651,12 @@ typedef struct {
 /* ---- the byte-crunching inner loops, with AVX2 where the CPU has it ----
  * (the plain C loops below do not get vectorised by the compiler: 0.9 GB/s per core; the explicit ones run at 7) */
 #include <immintrin.h>
+static int haveAvx2 (void)                       /* MODGPU_NO_AVX2=1 (tests): the portable loops */
+{
+  static int v = -1;
+  if (v < 0) { const char *e = getenv ("MODGPU_NO_AVX2"); v = (e && *e == '1') ? 0 : (__builtin_cpu_supports ("avx2") ? 1 : 0); }
+  return v;
+}
 static size_t countKept (const unsigned char *s, const unsigned char *e)      /* bytes convTable keeps */
 {
   size_t n = 0;
@@ -699,8 +705,7 @@ static void countAvx2 (const unsigned char *s, const unsigned char *e, size_t *k
 /* what a unit keeps and how many lines it holds, in ONE pass over its text */
 static void countKeptAndLines (const unsigned char *s, const unsigned char *e, size_t *kept, size_t *lines)
 {
-  static int avx2 = -1; if (avx2 < 0) avx2 = __builtin_cpu_supports ("avx2") ? 1 : 0;
-  if (avx2) countAvx2 (s, e, kept, lines); else countScalar (s, e, kept, lines);
+  if (haveAvx2 ()) countAvx2 (s, e, kept, lines); else countScalar (s, e, kept, lines);
 }
 
 /* A stretch of text without a line end -> bases, optimistically: ((c >> 1) ^ (c >> 2)) & 3 sends A C G T to 0 1 2 3 and
@@ -740,8 +745,7 @@ static int convScalar (const unsigned char *s, char *t, size_t len, int keepOthe
 }
 static int convStretch (const unsigned char *s, char *t, size_t len, int keepOthers)
 {
-  static int avx2 = -1; if (avx2 < 0) avx2 = __builtin_cpu_supports ("avx2") ? 1 : 0;
-  return avx2 ? convAvx2 (s, t, len, keepOthers) : convScalar (s, t, len, keepOthers);
+  return haveAvx2 () ? convAvx2 (s, t, len, keepOthers) : convScalar (s, t, len, keepOthers);
 }
 
 static void *worker (void *arg)

@@ -167,3 +167,18 @@ def test_fasta_reader_matches_seqio_conventions(golden_dir):
     assert names[-3:] == ["short", "exact21", "withN"] and offs[-1] == len(bases) and bases.max() <= 3
     assert offs[-1] - offs[-2] == 109          # Ns kept (as base 0), nothing dropped
     assert list(bases[offs[-2]:offs[-2] + 12]) == [0, 1, 2, 3, 0, 0, 0, 0, 0, 1, 2, 3]
+
+
+def test_pack_host_matches_the_word_layout():
+    """mgPackHost (AVX2 and portable loops): base i in bits [30-2(i%16), 32-2(i%16)) of word i/16, only the low two bits of
+    a byte count (FASTQ keeps other bytes as 0xFE), MG_PACK_PAD zero words follow"""
+    code = ("import sys, numpy as np\nsys.path.insert(0, 'ROOTDIR')\nimport modimizer_amd as mg\nrng = np.random.default_rng(4)\n"
+            "for n in list(range(0, 70)) + [127, 128, 129, 255, 256, 257, 1000, 4097, 65536 + 5]:\n"
+            "    b = rng.integers(0, 256, n).astype(np.uint8)\n    w = mg.pack_host(b)\n"
+            "    ref = np.zeros(len(w), np.uint32)\n"
+            "    for i in range(n): ref[i // 16] |= np.uint32((int(b[i]) & 3) << (30 - 2 * (i % 16)))\n"
+            "    assert np.array_equal(w, ref), n\n    assert len(w) == (n + 15) // 16 + 8\nprint('ok')").replace("ROOTDIR", ROOT)
+    for no in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                           env=dict(os.environ, MODGPU_NO_TORCH="1", MODGPU_NO_AVX2=no))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]

@@ -289,3 +289,19 @@ def test_modmap_from_files_gpu(tag, golden_dir, tmp_path):
     want = util.golden_text("modmap_%s.stdout.txt" % tag).splitlines()[1:]      # without the "initialised" line
     assert open(out).read().splitlines() == want
     L.mgReferenceDestroy(ref)
+
+
+@pytest.mark.parametrize("fname", ["mixed.fa", "mixed.fq", "many.fa", "unterminated.fa"])
+def test_portable_loops_equal_the_avx2_ones(fname, golden_dir):
+    """MODGPU_NO_AVX2=1 (a fresh process: the choice is made once) parses every golden text file to the same records"""
+    code = ("import sys, os, hashlib, numpy as np\nsys.path.insert(0, %r)\nfrom tests.test_seqio import parse_file\n"
+            "names, seqs = parse_file(%r, 5000, 3)\nh = hashlib.sha256()\n"
+            "[h.update(n.encode() + b'|' + s.tobytes() + b';') for n, s in zip(names, seqs)]\nprint(len(seqs), h.hexdigest())"
+            % (util.ROOT, os.path.join(golden_dir, fname)))
+    outs = []
+    for no in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=util.ROOT,
+                           env=dict(os.environ, MODGPU_NO_TORCH="1", MODGPU_NO_AVX2=no))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and int(outs[0].split()[0]) > 0
