@@ -168,6 +168,7 @@ def alg_bytes_table(total, S, entries, d, slots):
         "mgPartScatterKernel": 24.0 * S,             # (kmer 8 + ordinal 4) read and written, per pass
         "mgBucketDedupKernel": 12.0 * S + 16.0 * entries,
         "mgRankAssignKernel": 9.0 * S + 8.0 * entries,
+        "mgRankLookupKernel": 8.0 * entries,         # a unique's ordinal read, its index written
         "mgBucketMergeKernel": 16.0 * entries + 16.0 * slots,   # uniques in, table buckets out
         "mgTableInsertKernel": 16.0 * S,
         "mgTableFindKernel": 24.0 * S,               # kmer 8 read + one 16-byte slot probed + (index) 4 written ~ SURVEY's 24*S

@@ -606,10 +606,15 @@ struct MgBucketArgs {
   U32 *occ;                        /* [NB] entries per bucket */
   unsigned char *flags;            /* [n] first occurrence of a k-mer new to the table */
   const MgRankGrp *grp; U32 baseMax; U32 size;
+  /* a bucket's uniques leave the dedup kernel grouped by the SLICE of the ordinal range their first occurrence lies in
+     (groups 0..nSlices-1: new k-mers of slice tok >> sliceShift; group nSlices: k-mers the table already holds), so that
+     the rank lookups can run slice by slice against a piece of the rank records that stays in the L2 */
+  unsigned short *sliceOff;        /* [NB x (nSlices + 2)]: start of group g in bucket b's list; [nSlices + 1] = the list's length */
+  U32 nSlices; int sliceShift;
   int withDepth;
   U64 *counters;
 #ifdef MG_ABLATE
-  int debug;                       /* ablation builds only (MODGPU_BUCKET_DEBUG): 1 = no flag stores; results are wrong */
+  int debug;                       /* ablation builds only (MODGPU_BUCKET_DEBUG): dedup: 1 no flag stores, 2 plain stores for max/add, 4 no claim loop, 8 no list stores; merge: 32 no claim loop, 64 no image stores; lookup: 16 no rank gathers, 128 no index stores, 256 no ordinal loads; results are wrong */
 #endif
   unsigned long long *liveHist;    /* != 0: the merge kernel also counts the final depths of the entries it writes */
 };
@@ -638,6 +643,8 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
  * bucket is processed, and the LDS image is kept all-zero between buckets by clearing exactly the
  * slots the closing sweep visits (no 64 KiB re-zeroing per bucket). */
 #define MG_BUCKET_PREFETCH 2
+#define MG_RANK_GROUPS 64            /* most groups a bucket's list is cut into: slices of the ordinal range + 1 */
+#define MG_DEDUP_PER 4               /* slots of the LDS image per thread of the dedup kernel: R <= 4 x threads */
 #define MG_LIVE_BINS 256              /* depths below this are counted in LDS by the merge kernel's live histogram */
 
 /* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
@@ -653,19 +660,20 @@ __device__ __forceinline__ void mgOccurrence (const MgBucketArgs &a, U32 b, U64 
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__ (1024)
+__global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (8)))      /* 64 registers: two workgroups per CU */
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
   const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
   unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
   U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
   U32 *sCnt = sOrd + R;
-  U32 &sN = *(sCnt + R);
+  U32 *sGrp = sCnt + R;                            /* [MG_RANK_GROUPS] members of each group of the bucket's list */
+  const U32 nGrp = a.nSlices + 1;
   U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
   if (bEnd > a.nBuckets) bEnd = a.nBuckets;
   if (b >= bEnd) return;
   for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
-  if (tid == 0) sN = 0;
+  if (tid < MG_RANK_GROUPS) sGrp[tid] = 0;
   U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
   U32 occNow = a.occ[b];                          /* fetched one bucket ahead like the bounds: it gates a branch */
   U64 ck[MG_BUCKET_PREFETCH]; U32 ct[MG_BUCKET_PREFETCH];
@@ -687,7 +695,10 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
             { U64 i = nlo + (U64) j * T + tid; if (i < nhi) { nk[j] = __builtin_nontemporal_load (&a.pK[i]); if (!PACKED) nt[j] = __builtin_nontemporal_load (&a.pT[i]); } }
         }
-      if (hi == lo) { if (tid == 0) a.uniqCount[b] = 0; }
+      if (hi == lo)
+        { if (tid == 0) a.uniqCount[b] = 0;
+          if (tid < nGrp + 1) a.sliceOff[(U64) b * (nGrp + 1) + tid] = 0;
+        }
       else
         { if (occNow)
             { for (U32 i = tid ; i < R ; i += T)
@@ -700,40 +711,74 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
             if (lo + (U64) j * T + tid < hi)
               { U64 m; U32 ord; mgOccurrence<PACKED> (a, b, ck[j], ct[j], &m, &ord);
-                U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+                U32 at;
+#ifdef MG_ABLATE
+                if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
+#endif
+                at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
                 if (at == R) a.counters[1] = 1;
+#ifdef MG_ABLATE
+                else if (a.debug & 2) { sOrd[at] = mgToken (ord); sCnt[at] = 1; }
+#endif
                 else { atomicMax (&sOrd[at], mgToken (ord)); atomicAdd (&sCnt[at], 1u); }
               }
           for (U64 i = lo + (U64) MG_BUCKET_PREFETCH * T + tid ; i < hi ; i += T)
             { U64 m; U32 ord; mgOccurrence<PACKED> (a, b, a.pK[i], PACKED ? 0u : a.pT[i], &m, &ord);
-              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+              U32 at;
+#ifdef MG_ABLATE
+              if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
+#endif
+              at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
               if (at == R) { a.counters[1] = 1; continue; }
+#ifdef MG_ABLATE
+              if (a.debug & 2) { sOrd[at] = mgToken (ord); sCnt[at] = 1; continue; }
+#endif
               atomicMax (&sOrd[at], mgToken (ord));              /* assigned entries (bit 31) stay as they are */
               atomicAdd (&sCnt[at], 1u);
             }
           __syncthreads ();
-          /* whole waves sweep together: a wave reserves room for its uniques with ONE add on the list counter
-             (a thousand lanes adding 1 to the same LDS word serialise) */
-          for (U32 i0 = 0 ; i0 < R ; i0 += T)
-            { const U32 i = i0 + tid;
-              unsigned long long k = i < R ? sKey[i] : 0;
-              U32 c = 0, ord = 0;
-              if (k) { c = sCnt[i]; ord = sOrd[i]; sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }   /* leave the image clean for the next bucket */
-              const bool emit = k && c;
-              const U64 m = __ballot (emit);
-              if (!m) continue;                                    /* uniform */
-              const int lane = tid & 63;
-              U32 base = 0;
-              if (lane == 0) base = atomicAdd (&sN, (U32) __popcll (m));
-              base = (U32) __shfl ((int) base, 0);
-              if (emit)
-                { const U32 at = base + (U32) __popcll (m & (((U64) 1 << lane) - 1));
-                  __builtin_nontemporal_store ((U64) (k - 1), &a.pK[lo + at]); __builtin_nontemporal_store (ord, &a.pT[lo + at]); __builtin_nontemporal_store (c, &a.pC[lo + at]);
-                  if (!mgIsAssigned (ord) MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - ord] = 1;
+          /* the uniques leave grouped (see MgBucketArgs).  Every thread takes its slots of the image into registers
+             (clearing them for the next bucket) and counts the groups' members -- a unique's place inside its group is
+             what the add returns; the counts become places in the list; the entries go back into the (now free) LDS
+             arrays in list order, and leave from there with coalesced stores */
+          unsigned long long rk[MG_DEDUP_PER]; U32 rc[MG_DEDUP_PER], ro[MG_DEDUP_PER], rp[MG_DEDUP_PER];
+#pragma unroll
+          for (int j = 0 ; j < MG_DEDUP_PER ; ++j)
+            { const U32 i = (U32) j * T + tid;
+              rk[j] = 0; rc[j] = 0; ro[j] = 0; rp[j] = 0;
+              if (i < R) rk[j] = sKey[i];
+              if (rk[j])
+                { rc[j] = sCnt[i]; ro[j] = sOrd[i];
+                  sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;
+                  if (rc[j]) rp[j] = atomicAdd (&sGrp[mgIsAssigned (ro[j]) ? a.nSlices : ((0x7fffffffu - ro[j]) >> a.sliceShift)], 1u);
                 }
             }
           __syncthreads ();
-          if (tid == 0) { a.uniqCount[b] = sN; sN = 0; }
+          const int lane = (int) (tid & 63);
+          const U32 gv = (U32) lane < nGrp ? sGrp[lane] : 0;            /* every wave scans the counts for itself */
+          const U32 gIncl = mgWaveInclusiveSum (gv);
+          const U32 gBase = gIncl - gv;
+          const U32 total = (U32) __builtin_amdgcn_readlane ((int) gIncl, 63);
+          if (tid < 64)
+            { if ((U32) lane <= nGrp) a.sliceOff[(U64) b * (nGrp + 1) + lane] = (unsigned short) gBase;     /* [nGrp]: the list's length */
+              if (lane == 0) a.uniqCount[b] = total;
+            }
+#pragma unroll
+          for (int j = 0 ; j < MG_DEDUP_PER ; ++j)
+            { const U32 grp = mgIsAssigned (ro[j]) ? a.nSlices : ((0x7fffffffu - ro[j]) >> a.sliceShift);
+              const U32 at = (U32) __shfl ((int) gBase, (int) (rc[j] ? grp : 0)) + rp[j];
+              if (rc[j]) { sKey[at] = rk[j] - 1; sOrd[at] = ro[j]; sCnt[at] = rc[j]; }
+            }
+          __syncthreads ();
+          if (tid < MG_RANK_GROUPS) sGrp[tid] = 0;
+          for (U32 i = tid ; i < total ; i += T)
+            { const U64 k = sKey[i]; const U32 ord = sOrd[i], c = sCnt[i];
+              sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;
+              if (true MG_ABLATE_AND (!(a.debug & 8)))
+                { __builtin_nontemporal_store (k, &a.pK[lo + i]); __builtin_nontemporal_store (ord, &a.pT[lo + i]); __builtin_nontemporal_store (c, &a.pC[lo + i]); }
+              if (!mgIsAssigned (ord) MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - ord] = 1;
+            }
+          __syncthreads ();
         }
       lo = nlo; hi = nhi; occNow = occNext;
 #pragma unroll
@@ -749,32 +794,29 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
   U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
   U32 *sCnt = sOrd + R;
-  U32 &sNew = *(sCnt + R);
   U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
   if (bEnd > a.nBuckets) bEnd = a.nBuckets;
   if (b >= bEnd) return;
   for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
-  if (tid == 0) sNew = 0;
-  U32 *sLive = sCnt + R + 4;                       /* MG_LIVE_BINS small-depth bins (behind sNew) */
+  U32 *sLive = sCnt + R + 4;                       /* MG_LIVE_BINS small-depth bins */
   for (U32 i = tid ; i < MG_LIVE_BINS ; i += T) sLive[i] = 0;
   U32 n1 = 0, n2 = 0;                              /* depth 1 and 2, the commonest, counted per wave */
   U32 nu = a.uniqCount[b];
+  U32 nNew = a.sliceOff[(U64) b * (a.nSlices + 2) + a.nSlices];   /* the list's first nNew uniques are new to the table, the others are in it */
   U32 occNow = a.occ[b];                          /* one bucket ahead, like the counts */
   U64 lo = a.bucketStart[b];
   U64 ck = 0; U32 co = 0, cc = 0;
   if (tid < nu) { ck = __builtin_nontemporal_load (&a.pK[lo + tid]); co = __builtin_nontemporal_load (&a.pT[lo + tid]); cc = __builtin_nontemporal_load (&a.pC[lo + tid]); }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
-    { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0, occNext = 0;
+    { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0, occNext = 0, nNewNext = 0;
       if (b + 1 < bEnd)
         { nnu = a.uniqCount[b + 1]; nlo = a.bucketStart[b + 1]; occNext = a.occ[b + 1];
+          nNewNext = a.sliceOff[(U64) (b + 1) * (a.nSlices + 2) + a.nSlices];
           if (tid < nnu) { nk = __builtin_nontemporal_load (&a.pK[nlo + tid]); no = __builtin_nontemporal_load (&a.pT[nlo + tid]); ncc = __builtin_nontemporal_load (&a.pC[nlo + tid]); }
         }
       if (nu)
-        { /* the rank record of this lane's first unique: in flight while the bucket image is set up */
-          uint4 gv = make_uint4 (0, 0, 0, 0);
-          const bool isNew0 = tid < nu && !mgIsAssigned (co);
-          if (isNew0) gv = *reinterpret_cast<const uint4 *> (&a.grp[(0x7fffffffu - co) >> 6]);
+        {
           if (occNow)
             { for (U32 i = tid ; i < R ; i += T)
                 { uint4 v = *reinterpret_cast<const uint4 *> (&a.slots[(U64) b * R + i]);
@@ -782,32 +824,21 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 }
               __syncthreads ();
             }
-          U32 myNew = 0;
+          /* the rank lookup kernel has turned the new uniques' ordinals into indices: place and count */
           for (U32 i = tid ; i < nu ; i += T)
             { U64 km; U32 ord, c;
               if (i == tid) { km = ck; ord = co; c = cc; }
               else { km = __builtin_nontemporal_load (&a.pK[lo + i]); ord = __builtin_nontemporal_load (&a.pT[lo + i]); c = __builtin_nontemporal_load (&a.pC[lo + i]); }
               if (!a.withDepth) c = 0;
-              U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
+              U32 at;
+#ifdef MG_ABLATE
+              if (a.debug & 32) { at = mgHomeOfM (km, a.g); sKey[at] = km + 1; } else
+#endif
+              at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
               if (at == R) { a.counters[1] = 1; continue; }
-              if (mgIsAssigned (ord)) { if (c) atomicAdd (&sCnt[at], c); }
-              else
-                { U32 tok = 0x7fffffffu - ord;                    /* ordinal of the first occurrence */
-                  uint4 g4 = (i == tid) ? gv : *reinterpret_cast<const uint4 *> (&a.grp[tok >> 6]);
-                  U64 gbits = ((U64) g4.y << 32) | g4.x;
-                  U32 rank = g4.z + (U32) __popcll (gbits & (((U64) 1 << (tok & 63)) - 1));
-                  U64 idx = (U64) a.baseMax + 1 + rank;
-                  sOrd[at] = idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
-                  sCnt[at] = c;
-                  ++myNew;
-                }
+              if (i < nNew) { sOrd[at] = ord; sCnt[at] = c; }
+              else if (c) atomicAdd (&sCnt[at], c);
             }
-          /* new entries of the bucket: summed inside the wave first (one LDS add per wave, not per entry) */
-          { U32 v = myNew;
-#pragma unroll
-            for (int off = 32 ; off ; off >>= 1) v += (U32) __shfl_xor ((int) v, off);
-            if ((tid & 63) == 0 && v) atomicAdd (&sNew, v);
-          }
           __syncthreads ();
           for (U32 i0 = 0 ; i0 < R ; i0 += T)
             { const U32 i = i0 + tid;
@@ -817,6 +848,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                   uint4 v; v.x = (U32) k; v.y = (U32) (k >> 32); v.z = sOrd[i]; v.w = sCnt[i];
                   { typedef unsigned v4u __attribute__ ((ext_vector_type (4)));
                     v4u vv = { v.x, v.y, v.z, v.w };
+                    if (true MG_ABLATE_AND (!(a.debug & 64)))
                     asm volatile ("global_store_dwordx4 %0, %1, off nt" : : "v" (&a.slots[(U64) b * R + i]), "v" (vv) : "memory");   /* the 4.3 GB image is not read again this step: keep it out of the caches the rank records live in (2.58 -> 2.53 ms) */
                   }
                   dep = v.w > 0xffffu ? 0xffffu : v.w;
@@ -830,15 +862,71 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 }
             }
           __syncthreads ();
-          if (tid == 0 && sNew) { a.occ[b] += sNew; sNew = 0; }
+          if (tid == 0 && nNew) a.occ[b] += nNew;
         }
-      nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc; occNow = occNext;
+      nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc; occNow = occNext; nNew = nNewNext;
     }
   if (a.liveHist)
     { __syncthreads ();
       if ((tid & 63) == 0) { if (n1) atomicAdd (&sLive[1], n1); if (n2) atomicAdd (&sLive[2], n2); }
       __syncthreads ();
       for (U32 i = tid ; i < MG_LIVE_BINS ; i += T) if (sLive[i]) atomicAdd (&a.liveHist[i], (unsigned long long) sLive[i]);
+    }
+}
+
+/* step 3b: ordinal of the first occurrence -> index, for every new unique of every bucket's list, slice by slice.
+ * A wave takes 64 consecutive buckets' group s (one bucket per lane for the bounds, then list by list).  Workgroups
+ * b, b + 8, b + 16 ... are placed on one XCD (observed, MI355X_MICROARCH.md; it only matters for speed), and they
+ * take the slices x, x + 8, ... one after the other, so an XCD works on one slice at a time and reads its rank records
+ * (2^sliceShift / 4 bytes) from its own L2 instead of once per k-mer from the fabric (tools/ubench_rand: 240 G/s
+ * against 66 G/s at the whole structure's 39 MB). */
+#define MG_LOOKUP_UNROLL 4
+__global__ __launch_bounds__ (256)
+void mgRankLookupKernel (const MgBucketArgs a, U32 groupsPerSlice)
+{
+  const int lane = threadIdx.x & 63;
+  const U32 blocksPerSlice = (groupsPerSlice + 3) / 4;
+  const U32 xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const U32 s = xcd + 8 * (k / blocksPerSlice), g = (k % blocksPerSlice) * 4 + (threadIdx.x >> 6);
+  if (s >= a.nSlices || g >= groupsPerSlice) return;
+  const U32 b = g * 64 + (U32) lane;
+  U64 lo = 0; U32 n = 0;
+  if (b < a.nBuckets)
+    { const unsigned short *o = a.sliceOff + (U64) b * (a.nSlices + 2) + s;
+      const U32 o0 = o[0], o1 = o[1];
+      n = o1 - o0; lo = a.bucketStart[b] + o0;
+    }
+  auto indexOf = [&] (U32 tok, const uint4 &r) -> U32
+    { const U64 bits = ((U64) r.y << 32) | r.x;
+      const U64 idx = (U64) a.baseMax + 1 + r.z + (U32) __popcll (bits & (((U64) 1 << (tok & 63)) - 1));
+      return idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
+    };
+  /* MG_LOOKUP_UNROLL lists per round, all their loads in flight together.  (Fetching the next round's ordinals under
+     this round's gathers, or 8 lists per round, changes nothing: the kernel runs at the rate the CU's address unit
+     takes scattered lanes, tools/ubench_rand.) */
+  for (int j = 0 ; j < 64 ; j += MG_LOOKUP_UNROLL)
+    { U64 l[MG_LOOKUP_UNROLL]; U32 m[MG_LOOKUP_UNROLL], tok[MG_LOOKUP_UNROLL]; uint4 r[MG_LOOKUP_UNROLL];
+#pragma unroll
+      for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
+        { l[u] = ((U64) (U32) __shfl ((int) (U32) (lo >> 32), j + u) << 32) | (U32) __shfl ((int) (U32) lo, j + u);
+          m[u] = (U32) __shfl ((int) n, j + u);
+        }
+#pragma unroll
+      for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
+        { tok[u] = 0; if ((U32) lane < m[u] MG_ABLATE_AND (!(a.debug & 256))) tok[u] = 0x7fffffffu - __builtin_nontemporal_load (&a.pT[l[u] + lane]); }
+#pragma unroll
+      for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
+        { r[u] = make_uint4 (0, 0, 0, 0); if ((U32) lane < m[u] MG_ABLATE_AND (!(a.debug & 16))) r[u] = *reinterpret_cast<const uint4 *> (&a.grp[tok[u] >> 6]); }
+#pragma unroll
+      for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
+        if ((U32) lane < m[u] MG_ABLATE_AND (!(a.debug & 128))) a.pT[l[u] + lane] = indexOf (tok[u], r[u]);
+#pragma unroll
+      for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
+        for (U32 i = 64 + (U32) lane ; i < m[u] ; i += 64)                /* lists longer than a wave: rare at the usual slice size */
+          { const U32 t = 0x7fffffffu - __builtin_nontemporal_load (&a.pT[l[u] + i]);
+            const uint4 rr = *reinterpret_cast<const uint4 *> (&a.grp[t >> 6]);
+            a.pT[l[u] + i] = indexOf (t, rr);
+          }
     }
 }
 
@@ -870,7 +958,8 @@ size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
   size_t direct = mgAl (n * 4);
   size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
               + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3
-              + mgAl ((MG_PART_MAXBINS + 2) * 4) + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);
+              + mgAl ((MG_PART_MAXBINS + 2) * 4) + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4)
+              + mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short));
   return rank + (direct > part ? direct : part) + 4096;
 }
 
@@ -973,6 +1062,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   U64 *whole = (U64 *) wb;                    wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
   U32 *coarseCount = (U32 *) wb;              wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
   U32 *chunkBase = (U32 *) wb;                wb += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);   /* + the segment of every chunk */
+  unsigned short *sliceOff = (unsigned short *) wb;   wb += mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short));
   (void) spare64;
 
   /* split the bucket-id bits into a coarse digit (high) and a fine digit (low), each <= 9 bits */
@@ -1001,6 +1091,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
+  /* slices of the ordinal range for the rank lookups: 2^sliceShift ordinals each (2^22: 1 MiB of rank records, and a
+     bucket's share of a slice is usually shorter than a wave), at most MG_RANK_GROUPS - 1 of them */
+  { static int shEnv = -1; if (shEnv < 0) { const char *e = getenv ("MODGPU_RANK_SLICE_SHIFT"); shEnv = e ? atoi (e) : 22; }   /* dev knob */
+    a.sliceShift = shEnv;
+    while (((n - 1) >> a.sliceShift) + 1 > (U64) (MG_RANK_GROUPS - 1)) ++a.sliceShift;
+    a.nSlices = (U32) (((n - 1) >> a.sliceShift) + 1);
+    a.sliceOff = sliceOff;
+  }
   a.counters = t->counters; a.f = f;
 #ifdef MG_ABLATE
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_BUCKET_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = dbg; }
@@ -1014,7 +1112,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
       a.liveHist = (unsigned long long *) t->liveHist;
     }
   t->liveHistValid = track;
-  const size_t lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
+  size_t lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
+  { const size_t ldsDedup = (size_t) t->R * 16 + MG_RANK_GROUPS * 4; if (ldsDedup > lds) lds = ldsDedup; }
   if (lds > 48 * 1024)
     { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -1023,6 +1122,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   static int bThreadsEnv = -1;
   if (bThreadsEnv < 0) { const char *e = getenv ("MODGPU_BUCKET_T"); bThreadsEnv = e ? atoi (e) : 0; }
   unsigned bThreads = bThreadsEnv ? (unsigned) bThreadsEnv : (t->R >= 4096 ? 1024u : (t->R >= 2048 ? 512u : 256u));
+  while (bThreads < 1024 && (U64) bThreads * MG_DEDUP_PER < t->R) bThreads *= 2;
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
   U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
@@ -1032,6 +1132,10 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
   MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nRankBlocks), dim3 (256), 0, st,
              flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grp);
+  { const U32 groupsPerSlice = (U32) ((NB + 63) / 64);
+    const U32 blocksPerSlice = (groupsPerSlice + 3) / 4, rounds = (a.nSlices + 7) / 8;
+    MG_LAUNCH (MG_K_RANK_LOOKUP, st, mgRankLookupKernel, dim3 (8 * rounds * blocksPerSlice), dim3 (256), 0, st, a, groupsPerSlice);
+  }
   MG_LAUNCH (MG_K_BUCKET_MERGE, st, mgBucketMergeKernel, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
   MG_HIP (hipGetLastError ());
   return MG_OK;
@@ -1162,6 +1266,7 @@ static void mgSetGeometry (MgTable *t, int log2Slots)
 {
   t->nSlots = (U64) 1 << log2Slots;
   U32 R = t->wantR ? t->wantR : 4096;
+  if (R > 4096) R = 4096;                        /* the dedup kernel's threads hold MG_DEDUP_PER slots each */
   int lgR = mgLog2 (R); R = (U32) 1 << lgR;
   if (lgR > log2Slots) { lgR = log2Slots; R = (U32) 1 << lgR; }
   int lgNB = log2Slots - lgR;

@@ -371,6 +371,39 @@ print("chunked ok", n)
         assert r.returncode == 0 and "chunked ok" in r.stdout, (chunk, path, r.stderr[-1500:])
 
 
+def test_rank_slices():
+    """bucketed path: the rank lookups run per slice of the ordinal range (mg_table.hip, mgRankLookupKernel).  One slice
+    (a bucket's whole list in one group, far longer than a wave), the most slices the kernel takes (63 + the group of
+    k-mers already in the table), and something in between -- two batches each, the second mostly k-mers of the first"""
+    import subprocess, sys, os
+    code = r"""
+import numpy as np, modimizer_amd as mg
+from oracle import pyoracle as po
+from modimizer_amd import synth
+sh = mg.seqhashCreate(17, 4, 17); oh = po.Hasher(17, 4, 17)
+g = synth.iid_bases(30000, 3)
+st, offs, sd = synth.ont_read_plan(400000, len(g), 4, n50=3000, lo=50, hi=9000)
+b = synth.reads_from_genome(g, st, offs, sd, 0.02, 5)
+ms = mg.modsetCreate(sh, 22); oms = po.Modset(oh, 22)
+half = len(st) // 2
+n = mg.add_sequence_batch(ms, b[:int(offs[half])], offs[:half + 1].astype(np.int64))
+n += mg.add_sequence_batch(ms, b, offs.astype(np.int64))
+t = sum(oms.add_sequence(b[int(offs[r]):int(offs[r+1])]) for r in range(half))
+t += sum(oms.add_sequence(b[int(offs[r]):int(offs[r+1])]) for r in range(len(st)))
+mg.check(mg.lib().modsetSyncToHost(ms, 1))
+v, d, _ = mg.modset_arrays(ms)
+assert n == t and ms.contents.max == oms.max
+assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(d[1:], oms.depths()[1:])
+assert np.array_equal(np.ctypeslib.as_array(ms.contents.index, (1 << 22,)), oms.index_table())
+print("slices ok", n)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for shift in ("30", "1", "11"):
+        env = dict(os.environ, MODGPU_RANK_SLICE_SHIFT=shift, MODGPU_TABLE_PATH="bucket", PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "slices ok" in r.stdout, (shift, r.stderr[-1500:])
+
+
 def test_large_table_bits_geometry():
     """table bits 31/32 (the device limit): the device table is sized by content, so this is cheap"""
     L = mg.lib()

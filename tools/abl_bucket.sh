@@ -1,0 +1,5 @@
+#!/bin/bash
+# dev: ablation timing of the bucket / lookup kernels (tools/ablate_build.sh -> tools/variants_abl/libmodgpu.so)
+for dbg in ${@:-0 1 2 4 8 16 128 256 400 32 64}; do
+  MODGPU_BUCKET_DEBUG=$dbg MODGPU_LIB=$PWD/tools/variants_abl/libmodgpu.so python bench.py --steps 5 --warmup 1 --no-cpu --no-other 2>/dev/null | python tools/kern_ms.py "dbg=$dbg" | grep -o "^.*ms/step\|'mgBucket[A-Za-z]*': [0-9.]*\|'mgRank[A-Za-z]*': [0-9.]*" | tr '\n' ' '; echo
+done
