@@ -574,7 +574,7 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
 
 /* device forms of the whole-set passes, used when the modset lives on the device ------------- */
 static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            bool arenaLive, hipStream_t st, const MgHistReq *counted = 0);
+                            bool arenaLive, hipStream_t st, const MgHistReq *counted = 0, const MgSegSrc *segSrc = 0);
 
 /* fold the pending device counts into baseDepth (afterwards baseDepth[i] IS depth[i]) */
 static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
@@ -707,12 +707,12 @@ static U64 mgAddChunkSize (void)
 #define MG_ADD_CHUNK (mgAddChunkSize ())
 
 static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            void *scratch, hipStream_t st, const MgHistReq *counted = 0)
+                            void *scratch, hipStream_t st, const MgHistReq *counted = 0, const MgSegSrc *segSrc = 0)
 {
   MgTable &t = d->t;
   MgStatus s;
   MG_HIP (hipMemsetAsync (t.counters, 0, 16, st));
-  if ((s = mgTableAdd (&t, dKmer, n, withDepth, scratch, st, counted))) return s;
+  if ((s = mgTableAdd (&t, dKmer, n, withDepth, scratch, st, counted, segSrc))) return s;
   volatile U64 *c = d->hPin;
   MG_HIP (hipMemcpyAsync (d->hPin, t.counters, 16, hipMemcpyDeviceToHost, st));
   MG_HIP (hipStreamSynchronize (st));
@@ -731,7 +731,7 @@ static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
 /* arenaLive: dKmer itself lives in d->arena (mgAddReadsDevice), so the arena must not be reset
  * or reallocated; the caller reserved room for the temporaries taken here. */
 static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
-                            bool arenaLive, hipStream_t st, const MgHistReq *counted)
+                            bool arenaLive, hipStream_t st, const MgHistReq *counted, const MgSegSrc *segSrc)
 {
   if (!n) return MG_OK;
   U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
@@ -748,7 +748,8 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
     { U64 m = n - off < chunk ? n - off : chunk;
       if (off) s = mgTableEnsure (&d->t, m, st);
       if (!s) s = mgAddChunk (ms, d, dKmer + off, m, dIndexOut ? dIndexOut + off : 0, withDepth, scratch, st,
-                              (counted && n <= chunk) ? counted : 0);      /* the counts cover the whole batch */
+                              (counted && n <= chunk) ? counted : 0,       /* the counts cover the whole batch */
+                              n <= chunk ? segSrc : 0);
     }
   return s;
 }
@@ -817,7 +818,8 @@ extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *st
 /* ---------------------------------------------------------------------------------------- */
 /* composite: scan a device-resident batch straight into the modset                           */
 
-struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; MgHistReq counted; };
+struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; MgHistReq counted;
+                    MgSegSrc seg; bool lazy; };      /* lazy: kmer[] has not been written, the modimizers are in seg */
 
 /* scan into arena buffers, growing once if the survivor guess was too small */
 /* outPosF / outRid (with room for outCap entries): the caller's own arrays; when they are large enough for the scan's
@@ -826,8 +828,9 @@ struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 
 static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked, U64 totalBases,
                                  const U64 *dReadOffsets, U32 nReads, bool wantPos, size_t extraPerSurvivor,
                                  MgScanBufs *b, U64 *nOut, hipStream_t st,
-                                 U32 *outPosF = 0, U32 *outRid = 0, U64 outCap = 0)
+                                 U32 *outPosF = 0, U32 *outRid = 0, U64 outCap = 0, bool lazy = false)
 {
+  b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0;
   U64 cap = mgSurvivorGuess (sh, totalBases);
   MgHashParams p = mgMakeParams (sh);
   if (extraPerSurvivor)
@@ -855,8 +858,10 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
         { b->counted.binCount = (U32 *) d->arena.take (512 * sizeof (U32));
           b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
         }
+      const bool lz = lazy && !wantPos && b->counted.binCount;
       if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
-                             b->counted.binCount ? &b->counted : 0))) return s;
+                             b->counted.binCount ? &b->counted : 0, lz ? &b->seg : 0))) return s;
+      b->lazy = lz;
       volatile U64 *c = d->hPin + 8;
       MG_HIP (hipMemcpyAsync (d->hPin + 8, b->count, MG_COUNT_WORDS * sizeof (U64), hipMemcpyDeviceToHost, st));
       MG_HIP (hipStreamSynchronize (st));
@@ -876,8 +881,18 @@ extern "C" MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalB
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
   /* pos / isF / read are not needed by addSequence (modutils.c:24 passes 0 for isF and ignores pos) */
-  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, false, 4, &b, &n, st))) return s;
+  /* the dense k-mer array is only made if the insert turns out to need it (a small batch, the table regrown): a large
+     batch's first partition pass and index assignment read the scan's segments */
+  if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, false, 4, &b, &n, st, 0, 0, 0, true))) return s;
   if (nHash) *nHash = n;
+  if (!n) return MG_OK;
+  if (b.lazy)
+    { const U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
+      if ((s = mgTableEnsure (&d->t, chunk, st))) return s;
+      if (n <= MG_ADD_CHUNK && mgTableAddTakesSegments (&d->t, n, &b.counted))
+        return mgAddBatch (ms, d, 0, n, 0, 1, true, st, &b.counted, &b.seg);
+      if ((s = mgLaunchSegCompact (b.seg, b.kmer, b.cap, b.count, st))) return s;
+    }
   return mgAddBatch (ms, d, b.kmer, n, 0, 1, true, st, &b.counted);
 }
 

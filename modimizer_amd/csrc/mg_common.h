@@ -114,6 +114,11 @@ static inline void mgPartSplit (int log2NB, int *hiB, int *loB)
  * knows the table geometry asks for that with a request; log2NB says which geometry the counts are for. */
 struct MgHistReq { int log2NB; int kbits; U32 *binCount; };   /* binCount: device, 512 entries, zeroed by the launcher; kbits = 2k (the table hash is over 2k bits) */
 
+/* The scan's output BEFORE compaction: worker w's modimizers are segKmer[w * segCap + i], i < segCount[w], and
+ * segStart[w] (nSegs + 1 entries, the last one the total) is the ordinal of its first one.  The modset build of a large
+ * batch reads them from here (first partition pass and index assignment) instead of from a dense copy. */
+struct MgSegSrc { const U64 *segKmer; const U64 *segCount; const U64 *segStart; U64 segCap; U32 nSegs; };
+
 
 /* launchers implemented in the .hip files */
 MgStatus mgLaunchPack (const U8 *dBases, U64 nBases, U32 *dWords, hipStream_t st);
@@ -121,16 +126,19 @@ MgStatus mgLaunchUnpack (const U32 *dWords, U64 nBases, U8 *dBases, hipStream_t 
 MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                        const U64 *dReadOffsets, U32 nReads,
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                       U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0);
+                       U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0, MgSegSrc *lazy = 0);
 
 U64      mgScanTiles (U64 totalBases);
 size_t   mgScanInfoBytes (U64 totalBases);
 MgStatus mgScanPrepare (const U64 *dReadOffsets, U32 nReads, U64 totalBases, void *dInfo, hipStream_t st);
 size_t   mgScanRangeWorkBytes (U64 nTilesRange, U64 capacity);
+/* lazy != 0: the dense k-mer array is NOT written (only the first partition digit is counted, when hist asks for it); *lazy
+   describes the segments, and mgLaunchSegCompact makes the dense arrays from them later if they are wanted after all */
+MgStatus mgLaunchSegCompact (const MgSegSrc &src, U64 *dKmer, U64 capacity, const U64 *dCount, hipStream_t st);
 MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                             const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
                             U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                            U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0);
+                            U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0, MgSegSrc *lazy = 0);
 
 /* minimizers (seqhash.c:83-152) of every read: per-read counts -> exclusive scan in dReadStart[nReads+1] -> write */
 MgStatus mgLaunchMinimizers (const MgHashParams &p, U32 w, const U32 *dPacked, const U64 *dReadOffsets, U32 nReads,
@@ -164,7 +172,9 @@ void     mgTableForget (MgTable *t, hipStream_t st);                     /* all 
 size_t   mgTableAddScratchBytes (const MgTable *t, U64 n);
 bool     mgTableUseBuckets (const MgTable *t, U64 n);
 MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st,
-                     const MgHistReq *counted = 0);   /* counted: first-pass digit counts of exactly these n k-mers, if for this geometry */
+                     const MgHistReq *counted = 0,    /* counted: first-pass digit counts of exactly these n k-mers, if for this geometry */
+                     const MgSegSrc *segSrc = 0);     /* != 0 (and dKmer 0): the k-mers still sit in the scan's segments; only if mgTableAddTakesSegments */
+bool     mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *counted);
 MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st);
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);

@@ -512,7 +512,8 @@ void mgSegScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 segCa
       __syncthreads ();
     }
   if (tid == 0)
-    { dCount[0] = carry;
+    { segStart[nBlocks] = carry;                    /* one entry more than segments: ordinal -> segment searches need no bound */
+      dCount[0] = carry;
       dCount[1] = (gmx > segCap || carry > capacity) ? 1 : 0;
       dCount[2] = gmx;
       U64 need = gmx * (U64) nBlocks;               /* capacity whose per-segment share covers the fullest segment */
@@ -547,7 +548,7 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
           for (int j = 0 ; j < 4 ; ++j)
             { const U64 i = i0 + (U64) j * 256 + threadIdx.x;
               if (i >= n) continue;
-              outKmer[dst + i] = km[j];
+              if (outKmer) outKmer[dst + i] = km[j];       /* 0: only count (the dense copy is not wanted, or not yet) */
               if (outPosF) outPosF[dst + i] = segPosF[src + i];
               if (outRead) outRead[dst + i] = segRead[src + i];
               if (histBins)
@@ -614,7 +615,7 @@ size_t mgScanRangeWorkBytes (U64 nTilesRange, U64 capacity)
 {
   MgScanGeom g = mgScanGeometryTiles (nTilesRange, capacity);
   size_t segN = (size_t) g.nBlocks * g.segCap;
-  return mgAl (g.nBlocks * 8) * 2 + mgAl (segN * 8) + 2 * mgAl (segN * 4) + 256;
+  return mgAl (g.nBlocks * 8) + mgAl ((g.nBlocks + 1) * 8) + mgAl (segN * 8) + 2 * mgAl (segN * 4) + 256;
 }
 
 size_t mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity)
@@ -627,8 +628,9 @@ size_t mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity)
 MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                             const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
                             U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                            U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist)
+                            U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist, MgSegSrc *lazy)
 {
+  if (lazy) { lazy->segKmer = 0; lazy->nSegs = 0; }
   MG_HIP (hipMemsetAsync (dCount, 0, 4 * sizeof (U64), st));
   if (hist && hist->binCount) MG_HIP (hipMemsetAsync (hist->binCount, 0, 512 * sizeof (U32), st));
   if (tile1 <= tile0 || !nReads) return MG_OK;
@@ -636,7 +638,7 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   char *wb = (char *) dWork;
   size_t segN = (size_t) g.nBlocks * g.segCap;
   U64 *blockCount = (U64 *) wb;                  wb += mgAl (g.nBlocks * 8);
-  U64 *segStart = (U64 *) wb;                    wb += mgAl (g.nBlocks * 8);
+  U64 *segStart = (U64 *) wb;                    wb += mgAl ((g.nBlocks + 1) * 8);
   U64 *segKmer = (U64 *) wb;                     wb += mgAl (segN * 8);
   U32 *segPosF = (U32 *) wb;                     wb += mgAl (segN * 4);
   U32 *segRead = (U32 *) wb;
@@ -673,10 +675,24 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   { int hiB = 0, loB = 0; U32 bins = 0;
     if (hist && hist->binCount) { mgPartSplit (hist->log2NB, &hiB, &loB); bins = (U32) 1 << hiB; }
     const unsigned cgrid = g.nBlocks < 4096 ? g.nBlocks : 4096;
-    MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (cgrid), dim3 (256), 0, st,
-               segKmer, a.segPosF, a.segRead, g.segCap, g.nBlocks, blockCount, segStart, dKmer, dPosF, dReadId, capacity, dCount,
-               hist ? hist->log2NB : 0, hist ? hist->kbits : 64, loB, bins, hist ? hist->binCount : (U32 *) 0);
+    if (lazy) { lazy->segKmer = segKmer; lazy->segCount = blockCount; lazy->segStart = segStart; lazy->segCap = g.segCap; lazy->nSegs = g.nBlocks; }
+    if (!lazy || bins)
+      MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (cgrid), dim3 (256), 0, st,
+                 segKmer, a.segPosF, a.segRead, g.segCap, g.nBlocks, blockCount, segStart, lazy ? (U64 *) 0 : dKmer, dPosF, dReadId, capacity, dCount,
+                 hist ? hist->log2NB : 0, hist ? hist->kbits : 64, loB, bins, hist ? hist->binCount : (U32 *) 0);
   }
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+/* the dense k-mer array from the segments of a lazy scan */
+MgStatus mgLaunchSegCompact (const MgSegSrc &src, U64 *dKmer, U64 capacity, const U64 *dCount, hipStream_t st)
+{
+  if (!src.nSegs) return MG_OK;
+  const unsigned cgrid = src.nSegs < 4096 ? src.nSegs : 4096;
+  MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (cgrid), dim3 (256), 0, st,
+             src.segKmer, (const U32 *) 0, (const U32 *) 0, src.segCap, src.nSegs, src.segCount, src.segStart, dKmer, (U32 *) 0, (U32 *) 0, capacity, dCount,
+             0, 64, 0, 0u, (U32 *) 0);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -684,11 +700,11 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
 MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                        const U64 *dReadOffsets, U32 nReads,
                        U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
-                       U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist)
+                       U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist, MgSegSrc *lazy)
 {
   const U64 nTiles = mgNumTiles (totalBases);
   char *info = (char *) dWork + mgScanRangeWorkBytes (nTiles, capacity);
   MgStatus s = mgScanPrepare (dReadOffsets, nReads, totalBases, info, st); if (s) return s;
   return mgLaunchScanRange (p, dPacked, totalBases, dReadOffsets, nReads, info, 0, nTiles,
-                            dKmer, dPosF, dReadId, capacity, dCount, dWork, st, hist);
+                            dKmer, dPosF, dReadId, capacity, dCount, dWork, st, hist, lazy);
 }

@@ -140,34 +140,111 @@ void mgRankScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 *__r
   if (tid == 1023) counters[0] = sPart[1023];
 }
 
+/* ---- k-mers read from the scan's segments (MgSegSrc) instead of a dense array ---------------------------------
+ * A wave reads 64 consecutive ordinals at a time; they lie in one segment, rarely in two or more.  The wave keeps the
+ * segment of its first ordinal in scalar registers (w, its first ordinal s0 and the next segment's s1) and walks it
+ * forward as its ordinals grow; a lane behind s1 walks on by itself. */
+#define MG_PART_SUB 8192          /* elements of a sub-chunk of the partition passes (LDS counting sort) */
+struct MgSegCursor { U32 w; U64 s0, s1; };
+__device__ __forceinline__ U64 mgUniform64 (U64 x)
+{ return ((U64) (U32) __builtin_amdgcn_readfirstlane ((int) (U32) (x >> 32)) << 32) | (U32) __builtin_amdgcn_readfirstlane ((int) (U32) x); }
+/* the segment holding ordinal o (o < total): first w with segStart[w + 1] > o */
+__device__ __forceinline__ U32 mgSegOfOrdinal (const MgSegSrc &src, U64 o)
+{
+  U32 a = 0, b = src.nSegs - 1;
+  while (a < b) { const U32 m = (a + b) / 2; if (src.segStart[m + 1] > o) b = m; else a = m + 1; }
+  return a;
+}
+/* (w and o0 are the same in every lane: saying so keeps the cursor and its loads on the scalar unit) */
+__device__ __forceinline__ void mgSegCursorAt (const MgSegSrc &src, U32 w, MgSegCursor *c)
+{ w = (U32) __builtin_amdgcn_readfirstlane ((int) w); c->w = w; c->s0 = mgUniform64 (src.segStart[w]); c->s1 = mgUniform64 (src.segStart[w + 1]); }
+/* advance to the segment of o0 (uniform, o0 < total, not before the cursor) */
+__device__ __forceinline__ void mgSegCursorSeek (const MgSegSrc &src, MgSegCursor *c, U64 o0)
+{ o0 = mgUniform64 (o0); while (c->s1 <= o0) { ++c->w; c->s0 = c->s1; c->s1 = mgUniform64 (src.segStart[c->w + 1]); } }
+/* address of this lane's ordinal i = o0 + lane, for a cursor at o0 (uniform) and `last` = the last ordinal any lane asks
+ * for (uniform, < total).  The walk over the segments the 64 ordinals touch is the same in every lane and loads through
+ * the scalar unit only: a vector load inside it would make the compiler drain the k-mer loads already in flight. */
+__device__ __forceinline__ const U64 *mgSegAddr (const MgSegSrc &src, const MgSegCursor &c, U64 i, U64 last)
+{
+  U32 w = c.w; U64 b0 = c.s0, b1 = c.s1;
+  const U64 *addr = src.segKmer + (U64) w * src.segCap + (i - b0);
+  last = mgUniform64 (last);
+  while (b1 <= last)
+    { ++w; b0 = b1; b1 = mgUniform64 (src.segStart[w + 1]);
+      if (i >= b0) addr = src.segKmer + (U64) w * src.segCap + (i - b0);
+    }
+  return addr;
+}
+
+/* subSeg[q] = the cursor at ordinal q * MG_PART_SUB (w, s0, s1): where the first partition pass starts a sub-chunk's
+ * walk and the index assignment a wave's (one load instead of a binary search of dependent ones) */
+struct __attribute__ ((aligned (8))) MgSubSeg { U64 w, s0, s1; };
+__global__ void mgSubSegKernel (const MgSegSrc src, U64 n, U32 sub, MgSubSeg *__restrict__ subSeg)
+{
+  const U64 q = (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (q * sub >= n) return;
+  const U32 w = mgSegOfOrdinal (src, q * sub);
+  MgSubSeg e; e.w = w; e.s0 = src.segStart[w]; e.s1 = src.segStart[w + 1];
+  subSeg[q] = e;
+}
+__device__ __forceinline__ void mgSegCursorFrom (const MgSubSeg *__restrict__ subSeg, U64 q, MgSegCursor *c)
+{ const MgSubSeg e = subSeg[q]; c->w = (U32) __builtin_amdgcn_readfirstlane ((int) (U32) e.w); c->s0 = mgUniform64 (e.s0); c->s1 = mgUniform64 (e.s1); }
+
 /* pass B: every flagged ordinal o gets index baseMax+1+rank(o); value[index] = kmer[o].
  * DIRECT: also store the index in the slot.  BUCKETED: record, per row of 64 ordinals, the flag
  * bitmap and the number of flags before the row, for the merge kernel's rank(o) lookups. */
 #define MG_RANK_ROWS 8
-template <bool DIRECT>
+template <bool DIRECT, bool SEG>
 __global__ __launch_bounds__ (256)
-void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__restrict__ kmer, U64 n, U64 rowsPerUnit,
+void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__restrict__ kmer, const MgSegSrc src, const MgSubSeg *__restrict__ subSeg,
+                         U64 n, U64 rowsPerUnit,
                          const U64 *__restrict__ unitBase, U32 baseMax, U32 size,
                          U64 *__restrict__ value, MgSlot *__restrict__ slots, const U32 *__restrict__ slotId,
                          MgRankGrp *__restrict__ grp)
 {
   const int lane = threadIdx.x & 63;
-  const U64 unit = (U64) blockIdx.x * 4 + (threadIdx.x >> 6);
+  const U64 unit = (U64) blockIdx.x * 4 + (U32) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
   const U64 nRows = (n + 63) / 64;
   U64 row = unit * rowsPerUnit, rEnd = row + rowsPerUnit;
   if (rEnd > nRows) rEnd = nRows;
   if (row >= rEnd) return;
   U64 run = unitBase[unit];
   const U64 below = ((U64) 1 << lane) - 1;
+  MgSegCursor cur; cur.w = 0; cur.s0 = 0; cur.s1 = 0;
+  if (SEG) { mgSegCursorFrom (subSeg, row * 64 / MG_PART_SUB, &cur); mgSegCursorSeek (src, &cur, row * 64); }
   /* MG_RANK_ROWS rows per step: the loads of all four are in flight before the first ballot */
   for ( ; row < rEnd ; row += MG_RANK_ROWS)
-    { bool f[MG_RANK_ROWS]; U64 km[MG_RANK_ROWS];
+    { bool f[MG_RANK_ROWS]; U64 km[MG_RANK_ROWS]; U32 fl[MG_RANK_ROWS];
+      /* all the flag loads first, then all the k-mer loads, then the first use: with the segment walk's (uniform)
+         branches between them the compiler otherwise waits for each row's flags -- and everything older -- in turn */
 #pragma unroll
       for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
         { const U64 o = (row + j) * 64 + lane;
           const bool in = (row + j < rEnd) && (o < n);
-          f[j] = in && (flags[o] & 1);
-          km[j] = in ? __builtin_nontemporal_load (&kmer[o]) : 0;
+          fl[j] = flags[in ? o : 0];
+        }
+#pragma unroll
+      for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
+        { const U64 o = (row + j) * 64 + lane;
+          const bool in = (row + j < rEnd) && (o < n);
+          if (SEG)
+            { km[j] = 0;
+              if ((row + j) * 64 < n && row + j < rEnd)                      /* uniform */
+                { const U64 o0 = (row + j) * 64, last = o0 + 63 < n ? o0 + 63 : n - 1;
+                  mgSegCursorSeek (src, &cur, o0);
+                  const U64 *at = mgSegAddr (src, cur, o, last);
+                  if (in) km[j] = __builtin_nontemporal_load (at);
+                }
+            }
+          else km[j] = in ? __builtin_nontemporal_load (&kmer[o]) : 0;
+        }
+#pragma unroll
+      for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
+        { const U64 o = (row + j) * 64 + lane;
+          f[j] = (row + j < rEnd) && (o < n) && (fl[j] & 1);
+          /* every load has landed before the first store goes out: with loads and stores both in flight the counter
+             cannot tell them apart, and each row's store would wait for the stores of the rows before it */
+          asm volatile ("" : "+v" (km[j]));
         }
 #pragma unroll
       for (int j = 0 ; j < MG_RANK_ROWS ; ++j)
@@ -362,6 +439,7 @@ __global__ void mgIndexFinishKernel (U32 *__restrict__ index, U64 n)
 #define MG_EL_DENSE  0      /* input of the first pass: k-mers, ordinal = index */
 #define MG_EL_WIDE   1      /* (mixed k-mer, ordinal) */
 #define MG_EL_PACKED 2      /* (rem << ordBits) | ordinal */
+#define MG_EL_SEG    3      /* input of the first pass when the k-mers still sit in the scan's segments (MgSegSrc): ordinal = position in the concatenation */
 struct MgPartFmt { int ordBits, remBits, loB; };      /* remBits = 2k - hiB; loB = bits of the fine digit */
 
 /* digit of an element = bits [shift, shift+log2(nBins)) of its bucket id */
@@ -485,12 +563,40 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
 /* Scatter with LDS staging: a sub-chunk of 4096 elements is counting-sorted by bin in LDS, so the
  * elements of one bin leave as one contiguous run written by consecutive lanes (plain scattered
  * 8-byte stores ran at ~22 G/s: 9 ms per 1.5e8 elements for the two passes). */
-#define MG_PART_SUB 8192
 #define MG_PART_THREADS 1024
 #define MG_PART_PER_THREAD (MG_PART_SUB / MG_PART_THREADS)
+/* the elements [sub, subHi) of a sub-chunk into registers, MG_PART_THREADS apart */
+template <int INMODE>
+__device__ __forceinline__ void mgPartFetch (U64 *km, U32 *tk, const U64 *__restrict__ kIn, const U32 *__restrict__ tIn,
+                                             const MgSegSrc &src, const MgSubSeg *__restrict__ subSeg, U64 sub, U64 subHi, int tid)
+{
+  if (INMODE == MG_EL_SEG)
+    { const U32 wave = (U32) __builtin_amdgcn_readfirstlane (tid >> 6);
+      const int lane = tid & 63;
+      MgSegCursor cur;
+      mgSegCursorFrom (subSeg, sub / MG_PART_SUB, &cur);            /* the first partition pass has one segment [0, n): sub is a multiple of MG_PART_SUB */
+#pragma unroll
+      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+        { const U64 o0 = sub + (U64) j * MG_PART_THREADS + (U64) wave * 64;
+          if (o0 >= subHi) break;                                     /* uniform */
+          mgSegCursorSeek (src, &cur, o0);
+          const U64 i = o0 + (U64) lane;
+          const U64 *at = mgSegAddr (src, cur, i, o0 + 63 < subHi ? o0 + 63 : subHi - 1);
+          if (i < subHi) km[j] = *at;
+        }
+      return;
+    }
+#pragma unroll
+  for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+    { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
+      if (i < subHi) { km[j] = kIn[i]; if (INMODE == MG_EL_WIDE) tk[j] = tIn[i]; }
+    }
+}
+
 template <int INMODE, bool PACKOUT>     /* INMODE: what kIn holds; PACKOUT: one packed word out, otherwise (mixed k-mer, ordinal) */
 __global__ __launch_bounds__ (MG_PART_THREADS)
-void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, MgGeom g, MgPartFmt f, int shift, U32 nBins,
+void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, const MgSegSrc src, const MgSubSeg *__restrict__ subSeg,
+                          MgGeom g, MgPartFmt f, int shift, U32 nBins,
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                           unsigned long long *__restrict__ cursor, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
 {
@@ -510,14 +616,11 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
   bool have = mgChunkRange (segStart, chunkBase, nSeg, c, &seg, &lo, &hi);
   U64 sub = have ? lo : 0;
   U64 km[MG_PART_PER_THREAD]; U32 tk[MG_PART_PER_THREAD];
+#pragma unroll
+  for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j) { km[j] = 0; tk[j] = 0; }
   if (have)
     { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
-#pragma unroll
-      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
-        { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
-          km[j] = 0; tk[j] = 0;
-          if (i < subHi) { km[j] = kIn[i]; if (INMODE == MG_EL_WIDE) tk[j] = tIn[i]; }
-        }
+      mgPartFetch<INMODE> (km, tk, kIn, tIn, src, subSeg, sub, subHi, tid);
     }
   while (have)
     { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
@@ -533,11 +636,12 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
         { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
           dr[j] = 0xffffffffu;
           if (i < subHi)
-            { if (INMODE == MG_EL_DENSE)                         /* into mixed space, once */
+            { constexpr bool FIRST = INMODE == MG_EL_DENSE || INMODE == MG_EL_SEG;
+              if (FIRST)                                         /* into mixed space, once */
                 { km[j] = mgMixK (km[j], g.kbits); tk[j] = (U32) i; }
-              U32 d = mgDigitOf<(INMODE == MG_EL_DENSE ? MG_EL_WIDE : INMODE)> (km[j], g, f, shift, nBins - 1);
+              U32 d = mgDigitOf<(FIRST ? MG_EL_WIDE : INMODE)> (km[j], g, f, shift, nBins - 1);
               dr[j] = (d << 16) | atomicAdd (&sH[d], 1u);        /* rank within (sub-chunk, bin) */
-              if (INMODE == MG_EL_DENSE && PACKOUT) km[j] = ((km[j] & remMask) << f.ordBits) | (U64) tk[j];
+              if (FIRST && PACKOUT) km[j] = ((km[j] & remMask) << f.ordBits) | (U64) tk[j];
             }
         }
       __syncthreads ();
@@ -574,11 +678,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
       /* the registers are free: fetch the next sub-chunk */
       if (nhave)
         { const U64 nsubHi = nsub + MG_PART_SUB < nhi ? nsub + MG_PART_SUB : nhi;
-#pragma unroll
-          for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
-            { U64 i = nsub + (U64) j * MG_PART_THREADS + tid;
-              if (i < nsubHi) { km[j] = kIn[i]; if (INMODE == MG_EL_WIDE) tk[j] = tIn[i]; }
-            }
+          mgPartFetch<INMODE> (km, tk, kIn, tIn, src, subSeg, nsub, nsubHi, tid);
         }
       __syncthreads ();
       for (U32 p = tid ; p < cnt ; p += MG_PART_THREADS)
@@ -918,6 +1018,8 @@ void mgRankLookupKernel (const MgBucketArgs a, U32 groupsPerSlice)
       for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
         { r[u] = make_uint4 (0, 0, 0, 0); if ((U32) lane < m[u] MG_ABLATE_AND (!(a.debug & 16))) r[u] = *reinterpret_cast<const uint4 *> (&a.grp[tok[u] >> 6]); }
 #pragma unroll
+      for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u) asm volatile ("" : "+v" (r[u].x), "+v" (r[u].y), "+v" (r[u].z));   /* all records in before the first store (see mgRankAssignKernel) */
+#pragma unroll
       for (int u = 0 ; u < MG_LOOKUP_UNROLL ; ++u)
         if ((U32) lane < m[u] MG_ABLATE_AND (!(a.debug & 128))) a.pT[l[u] + lane] = indexOf (tok[u], r[u]);
 #pragma unroll
@@ -959,7 +1061,7 @@ size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
   size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
               + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3
               + mgAl ((MG_PART_MAXBINS + 2) * 4) + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4)
-              + mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short));
+              + mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short)) + mgAl ((n / MG_PART_SUB + 2) * 24);
   return rank + (direct > part ? direct : part) + 4096;
 }
 
@@ -971,6 +1073,15 @@ static int mgPathOverride (void)
       v = !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0));
     }
   return v;
+}
+
+bool mgTableUseBuckets (const MgTable *t, U64 n);
+/* can mgTableAdd read this batch from the scan's segments?  Only the bucketed path does, and its first pass then
+   needs the digit counts the scan made for exactly this table geometry */
+bool mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *counted)
+{
+  static int off = -1; if (off < 0) { const char *e = getenv ("MODGPU_NO_SEGMENT_INPUT"); off = (e && *e == '1') ? 1 : 0; }   /* test knob: always compact first */
+  return !off && n && mgTableUseBuckets (t, n) && counted && counted->binCount && counted->log2NB == t->log2NB && counted->kbits == t->kbits;
 }
 
 bool mgTableUseBuckets (const MgTable *t, U64 n)
@@ -986,9 +1097,16 @@ bool mgTableUseBuckets (const MgTable *t, U64 n)
 static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgPartFmt &f, const U64 *kIn, const U32 *tIn, U64 n,
                             const U64 *segStart, U32 nSeg, int shift, U32 nBins,
                             U64 *kOut, U32 *tOut, U64 *binStart, unsigned long long *cursor, U32 *binCount, U32 *chunkBase,
-                            hipStream_t st, const U32 *counted = 0)
+                            hipStream_t st, const U32 *counted = 0, const MgSegSrc *segSrc = 0, MgSubSeg *subSeg = 0)
 {
   MgGeom g = mgGeomOf (t);
+  MgSegSrc src; src.segKmer = 0; src.segCount = 0; src.segStart = 0; src.segCap = 0; src.nSegs = 0;
+  if (inMode == MG_EL_SEG)
+    { if (!segSrc || !subSeg || !counted) { mgSetError ("internal: segment input needs its counts"); return MG_ERR_ARG; }
+      src = *segSrc;
+      const U64 nSub = (n + MG_PART_SUB - 1) / MG_PART_SUB;
+      MG_LAUNCH (MG_K_PART, st, mgSubSegKernel, dim3 ((unsigned) ((nSub + 255) / 256)), dim3 (256), 0, st, src, n, (U32) MG_PART_SUB, subSeg);
+    }
   if (counted) MG_HIP (hipMemcpyAsync (binCount, counted, (size_t) nBins * sizeof (U32), hipMemcpyDeviceToDevice, st));   /* the compaction kernel counted them */
   else MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkBase);
@@ -1006,8 +1124,9 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
     }
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, nSeg, n);
 #define MG_SCATTER(IN, PK) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK>), sg, dim3 (MG_PART_THREADS), 0, st, \
-                                      kIn, tIn, g, f, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut)
+                                      kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, cursor, kOut, tOut)
   if (inMode == MG_EL_DENSE) { if (packed) MG_SCATTER (MG_EL_DENSE, true); else MG_SCATTER (MG_EL_DENSE, false); }
+  else if (inMode == MG_EL_SEG) { if (packed) MG_SCATTER (MG_EL_SEG, true); else MG_SCATTER (MG_EL_SEG, false); }
   else if (inMode == MG_EL_WIDE) MG_SCATTER (MG_EL_WIDE, false);
   else MG_SCATTER (MG_EL_PACKED, true);
 #undef MG_SCATTER
@@ -1017,9 +1136,11 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
 
 /* insert a batch (ordinal order = array order); counters[0] = number of new entries afterwards */
 MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st,
-                     const MgHistReq *counted)
+                     const MgHistReq *counted, const MgSegSrc *segSrc)
 {
   if (!n) return MG_OK;
+  if (segSrc && !mgTableAddTakesSegments (t, n, counted)) { mgSetError ("internal: this insert needs the dense k-mers"); return MG_ERR_ARG; }
+  MgSegSrc noSrc; noSrc.segKmer = 0; noSrc.segCount = 0; noSrc.segStart = 0; noSrc.segCap = 0; noSrc.nSegs = 0;
   t->liveHistValid = false;                          /* set again below if this add is the set's only one */
   if (withDepth) t->pendingDepth = true;
   MgGeom g = mgGeomOf (t);
@@ -1038,8 +1159,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
       MG_LAUNCH (MG_K_TABLE_FLAG, st, mgDirectFlagKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, slotId, n, flags);
       MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
       MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
-      MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<true>, dim3 (nRankBlocks), dim3 (256), 0, st,
-                 flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, slotId, grp);
+      MG_LAUNCH (MG_K_TABLE_ASSIGN, st, (mgRankAssignKernel<true, false>), dim3 (nRankBlocks), dim3 (256), 0, st,
+                 flags, dKmer, noSrc, (const MgSubSeg *) 0, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, slotId, grp);
       MG_HIP (hipGetLastError ());
       /* occ[] is kept exact only by the bucketed path and the loader; the direct path marks buckets non-empty */
       return mgTableMarkOccupied (t, dKmer, n, st);
@@ -1063,6 +1184,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   U32 *coarseCount = (U32 *) wb;              wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
   U32 *chunkBase = (U32 *) wb;                wb += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);   /* + the segment of every chunk */
   unsigned short *sliceOff = (unsigned short *) wb;   wb += mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short));
+  MgSubSeg *subSeg = (MgSubSeg *) wb;         wb += mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg));
   (void) spare64;
 
   /* split the bucket-id bits into a coarse digit (high) and a fine digit (low), each <= 9 bits */
@@ -1079,10 +1201,11 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   const bool packed = packEnv && t->kbits >= j + 4 && f.remBits + f.ordBits <= 64;
   MgStatus s;
   const U64 *bucketStart = fineStart;
+  const int firstMode = segSrc ? MG_EL_SEG : MG_EL_DENSE;
   if (!loB)
-    { if ((s = mgPartPass (t, MG_EL_DENSE, packed, f, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st, pre))) return s; }
+    { if ((s = mgPartPass (t, firstMode, packed, f, dKmer, 0, n, whole, 1, 0, (U32) 1 << hiB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st, pre, segSrc, subSeg))) return s; }
   else
-    { if ((s = mgPartPass (t, MG_EL_DENSE, packed, f, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st, pre))) return s;
+    { if ((s = mgPartPass (t, firstMode, packed, f, dKmer, 0, n, whole, 1, loB, (U32) 1 << hiB, kA, tA, coarseStart, coarseCursor, coarseCount, chunkBase, st, pre, segSrc, subSeg))) return s;
       if ((s = mgPartPass (t, packed ? MG_EL_PACKED : MG_EL_WIDE, packed, f, kA, tA, n, coarseStart, (U32) 1 << hiB, 0, (U32) 1 << loB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s;
     }
 
@@ -1130,8 +1253,12 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   else        MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel<false>, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
-  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nRankBlocks), dim3 (256), 0, st,
-             flags, dKmer, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grp);
+  if (segSrc)
+    MG_LAUNCH (MG_K_TABLE_ASSIGN, st, (mgRankAssignKernel<false, true>), dim3 (nRankBlocks), dim3 (256), 0, st,
+               flags, (const U64 *) 0, *segSrc, subSeg, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grp);
+  else
+    MG_LAUNCH (MG_K_TABLE_ASSIGN, st, (mgRankAssignKernel<false, false>), dim3 (nRankBlocks), dim3 (256), 0, st,
+               flags, dKmer, noSrc, (const MgSubSeg *) 0, n, rankTiles, blockBase, t->max, t->size, t->value, t->slots, (const U32 *) 0, grp);
   { const U32 groupsPerSlice = (U32) ((NB + 63) / 64);
     const U32 blocksPerSlice = (groupsPerSlice + 3) / 4, rounds = (a.nSlices + 7) / 8;
     MG_LAUNCH (MG_K_RANK_LOOKUP, st, mgRankLookupKernel, dim3 (8 * rounds * blocksPerSlice), dim3 (256), 0, st, a, groupsPerSlice);
@@ -1407,8 +1534,9 @@ MgStatus mgTablePrune (MgTable *t, const U8 *dInfo, int lo, int hi, U64 *dNewVal
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nBlocks), dim3 (256), 0, st, keep, (U64) n, rows, unitCount);
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, unitCount, nBlocks * 4, unitBase, t->counters);
   /* value[i+1] of survivor i -> newValue[1 + rank]: the assign kernel with "kmer" = value + 1, base 0 */
-  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, mgRankAssignKernel<false>, dim3 (nBlocks), dim3 (256), 0, st,
-             keep, t->value + 1, (U64) n, rows, unitBase, 0u, 0xffffffffu, dNewValue, t->slots, (const U32 *) 0, grp);
+  MgSegSrc noSrc; noSrc.segKmer = 0; noSrc.segCount = 0; noSrc.segStart = 0; noSrc.segCap = 0; noSrc.nSegs = 0;
+  MG_LAUNCH (MG_K_TABLE_ASSIGN, st, (mgRankAssignKernel<false, false>), dim3 (nBlocks), dim3 (256), 0, st,
+             keep, t->value + 1, noSrc, (const MgSubSeg *) 0, (U64) n, rows, unitBase, 0u, 0xffffffffu, dNewValue, t->slots, (const U32 *) 0, grp);
   MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgPruneMoveKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, keep, grp, n, t->baseDepth, dInfo, dNewDepth, dNewInfo);
   MG_HIP (hipGetLastError ());
   return MG_OK;
