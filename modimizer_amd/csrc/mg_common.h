@@ -87,7 +87,7 @@ __device__ __forceinline__ U32 mgWaveInclusiveSum (U32 v)
  * bucket digits are a prefix of its key -- which lets the partition passes drop the digits a bin already implies and
  * carry the first-occurrence ordinal in the freed bits of one 8-byte element (see mg_table.hip). */
 struct MgGeom { U32 R, rMask; int log2NB; int kbits; };      /* kbits = 2k */
-__device__ __forceinline__ U64 mgMixK (U64 x, int b)
+__device__ __forceinline__ U64 mgMixBits (U64 x, int b)        /* murmur-style bijection of b-bit values */
 {
   const U64 mask = b >= 64 ? ~0ull : (((U64) 1 << b) - 1);
   const int h = (b + 1) >> 1;
@@ -96,13 +96,42 @@ __device__ __forceinline__ U64 mgMixK (U64 x, int b)
   x ^= x >> h;
   return x;
 }
+/* From 2k = 24 bits up the mix is built so that its top MG_MIX_TOP bits -- which hold the coarse digit of the bucket id,
+ * what the first partition pass sorts by -- cost a multiply and a shift: the scan kernel counts them per modimizer on
+ * the way (a full mix there would be two 64-bit multiplies in an instruction-bound kernel).  With x = (A : L), A the top
+ * MG_MIX_TOP bits:  mix = (A ^ g(L)) : mixBits (L),  g(L) = top bits of a 32-bit multiplicative hash of L's low word.
+ * A bijection: L comes back from its own mix, then A from the top part. */
+#define MG_MIX_TOP 9
+#define MG_MIX_MUL 0x9E3779B1u
+__device__ __forceinline__ U64 mgMixK (U64 x, int b)
+{
+  if (b < 24) return mgMixBits (x, b);
+  const int lb = b - MG_MIX_TOP;
+  const U64 L = x & (((U64) 1 << lb) - 1), A = x >> lb;
+  const U32 low = lb >= 32 ? (U32) L : ((U32) L & (((U32) 1 << lb) - 1));
+  const U32 g = (low * MG_MIX_MUL) >> (32 - MG_MIX_TOP);
+  return ((A ^ (U64) g) << lb) | mgMixBits (L, lb);
+}
+/* the top hiB <= MG_MIX_TOP bits of mgMixK (x, b), b >= 24, from the k-mer itself */
+__device__ __forceinline__ U32 mgMixTopOfKmer (U64 x, int b, int hiB)
+{
+  const int lb = b - MG_MIX_TOP;
+  const U32 low = lb >= 32 ? (U32) x : ((U32) x & (((U32) 1 << lb) - 1));
+  return (U32) (x >> (b - hiB)) ^ ((low * MG_MIX_MUL) >> (32 - hiB));
+}
 __device__ __forceinline__ U32 mgBucketOfM (U64 m, const MgGeom &g)
 {
   if (!g.log2NB) return 0u;
   const int s = g.kbits - g.log2NB;
   return s >= 0 ? (U32) (m >> s) : ((U32) m << (-s));
 }
-__device__ __forceinline__ U32 mgHomeOfM (U64 m, const MgGeom &g) { return (U32) m & g.rMask; }
+/* home slot: the low bits, stirred with the top part (k-mers that share their low bits -- and so the mix of them --
+   differ there) */
+__device__ __forceinline__ U32 mgHomeOfM (U64 m, const MgGeom &g)
+{
+  if (g.kbits < 24) return (U32) m & g.rMask;
+  return ((U32) m ^ ((U32) (m >> (g.kbits - MG_MIX_TOP)) * 0x9E5u)) & g.rMask;
+}
 #endif /* __HIPCC__ */
 
 /* The bucket id (log2NB bits) is split into a coarse digit (high bits, first partition pass) and a fine one. */

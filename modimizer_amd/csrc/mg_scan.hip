@@ -124,6 +124,8 @@ struct MgScanArgs {
   U64 *segKmer; U32 *segPosF; U32 *segRead;        /* [nWorkers * segCap] */
   U64 *blockCount;       /* [nWorkers] true number of modimizers each worker found */
   U32 fS, thresh;        /* fast path: factor1 << (32-B), 2^(32-m) */
+  U32 *histCount;        /* != 0: count the modimizers per coarse digit of their table bucket (what the first partition pass of the modset build sorts by) */
+  int histKbits, histHiB;   /* the digit = top histHiB bits of mgMixK (kmer, histKbits); histKbits >= 24 */
 #ifdef MG_ABLATE
   U32 debug;             /* ablation builds only (tools/ablate_scan.sh): bit0 = stop after phase B, bit1 = no stores, bit2 = no evaluation */
 #endif
@@ -219,6 +221,18 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
  * Latency: the next tile's words, halo and metadata are fetched while the current tile is processed
  * (registers), and the tile staging in LDS is double-buffered.
  */
+/* a wave has made its last count: the workgroup's last wave adds the LDS counts to the global ones.  (The LDS unit takes a
+ * CU's operations in order, so once the other waves' ticks on sDone are in, so are their counts.) */
+__device__ __forceinline__ void mgScanHistDone (const MgScanArgs &a, U32 *sHist, U32 *sDone, int lane)
+{
+  U32 before = 0;
+  if (lane == 0) before = atomicAdd (sDone, 1u);
+  before = (U32) __builtin_amdgcn_readfirstlane ((int) before);
+  if (before != MG_WAVES - 1) return;
+  const U32 bins = (U32) 1 << a.histHiB;
+  for (U32 b = (U32) lane ; b < bins ; b += 64) { const U32 v = sHist[b]; if (v) atomicAdd (&a.histCount[b], v); }
+}
+
 template <int MODE>
 __global__ __launch_bounds__ (MG_SCAN_THREADS)
 void mgScanKernel (const MgScanArgs a)
@@ -226,11 +240,17 @@ void mgScanKernel (const MgScanArgs a)
   __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_WAVES][2][MG_TILE_WORDS + 8];
   __shared__ unsigned short sCandAll[MG_WAVES][MG_CAND_CAP + 2];      /* [MG_CAND_CAP]: where stores of other rounds' entries land */
   __shared__ U64 sOffAll[MG_WAVES][64];                              /* read offsets of a tile that holds read boundaries */
+  __shared__ U32 sHist[512]; __shared__ U32 sDone;                   /* the workgroup's digit counts; waves that have finished */
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));   /* uniform: the worker's state lives in SGPRs */
   const U64 worker = (U64) blockIdx.x * MG_WAVES + wave;
-  if (worker >= a.nWorkers) return;
+  if (a.histCount)
+    { for (U32 b = threadIdx.x ; b < 512 ; b += MG_SCAN_THREADS) sHist[b] = 0;
+      if (threadIdx.x == 0) sDone = 0;
+      __syncthreads ();
+    }
+  if (worker >= a.nWorkers) { if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane); return; }
   unsigned short *sCand = sCandAll[wave];
   U64 *sOff = sOffAll[wave];
   const MgHashParams &p = a.p;
@@ -447,6 +467,7 @@ void mgScanKernel (const MgScanArgs a)
                     { if (offInLds) { while (sOff[r + 1 - ti.firstRead] <= pos) ++r; rs = sOff[r - ti.firstRead]; }
                       else { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
                     }
+                  if (a.histCount) atomicAdd (&sHist[mgMixTopOfKmer (F, a.histKbits, a.histHiB)], 1u);
                   if (o < a.segCap MG_ABLATE_AND (!(a.debug & 2)))
                     { a.segKmer[segBase + o] = F;
                       if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
@@ -461,6 +482,7 @@ void mgScanKernel (const MgScanArgs a)
       curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
     }
   if (lane == 0) a.blockCount[worker] = found;
+  if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane);
 }
 
 /* exclusive scan of the per-block counts (one workgroup): segStart[b], and
@@ -540,17 +562,27 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
   const U32 sgEnd = sg + per < nSegs ? sg + per : nSegs;
   for ( ; sg < sgEnd ; ++sg)
     { const U64 n = blockCount[sg], dst = segStart[sg], src = (U64) sg * segCap;
-      for (U64 i0 = 0 ; i0 < n ; i0 += 4 * 256)            /* four loads per lane in flight */
-        { U64 km[4];
+      for (U64 i0 = 0 ; i0 < n ; i0 += 4 * 256)            /* four elements per lane: every load in flight, and landed, before the first store (with loads and stores both outstanding each store waits for the one before) */
+        { U64 km[4]; U32 pf[4], rd[4];
 #pragma unroll
-          for (int j = 0 ; j < 4 ; ++j) { const U64 i = i0 + (U64) j * 256 + threadIdx.x; km[j] = i < n ? segKmer[src + i] : 0; }
+          for (int j = 0 ; j < 4 ; ++j)
+            { const U64 i = i0 + (U64) j * 256 + threadIdx.x;
+              km[j] = 0; pf[j] = 0; rd[j] = 0;
+              if (i < n)
+                { km[j] = segKmer[src + i];
+                  if (outPosF) pf[j] = segPosF[src + i];
+                  if (outRead) rd[j] = segRead[src + i];
+                }
+            }
+#pragma unroll
+          for (int j = 0 ; j < 4 ; ++j) asm volatile ("" : "+v" (km[j]), "+v" (pf[j]), "+v" (rd[j]));
 #pragma unroll
           for (int j = 0 ; j < 4 ; ++j)
             { const U64 i = i0 + (U64) j * 256 + threadIdx.x;
               if (i >= n) continue;
               if (outKmer) outKmer[dst + i] = km[j];       /* 0: only count (the dense copy is not wanted, or not yet) */
-              if (outPosF) outPosF[dst + i] = segPosF[src + i];
-              if (outRead) outRead[dst + i] = segRead[src + i];
+              if (outPosF) outPosF[dst + i] = pf[j];
+              if (outRead) outRead[dst + i] = rd[j];
               if (histBins)
                 { MgGeom hg; hg.R = 0; hg.rMask = 0; hg.log2NB = histLog2NB; hg.kbits = histKbits;
                   const U32 bucket = mgBucketOfM (mgMixK (km[j], histKbits), hg);
@@ -650,6 +682,11 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   a.tilesPerWorker = g.tilesPerBlock; a.nWorkers = g.nBlocks; a.segCap = g.segCap;
   a.segKmer = segKmer; a.segPosF = dPosF ? segPosF : 0; a.segRead = dReadId ? segRead : 0; a.blockCount = blockCount;
   a.fS = 0; a.thresh = 0;
+  /* the first partition digit, counted by the scan itself when the table hash allows it (2k >= 24); otherwise by the compaction kernel */
+  int hHiB = 0, hLoB = 0;
+  if (hist && hist->binCount) mgPartSplit (hist->log2NB, &hHiB, &hLoB);
+  const bool scanCounts = hist && hist->binCount && hist->kbits >= 24 && hHiB >= 1 && hHiB <= MG_MIX_TOP && hLoB + hHiB == hist->log2NB;
+  a.histCount = scanCounts ? hist->binCount : 0; a.histKbits = hist ? hist->kbits : 64; a.histHiB = hHiB;
 #ifdef MG_ABLATE
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
 #endif
@@ -673,7 +710,7 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
   MG_HIP (hipGetLastError ());
   { int hiB = 0, loB = 0; U32 bins = 0;
-    if (hist && hist->binCount) { mgPartSplit (hist->log2NB, &hiB, &loB); bins = (U32) 1 << hiB; }
+    if (hist && hist->binCount && !scanCounts) { mgPartSplit (hist->log2NB, &hiB, &loB); bins = (U32) 1 << hiB; }
     const unsigned cgrid = g.nBlocks < 4096 ? g.nBlocks : 4096;
     if (lazy) { lazy->segKmer = segKmer; lazy->segCount = blockCount; lazy->segStart = segStart; lazy->segCap = g.segCap; lazy->nSegs = g.nBlocks; }
     if (!lazy || bins)
