@@ -842,7 +842,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
     }
   for (int attempt = 0 ; attempt < 3 ; ++attempt)
     { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
-      size_t need = al256 (cap * perS) + 4 * 4096 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
+      size_t need = al256 (cap * perS) + 4 * 4096 + 512 * MG_HIST_STRIDE * 4 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
                     + (extraPerSurvivor ? mgTableAddScratchBytes (&d->t, cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK) + 8192 : 0) + 8 * 256;
       MgStatus s = d->arena.reserve (need); if (s) return s;
       d->arena.reset ();
@@ -855,7 +855,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
       b->counted.log2NB = 0; b->counted.kbits = 64; b->counted.binCount = 0;
       if (extraPerSurvivor)                           /* the survivors go into the modset: have the compaction count the first partition digit */
-        { b->counted.binCount = (U32 *) d->arena.take (512 * sizeof (U32));
+        { b->counted.binCount = (U32 *) d->arena.take (512 * MG_HIST_STRIDE * sizeof (U32));
           b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
         }
       const bool lz = lazy && !wantPos && b->counted.binCount;

@@ -141,7 +141,8 @@ static inline void mgPartSplit (int log2NB, int *hiB, int *loB)
 /* The first partition pass needs the number of modimizers per coarse digit.  The scan's compaction kernel
  * reads every k-mer anyway, so it can count them on the way (its ALUs are idle: it is a copy): a caller that
  * knows the table geometry asks for that with a request; log2NB says which geometry the counts are for. */
-struct MgHistReq { int log2NB; int kbits; U32 *binCount; };   /* binCount: device, 512 entries, zeroed by the launcher; kbits = 2k (the table hash is over 2k bits) */
+#define MG_HIST_STRIDE 16      /* words between the counts of consecutive digits: one count per 64 bytes, thousands of workgroups add to each */
+struct MgHistReq { int log2NB; int kbits; U32 *binCount; };   /* binCount: device, 512 x MG_HIST_STRIDE words, zeroed by the launcher; kbits = 2k (the table hash is over 2k bits) */
 
 /* The scan's output BEFORE compaction: worker w's modimizers are segKmer[w * segCap + i], i < segCount[w], and
  * segStart[w] (nSegs + 1 entries, the last one the total) is the ordinal of its first one.  The modset build of a large

@@ -230,7 +230,7 @@ __device__ __forceinline__ void mgScanHistDone (const MgScanArgs &a, U32 *sHist,
   before = (U32) __builtin_amdgcn_readfirstlane ((int) before);
   if (before != MG_WAVES - 1) return;
   const U32 bins = (U32) 1 << a.histHiB;
-  for (U32 b = (U32) lane ; b < bins ; b += 64) { const U32 v = sHist[b]; if (v) atomicAdd (&a.histCount[b], v); }
+  for (U32 b = (U32) lane ; b < bins ; b += 64) { const U32 v = sHist[b]; if (v) atomicAdd (&a.histCount[b * MG_HIST_STRIDE], v); }
 }
 
 template <int MODE>
@@ -593,7 +593,7 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
     }
   if (histBins)
     { __syncthreads ();
-      for (U32 b = threadIdx.x ; b < histBins ; b += 256) if (sH[b]) atomicAdd (&histCount[b], sH[b]);
+      for (U32 b = threadIdx.x ; b < histBins ; b += 256) if (sH[b]) atomicAdd (&histCount[b * MG_HIST_STRIDE], sH[b]);
     }
 }
 
@@ -664,7 +664,7 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
 {
   if (lazy) { lazy->segKmer = 0; lazy->nSegs = 0; }
   MG_HIP (hipMemsetAsync (dCount, 0, 4 * sizeof (U64), st));
-  if (hist && hist->binCount) MG_HIP (hipMemsetAsync (hist->binCount, 0, 512 * sizeof (U32), st));
+  if (hist && hist->binCount) MG_HIP (hipMemsetAsync (hist->binCount, 0, 512 * MG_HIST_STRIDE * sizeof (U32), st));
   if (tile1 <= tile0 || !nReads) return MG_OK;
   MgScanGeom g = mgScanGeometryTiles (tile1 - tile0, capacity);
   char *wb = (char *) dWork;
