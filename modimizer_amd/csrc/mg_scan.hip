@@ -685,7 +685,8 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   /* the first partition digit, counted by the scan itself when the table hash allows it (2k >= 24); otherwise by the compaction kernel */
   int hHiB = 0, hLoB = 0;
   if (hist && hist->binCount) mgPartSplit (hist->log2NB, &hHiB, &hLoB);
-  const bool scanCounts = hist && hist->binCount && hist->kbits >= 24 && hHiB >= 1 && hHiB <= MG_MIX_TOP && hLoB + hHiB == hist->log2NB;
+  static int histEnv = -1; if (histEnv < 0) { const char *e = getenv ("MODGPU_SCAN_HIST"); histEnv = (e && *e == '0') ? 0 : 1; }   /* test knob: 0 = the compaction kernel counts */
+  const bool scanCounts = histEnv && hist && hist->binCount && hist->kbits >= 24 && hHiB >= 1 && hHiB <= MG_MIX_TOP && hLoB + hHiB == hist->log2NB;
   a.histCount = scanCounts ? hist->binCount : 0; a.histKbits = hist ? hist->kbits : 64; a.histHiB = hHiB;
 #ifdef MG_ABLATE
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
