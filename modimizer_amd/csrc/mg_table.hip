@@ -264,28 +264,51 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
     }
 }
 
-__device__ __forceinline__ U32 mgProbeFind (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, const MgGeom &g, U64 km)
+/* The query's lookups.  MG_FIND_PER k-mers per thread and step: all the k-mer loads, then all the first probes (one
+ * 16-byte load each: key and index together), land before anything is stored -- a loop of "load, probe, store" made
+ * every store wait for the one before it; only the probes that hit another k-mer's slot walk on.  CHECK_OCC = false
+ * when every bucket's bytes are defined (mgTableClean has zeroed the never-written ones): no dependent load in front. */
+#ifndef MG_FIND_PER
+#define MG_FIND_PER 1
+#endif
+template <bool CHECK_OCC>
+__global__ __launch_bounds__ (256)
+void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, MgGeom g,
+                        const U64 *__restrict__ kmer, U64 n, U32 *__restrict__ out)
 {
-  const U64 m = mgMixK (km, g.kbits), key = m + 1;
-  const U32 bkt = mgBucketOfM (m, g);
-  if (!occ[bkt]) return 0;                         /* never written: its bytes are undefined */
-  const U64 base = (U64) bkt * g.R;
-  U32 at = mgHomeOfM (m, g);
-  for (U32 probes = 0 ; probes < g.R ; ++probes)
-    { U64 cur = slots[base + at].key;
-      if (cur == key) { U32 v = slots[base + at].ord; return mgIsAssigned (v) ? (v & ~MG_ASSIGNED) : 0; }
-      if (cur == 0) return 0;
-      at = (at + 1) & g.rMask;
-    }
-  return 0;
-}
-
-__global__ void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, MgGeom g,
-                                   const U64 *__restrict__ kmer, U64 n, U32 *__restrict__ out)
-{
-  U64 o = (U64) blockIdx.x * blockDim.x + threadIdx.x;
   const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; o < n ; o += stride) out[o] = mgProbeFind (slots, occ, g, kmer[o]);
+  for (U64 o0 = (U64) blockIdx.x * blockDim.x + threadIdx.x ; o0 < n ; o0 += stride * MG_FIND_PER)
+    { U64 km[MG_FIND_PER], key[MG_FIND_PER], base[MG_FIND_PER]; U32 at[MG_FIND_PER], res[MG_FIND_PER]; bool live[MG_FIND_PER];
+      uint4 v[MG_FIND_PER];
+#pragma unroll
+      for (int j = 0 ; j < MG_FIND_PER ; ++j) { const U64 o = o0 + (U64) j * stride; km[j] = o < n ? __builtin_nontemporal_load (&kmer[o]) : 0; }
+#pragma unroll
+      for (int j = 0 ; j < MG_FIND_PER ; ++j)
+        { const U64 m = mgMixK (km[j], g.kbits);
+          const U32 bkt = mgBucketOfM (m, g);
+          key[j] = m + 1; base[j] = (U64) bkt * g.R; at[j] = mgHomeOfM (m, g);
+          live[j] = o0 + (U64) j * stride < n;
+          if (CHECK_OCC && live[j] && !occ[bkt]) live[j] = false;      /* never written: its bytes are undefined */
+          v[j] = make_uint4 (0, 0, 0, 0);
+          if (live[j]) v[j] = *reinterpret_cast<const uint4 *> (&slots[base[j] + at[j]]);
+        }
+#pragma unroll
+      for (int j = 0 ; j < MG_FIND_PER ; ++j) asm volatile ("" : "+v" (v[j].x), "+v" (v[j].y), "+v" (v[j].z));
+#pragma unroll
+      for (int j = 0 ; j < MG_FIND_PER ; ++j)
+        { res[j] = 0;
+          U64 cur = ((U64) v[j].y << 32) | v[j].x; U32 ord = v[j].z;
+          for (U32 probes = 1 ; live[j] && cur != 0 ; ++probes)
+            { if (cur == key[j]) { res[j] = mgIsAssigned (ord) ? (ord & ~MG_ASSIGNED) : 0; break; }
+              if (probes >= g.R) break;
+              at[j] = (at[j] + 1) & g.rMask;
+              const uint4 w = *reinterpret_cast<const uint4 *> (&slots[base[j] + at[j]]);
+              cur = ((U64) w.y << 32) | w.x; ord = w.z;
+            }
+        }
+#pragma unroll
+      for (int j = 0 ; j < MG_FIND_PER ; ++j) { const U64 o = o0 + (U64) j * stride; if (o < n) __builtin_nontemporal_store (res[j], &out[o]); }
+    }
 }
 
 /* entries first..last (with their existing indices) from a host modset into the device table */
@@ -1292,7 +1315,11 @@ MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t s
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st)
 {
   if (!n) return MG_OK;
-  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel, dim3 (mgGrid (n)), dim3 (256), 0, st, t->slots, t->occ, mgGeomOf (t), dKmer, n, dIndexOut);
+  /* with the never-written buckets zeroed once, a probe needs no look at occ[] first */
+  { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
+  static int fgEnv = -1; if (fgEnv < 0) { const char *e = getenv ("MODGPU_FIND_GRID"); fgEnv = e ? atoi (e) : 0; }   /* dev knob */
+  unsigned fgrid = mgGrid ((n + MG_FIND_PER - 1) / MG_FIND_PER); if (fgEnv > 0 && fgrid > (unsigned) fgEnv) fgrid = (unsigned) fgEnv;
+  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel<false>, dim3 (fgrid), dim3 (256), 0, st, t->slots, t->occ, mgGeomOf (t), dKmer, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
