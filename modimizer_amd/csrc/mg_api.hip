@@ -765,6 +765,8 @@ extern "C" MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, 
 {
   hipStream_t st = (hipStream_t) stream;
   MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  d->t.loadPct = 60;
+  if (d->t.slots && (s = mgTableEnsure (&d->t, 0, st))) return s;
   return mgTableFind (&d->t, dKmer, n, dIndexOut, st);
 }
 
@@ -880,6 +882,7 @@ extern "C" MgStatus mgAddReadsDevice (Modset *ms, const U32 *dPacked, U64 totalB
   if (nHash) *nHash = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
+  d->t.loadPct = 75;                                   /* built and counted: see MgTable.loadPct */
   /* pos / isF / read are not needed by addSequence (modutils.c:24 passes 0 for isF and ignores pos) */
   /* the dense k-mer array is only made if the insert turns out to need it (a small batch, the table regrown): a large
      batch's first partition pass and index assignment read the scan's segments */
@@ -906,6 +909,8 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (nSeeds) *nSeeds = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
+  d->t.loadPct = 60;                                   /* lookups follow (or are this call): see MgTable.loadPct */
+  if (mode == 0 && d->t.slots && (s = mgTableEnsure (&d->t, 0, st))) return s;
   static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_SEED_TIMING"); timing = e && *e == '1'; }   /* dev */
   struct timespec q0, q1, q2; if (timing) clock_gettime (CLOCK_MONOTONIC, &q0);
   if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st,

@@ -1462,8 +1462,9 @@ MgStatus mgTableClean (MgTable *t, hipStream_t st)
 /* slots needed so that `entries` fit at load <= 0.6 */
 static int mgLog2SlotsFor (const MgTable *t, U64 entries)
 {
-  static int loadPct = -1;
-  if (loadPct < 0) { const char *e = getenv ("MODGPU_TABLE_LOAD"); loadPct = e && atoi (e) >= 10 && atoi (e) <= 150 ? atoi (e) : 60; }   /* dev knob (above 100: experiments only) */
+  static int envPct = -1;
+  if (envPct < 0) { const char *e = getenv ("MODGPU_TABLE_LOAD"); envPct = e && atoi (e) >= 10 && atoi (e) <= 150 ? atoi (e) : 0; }   /* dev knob (above 100: experiments only) */
+  const int loadPct = envPct ? envPct : (t->loadPct ? t->loadPct : 60);
   U64 need = entries * 100 / (U64) loadPct + 1;      /* entries / 0.6 by default */
   int lg = mgLog2 (need);
   if (lg < 16) lg = 16;

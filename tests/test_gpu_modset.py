@@ -371,6 +371,34 @@ print("chunked ok", n)
         assert r.returncode == 0 and "chunked ok" in r.stdout, (chunk, path, r.stderr[-1500:])
 
 
+def test_table_regrown_before_lookups():
+    """mgAddReadsDevice sizes the device table for entries / 0.75 (a set being built and counted); a lookup batch first
+    brings it back to entries / 0.6 (rehash on the device).  90 000 distinct k-mers: 2^17 slots after the build (load 0.69),
+    2^18 after the first lookup; indices, values and depths unchanged, found and absent k-mers answered as before"""
+    L = mg.lib()
+    k, w, bits = 21, 4, 22
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(123)
+    b = rng.integers(0, 4, 360_000).astype(np.uint8)
+    offs = np.array([0, len(b)], np.int64)
+    ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
+    assert mg.add_sequence_batch(ms, b, offs) == oms.add_sequence(b)
+    slots0 = L.mgModsetDeviceSlots(ms)
+    assert slots0 == 1 << 17 and oms.max / slots0 > 0.6, (slots0, oms.max)
+    present = oms.values()[1:20001].copy()
+    absent = (present ^ np.uint64(0x15555)) & np.uint64((1 << (2 * k)) - 1)
+    q = np.concatenate([present, absent])
+    d_q = mg.DeviceBuffer.from_numpy(q); d_o = mg.DeviceBuffer(len(q) * 4)
+    mg.check(L.modsetFindBatchDevice(ms, d_q.ptr, len(q), d_o.ptr, None))
+    got = d_o.to_numpy(np.uint32, len(q))
+    want = np.array([oms.find(int(x)) for x in q], np.uint32)
+    assert np.array_equal(got, want)
+    assert L.mgModsetDeviceSlots(ms) == 1 << 18
+    b2 = rng.integers(0, 4, 50_000).astype(np.uint8)
+    assert mg.add_sequence_batch(ms, b2, np.array([0, len(b2)], np.int64)) == oms.add_sequence(b2)
+    assert_same_modset(ms, oms, bits)
+
+
 def test_rank_slices():
     """bucketed path: the rank lookups run per slice of the ordinal range (mg_table.hip, mgRankLookupKernel).  One slice
     (a bucket's whole list in one group, far longer than a wave), the most slices the kernel takes (63 + the group of
