@@ -410,7 +410,19 @@ void mgScanKernel (const MgScanArgs a)
           /* the lane's candidates, low half of the mask then high half: 32-bit bit tricks, one LDS store each.
              o is the slot in this round's list; it wraps below lo, so "o < CAP" alone selects the round's entries
              (a loop condition on o costs more than it saves when there is one round, the usual case). */
-          if (myFirst < lo + MG_CAND_CAP && myFirst + cnt > lo)
+          if (nRounds == 1)                                  /* the usual case: every candidate has its slot, nothing to clamp */
+            { unsigned short *pp = sCand + myFirst;
+#pragma unroll
+              for (int half = 0 ; half < 2 ; ++half)
+                { U32 c = half ? (U32) (cand >> 32) : (U32) cand;
+                  const U32 base = (U32) lane * MG_POS_PER_THREAD + 32u * half;
+                  while (c)
+                    { *pp++ = (unsigned short) (base | (U32) __builtin_ctz (c));
+                      c &= c - 1;
+                    }
+                }
+            }
+          else if (myFirst < lo + MG_CAND_CAP && myFirst + cnt > lo)
             { U32 o = myFirst - lo;
 #pragma unroll
               for (int half = 0 ; half < 2 ; ++half)
