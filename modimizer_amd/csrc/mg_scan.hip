@@ -470,7 +470,8 @@ void mgScanKernel (const MgScanArgs a)
                   if (!fwd) F = R;
                 }
               const U64 bs = __ballot (surv);
-              U32 r = (U32) __shfl ((int) rFirst, (int) (q >> 6));            /* first read of the owner lane's starts */
+              U32 r = 0;
+              if (!oneRead || a.segRead) r = (U32) __shfl ((int) rFirst, (int) (q >> 6));   /* first read of the owner lane's starts (uniform test: the build of a tile inside one read needs neither) */
               if (surv)
                 { const U64 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
                   const U64 pos = tile0 + q;
