@@ -724,6 +724,7 @@ static MgStatus mgAddChunk (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
     }
   t.max = (U32) newMax;
   ms->max = t.max;
+  if (n >= 4096) t.newPct = (int) (c[0] * 100 / n);
   if (dIndexOut && (s = mgTableFind (&t, dKmer, n, dIndexOut, st))) return s;
   return MG_OK;
 }

@@ -192,6 +192,7 @@ struct MgTable {
   U64 *counters;       /* device U64[8]: 0 = new entries of the last add, 1 = bucket overflow */
   bool pendingDepth;   /* an add with depth counting ran since the counts were last folded into baseDepth / the host's depth[] */
   bool dirty;          /* buckets with occ == 0 hold undefined bytes (never zeroed): see mgTableClean */
+  int newPct;          /* new entries per 100 modimizers in the last bucketed add (a hint for the next one: mg_table.hip, markDup) */
   int loadPct;         /* slots are provided for entries * 100 / loadPct (0: 60).  A set that is only being built and counted
                           (mgAddReadsDevice) takes 75: its size is set from the OCCURRENCES of a batch, an upper bound of
                           the new entries, and the bucket images are the largest stream of the build; before lookups the

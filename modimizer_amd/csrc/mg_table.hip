@@ -734,6 +734,9 @@ struct MgBucketArgs {
      the rank lookups can run slice by slice against a piece of the rank records that stays in the L2 */
   unsigned short *sliceOff;        /* [NB x (nSlices + 2)]: start of group g in bucket b's list; [nSlices + 1] = the list's length */
   U32 nSlices; int sliceShift;
+  int markDup;                     /* which way round the flags are written: 0 = cleared by a memset, the dedup kernel sets the first occurrence
+                                      of every new k-mer (one store per unique); 1 = preset to 1, it clears every occurrence that is NOT one (one
+                                      store per duplicate: fewer when most of a batch's modimizers are new k-mers) */
   int withDepth;
   U64 *counters;
 #ifdef MG_ABLATE
@@ -780,6 +783,21 @@ __device__ __forceinline__ void mgOccurrence (const MgBucketArgs &a, U32 b, U64 
       *m = ((U64) (b >> a.f.loB) << a.f.remBits) | (x >> a.f.ordBits);     /* the bin's coarse digit in front of rem */
     }
   else { *m = x; *ord = t; }
+}
+
+/* one more occurrence (ordinal ord) of the k-mer in LDS slot at: the earliest ordinal wins the slot's token (assigned
+ * entries carry bit 31 and stay as they are).  markDup: whoever loses -- this occurrence, or the one that held the token --
+ * is not a first occurrence of a new k-mer: its flag is cleared */
+__device__ __forceinline__ void mgDedupCount (const MgBucketArgs &a, U32 *sOrd, U32 *sCnt, U32 at, U32 ord)
+{
+  const U32 tok = mgToken (ord);
+  if (a.markDup)
+    { const U32 old = atomicMax (&sOrd[at], tok);
+      const U32 loser = old > tok ? tok : old;
+      if (loser MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - loser] = 0;
+    }
+  else atomicMax (&sOrd[at], tok);
+  atomicAdd (&sCnt[at], 1u);
 }
 
 template <bool PACKED>
@@ -843,7 +861,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #ifdef MG_ABLATE
                 else if (a.debug & 2) { sOrd[at] = mgToken (ord); sCnt[at] = 1; }
 #endif
-                else { atomicMax (&sOrd[at], mgToken (ord)); atomicAdd (&sCnt[at], 1u); }
+                else { mgDedupCount (a, sOrd, sCnt, at, ord); }
               }
           for (U64 i = lo + (U64) MG_BUCKET_PREFETCH * T + tid ; i < hi ; i += T)
             { U64 m; U32 ord; mgOccurrence<PACKED> (a, b, a.pK[i], PACKED ? 0u : a.pT[i], &m, &ord);
@@ -856,8 +874,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #ifdef MG_ABLATE
               if (a.debug & 2) { sOrd[at] = mgToken (ord); sCnt[at] = 1; continue; }
 #endif
-              atomicMax (&sOrd[at], mgToken (ord));              /* assigned entries (bit 31) stay as they are */
-              atomicAdd (&sCnt[at], 1u);
+              mgDedupCount (a, sOrd, sCnt, at, ord);
             }
           __syncthreads ();
           /* the uniques leave grouped (see MgBucketArgs).  Every thread takes its slots of the image into registers
@@ -899,7 +916,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;
               if (true MG_ABLATE_AND (!(a.debug & 8)))
                 { __builtin_nontemporal_store (k, &a.pK[lo + i]); __builtin_nontemporal_store (ord, &a.pT[lo + i]); __builtin_nontemporal_store (c, &a.pC[lo + i]); }
-              if (!mgIsAssigned (ord) MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - ord] = 1;
+              if (!a.markDup && !mgIsAssigned (ord) MG_ABLATE_AND (!(a.debug & 1))) a.flags[0x7fffffffu - ord] = 1;
             }
           __syncthreads ();
         }
@@ -1236,8 +1253,12 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
       if ((s = mgPartPass (t, packed ? MG_EL_PACKED : MG_EL_WIDE, packed, f, kA, tA, n, coarseStart, (U32) 1 << hiB, 0, (U32) 1 << loB, kB, tB, fineStart, fineCursor, fineCount, chunkBase, st))) return s;
     }
 
-  MG_HIP (hipMemsetAsync (flags, 0, n, st));
   MgBucketArgs a;
+  /* flag polarity from what the previous bucketed add saw (MgTable.newPct: new entries per 100 modimizers) */
+  { static int polEnv = -2; if (polEnv == -2) { const char *e = getenv ("MODGPU_FLAG_POLARITY"); polEnv = e ? atoi (e) : -1; }   /* test knob: 0 / 1 force it */
+    a.markDup = polEnv >= 0 ? (polEnv ? 1 : 0) : (t->newPct > 50 ? 1 : 0);
+  }
+  MG_HIP (hipMemsetAsync (flags, a.markDup ? 1 : 0, n, st));
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
