@@ -144,7 +144,9 @@ void mgRankScanKernel (const U64 *__restrict__ blockCount, U32 nBlocks, U64 *__r
  * A wave reads 64 consecutive ordinals at a time; they lie in one segment, rarely in two or more.  The wave keeps the
  * segment of its first ordinal in scalar registers (w, its first ordinal s0 and the next segment's s1) and walks it
  * forward as its ordinals grow; a lane behind s1 walks on by itself. */
-#define MG_PART_SUB 8192          /* elements of a sub-chunk of the partition passes (LDS counting sort) */
+#ifndef MG_PART_SUB
+#define MG_PART_SUB 8192
+#endif                            /* elements of a sub-chunk of the partition passes (LDS counting sort) */
 struct MgSegCursor { U32 w; U64 s0, s1; };
 __device__ __forceinline__ U64 mgUniform64 (U64 x)
 { return ((U64) (U32) __builtin_amdgcn_readfirstlane ((int) (U32) (x >> 32)) << 32) | (U32) __builtin_amdgcn_readfirstlane ((int) (U32) x); }
@@ -449,7 +451,7 @@ __global__ void mgIndexFinishKernel (U32 *__restrict__ index, U64 n)
 /* ======================================================================================== */
 /* bucketed path, step 1: radix partition of (kmer, ordinal) by bucket id                     */
 
-#define MG_PART_CHUNK 16384          /* elements per workgroup pass */
+#define MG_PART_CHUNK (2 * MG_PART_SUB)          /* elements per workgroup pass */
 #define MG_PART_MAXBINS 512
 
 /* What a partition pass reads and writes.  The first pass reads the dense k-mers (an element's ordinal is its
@@ -586,7 +588,9 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
 /* Scatter with LDS staging: a sub-chunk of 4096 elements is counting-sorted by bin in LDS, so the
  * elements of one bin leave as one contiguous run written by consecutive lanes (plain scattered
  * 8-byte stores ran at ~22 G/s: 9 ms per 1.5e8 elements for the two passes). */
+#ifndef MG_PART_THREADS
 #define MG_PART_THREADS 1024
+#endif
 #define MG_PART_PER_THREAD (MG_PART_SUB / MG_PART_THREADS)
 /* the elements [sub, subHi) of a sub-chunk into registers, MG_PART_THREADS apart */
 template <int INMODE>

@@ -1,4 +1,4 @@
-"""BASELINE configs 3 and 5 at their full sizes on the GPU, through the C ABI.
+"""BASELINE configs 2, 3, 5 and one GPU's block of config 4 at their full sizes on the GPU, through the C ABI.
 
 The oracle cannot build a 3 Gbp reference or sketch 1 Gbp of short reads in seconds, so at full size the checks are
 (i) bit-exact comparisons with the oracle on a sample it does finish quickly, tied to the full-size result by a
@@ -98,6 +98,58 @@ def test_config5_full_size_depth_histogram():
     assert int(df[1:].astype(np.int64).sum()) == S
     L.modsetDestroy(ms); L.modsetDestroy(ms2)
     d_r.free(); d_of.free(); d_h.free()
+
+
+@pytest.mark.parametrize("name,total,G,bits", [("config 2", 10_000_000_000, 333_333_333, 30),
+                                               ("one block of config 4", 12_500_000_000, 3_333_333_333, 30)])
+def test_config2_and_config4_block_prefix_exact(name, total, G, bits):
+    """BASELINE config 2 (10 Gbp at 30x of a 333 Mbp genome) and one GPU's block of config 4 (12.5 Gbp of the 100 Gbp set:
+    3.75x of a 3.33 Gbp genome, 1.66e8 distinct modimizers), k=21 d=64, built at full size by mgAddReadsDevice; the first
+    ~40 Mbp of reads also through the oracle: bit-exact on their own, and as the prefix of the full-size value[] / depth[]"""
+    L = mg.lib()
+    k, w = 21, 64
+    plan = synth.ont_read_plan(total, G, 4242)
+    d_r, d_of, _ = device_reads(L, G, 4241, plan, 0.05, 4243)
+    n_reads = len(plan[0])
+    sh = mg.seqhashCreate(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    n = C.c_uint64()
+    mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, C.byref(n), None))
+    S, U = n.value, ms.contents.max
+    assert abs(S / (total / 64.0) - 1) < 0.01 and 0 < U <= S, name
+    d_h = mg.DeviceBuffer(65536 * 8)
+    mg.check(L.mgMemsetD(d_h.ptr, 0, 65536 * 8, None))
+    mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
+    h = d_h.to_numpy(np.uint64, 65536)
+    assert int(h.sum()) == U and h[0] == 0 and h[65535] == 0
+    assert int((h * np.arange(65536, dtype=np.uint64)).sum()) == S
+
+    offs = plan[1].astype(np.int64)
+    m = int(np.searchsorted(offs, 40_000_000))                        # reads wholly inside the first ~40 Mbp
+    host = unpack_range(L, d_r, 0, int(offs[m]))
+    oh = po.Hasher(k, w, 17); oms = po.Modset(oh, 24)
+    tot = sum(oms.add_sequence(host[offs[r]:offs[r + 1]]) for r in range(m))
+    ms2 = mg.modsetCreate(sh, 24)
+    n2 = C.c_uint64()
+    mg.check(L.mgAddReadsDevice(ms2, d_r.ptr, int(offs[m]), d_of.ptr, m, C.byref(n2), None))
+    assert n2.value == tot
+    mg.check(L.modsetSyncToHost(ms2, 0))
+    v2, dep2, _ = mg.modset_arrays(ms2)
+    assert ms2.contents.max == oms.max and np.array_equal(v2[1:], oms.values()[1:]) and np.array_equal(dep2[1:], oms.depths()[1:])
+    mg.check(L.modsetSyncToHost(ms, 0))
+    vf = np.ctypeslib.as_array(ms.contents.value, (U + 1,))
+    df = np.ctypeslib.as_array(ms.contents.depth, (U + 1,))
+    assert np.array_equal(vf[1:oms.max + 1], oms.values()[1:]), name        # indices in order of first occurrence (modset.c:57)
+    assert np.all(df[1:oms.max + 1] >= oms.depths()[1:])
+    assert int(df[1:].astype(np.int64).sum()) == S
+    # a sample of the entries behind the prefix: each is a k-mer the scan of SOME read produces, and finds its own index
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(np.arange(oms.max + 1, U + 1), 200_000, replace=False))
+    d_v = mg.DeviceBuffer.from_numpy(np.ascontiguousarray(vf[pick])); d_o = mg.DeviceBuffer(len(pick) * 4)
+    mg.check(L.modsetFindBatchDevice(ms, d_v.ptr, len(pick), d_o.ptr, None))
+    assert np.array_equal(d_o.to_numpy(np.uint32, len(pick)), pick.astype(np.uint32))
+    L.modsetDestroy(ms); L.modsetDestroy(ms2)
+    d_r.free(); d_of.free(); d_h.free(); d_v.free(); d_o.free()
 
 
 def test_config3_full_size_reference_and_queries(tmp_path):
