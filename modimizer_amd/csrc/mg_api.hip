@@ -861,7 +861,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
         { b->counted.binCount = (U32 *) d->arena.take (512 * MG_HIST_STRIDE * sizeof (U32));
           b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
         }
-      const bool lz = lazy && !wantPos && b->counted.binCount;
+      const bool lz = lazy && (wantPos ? extraPerSurvivor == 0 : b->counted.binCount != 0);   /* a build needs the digit counts; a pure lookup just the segments */
       if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
                              b->counted.binCount ? &b->counted : 0, lz ? &b->seg : 0))) return s;
       b->lazy = lz;
@@ -914,13 +914,14 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (mode == 0 && d->t.slots && (s = mgTableEnsure (&d->t, 0, st))) return s;
   static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_SEED_TIMING"); timing = e && *e == '1'; }   /* dev */
   struct timespec q0, q1, q2; if (timing) clock_gettime (CLOCK_MONOTONIC, &q0);
+  /* lookups read the k-mers from the scan's segments (no dense copy of them); pos / read are compacted as before */
   if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st,
-                            dSeedPosF, dSeedRead, capacity))) return s;
+                            dSeedPosF, dSeedRead, capacity, mode == 0))) return s;
   if (timing) clock_gettime (CLOCK_MONOTONIC, &q1);
   if (nSeeds) *nSeeds = n;
   if (n > capacity)
     { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
-  if (mode == 0) s = mgTableFind (&d->t, b.kmer, n, dSeedIndex, st);
+  if (mode == 0) s = b.lazy ? mgTableFindSegments (&d->t, b.seg, n, dSeedIndex, st) : mgTableFind (&d->t, b.kmer, n, dSeedIndex, st);
   else s = mgAddBatch (ms, d, b.kmer, n, dSeedIndex, 0, true, st, &b.counted);
   if (s) return s;
   if (dSeedPosF && b.posF != dSeedPosF) MG_HIP (hipMemcpyAsync (dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st));

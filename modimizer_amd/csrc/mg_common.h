@@ -212,6 +212,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
 bool     mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *counted);
 MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st);
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
+MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dIndexOut, hipStream_t st);   /* the n k-mers of a lazy scan, in order */
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);
 MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st);
 MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st);

@@ -582,7 +582,7 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
             { const U64 i = i0 + (U64) j * 256 + threadIdx.x;
               km[j] = 0; pf[j] = 0; rd[j] = 0;
               if (i < n)
-                { km[j] = segKmer[src + i];
+                { if (outKmer || histBins) km[j] = segKmer[src + i];
                   if (outPosF) pf[j] = segPosF[src + i];
                   if (outRead) rd[j] = segRead[src + i];
                 }
@@ -727,7 +727,7 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
     if (hist && hist->binCount && !scanCounts) { mgPartSplit (hist->log2NB, &hiB, &loB); bins = (U32) 1 << hiB; }
     const unsigned cgrid = g.nBlocks < 4096 ? g.nBlocks : 4096;
     if (lazy) { lazy->segKmer = segKmer; lazy->segCount = blockCount; lazy->segStart = segStart; lazy->segCap = g.segCap; lazy->nSegs = g.nBlocks; }
-    if (!lazy || bins)
+    if (!lazy || bins || dPosF || dReadId)                /* lazy: the k-mers stay in the segments; pos / read, when asked for, are made dense all the same */
       MG_LAUNCH (MG_K_SEG_COMPACT, st, mgSegCompactKernel, dim3 (cgrid), dim3 (256), 0, st,
                  segKmer, a.segPosF, a.segRead, g.segCap, g.nBlocks, blockCount, segStart, lazy ? (U64 *) 0 : dKmer, dPosF, dReadId, capacity, dCount,
                  hist ? hist->log2NB : 0, hist ? hist->kbits : 64, loB, bins, hist ? hist->binCount : (U32 *) 0);

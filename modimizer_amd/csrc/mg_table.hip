@@ -313,6 +313,38 @@ void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict_
     }
 }
 
+/* the same lookups for k-mers that still sit in the scan's segments: a wave walks a contiguous range of rows of 64
+ * ordinals with a segment cursor (see MgSegCursor) */
+__global__ __launch_bounds__ (256)
+void mgTableFindSegKernel (const MgSlot *__restrict__ slots, MgGeom g, const MgSegSrc src, U64 n, U64 rowsPerWave, U32 *__restrict__ out)
+{
+  const int lane = threadIdx.x & 63;
+  const U64 wave = (U64) blockIdx.x * 4 + (U32) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
+  const U64 nRows = (n + 63) / 64;
+  U64 row = wave * rowsPerWave, rEnd = row + rowsPerWave;
+  if (rEnd > nRows) rEnd = nRows;
+  if (row >= rEnd) return;
+  MgSegCursor cur;
+  mgSegCursorAt (src, mgSegOfOrdinal (src, row * 64), &cur);
+  for ( ; row < rEnd ; ++row)
+    { const U64 o0 = row * 64, o = o0 + (U64) lane, last = o0 + 63 < n ? o0 + 63 : n - 1;
+      mgSegCursorSeek (src, &cur, o0);
+      const U64 *at = mgSegAddr (src, cur, o < n ? o : last, last);
+      if (o >= n) continue;
+      const U64 m = mgMixK (__builtin_nontemporal_load (at), g.kbits), key = m + 1;
+      const U64 base = (U64) mgBucketOfM (m, g) * g.R;
+      U32 slot = mgHomeOfM (m, g), res = 0;
+      for (U32 probes = 0 ; probes < g.R ; ++probes)
+        { const uint4 w = *reinterpret_cast<const uint4 *> (&slots[base + slot]);
+          const U64 cur64 = ((U64) w.y << 32) | w.x;
+          if (cur64 == key) { res = mgIsAssigned (w.z) ? (w.z & ~MG_ASSIGNED) : 0; break; }
+          if (cur64 == 0) break;
+          slot = (slot + 1) & g.rMask;
+        }
+      __builtin_nontemporal_store (res, &out[o]);
+    }
+}
+
 /* entries first..last (with their existing indices) from a host modset into the device table */
 __global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, MgGeom g, const U64 *__restrict__ value,
                                    U32 first, U32 last, U32 *__restrict__ occ, U64 *counters)
@@ -1345,6 +1377,20 @@ MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipSt
   static int fgEnv = -1; if (fgEnv < 0) { const char *e = getenv ("MODGPU_FIND_GRID"); fgEnv = e ? atoi (e) : 0; }   /* dev knob */
   unsigned fgrid = mgGrid ((n + MG_FIND_PER - 1) / MG_FIND_PER); if (fgEnv > 0 && fgrid > (unsigned) fgEnv) fgrid = (unsigned) fgEnv;
   MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel<false>, dim3 (fgrid), dim3 (256), 0, st, t->slots, t->occ, mgGeomOf (t), dKmer, n, dIndexOut);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dIndexOut, hipStream_t st)
+{
+  if (!n) return MG_OK;
+  { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
+  const U64 nRows = (n + 63) / 64;
+  U64 waves = 256ull * 4 * 8;                           /* eight waves per SIMD */
+  if (waves > nRows) waves = nRows;
+  const U64 rowsPerWave = (nRows + waves - 1) / waves;
+  waves = (nRows + rowsPerWave - 1) / rowsPerWave;
+  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindSegKernel, dim3 ((unsigned) ((waves + 3) / 4)), dim3 (256), 0, st, t->slots, mgGeomOf (t), src, n, rowsPerWave, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
