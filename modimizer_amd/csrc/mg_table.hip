@@ -1200,8 +1200,7 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
     }
   /* one segment (the first pass): every workgroup reserves in the same few hundred cursors -- one cache line each
      (scatter 0.88 -> 0.73 ms: returning atomics on cursors that share a line queue behind each other) */
-  static int csEnv = -1; if (csEnv < 0) { const char *e = getenv ("MODGPU_CURSOR_STRIDE"); csEnv = e ? atoi (e) : 16; }   /* dev knob */
-  const U32 cstride = nSeg == 1 ? (U32) csEnv : 1u;                  /* (the second pass's 65536 cursors: no gain from padding) */
+  const U32 cstride = nSeg == 1 ? 16u : 1u;                  /* (the second pass's 65536 cursors: no gain from padding) */
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, cstride, nSeg, n);
 #define MG_SCATTER(IN, PK) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK>), sg, dim3 (MG_PART_THREADS), 0, st, \
                                       kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, cursor, cstride, kOut, tOut)
@@ -1374,8 +1373,7 @@ MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipSt
   if (!n) return MG_OK;
   /* with the never-written buckets zeroed once, a probe needs no look at occ[] first */
   { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
-  static int fgEnv = -1; if (fgEnv < 0) { const char *e = getenv ("MODGPU_FIND_GRID"); fgEnv = e ? atoi (e) : 0; }   /* dev knob */
-  unsigned fgrid = mgGrid ((n + MG_FIND_PER - 1) / MG_FIND_PER); if (fgEnv > 0 && fgrid > (unsigned) fgEnv) fgrid = (unsigned) fgEnv;
+  const unsigned fgrid = mgGrid ((n + MG_FIND_PER - 1) / MG_FIND_PER);
   MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindKernel<false>, dim3 (fgrid), dim3 (256), 0, st, t->slots, t->occ, mgGeomOf (t), dKmer, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
