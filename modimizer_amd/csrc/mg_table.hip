@@ -107,6 +107,16 @@ void mgRankCountKernel (const unsigned char *__restrict__ flags, U64 n, U64 rows
   U64 row = unit * rowsPerUnit, rEnd = row + rowsPerUnit;
   if (rEnd > nRows) rEnd = nRows;
   U32 c = 0;
+  /* a lane reads 16 consecutive flags at once (one 16-byte load: a wave covers 16 rows), four such loads in flight */
+  if ((reinterpret_cast<uintptr_t> (flags) & 15) == 0)
+    for ( ; row + 64 <= rEnd && (row + 64) * 64 <= n ; row += 64)
+      { uint4 q[4];
+#pragma unroll
+        for (int j = 0 ; j < 4 ; ++j) q[j] = *reinterpret_cast<const uint4 *> (flags + (row + 16 * j) * 64 + (U64) lane * 16);
+#pragma unroll
+        for (int j = 0 ; j < 4 ; ++j)
+          c += (U32) __popc (q[j].x & 0x01010101u) + (U32) __popc (q[j].y & 0x01010101u) + (U32) __popc (q[j].z & 0x01010101u) + (U32) __popc (q[j].w & 0x01010101u);
+      }
   for ( ; row + 4 <= rEnd ; row += 4)
     { U32 v[4];
 #pragma unroll
