@@ -396,8 +396,8 @@ def gpu_rank(args):
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not multi and not args.no_other:
         other = {}
-        for name, fn in (("c5", bench_c5), ("c3", bench_c3)):
-            if name not in os.environ.get("MODGPU_BENCH_OTHER", "c5,c3").split(","):      # dev: run a subset
+        for name, fn in (("c4_block", bench_c4_block), ("c5", bench_c5), ("c3", bench_c3)):
+            if name not in os.environ.get("MODGPU_BENCH_OTHER", "c4_block,c5,c3").split(","):      # dev: run a subset
                 continue
             try:
                 other[name] = fn(cx, args)
@@ -416,6 +416,44 @@ def gpu_rank(args):
 
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs 5 and 3 (N = 1)
+
+def bench_c4_block(cx, args):
+    """What ONE GPU does at N > 1 (configs[3]): block 0 of the 100 Gbp set — 12.5 Gbp of reads from the 3.33 Gbp genome —
+    scan + modset build + depth histogram, without the collective.  N x this is what `--gpus N` can reach; it is not
+    config 2 (3.75x coverage per block: 1.66e8 distinct modimizers against 1.03e8), so a scaling efficiency taken against
+    the N = 1 line (config 2) starts at this ratio."""
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    k, d, bits = 21, 64, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
+    total = int(12.5e9)
+    genome_bases = int(total * 8 / 30)
+    genome = make_genome(cx, genome_bases, 12345)
+    reads, d_offsets, offsets, n_reads = make_reads(cx, total, genome, genome_bases, 1000, 0.05, 777)
+    del genome
+    sh = mg.seqhashCreate(k, d, 17)
+    ms = mg.modsetCreate(sh, bits)
+    hist = torch.zeros(65536, dtype=torch.int64, device=cx.dev)
+    n_hash = C.c_uint64(0)
+
+    def step():
+        mg.check(L.mgModsetClear(ms, cx.stream))
+        mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads, C.byref(n_hash), cx.stream))
+        hist.zero_()
+        mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), cx.stream))
+
+    steps = max(3, min(args.steps, 10))
+    dt, kern, table = time_steps(cx, step, steps, 1, False)
+    S, entries = n_hash.value, ms.contents.max
+    alg = alg_bytes_table(total, S, entries, d, float(L.mgModsetDeviceSlots(ms)))
+    res = {"workload": "one GPU's share of BASELINE config 4 on this GPU alone: block 0 of 8 (12.5 Gbp of reads from the %d Mbp genome), "
+                       "k=21 d=64, table bits %d: seqhash scan + modset build + depth histogram (no all-reduce)" % (genome_bases // 1_000_000, bits),
+           "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "bases": total, "modimizers": S, "modset_entries": entries, "histogram_entries": int(hist.sum().item()),
+           "roofline": roofline_of(kern, table, alg, "12.5")}
+    L.modsetDestroy(ms)
+    del reads, d_offsets
+    torch.cuda.empty_cache()
+    return res
+
 
 def bench_c5(cx, args):
     """configs[4]: modutils depth histogram on 50x synthetic Illumina 150 b reads, k=31 d=4 (20 Mbp genome,
