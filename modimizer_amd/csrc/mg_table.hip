@@ -780,6 +780,9 @@ struct MgBucketArgs {
      the rank lookups can run slice by slice against a piece of the rank records that stays in the L2 */
   unsigned short *sliceOff;        /* [NB x (nSlices + 2)]: start of group g in bucket b's list; [nSlices + 1] = the list's length */
   U32 nSlices; int sliceShift;
+  int slotShift;                   /* != 0 (2k <= 48): a list entry carries, above bit slotShift of its mixed k-mer, the slot the k-mer holds in
+                                      the dedup kernel's LDS image of the bucket -- a valid place in the bucket (the image starts from the
+                                      table's own), so the merge kernel puts it there without probing */
   int markDup;                     /* which way round the flags are written: 0 = cleared by a memset, the dedup kernel sets the first occurrence
                                       of every new k-mer (one store per unique); 1 = preset to 1, it clears every occurrence that is NOT one (one
                                       store per duplicate: fewer when most of a batch's modimizers are new k-mers) */
@@ -816,6 +819,7 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
  * slots the closing sweep visits (no 64 KiB re-zeroing per bucket). */
 #define MG_BUCKET_PREFETCH 2
 #define MG_RANK_GROUPS 64            /* most groups a bucket's list is cut into: slices of the ordinal range + 1 */
+#define MG_SLOT_SHIFT 48             /* a list entry's slot sits above this bit of its mixed k-mer (when 2k <= 48) */
 #define MG_DEDUP_PER 4               /* slots of the LDS image per thread of the dedup kernel: R <= 4 x threads */
 #define MG_LIVE_BINS 256              /* depths below this are counted in LDS by the merge kernel's live histogram */
 
@@ -846,7 +850,7 @@ __device__ __forceinline__ void mgDedupCount (const MgBucketArgs &a, U32 *sOrd, 
   atomicAdd (&sCnt[at], 1u);
 }
 
-template <bool PACKED>
+template <bool PACKED, bool SLOT>       /* SLOT: a.slotShift != 0 */
 __global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (8)))      /* 64 registers: two workgroups per CU */
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
@@ -936,6 +940,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (rk[j])
                 { rc[j] = sCnt[i]; ro[j] = sOrd[i];
                   sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;
+                  rk[j] = (rk[j] - 1) | (SLOT ? (unsigned long long) i << MG_SLOT_SHIFT : 0ull);   /* the list holds the mixed k-mer (key - 1), under its slot where there is room */
                   if (rc[j]) rp[j] = atomicAdd (&sGrp[mgIsAssigned (ro[j]) ? a.nSlices : ((0x7fffffffu - ro[j]) >> a.sliceShift)], 1u);
                 }
             }
@@ -953,7 +958,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           for (int j = 0 ; j < MG_DEDUP_PER ; ++j)
             { const U32 grp = mgIsAssigned (ro[j]) ? a.nSlices : ((0x7fffffffu - ro[j]) >> a.sliceShift);
               const U32 at = (U32) __shfl ((int) gBase, (int) (rc[j] ? grp : 0)) + rp[j];
-              if (rc[j]) { sKey[at] = rk[j] - 1; sOrd[at] = ro[j]; sCnt[at] = rc[j]; }
+              if (rc[j]) { sKey[at] = rk[j]; sOrd[at] = ro[j]; sCnt[at] = rc[j]; }
             }
           __syncthreads ();
           if (tid < MG_RANK_GROUPS) sGrp[tid] = 0;
@@ -1017,6 +1022,12 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               else { km = __builtin_nontemporal_load (&a.pK[lo + i]); ord = __builtin_nontemporal_load (&a.pT[lo + i]); c = __builtin_nontemporal_load (&a.pC[lo + i]); }
               if (!a.withDepth) c = 0;
               U32 at;
+              if (a.slotShift)                                   /* the slot comes with the entry: every entry its own */
+                { at = (U32) (km >> MG_SLOT_SHIFT); km &= ((U64) 1 << MG_SLOT_SHIFT) - 1;
+                  if (i < nNew) { sKey[at] = km + 1; sOrd[at] = ord; sCnt[at] = c; }
+                  else if (c) sCnt[at] += c;
+                  continue;
+                }
 #ifdef MG_ABLATE
               if (a.debug & 32) { at = mgHomeOfM (km, a.g); sKey[at] = km + 1; } else
 #endif
@@ -1304,6 +1315,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
     a.markDup = polEnv >= 0 ? (polEnv ? 1 : 0) : (t->newPct > 50 ? 1 : 0);
   }
   MG_HIP (hipMemsetAsync (flags, a.markDup ? 1 : 0, n, st));
+  /* the merge kernel takes the slots from the dedup kernel when the buckets will be more than half full (there its
+     probing costs more than the dedup kernel's extra work: a 12.5 Gbp block at load 0.62 gains 0.4 ms, config 2 at 0.38
+     nothing); the load is estimated from the share of new k-mers the previous add saw */
+  { static int slotEnv = -2; if (slotEnv == -2) { const char *e = getenv ("MODGPU_MERGE_SLOTS"); slotEnv = e ? atoi (e) : -1; }   /* test knob: 0 / 1 force it */
+    const U64 expectNew = t->newPct > 0 ? n * (U64) t->newPct / 100 : n;
+    const bool dense = ((U64) t->max + expectNew) * 2 > t->nSlots;
+    a.slotShift = (t->kbits <= MG_SLOT_SHIFT && (slotEnv >= 0 ? slotEnv != 0 : dense)) ? MG_SLOT_SHIFT : 0;
+  }
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
@@ -1331,8 +1350,10 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   size_t lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
   { const size_t ldsDedup = (size_t) t->R * 16 + MG_RANK_GROUPS * 4; if (ldsDedup > lds) lds = ldsDedup; }
   if (lds > 48 * 1024)
-    { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
   static int bThreadsEnv = -1;
@@ -1342,8 +1363,10 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
   U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
-  if (packed) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel<true>, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
-  else        MG_LAUNCH (MG_K_BUCKET_DEDUP, st, mgBucketDedupKernel<false>, dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
+  if (packed) { if (a.slotShift) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<true, true>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
+                else             MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<true, false>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock); }
+  else        { if (a.slotShift) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<false, true>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
+                else             MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<false, false>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock); }
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
   if (segSrc)
