@@ -817,7 +817,12 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
  * so the next bucket's bounds and first elements are fetched into registers while the current
  * bucket is processed, and the LDS image is kept all-zero between buckets by clearing exactly the
  * slots the closing sweep visits (no 64 KiB re-zeroing per bucket). */
-#define MG_BUCKET_PREFETCH 2
+#ifndef MG_BUCKET_PREFETCH
+#define MG_BUCKET_PREFETCH 3         /* occurrences per thread of the dedup kernel fetched one bucket ahead: with 1024 threads a whole bucket of config 2 (1.42 -> 1.20 ms against 2) */
+#endif
+#ifndef MG_MERGE_PREFETCH
+#define MG_MERGE_PREFETCH 2          /* uniques per thread of the merge kernel fetched one bucket ahead */
+#endif
 #define MG_RANK_GROUPS 64            /* most groups a bucket's list is cut into: slices of the ordinal range + 1 */
 #define MG_SLOT_SHIFT 48             /* a list entry's slot sits above this bit of its mixed k-mer (when 2k <= 48) */
 #define MG_DEDUP_PER 4               /* slots of the LDS image per thread of the dedup kernel: R <= 4 x threads */
@@ -996,15 +1001,25 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   U32 nNew = a.sliceOff[(U64) b * (a.nSlices + 2) + a.nSlices];   /* the list's first nNew uniques are new to the table, the others are in it */
   U32 occNow = a.occ[b];                          /* one bucket ahead, like the counts */
   U64 lo = a.bucketStart[b];
-  U64 ck = 0; U32 co = 0, cc = 0;
-  if (tid < nu) { ck = __builtin_nontemporal_load (&a.pK[lo + tid]); co = __builtin_nontemporal_load (&a.pT[lo + tid]); cc = __builtin_nontemporal_load (&a.pC[lo + tid]); }
+  U64 ck[MG_MERGE_PREFETCH]; U32 co[MG_MERGE_PREFETCH], cc[MG_MERGE_PREFETCH];
+#pragma unroll
+  for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j)
+    { const U32 i = (U32) j * T + tid; ck[j] = 0; co[j] = 0; cc[j] = 0;
+      if (i < nu) { ck[j] = __builtin_nontemporal_load (&a.pK[lo + i]); co[j] = __builtin_nontemporal_load (&a.pT[lo + i]); cc[j] = __builtin_nontemporal_load (&a.pC[lo + i]); }
+    }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
-    { U32 nnu = 0; U64 nlo = 0; U64 nk = 0; U32 no = 0, ncc = 0, occNext = 0, nNewNext = 0;
+    { U32 nnu = 0; U64 nlo = 0; U64 nk[MG_MERGE_PREFETCH]; U32 no[MG_MERGE_PREFETCH], ncc[MG_MERGE_PREFETCH], occNext = 0, nNewNext = 0;
+#pragma unroll
+      for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j) { nk[j] = 0; no[j] = 0; ncc[j] = 0; }
       if (b + 1 < bEnd)
         { nnu = a.uniqCount[b + 1]; nlo = a.bucketStart[b + 1]; occNext = a.occ[b + 1];
           nNewNext = a.sliceOff[(U64) (b + 1) * (a.nSlices + 2) + a.nSlices];
-          if (tid < nnu) { nk = __builtin_nontemporal_load (&a.pK[nlo + tid]); no = __builtin_nontemporal_load (&a.pT[nlo + tid]); ncc = __builtin_nontemporal_load (&a.pC[nlo + tid]); }
+#pragma unroll
+          for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j)
+            { const U32 i = (U32) j * T + tid;
+              if (i < nnu) { nk[j] = __builtin_nontemporal_load (&a.pK[nlo + i]); no[j] = __builtin_nontemporal_load (&a.pT[nlo + i]); ncc[j] = __builtin_nontemporal_load (&a.pC[nlo + i]); }
+            }
         }
       if (nu)
         {
@@ -1016,9 +1031,13 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               __syncthreads ();
             }
           /* the rank lookup kernel has turned the new uniques' ordinals into indices: place and count */
-          for (U32 i = tid ; i < nu ; i += T)
+          for (U32 i = tid, jj = 0 ; i < nu ; i += T, ++jj)
             { U64 km; U32 ord, c;
-              if (i == tid) { km = ck; ord = co; c = cc; }
+              if (jj < MG_MERGE_PREFETCH)
+                { km = ck[0]; ord = co[0]; c = cc[0];
+#pragma unroll
+                  for (int j = 1 ; j < MG_MERGE_PREFETCH ; ++j) if (jj == (U32) j) { km = ck[j]; ord = co[j]; c = cc[j]; }
+                }
               else { km = __builtin_nontemporal_load (&a.pK[lo + i]); ord = __builtin_nontemporal_load (&a.pT[lo + i]); c = __builtin_nontemporal_load (&a.pC[lo + i]); }
               if (!a.withDepth) c = 0;
               U32 at;
@@ -1061,7 +1080,9 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           __syncthreads ();
           if (tid == 0 && nNew) a.occ[b] += nNew;
         }
-      nu = nnu; lo = nlo; ck = nk; co = no; cc = ncc; occNow = occNext; nNew = nNewNext;
+      nu = nnu; lo = nlo; occNow = occNext; nNew = nNewNext;
+#pragma unroll
+      for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j) { ck[j] = nk[j]; co[j] = no[j]; cc[j] = ncc[j]; }
     }
   if (a.liveHist)
     { __syncthreads ();
