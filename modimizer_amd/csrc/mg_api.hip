@@ -838,7 +838,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
   MgHashParams p = mgMakeParams (sh);
   if (extraPerSurvivor)
     { /* size the table now for the expected number of modimizers (N/d): the insert would do it anyway once the
-         count is known, and with the geometry fixed the compaction kernel can count for the first partition pass */
+         count is known, and with the geometry fixed the scan (or, for 2k < 24, the compaction kernel) can count for the first partition pass */
       U64 expect = totalBases / (U64) (sh->w > 0 ? sh->w : 1) + 1;
       if (expect > MG_ADD_CHUNK) expect = MG_ADD_CHUNK;
       MgStatus es = mgTableEnsure (&d->t, expect, st); if (es) return es;

@@ -14,8 +14,11 @@
  * inter-workgroup protocol: a first version handed tiles out by an atomic ticket and ordered the output
  * by decoupled look-back; at > 50 M tiles/s both the single ticket word and the descriptor polling
  * saturated and capped the kernel near 0.8 Tbp/s).  The per-worker counts are scanned by a one-block
- * kernel and the segments are copied into the dense (read,pos)-ordered arrays by a streaming compaction
- * kernel.  A tile's 1 KiB is fetched one tile ahead with one 16-byte load per lane (registers) and staged,
+ * kernel; the consumers of a large batch read the segments where they are (the modset build's first
+ * partition pass and index assignment, the query's lookups: MgSegSrc), and a streaming compaction kernel
+ * makes dense (read,pos)-ordered arrays where those are wanted (pos / read of the query path, small
+ * batches, the scan API).  On the way the kernel counts every modimizer's first partition digit for the
+ * modset build (mgMixTopOfKmer).  A tile's 1 KiB is fetched one tile ahead with one 16-byte load per lane (registers) and staged,
  * double-buffered, in the wavefront's LDS with a (k-1)-base halo; each lane owns 64 consecutive k-mer starts.
  */
 #include <stdlib.h>

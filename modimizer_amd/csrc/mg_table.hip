@@ -24,12 +24,16 @@
  *
  *  bucketed (large batches)  no global atomics on the data path.  Measured on MI355X: a random
  *           global atomic costs ~1/17 G/s (three on one slot serialise), a random load ~1/45 G/s,
- *           streaming ~5 TB/s.  So: (1) radix-partition the batch by bucket (two streaming passes),
- *           (2) one workgroup per bucket dedups its occurrences in LDS (LDS atomics) and flags the
- *           first occurrence of every k-mer that is new to the table, (3) an ordered count over the
- *           flags gives every new k-mer its index and writes value[] in order, (4) one workgroup
- *           per bucket merges the bucket's unique k-mers into its LDS copy of the table bucket and
- *           streams it back.
+ *           streaming ~5 TB/s.  So: (1) radix-partition the batch by bucket (two streaming passes; the
+ *           first reads the scan's per-worker segments as they are, MgSegSrc, and its digit counts come
+ *           from the scan kernel), (2) one workgroup per bucket dedups its occurrences in LDS (LDS
+ *           atomics), flags the first occurrence of every k-mer that is new to the table (or clears the
+ *           flags of the others: markDup) and writes the bucket's unique k-mers back grouped by the slice
+ *           of the ordinal range their first occurrence lies in, (3) an ordered count over the flags gives
+ *           every new k-mer its index, writes value[] in order and leaves a rank record per 64 ordinals,
+ *           (3b) the rank lookups turn the uniques' ordinals into indices slice by slice, an XCD reading
+ *           one slice's rank records from its own L2, (4) one workgroup per bucket merges the bucket's
+ *           unique k-mers into its LDS copy of the table bucket and streams it back.
  */
 #include <stdlib.h>
 #include "mg_common.h"
@@ -204,7 +208,7 @@ __device__ __forceinline__ void mgSegCursorFrom (const MgSubSeg *__restrict__ su
 
 /* pass B: every flagged ordinal o gets index baseMax+1+rank(o); value[index] = kmer[o].
  * DIRECT: also store the index in the slot.  BUCKETED: record, per row of 64 ordinals, the flag
- * bitmap and the number of flags before the row, for the merge kernel's rank(o) lookups. */
+ * bitmap and the number of flags before the row, for mgRankLookupKernel's rank(o) lookups. */
 #define MG_RANK_ROWS 8
 template <bool DIRECT, bool SEG>
 __global__ __launch_bounds__ (256)
