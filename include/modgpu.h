@@ -268,6 +268,7 @@ MgSeqReader *mgSeqOpen (const char *filename) ;                        /* 0 if u
 int  mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out) ; /* whole records, at least one; 0 at the end */
 void mgSeqBatchFree (MgSeqBatch *b) ;
 void mgSeqClose (MgSeqReader *r) ;
+void mgSeqReleaseBuffers (void) ;	/* the readers keep their two largest buffers for the next file (unmapping and touching gigabytes again costs as much as parsing them); this gives them back -- a no-op while a reader is open; also run when the library is unloaded */
 /* the callers' per-file loops: parsing of the next batch overlaps the GPU work on the current one */
 int  mgAddSequenceFile (Modset *ms, const char *filename, FILE *out) ;                        /* modutils.c:33-51 */
 int  mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out) ;   /* modmap.c:93-134 */
