@@ -40,7 +40,25 @@ for t in range(trials):
         bits = 20
         oms = orc.Modset(h, bits); tot = sum(oms.add_sequence(r) for r in reads)
         ms = mg.modsetCreate(sh, bits)
-        n = mg.add_sequence_batch(ms, bases, offs); L.modsetSyncToHost(ms, 1)
+        # the reads in one to three batches, with a lookup of present and absent k-mers after the first
+        cuts = sorted(set([0, len(reads)] + [int(c) for c in rng.integers(0, len(reads) + 1, int(rng.integers(0, 3)))]))
+        n = 0
+        for bi in range(len(cuts) - 1):
+            a, b = cuts[bi], cuts[bi + 1]
+            if a == b: continue
+            n += mg.add_sequence_batch(ms, bases[offs[a]:offs[b]], offs[a:b + 1] - offs[a])
+            if bi == 0 and ms.contents.max > 0 and k <= 31:
+                import ctypes as C
+                L.modsetSyncToHost(ms, 0)
+                vv = np.ctypeslib.as_array(ms.contents.value, (ms.contents.max + 1,))[1:].copy()
+                probe = np.concatenate([vv[::3], (vv[::5] ^ np.uint64(5)) & np.uint64((1 << (2 * k)) - 1)])
+                d_p = mg.DeviceBuffer.from_numpy(probe); d_o = mg.DeviceBuffer(len(probe) * 4)
+                mg.check(L.modsetFindBatchDevice(ms, d_p.ptr, len(probe), d_o.ptr, None))
+                got = d_o.to_numpy(np.uint32, len(probe))
+                index_of = {int(x): i + 1 for i, x in enumerate(vv)}
+                ok = ok and all(int(got[i]) == index_of.get(int(probe[i]), 0) for i in range(len(probe)))
+                d_p.free(); d_o.free()
+        L.modsetSyncToHost(ms, 1)
         v, d, _ = mg.modset_arrays(ms)
         ok = ok and n == tot and ms.contents.max == oms.max and np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(d[1:], oms.depths()[1:])
         ok = ok and np.array_equal(np.ctypeslib.as_array(ms.contents.index, (1 << bits,)), oms.index_table())
