@@ -473,13 +473,14 @@ void mgScanKernel (const MgScanArgs a)
                   if (!fwd) F = R;
                 }
               const U64 bs = __ballot (surv);
+              const bool wantWhere = a.segPosF || a.segRead;              /* uniform: the modset build wants the k-mers alone */
               U32 r = 0;
-              if (!oneRead || a.segRead) r = (U32) __shfl ((int) rFirst, (int) (q >> 6));   /* first read of the owner lane's starts (uniform test: the build of a tile inside one read needs neither) */
+              if (wantWhere && (!oneRead || a.segRead)) r = (U32) __shfl ((int) rFirst, (int) (q >> 6));   /* first read of the owner lane's starts */
               if (surv)
                 { const U64 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
                   const U64 pos = tile0 + q;
                   U64 rs = ti.start;
-                  if (!oneRead)
+                  if (!oneRead && wantWhere)
                     { if (offInLds) { while (sOff[r + 1 - ti.firstRead] <= pos) ++r; rs = sOff[r - ti.firstRead]; }
                       else { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
                     }
