@@ -159,14 +159,16 @@ def make_genome(cx, genome_bases, seed):
     return genome
 
 
-def alg_bytes_table(total, S, entries, d, slots):
+def alg_bytes_table(total, S, entries, d, slots, k=21):
     """algorithmic bytes per launch: SURVEY §8(d)'s per-unit figures x the units a launch processes"""
+    import math
+    packed = 2 * k - 8 + max(1, math.ceil(math.log2(max(S, 2)))) <= 64      # the partition's one-word element format (mg_table.hip)
     return {
         "mgScanKernel": (0.25 + 8.0 / d) * total,    # 2-bit read + the 8-byte k-mer per modimizer (this path needs no pos)
         "mgSegCompactKernel": 16.0 * S,              # kmer read + written
         "mgPartHistKernel": 8.0 * S,
-        "mgPartScatterKernel": 24.0 * S,             # (kmer 8 + ordinal 4) read and written, per pass
-        "mgBucketDedupKernel": 12.0 * S + 16.0 * entries,
+        "mgPartScatterKernel": (16.0 if packed else 24.0) * S,      # one 8-byte word (or k-mer 8 + ordinal 4) read and written, per pass
+        "mgBucketDedupKernel": (8.0 if packed else 12.0) * S + 16.0 * entries,
         "mgRankAssignKernel": 9.0 * S + 8.0 * entries,
         "mgRankLookupKernel": 8.0 * entries,         # a unique's ordinal read, its index written
         "mgBucketMergeKernel": 16.0 * entries + 16.0 * slots,   # uniques in, table buckets out
@@ -232,6 +234,8 @@ def roofline_of(kern, table, alg_bytes, tag, extra=None):
          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": tfrom,
          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": ab,
          "kernels_ms_per_step": {k: round(v[0], 4) for k, v in sorted(table.items())},
+         "kernels_hbm_frac": {k: round(alg_bytes[k] * max(v[1], 1) / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                              for k, v in sorted(table.items()) if alg_bytes.get(k) and v[0] > 0},   # algorithmic bytes of all its launches in a step / its time in the step / 8 TB/s
          "kernels_ms_per_step_from": "one extra step after the timed region, every launch bracketed"}
     if extra:
         r.update(extra)
@@ -482,7 +486,7 @@ def bench_c5(cx, args):
     steps = max(3, min(args.steps, 10))
     dt, kern, table = time_steps(cx, step, steps, 1, False)
     S, entries = n_hash.value, ms.contents.max
-    alg = alg_bytes_table(total, S, entries, d, float(L.mgModsetDeviceSlots(ms)))
+    alg = alg_bytes_table(total, S, entries, d, float(L.mgModsetDeviceSlots(ms)), k)
     h = hist.cpu().numpy()
     res = {"workload": "BASELINE config 5: %d x 150 b reads (50x of a %d Mbp genome, 0.5%% subs), k=31 d=4 seed=17, table bits %d: "
                        "seqhash scan + modset build + depth histogram" % (n_reads, genome_bases // 1_000_000, bits),
