@@ -26,7 +26,8 @@ mg.check(L.seqhashScanBatchDevice(sh, r.data_ptr(), total, do.data_ptr(), len(st
 torch.cuda.synchronize()
 n = int(cnt[0].item()); print("modimizers", n)
 ms = mg.modsetCreate(sh, 29)
-sA = torch.cuda.Stream(); sB = torch.cuda.Stream()
+pri = int(os.environ.get("CORUN_BUILD_PRIORITY", "0"))           # -1: the build's stream gets the higher priority
+sA = torch.cuda.Stream(priority=0 if pri else 0); sB = torch.cuda.Stream(priority=pri)
 A = C.c_void_p(sA.cuda_stream); B = C.c_void_p(sB.cuda_stream)
 def scan_loop(k):
     for _ in range(k):
