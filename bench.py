@@ -174,7 +174,33 @@ def alg_bytes_table(total, S, entries, d, slots, k=21):
         "mgBucketMergeKernel": 16.0 * entries + 16.0 * slots,   # uniques in, table buckets out
         "mgTableInsertKernel": 16.0 * S,
         "mgTableFindKernel": 24.0 * S,               # kmer 8 read + one 16-byte slot probed + (index) 4 written ~ SURVEY's 24*S
+        "mgTableFindSegKernel": 24.0 * S,            # the same lookups, k-mers read from the scan's segments
     }
+
+
+# What really bounds a kernel, where it is not HBM bytes, with the ceiling measured by the microbenchmarks
+# under tools/ (profiles/r02_ubench*): the achieved fraction OF THAT ceiling goes into roofline.bound_actual.
+RANDOM_LOADS_PER_S_BIG = 55e9        # tools/ubench_rand: random 16-byte loads from a footprint above 64 MB (Infinity Cache or HBM alike)
+RANDOM_LOADS_PER_S_L2 = 250e9        # the same from a footprint inside one XCD's L2 (<= 4 MB): 235-260 G/s
+
+
+def bound_actual(kernel, avg_ms, units, alu=None):
+    """units: what the kernel does per launch in the unit of its real bound (probes, lookups)"""
+    if kernel == "mgScanKernel":
+        if not alu or not alu.get("issue_frac"):
+            return {"bound": "valu_issue"}
+        return {"bound": "valu_issue", "ceiling": alu["issue_peak_wave_insts_per_s"], "unit": "wave VALU instructions/s (measured, tools/ubench.hip)",
+                "achieved": round(alu["valu_per_start"] * units / 64 / (avg_ms * 1e-3), 1), "frac_of_ceiling": alu["issue_frac"]}
+    if kernel in ("mgTableFindKernel", "mgTableFindSegKernel"):
+        ach = units / (avg_ms * 1e-3)
+        return {"bound": "random_access", "ceiling": RANDOM_LOADS_PER_S_BIG, "unit": "random 16-byte loads/s, footprint > 64 MB (measured, tools/ubench_rand.hip)",
+                "achieved": round(ach, 1), "frac_of_ceiling": round(ach / RANDOM_LOADS_PER_S_BIG, 3),
+                "note": "achieved counts one load per lookup; a lookup that collides probes again (about 1.3 probes per lookup at load 0.6)"}
+    if kernel == "mgRankLookupKernel":
+        ach = units / (avg_ms * 1e-3)
+        return {"bound": "random_access", "ceiling": RANDOM_LOADS_PER_S_L2, "unit": "random 16-byte loads/s, footprint inside one XCD's L2 (measured, tools/ubench_rand.hip)",
+                "achieved": round(ach, 1), "frac_of_ceiling": round(ach / RANDOM_LOADS_PER_S_L2, 3)}
+    return None
 
 
 def time_steps(cx, step, steps, warmup, multi):
@@ -213,7 +239,8 @@ def time_steps(cx, step, steps, warmup, multi):
     return dt, kern, table
 
 
-def roofline_of(kern, table, alg_bytes, tag, extra=None):
+def roofline_of(kern, table, alg_bytes, tag, extra=None, units=None):
+    """units: {kernel: work items per launch in the unit of the kernel's real bound} for bound_actual"""
     if not kern:
         return None
     dom = max(kern.items(), key=lambda kv: kv[1][0])[0]
@@ -239,6 +266,17 @@ def roofline_of(kern, table, alg_bytes, tag, extra=None):
          "kernels_ms_per_step_from": "one extra step after the timed region, every launch bracketed"}
     if extra:
         r.update(extra)
+    ba = bound_actual(dom, avg_ms, (units or {}).get(dom, 0), (extra or {}).get("alu"))
+    if ba:
+        r["bound_actual"] = ba
+    others = {}
+    for kname, v in table.items():                    # the kernels of the step that sit on another bound than HBM bytes
+        if kname != dom and (units or {}).get(kname) and v[0] > 0:
+            o = bound_actual(kname, v[0] / max(v[1], 1), units[kname])
+            if o:
+                others[kname] = o
+    if others:
+        r["bound_actual_other_kernels"] = others
     return r
 
 
@@ -340,7 +378,7 @@ def gpu_rank(args):
              "whole_step": {"bytes_per_base": 0.25 + 28.0 / d,
                             "GBps": round((0.25 + 28.0 / d) * total * args.steps / dt / 1e9, 1),
                             "frac": round((0.25 + 28.0 / d) * total * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)}}
-    roofline = roofline_of(kern, table, alg, "%g" % gbp, extra)
+    roofline = roofline_of(kern, table, alg, "%g" % gbp, extra, units={"mgScanKernel": starts, "mgRankLookupKernel": float(entries)})
 
     value = world * total * args.steps / dt / 1e9
     scan_step_ms = sum(v[0] for kname, v in table.items() if kname in ("mgScanKernel", "mgSegScanKernel", "mgSegCompactKernel", "mgTileInfoKernel"))
@@ -452,7 +490,7 @@ def bench_c4_block(cx, args):
                        "k=21 d=64, table bits %d: seqhash scan + modset build + depth histogram (no all-reduce)" % (genome_bases // 1_000_000, bits),
            "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "bases": total, "modimizers": S, "modset_entries": entries, "histogram_entries": int(hist.sum().item()),
-           "roofline": roofline_of(kern, table, alg, "12.5")}
+           "roofline": roofline_of(kern, table, alg, "12.5", units={"mgRankLookupKernel": float(entries)})}
     L.modsetDestroy(ms)
     del reads, d_offsets
     torch.cuda.empty_cache()
@@ -572,7 +610,7 @@ def bench_c3(cx, args):
     S = tot_seeds / n_batches
     alg = alg_bytes_table(batch, S, ref_entries, d, float(L.mgModsetDeviceSlots(ms)))
     alg["mgScanKernel"] = (0.25 + 16.0 / d) * batch              # this path writes kmer 8 + pos 4 + read 4 per modimizer
-    alg["mgSegCompactKernel"] = 32.0 * S
+    alg["mgSegCompactKernel"] = 16.0 * S                         # pos + read, 4 bytes each, read and written (the lookups read the k-mers from the segments)
     kern = {kname: (v[0], v[1], v[2]) for kname, v in table.items()}
     res = {"workload": "BASELINE config 3: modmap, reference %d x %d Mbp = %.1f Gbp (table bits %d, %d occurrences, %d modset entries), "
                        "%d query batches of %g Gbp ONT-like reads from it (5%% subs): scan + lookup, seeds (index,pos,read) out"
@@ -583,7 +621,7 @@ def bench_c3(cx, args):
            "whole_batch": {"bytes_per_base": 0.25 + 36.0 / d, "GBps": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9, 1),
                            "frac": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9 / HBM_PEAK_GBS, 4),
                            "note": "0.25 B/base read + per seed: 12 B written by the scan + 24 B lookup (kmer 8, one 16-byte slot, wait index 4 out)"},
-           "roofline": roofline_of(kern, per_batch, alg, "c3")}
+           "roofline": roofline_of(kern, per_batch, alg, "c3", units={"mgTableFindSegKernel": S, "mgTableFindKernel": S})}
     L.modsetDestroy(ms)
     del genome, q_pos, q_rd
     torch.cuda.empty_cache()
@@ -652,7 +690,60 @@ def end_to_end(cx, reads, offsets, k, d, seed):
         if os.path.exists(path):
             os.remove(path)
     L.modsetDestroy(ms)
+    try:
+        res["dropin_unmodified"] = dropin_unmodified(h, shm)
+    except Exception as e:
+        res["dropin_unmodified"] = {"error": str(e)[:300]}
     return res
+
+
+def dropin_unmodified(h, shm):
+    """The reference's UNMODIFIED modutils.c (its own main(), seqio and per-read loop modutils.c:19-51: modRCiterator /
+    modRCnext / modsetIndexFind per read) linked on libmodgpu.so (oracle/_ref/modutils_dropin) beside the reference program
+    itself (oracle/_ref/modutils_ref) and the batch-patched one (oracle/_ref/modutils_batch, examples/modutils_batch.patch)
+    on the same FASTA files: 10 kb reads and 150 b reads cut from the bench's reads.  Wall clock of the whole program, and the
+    marginal rate (big file minus a 1/20 file: start-up, HIP initialisation and table allocation cancel)."""
+    import numpy as np
+    refdir = os.path.join(HERE, "oracle", "_ref")
+    progs = {n: os.path.join(refdir, n) for n in ("modutils_ref", "modutils_dropin", "modutils_batch")}
+    if not all(os.path.exists(p) for p in progs.values()):
+        return {"skipped": "oracle/_ref programs not present (built where the reference tree is)"}
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    out = {"what": "whole-program wall clock, `modutils -c 26 21 64 17 -a <file>`; Mbp/s = marginal (big file minus small file)"}
+    for tag, rl, mbp in (("reads_10kb", 10000, 200), ("reads_150b", 150, 30)):
+        paths = []
+        for frac in (20, 1):
+            nb = min(len(h), int(mbp * 1e6) // frac) // rl * rl
+            seq = letters[h[:nb]].reshape(-1, rl)
+            path = os.path.join(shm, "modgpu_dropin_%d_%s_%d.fa" % (os.getpid(), tag, frac))
+            with open(path, "wb") as f:
+                hdr = np.frombuffer(b">r\n", np.uint8)
+                rec = np.concatenate([np.tile(hdr, (len(seq), 1)), seq, np.full((len(seq), 1), 10, np.uint8)], axis=1)
+                f.write(rec.tobytes())
+            paths.append((path, nb))
+        row = {"read_length": rl, "bases": paths[1][1], "reads": paths[1][1] // rl}
+        try:
+            for name, prog in progs.items():
+                t = []
+                for path, nb in paths:
+                    t0 = time.perf_counter()
+                    r = subprocess.run([prog, "-c", "26", "21", "64", "17", "-a", path], capture_output=True, text=True, timeout=1200)
+                    t.append(time.perf_counter() - t0)
+                    if r.returncode != 0:
+                        raise RuntimeError("%s failed: %s" % (name, r.stderr[-200:]))
+                    line = [l for l in r.stdout.splitlines() if l.startswith("added ")]
+                    row.setdefault("stdout_added_line", {})[name] = line[-1] if line else None
+                d_b, d_t = paths[1][1] - paths[0][1], t[1] - t[0]
+                row[name] = {"wall_s_small": round(t[0], 3), "wall_s": round(t[1], 3),
+                             "Mbp_per_s": round(d_b / d_t / 1e6, 1) if d_t > 0 else None,
+                             "us_per_read": round(d_t / (d_b / rl) * 1e6, 2) if d_t > 0 else None}
+            row["same_result"] = len(set(row["stdout_added_line"].values())) == 1
+        finally:
+            for path, _ in paths:
+                if os.path.exists(path):
+                    os.remove(path)
+        out[tag] = row
+    return out
 
 
 def cpu_baseline(cx, reads, offsets, k, d, seed):

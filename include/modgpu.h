@@ -269,6 +269,7 @@ int  mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out) ; /* who
 void mgSeqBatchFree (MgSeqBatch *b) ;
 void mgSeqClose (MgSeqReader *r) ;
 void mgSeqReleaseBuffers (void) ;	/* the readers keep their two largest buffers for the next file (unmapping and touching gigabytes again costs as much as parsing them); this gives them back -- a no-op while a reader is open; also run when the library is unloaded */
+void mgReleaseBuffers (void) ;	/* everything the library caches between calls: the readers' buffers (mgSeqReleaseBuffers), the device buffers and pinned staging of the host-buffer entry points (mgAddSequenceBatch, mgUploadPack: they live on the device the last call ran on and are re-made by themselves when the caller moves to another one), the calling thread's iterator scratch (modRCiterator) */
 /* the callers' per-file loops: parsing of the next batch overlaps the GPU work on the current one */
 int  mgAddSequenceFile (Modset *ms, const char *filename, FILE *out) ;                        /* modutils.c:33-51 */
 int  mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out) ;   /* modmap.c:93-134 */

@@ -64,7 +64,7 @@ static const char *gKernelNames[MG_K_COUNT] = {
   "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
   "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel",
   "mgPartChunks+ScanKernel", "mgPartHistKernel", "mgPartScatterKernel", "mgRankCountKernel", "mgRankScanKernel", "mgBucketDedupKernel",
-  "mgBucketMergeKernel", "mgRankLookupKernel" };
+  "mgBucketMergeKernel", "mgRankLookupKernel", "mgTableFindSegKernel" };
 #define MG_PROF_POOL 8192
 struct MgProfRec { int id; hipEvent_t a, b; };
 static struct {
@@ -208,11 +208,12 @@ static U64 mgSurvivorGuess (const Seqhash *sh, U64 totalBases)
  * across PCIe as packed words (a quarter of the bytes) with an asynchronous copy that overlaps the packing of the
  * next piece.  (Before: the bytes crossed as they were and were packed on the device: 1 byte per base on the link.) */
 #include <pthread.h>
+#include <atomic>
 #include <thread>
 #include <vector>
 #include <unistd.h>
 #define MG_UP_PIECE ((U64) 128 << 20)                 /* bases per piece (a multiple of 16): 32 MiB of packed words */
-static struct MgUpStage { U32 *pin[2] = { 0, 0 }; hipEvent_t done[2]; bool ready = false; std::mutex lock; } gUp;
+static struct MgUpStage { U32 *pin[2] = { 0, 0 }; hipEvent_t done[2]; bool ready = false; int dev = -1; std::mutex lock; } gUp;   /* the events belong to a device: re-made when the caller has moved to another one */
 
 static int mgHostThreads (void)
 {
@@ -238,18 +239,22 @@ extern "C" MgStatus mgUploadPack (const char *bases, U64 nBases, U32 *dPacked, v
   hipStream_t st = (hipStream_t) stream;
   if (!nBases) { MG_HIP (hipMemsetAsync (dPacked, 0, mgPackedWords (0) * 4, st)); return MG_OK; }
   std::lock_guard<std::mutex> g (gUp.lock);
+  int curDev = 0; MG_HIP (hipGetDevice (&curDev));
+  if (gUp.ready && gUp.dev != curDev)
+    { for (int i = 0 ; i < 2 ; ++i) { (void) hipEventDestroy (gUp.done[i]); (void) hipHostFree (gUp.pin[i]); gUp.pin[i] = 0; }
+      gUp.ready = false;
+    }
   if (!gUp.ready)
     { for (int i = 0 ; i < 2 ; ++i)
         { MG_HIP (hipHostMalloc ((void **) &gUp.pin[i], (MG_UP_PIECE / 16 + MG_PACK_PAD) * 4, hipHostMallocDefault));
           MG_HIP (hipEventCreateWithFlags (&gUp.done[i], hipEventDisableTiming));
         }
-      gUp.ready = true;
+      gUp.ready = true; gUp.dev = curDev;
     }
   const U64 nPieces = (nBases + MG_UP_PIECE - 1) / MG_UP_PIECE;
   int T = mgHostThreads ();
   if (nBases < ((U64) 1 << 20)) T = 1;
   pthread_barrier_t bar;
-  pthread_barrier_init (&bar, 0, (unsigned) T);
   /* every thread packs its share of every piece; thread 0 also waits for the staging buffer to be free before a
      piece and sends the piece off after it */
   volatile int failed = 0;
@@ -274,8 +279,15 @@ extern "C" MgStatus mgUploadPack (const char *bases, U64 nBases, U32 *dPacked, v
             }
         }
     };
+  /* the helpers are started first and held at a gate: if the system will not give T threads, those that did start are
+     sent home and the caller packs alone (a thread constructor that throws must not leave threads at the barrier) */
   std::vector<std::thread> th;
-  for (int t = 1 ; t < T ; ++t) th.emplace_back (work, t);
+  std::atomic<int> gate (0);
+  auto helper = [&] (int t) { int v; while (!(v = gate.load (std::memory_order_acquire))) std::this_thread::yield (); if (v > 0) work (t); };
+  try { for (int t = 1 ; t < T ; ++t) th.emplace_back (helper, t); }
+  catch (...) { gate.store (-1, std::memory_order_release); for (auto &x : th) x.join (); th.clear (); T = 1; }
+  pthread_barrier_init (&bar, 0, (unsigned) T);
+  gate.store (1, std::memory_order_release);
   work (0);
   for (auto &x : th) x.join ();
   pthread_barrier_destroy (&bar);
@@ -952,7 +964,13 @@ extern "C" MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 tot
 
 /* grow-only device buffers for the host-buffer entry points (a hipMalloc + hipFree of a gigabyte per call costs
  * milliseconds): the packed reads and their offsets of the batch in flight */
-static struct MgHostBatchBufs { U32 *dP = 0; size_t words = 0; U64 *dOff = 0; size_t offs = 0; std::mutex lock; } gHb;
+static struct MgHostBatchBufs { U32 *dP = 0; size_t words = 0; U64 *dOff = 0; size_t offs = 0; int dev = -1; std::mutex lock; } gHb;   /* on device `dev` */
+extern "C" void mgHostBatchRelease (void)
+{ std::lock_guard<std::mutex> g (gHb.lock);
+  if (gHb.dP) (void) hipFree (gHb.dP);
+  if (gHb.dOff) (void) hipFree (gHb.dOff);
+  gHb.dP = 0; gHb.words = 0; gHb.dOff = 0; gHb.offs = 0; gHb.dev = -1;
+}
 static double mgNowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads)
@@ -960,6 +978,11 @@ extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int6
   if (mgEnsureDevice ()) return -1;
   if (nReads <= 0) return 0;
   static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_UPLOAD_TIMING"); timing = e && *e == '1'; }   /* dev */
+  { int curDev = 0; if (hipGetDevice (&curDev) != hipSuccess) { mgSetError ("mgAddSequenceBatch: no current device"); return -1; }
+    bool moved; { std::lock_guard<std::mutex> g0 (gHb.lock); moved = gHb.dev >= 0 && gHb.dev != curDev; }
+    if (moved) mgHostBatchRelease ();                  /* the cached buffers live on the device the previous call ran on */
+    std::lock_guard<std::mutex> g0 (gHb.lock); gHb.dev = curDev;
+  }
   std::lock_guard<std::mutex> g (gHb.lock);
   U64 total = (U64) readOffsets[nReads];
   size_t nw = mgPackedWords (total);
@@ -1012,22 +1035,74 @@ extern "C" void mgDepthHistogram (Modset *ms, FILE *f)
 /* ---------------------------------------------------------------------------------------- */
 /* per-read iterator facade: one GPU scan per modRCiterator call, replayed by modRCnext       */
 
+/* The reference's callers scan read by read (modutils.c:19-31, modmap.c:197-206): modRCiterator, modRCnext until false,
+ * destroy.  One call here = pack the read into a pinned host buffer the GPU reads in place, ONE kernel launch
+ * (mgIterScanKernel: scan + ordered concatenation + completion flag), the replay block {n, k-mers, pos|isF} written by the
+ * kernel straight into pinned host memory, the host polling the flag: no host-to-device or device-to-host copy call and
+ * no stream wait on the way.  Reads longer than mgIterMaxBases () take the batch scan with the block copied back.
+ * The scratch is per host thread and per device. */
+#include <immintrin.h>
 struct MgIterScratch {
+  int dev = -1; hipStream_t st = 0;
+  char *hIn = 0; char *dIn = 0; size_t inBytes = 0;          /* pinned: {0, len} (2 x U64), then the packed words */
+  U64 *hOut = 0; U64 *dOut = 0; size_t outEntries = 0;       /* pinned: the replay block */
+  U64 *hFlag = 0; U64 *dFlag = 0; U64 seq = 0;               /* pinned: the kernel's completion flag */
+  U64 *dSegK = 0; U32 *dSegP = 0;                            /* device: the workers' segments */
+  /* the long-read path */
   U32 *dPacked = 0; U64 *dOff = 0; U64 *dKmer = 0; U32 *dPosF = 0; void *dWork = 0; U64 *dCount = 0;
   size_t wordsCap = 0, survCap = 0, workCap = 0;
   U32 *hPacked = 0; size_t hWordsCap = 0;
+  void release ()
+  { if (hIn) (void) hipHostFree (hIn);
+    if (hOut) (void) hipHostFree (hOut);
+    if (hFlag) (void) hipHostFree (hFlag);
+    (void) hipFree (dSegK); (void) hipFree (dSegP); (void) hipFree (dPacked); (void) hipFree (dOff); (void) hipFree (dKmer);
+    (void) hipFree (dPosF); (void) hipFree (dWork); (void) hipFree (dCount);
+    if (st) (void) hipStreamDestroy (st);
+    free (hPacked);
+    *this = MgIterScratch ();
+  }
 };
 static thread_local MgIterScratch gIt;
 
-extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut)
+static int mgIterPinned (void **h, void **d, size_t bytes)
 {
-  /* returns 0 on success; *rec is a malloc()ed block {n kmers (U64), n posF (U32)} */
-  *rec = 0; *nOut = 0;
-  if (mgEnsureDevice ()) return -1;
-  if (len < sh->k) return 0;
-  U64 total = (U64) len;
+  if (hipHostMalloc (h, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
+  if (hipHostGetDevicePointer (d, *h, 0) != hipSuccess) return -1;
+  return 0;
+}
+
+/* the scratch for the calling thread on the current device */
+static int mgIterPrepare (MgIterScratch &g)
+{
+  int dev = 0;
+  if (hipGetDevice (&dev) != hipSuccess) return -1;
+  if (g.dev == dev) return 0;
+  if (g.dev >= 0) g.release ();                        /* the thread moved to another GPU (mgSetDevice) */
+  g.inBytes = 16 + mgPackedWords (mgIterMaxBases ()) * 4;
+  if (hipStreamCreateWithFlags (&g.st, hipStreamNonBlocking) != hipSuccess) return -1;
+  if (mgIterPinned ((void **) &g.hIn, (void **) &g.dIn, g.inBytes)) return -1;
+  if (mgIterPinned ((void **) &g.hFlag, (void **) &g.dFlag, 64)) return -1;
+  g.hFlag[0] = 0;
+  if (hipMalloc ((void **) &g.dSegK, mgIterSegEntries () * 8) != hipSuccess || hipMalloc ((void **) &g.dSegP, mgIterSegEntries () * 4) != hipSuccess) return -1;
+  g.dev = dev;
+  return 0;
+}
+
+static int mgIterOutReserve (MgIterScratch &g, size_t entries)
+{
+  if (entries <= g.outEntries) return 0;
+  if (g.hOut) { (void) hipStreamSynchronize (g.st); (void) hipHostFree (g.hOut); g.hOut = 0; g.outEntries = 0; }
+  const size_t want = entries + entries / 4 + 4096;
+  if (mgIterPinned ((void **) &g.hOut, (void **) &g.dOut, (want + 2) * 12)) return -1;
+  g.outEntries = want;
+  return 0;
+}
+
+/* reads beyond the one-launch kernel's reach: the batch scan, the block copied back */
+static int mgIterScanLong (MgIterScratch &g, Seqhash *sh, const char *s, U64 total, U64 **blkOut)
+{
   size_t nw = mgPackedWords (total);
-  MgIterScratch &g = gIt;
   if (nw > g.hWordsCap) { free (g.hPacked); g.hPacked = (U32 *) malloc (2 * nw * 4); g.hWordsCap = 2 * nw; }
   mgPackHost (s, total, g.hPacked);
   if (!g.dOff) { if (hipMalloc ((void **) &g.dOff, 16) != hipSuccess || hipMalloc ((void **) &g.dCount, 8 * MG_COUNT_WORDS) != hipSuccess) return -1; }
@@ -1052,22 +1127,81 @@ extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *
           if (hipMalloc (&g.dWork, 2 * wb) != hipSuccess) return -1;
           g.workCap = 2 * wb;
         }
-      if (hipMemcpyAsync (g.dPacked, g.hPacked, nw * 4, hipMemcpyHostToDevice, 0) != hipSuccess) return -1;
-      if (hipMemcpyAsync (g.dOff, off, 16, hipMemcpyHostToDevice, 0) != hipSuccess) return -1;
-      if (mgLaunchScan (p, g.dPacked, total, g.dOff, 1, g.dKmer, g.dPosF, 0, g.survCap, g.dCount, g.dWork, 0)) return -1;
+      if (hipMemcpyAsync (g.dPacked, g.hPacked, nw * 4, hipMemcpyHostToDevice, g.st) != hipSuccess) return -1;
+      if (hipMemcpyAsync (g.dOff, off, 16, hipMemcpyHostToDevice, g.st) != hipSuccess) return -1;
+      if (mgLaunchScan (p, g.dPacked, total, g.dOff, 1, g.dKmer, g.dPosF, 0, g.survCap, g.dCount, g.dWork, g.st)) return -1;
       U64 c[MG_COUNT_WORDS];
-      if (hipMemcpy (c, g.dCount, sizeof (c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      if (hipMemcpyAsync (c, g.dCount, sizeof (c), hipMemcpyDeviceToHost, g.st) != hipSuccess || hipStreamSynchronize (g.st) != hipSuccess) return -1;
       if (c[1] || c[0] > g.survCap) { cap = c[3]; continue; }
-      U64 n = c[0];
-      U64 *blk = (U64 *) malloc ((size_t) n * 12 + 16);
-      if (n)
-        { if (hipMemcpy (blk, g.dKmer, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { free (blk); return -1; }
-          if (hipMemcpy (blk + n, g.dPosF, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { free (blk); return -1; }
-        }
-      *rec = blk; *nOut = n;
+      const U64 n = c[0];
+      U64 *blk = (U64 *) malloc ((size_t) (n + 1) * 8 + (size_t) n * 4 + 8);
+      if (!blk) return -1;
+      blk[0] = n;
+      if (n && (hipMemcpyAsync (blk + 1, g.dKmer, n * 8, hipMemcpyDeviceToHost, g.st) != hipSuccess
+                || hipMemcpyAsync (blk + 1 + n, g.dPosF, n * 4, hipMemcpyDeviceToHost, g.st) != hipSuccess
+                || hipStreamSynchronize (g.st) != hipSuccess)) { free (blk); return -1; }
+      *blkOut = blk;
       return 0;
     }
   return -1;
+}
+
+/* returns 0 on success; *blkOut is the malloc()ed replay block {n, n k-mers (U64), n pos | isF << 31 (U32)} -- what the
+   iterator's hashBuf points to (the reference's callers free () it: seqhash.h:54-55) */
+extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **blkOut)
+{
+  *blkOut = 0;
+  if (mgEnsureDevice ()) return -1;
+  if (len < sh->k)
+    { U64 *blk = (U64 *) malloc (16); if (!blk) return -1;
+      blk[0] = 0; *blkOut = blk; return 0;
+    }
+  MgIterScratch &g = gIt;
+  if (mgIterPrepare (g)) { if (!gErr[0]) mgSetError ("iterator scratch: %s", hipGetErrorString (hipGetLastError ())); return -1; }
+  const U64 total = (U64) len;
+  if (total > mgIterMaxBases ()) return mgIterScanLong (g, sh, s, total, blkOut);
+  U64 *hdr = (U64 *) g.hIn; hdr[0] = 0; hdr[1] = total;
+  mgPackHost (s, total, (U32 *) (g.hIn + 16));
+  U64 want = total / (U64) sh->w + total / (4 * (U64) sh->w) + 256;      /* expected modimizers, a quarter more; the kernel says so if it was not enough */
+  const MgHashParams p = mgMakeParams (sh);
+  for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    { if (mgIterOutReserve (g, want)) { mgSetError ("iterator scratch: pinned allocation failed"); return -1; }
+      const U64 seq = ++g.seq;
+      if (mgLaunchIterScan (p, (const U32 *) (g.dIn + 16), total, (const U64 *) g.dIn, g.dSegK, g.dSegP, g.dOut, g.outEntries, g.dFlag, seq, g.st)) return -1;
+      volatile U64 *flag = g.hFlag;
+      bool done = false;
+      for (int spin = 0 ; spin < (1 << 22) ; ++spin) { if (*flag == seq) { done = true; break; } _mm_pause (); }
+      if (!done)                                           /* a kernel that takes this long, or one that failed: ask the runtime */
+        { hipError_t e = hipStreamSynchronize (g.st);
+          if (e != hipSuccess) { mgHipFail (e, "iterator scan"); return -1; }
+          if (*flag != seq) { mgSetError ("iterator scan: no completion flag"); return -1; }
+        }
+      const U64 n = g.hOut[0];
+      if (n > g.outEntries) { want = n; continue; }
+      const size_t bytes = (size_t) (n + 1) * 8 + (size_t) n * 4;
+      U64 *blk = (U64 *) malloc (bytes + 8);
+      if (!blk) return -1;
+      memcpy (blk, g.hOut, bytes);
+      *blkOut = blk;
+      return 0;
+    }
+  mgSetError ("iterator scan: output capacity could not be established");
+  return -1;
+}
+
+extern "C" void mgIterReleaseBuffers (void) { if (gIt.dev >= 0) gIt.release (); }
+
+extern "C" void mgSeqReleaseBuffers (void);
+extern "C" void mgReleaseBuffers (void)
+{
+  mgSeqReleaseBuffers ();
+  mgHostBatchRelease ();
+  mgIterReleaseBuffers ();
+  std::lock_guard<std::mutex> g (gUp.lock);
+  if (gUp.ready)
+    { for (int i = 0 ; i < 2 ; ++i) { (void) hipEventDestroy (gUp.done[i]); (void) hipHostFree (gUp.pin[i]); gUp.pin[i] = 0; }
+      gUp.ready = false; gUp.dev = -1;
+    }
 }
 
 /* ---------------------------------------------------------------------------------------- */

@@ -36,7 +36,7 @@ enum MgKernelId {
   MG_K_TABLE_FLAG, MG_K_TABLE_FIND, MG_K_TABLE_LOAD, MG_K_TABLE_EXPORT, MG_K_TABLE_HIST,
   MG_K_INDEX_REPLAY, MG_K_INDEX_FINISH, MG_K_SYNTH_GENOME, MG_K_SYNTH_READS, MG_K_MEMSET,
   MG_K_SEG_SCAN, MG_K_SEG_COMPACT, MG_K_PART, MG_K_PART_HIST, MG_K_PART_SCATTER, MG_K_RANK_COUNT, MG_K_RANK_SCAN, MG_K_BUCKET_DEDUP,
-  MG_K_BUCKET_MERGE, MG_K_RANK_LOOKUP, MG_K_COUNT
+  MG_K_BUCKET_MERGE, MG_K_RANK_LOOKUP, MG_K_TABLE_FIND_SEG, MG_K_COUNT
 };
 void mgProfBegin (int id, hipStream_t st);
 void mgProfEnd (int id, hipStream_t st);
@@ -169,6 +169,12 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
                             const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
                             U64 *dKmer, U32 *dPosF, U32 *dReadId, U64 capacity,
                             U64 *dCount, void *dWork, hipStream_t st, const MgHistReq *hist = 0, MgSegSrc *lazy = 0);
+
+/* the per-read iterator facade: one read of at most mgIterMaxBases () in one launch, replay block into (pinned host) out[] */
+U64      mgIterMaxBases (void);
+U64      mgIterSegEntries (void);
+MgStatus mgLaunchIterScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases, const U64 *dReadOff,
+                           U64 *dSegKmer, U32 *dSegPosF, U64 *out, U64 capEntries, U64 *flag, U64 seq, hipStream_t st);
 
 /* minimizers (seqhash.c:83-152) of every read: per-read counts -> exclusive scan in dReadStart[nReads+1] -> write */
 MgStatus mgLaunchMinimizers (const MgHashParams &p, U32 w, const U32 *dPacked, const U64 *dReadOffsets, U32 nReads,

@@ -101,18 +101,11 @@ static SeqhashRCiterator *iterAlloc (Seqhash *sh, char *s, int len)
 SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len)
 {
   SeqhashRCiterator *si = iterAlloc (sh, s, len);
-  U64 *rec = 0, n = 0;
-  if (mgIterScan (sh, s, len, &rec, &n)) die ("modRCiterator: GPU scan failed: %s", mgLastError ());
-  U64 *blk = (U64 *) xalloc ((size_t) (n + 1) * 8 + (size_t) n * 4 + 8, 0);
-  blk[0] = n;
-  if (n)
-    { memcpy (blk + 1, rec, (size_t) n * 8);
-      memcpy (blk + 1 + n, rec + n, (size_t) n * 4);
-    }
-  free (rec);
-  si->hashBuf = blk;
+  U64 *blk = 0;
+  if (mgIterScan (sh, s, len, &blk)) die ("modRCiterator: GPU scan failed: %s", mgLastError ());
+  si->hashBuf = blk;                       /* the replay block as the scan wrote it: no second copy */
   si->iMin = 0;
-  si->isDone = (n == 0);
+  si->isDone = (blk[0] == 0);
   return si;
 }
 

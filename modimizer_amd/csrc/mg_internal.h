@@ -14,8 +14,9 @@ void mgHookNeedHostAll (Modset *ms, int wantIndex);/* also fold pending device d
 int  mgHookHasDevice (Modset *ms);
 int  mgHookMergeDevice (Modset *ms1, Modset *ms2);   /* modsetMerge with ms1 on the device; 0 = done */
 int  mgHookPruneDevice (Modset *ms, int lo, int hi);  /* modsetDepthPrune on the device; 0 = done */
-/* one GPU scan of one read for the iterator facade: *rec = malloc()ed {U64 kmer[n]; U32 posF[n]} */
-int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
+/* one GPU scan of one read for the iterator facade: *blk = malloc()ed replay block {U64 n; U64 kmer[n]; U32 posF[n]} */
+int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **blk);
+void mgIterReleaseBuffers (void);                  /* the calling thread's iterator scratch (pinned buffers, stream) */
 /* the same for the minimizer iterator: *rec = malloc()ed {U64 hash[n]; U32 posF[n]} */
 int  mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
 /* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */

@@ -236,26 +236,13 @@ __device__ __forceinline__ void mgScanHistDone (const MgScanArgs &a, U32 *sHist,
   for (U32 b = (U32) lane ; b < bins ; b += 64) { const U32 v = sHist[b]; if (v) atomicAdd (&a.histCount[b * MG_HIST_STRIDE], v); }
 }
 
-template <int MODE>
-__global__ __launch_bounds__ (MG_SCAN_THREADS)
-void mgScanKernel (const MgScanArgs a)
+/* the work of one worker (wavefront): its tiles, its segment; returns the number of modimizers it found (uniform).
+ * SINGLE: the batch is one read [0, totalBases) (the per-read iterator facade): no per-tile metadata array, every tile's
+ * first read is read 0. */
+template <int MODE, bool SINGLE>
+__device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 worker, const int lane,
+                                             U32 (*sWordsW)[MG_TILE_WORDS + 8], unsigned short *sCand, U64 *sOff, U32 *sHist)
 {
-  __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_WAVES][2][MG_TILE_WORDS + 8];
-  __shared__ unsigned short sCandAll[MG_WAVES][MG_CAND_CAP + 2];      /* [MG_CAND_CAP]: where stores of other rounds' entries land */
-  __shared__ U64 sOffAll[MG_WAVES][64];                              /* read offsets of a tile that holds read boundaries */
-  __shared__ U32 sHist[512]; __shared__ U32 sDone;                   /* the workgroup's digit counts; waves that have finished */
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));   /* uniform: the worker's state lives in SGPRs */
-  const U64 worker = (U64) blockIdx.x * MG_WAVES + wave;
-  if (a.histCount)
-    { for (U32 b = threadIdx.x ; b < 512 ; b += MG_SCAN_THREADS) sHist[b] = 0;
-      if (threadIdx.x == 0) sDone = 0;
-      __syncthreads ();
-    }
-  if (worker >= a.nWorkers) { if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane); return; }
-  unsigned short *sCand = sCandAll[wave];
-  U64 *sOff = sOffAll[wave];
   const MgHashParams &p = a.p;
   const int k = p.k, sh1 = p.shift1;
   const U64 f1 = p.factor1;
@@ -272,13 +259,13 @@ void mgScanKernel (const MgScanArgs a)
   if (tile < tileEnd)
     { curV = mgLoadTileWords (a, tile, lane);
       if (lane < 8) { U64 gh = tile * MG_TILE_WORDS + MG_TILE_WORDS + lane; curHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
-      ti = a.tileInfo[tile];
-      nextFirstRead = a.tileInfo[tile + 1].firstRead;
+      if (SINGLE) { ti.start = 0; ti.end = a.totalBases; ti.firstRead = 0; }
+      else { ti = a.tileInfo[tile]; nextFirstRead = a.tileInfo[tile + 1].firstRead; }
     }
 
   int buf = 0;
   while (tile < tileEnd)
-    { U32 *sWords = sWordsAll[wave][buf]; buf ^= 1;
+    { U32 *sWords = sWordsW[buf]; buf ^= 1;
       *reinterpret_cast<uint4 *> (&sWords[4 * lane]) = curV;
       if (lane < 8) sWords[MG_TILE_WORDS + lane] = curHalo;
 
@@ -315,8 +302,8 @@ void mgScanKernel (const MgScanArgs a)
       if (nextTile < tileEnd)
         { nextV = mgLoadTileWords (a, nextTile, lane);
           if (lane < 8) { U64 gh = nextTile * MG_TILE_WORDS + MG_TILE_WORDS + lane; nextHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
-          tiNext = a.tileInfo[nextTile];
-          nextNextFirst = a.tileInfo[nextTile + 1].firstRead;
+          if (SINGLE) tiNext = ti;
+          else { tiNext = a.tileInfo[nextTile]; nextNextFirst = a.tileInfo[nextTile + 1].firstRead; }
         }
 
       /* ---- Phase A ---- */
@@ -498,8 +485,70 @@ void mgScanKernel (const MgScanArgs a)
       tile = nextTile;
       curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
     }
+  return found;
+}
+
+template <int MODE>
+__global__ __launch_bounds__ (MG_SCAN_THREADS)
+void mgScanKernel (const MgScanArgs a)
+{
+  __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_WAVES][2][MG_TILE_WORDS + 8];
+  __shared__ unsigned short sCandAll[MG_WAVES][MG_CAND_CAP + 2];      /* [MG_CAND_CAP]: where stores of other rounds' entries land */
+  __shared__ U64 sOffAll[MG_WAVES][64];                              /* read offsets of a tile that holds read boundaries */
+  __shared__ U32 sHist[512]; __shared__ U32 sDone;                   /* the workgroup's digit counts; waves that have finished */
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));   /* uniform: the worker's state lives in SGPRs */
+  const U64 worker = (U64) blockIdx.x * MG_WAVES + wave;
+  if (a.histCount)
+    { for (U32 b = threadIdx.x ; b < 512 ; b += MG_SCAN_THREADS) sHist[b] = 0;
+      if (threadIdx.x == 0) sDone = 0;
+      __syncthreads ();
+    }
+  if (worker >= a.nWorkers) { if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane); return; }
+  const U64 found = mgScanWorker<MODE, false> (a, worker, lane, sWordsAll[wave], sCandAll[wave], sOffAll[wave], sHist);
   if (lane == 0) a.blockCount[worker] = found;
   if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane);
+}
+
+/* The per-read iterator facade (modRCiterator, seqhash.c:154-177) in ONE launch: a single workgroup of MG_ITER_WAVES
+ * workers scans one read of up to MG_ITER_MAX_TILES tiles -- its packed bases read straight from the caller's pinned host
+ * buffer -- each worker into its own segment of a device scratch; then the workgroup concatenates the segments, in order,
+ * into the replay block the iterator hands to modRCnext: out[0] = n, out[1 .. n] the k-mers, then n words pos | isF << 31
+ * -- in pinned host memory, followed by a completion flag the host polls (no device-to-host copy, no stream wait). */
+#define MG_ITER_WAVES     8
+#define MG_ITER_MAX_TILES 64
+struct MgIterOut { U64 *out; U64 capEntries; volatile U64 *flag; U64 seq; };
+
+template <int MODE>
+__global__ __launch_bounds__ (MG_ITER_WAVES * 64)
+void mgIterScanKernel (const MgScanArgs a, const MgIterOut o)
+{
+  __shared__ __attribute__ ((aligned (16))) U32 sWordsAll[MG_ITER_WAVES][2][MG_TILE_WORDS + 8];
+  __shared__ unsigned short sCandAll[MG_ITER_WAVES][MG_CAND_CAP + 2];
+  __shared__ U64 sOffAll[MG_ITER_WAVES][64];
+  __shared__ U64 sFound[MG_ITER_WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
+  U64 found = 0;
+  if ((U64) wave < a.nWorkers) found = mgScanWorker<MODE, true> (a, (U64) wave, lane, sWordsAll[wave], sCandAll[wave], sOffAll[wave], (U32 *) 0);
+  if (lane == 0) sFound[wave] = found;
+  __syncthreads ();                                   /* the segments (global memory, written by this workgroup) and the counts are in */
+  U64 before = 0, total = 0;
+#pragma unroll
+  for (int w = 0 ; w < MG_ITER_WAVES ; ++w) { const U64 v = sFound[w]; if (w < wave) before += v; total += v; }
+  if (total <= o.capEntries)
+    { U32 *posOut = reinterpret_cast<U32 *> (o.out + 1 + total);
+      const U64 src = (U64) wave * a.segCap;
+      for (U64 i = (U64) lane ; i < found ; i += 64)
+        { o.out[1 + before + i] = a.segKmer[src + i];
+          posOut[before + i] = a.segPosF[src + i];
+        }
+    }
+  if (threadIdx.x == 0) o.out[0] = total;              /* > capEntries: nothing else was written, the host retries with room for it */
+  __threadfence_system ();
+  __syncthreads ();
+  if (threadIdx.x == 0) __hip_atomic_store (const_cast<U64 *> (o.flag), o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* exclusive scan of the per-block counts (one workgroup): segStart[b], and
@@ -673,6 +722,24 @@ size_t mgScanWorkBytes (U64 totalBases, U32 nReads, U64 capacity)
   return mgScanRangeWorkBytes (mgNumTiles (totalBases), capacity) + mgScanInfoBytes (totalBases);
 }
 
+/* which phase-A mode a hasher gets; sets the filter's constants in *a */
+static int mgScanMode (const MgHashParams &p, MgScanArgs *a)
+{
+  const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
+  const int B = p.shift1 + p.dShift;
+  static int forceGeneric = -1;
+  if (forceGeneric < 0) { const char *e = getenv ("MODGPU_SCAN_GENERIC"); forceGeneric = (e && *e == '1') ? 1 : 0; }
+  a->fS = 0; a->thresh = 0;
+  /* the filter passes 2/d of the starts to the exact evaluation: from d = 8 up that beats computing both full
+     hashes everywhere (measured at k=31: d=4 1.80 ms/Gbp exact vs 2.29 filtered) */
+  if (pow2 && p.dShift >= 3 && B <= 32 && p.k >= 17 && !forceGeneric)
+    { a->fS = (U32) (p.factor1 << (32 - B));
+      a->thresh = (U32) 1 << (32 - p.dShift);
+      return MG_MODE_FAST;
+    }
+  return pow2 ? MG_MODE_POW2 : MG_MODE_ANY;
+}
+
 /* scan tiles [tile0, tile1) of the batch: the modimizers of those k-mer starts, dense and in order */
 MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 totalBases,
                             const U64 *dReadOffsets, U32 nReads, const void *dInfo, U64 tile0, U64 tile1,
@@ -709,21 +776,10 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
 #endif
   const unsigned grid = (g.nBlocks + MG_WAVES - 1) / MG_WAVES;
-  const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
-  const int B = p.shift1 + p.dShift;
-  static int forceGeneric = -1;
-  if (forceGeneric < 0) { const char *e = getenv ("MODGPU_SCAN_GENERIC"); forceGeneric = (e && *e == '1') ? 1 : 0; }
-  /* the filter passes 2/d of the starts to the exact evaluation: from d = 8 up that beats computing both full
-     hashes everywhere (measured at k=31: d=4 1.80 ms/Gbp exact vs 2.29 filtered) */
-  if (pow2 && p.dShift >= 3 && B <= 32 && p.k >= 17 && !forceGeneric)
-    { a.fS = (U32) (p.factor1 << (32 - B));
-      a.thresh = (U32) 1 << (32 - p.dShift);
-      MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_FAST>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
-    }
-  else if (pow2)
-    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_POW2>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
-  else
-    MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_ANY>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+  const int mode = mgScanMode (p, &a);
+  if (mode == MG_MODE_FAST)      MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_FAST>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+  else if (mode == MG_MODE_POW2) MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_POW2>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+  else                           MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_ANY>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
   MG_HIP (hipGetLastError ());
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
   MG_HIP (hipGetLastError ());
@@ -762,4 +818,38 @@ MgStatus mgLaunchScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases
   MgStatus s = mgScanPrepare (dReadOffsets, nReads, totalBases, info, st); if (s) return s;
   return mgLaunchScanRange (p, dPacked, totalBases, dReadOffsets, nReads, info, 0, nTiles,
                             dKmer, dPosF, dReadId, capacity, dCount, dWork, st, hist, lazy);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* the per-read iterator facade: one launch per read (see mgIterScanKernel)                   */
+
+U64 mgIterMaxBases (void) { return (U64) MG_ITER_MAX_TILES * MG_TILE_BASES; }
+/* entries of device scratch (k-mers: 8 bytes, pos: 4 bytes each) the launch below needs */
+U64 mgIterSegEntries (void) { return (U64) MG_ITER_MAX_TILES * MG_TILE_BASES; }
+
+/* dPacked / dReadOff / out / flag: device-visible addresses of pinned host memory (or device memory); dReadOff = {0, totalBases} */
+MgStatus mgLaunchIterScan (const MgHashParams &p, const U32 *dPacked, U64 totalBases, const U64 *dReadOff,
+                           U64 *dSegKmer, U32 *dSegPosF, U64 *out, U64 capEntries, U64 *flag, U64 seq, hipStream_t st)
+{
+  const U64 nTiles = mgNumTiles (totalBases);
+  if (!nTiles || nTiles > MG_ITER_MAX_TILES) { mgSetError ("internal: iterator scan of %llu bases", (unsigned long long) totalBases); return MG_ERR_ARG; }
+  MgScanArgs a;
+  a.p = p; a.packed = dPacked; a.nWordsAlloc = (U64) mgPackedWords (totalBases); a.totalBases = totalBases;
+  a.readOff = dReadOff; a.nReads = 1; a.tileInfo = 0;
+  a.tileBegin = 0; a.tileLimit = nTiles;
+  a.tilesPerWorker = (nTiles + MG_ITER_WAVES - 1) / MG_ITER_WAVES;
+  a.nWorkers = (nTiles + a.tilesPerWorker - 1) / a.tilesPerWorker;
+  a.segCap = a.tilesPerWorker * (U64) MG_TILE_BASES;                 /* every start of a worker's tiles: cannot overflow */
+  a.segKmer = dSegKmer; a.segPosF = dSegPosF; a.segRead = 0; a.blockCount = 0;
+  a.histCount = 0; a.histKbits = 64; a.histHiB = 0;
+#ifdef MG_ABLATE
+  a.debug = 0;
+#endif
+  MgIterOut o; o.out = out; o.capEntries = capEntries; o.flag = flag; o.seq = seq;
+  const int mode = mgScanMode (p, &a);
+  if (mode == MG_MODE_FAST)      hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_FAST>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
+  else if (mode == MG_MODE_POW2) hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_POW2>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
+  else                           hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ANY>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
 }

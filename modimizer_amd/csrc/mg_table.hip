@@ -829,7 +829,8 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
 #endif
 #define MG_RANK_GROUPS 64            /* most groups a bucket's list is cut into: slices of the ordinal range + 1 */
 #define MG_SLOT_SHIFT 48             /* a list entry's slot sits above this bit of its mixed k-mer (when 2k <= 48) */
-#define MG_DEDUP_PER 4               /* slots of the LDS image per thread of the dedup kernel: R <= 4 x threads */
+#define MG_DEDUP_PER 4               /* slots of the LDS image per thread of the dedup kernel: R <= 4 x threads ... */
+#define MG_DEDUP_PER_BIG 8           /* ... or 8 (R = 8192: a table of 2^31 slots, i.e. more than 6.4e8 entries at table bits 32; one workgroup per CU, 128 registers) */
 #define MG_LIVE_BINS 256              /* depths below this are counted in LDS by the merge kernel's live histogram */
 
 /* step 2: dedup the bucket's occurrences; uniques written in place over the bucket's range */
@@ -859,8 +860,8 @@ __device__ __forceinline__ void mgDedupCount (const MgBucketArgs &a, U32 *sOrd, 
   atomicAdd (&sCnt[at], 1u);
 }
 
-template <bool PACKED, bool SLOT>       /* SLOT: a.slotShift != 0 */
-__global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (8)))      /* 64 registers: two workgroups per CU */
+template <bool PACKED, bool SLOT, int PER>       /* SLOT: a.slotShift != 0; PER: slots of the image per thread, R <= PER x threads */
+__global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (PER == MG_DEDUP_PER ? 8 : 4)))      /* 64 registers: two workgroups per CU */
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
   const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
@@ -940,9 +941,9 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
              (clearing them for the next bucket) and counts the groups' members -- a unique's place inside its group is
              what the add returns; the counts become places in the list; the entries go back into the (now free) LDS
              arrays in list order, and leave from there with coalesced stores */
-          unsigned long long rk[MG_DEDUP_PER]; U32 rc[MG_DEDUP_PER], ro[MG_DEDUP_PER], rp[MG_DEDUP_PER];
+          unsigned long long rk[PER]; U32 rc[PER], ro[PER], rp[PER];
 #pragma unroll
-          for (int j = 0 ; j < MG_DEDUP_PER ; ++j)
+          for (int j = 0 ; j < PER ; ++j)
             { const U32 i = (U32) j * T + tid;
               rk[j] = 0; rc[j] = 0; ro[j] = 0; rp[j] = 0;
               if (i < R) rk[j] = sKey[i];
@@ -964,7 +965,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
               if (lane == 0) a.uniqCount[b] = total;
             }
 #pragma unroll
-          for (int j = 0 ; j < MG_DEDUP_PER ; ++j)
+          for (int j = 0 ; j < PER ; ++j)
             { const U32 grp = mgIsAssigned (ro[j]) ? a.nSlices : ((0x7fffffffu - ro[j]) >> a.sliceShift);
               const U32 at = (U32) __shfl ((int) gBase, (int) (rc[j] ? grp : 0)) + rp[j];
               if (rc[j]) { sKey[at] = rk[j]; sOrd[at] = ro[j]; sCnt[at] = rc[j]; }
@@ -1069,7 +1070,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                   { typedef unsigned v4u __attribute__ ((ext_vector_type (4)));
                     v4u vv = { v.x, v.y, v.z, v.w };
                     if (true MG_ABLATE_AND (!(a.debug & 64)))
-                    asm volatile ("global_store_dwordx4 %0, %1, off nt" : : "v" (&a.slots[(U64) b * R + i]), "v" (vv) : "memory");   /* the 4.3 GB image is not read again this step: keep it out of the caches the rank records live in (2.58 -> 2.53 ms) */
+                    __builtin_nontemporal_store (vv, reinterpret_cast<v4u *> (&a.slots[(U64) b * R + i]));   /* one 16-byte nt store; the 4.3 GB image is not read again this step: keep it out of the caches the rank records live in (2.58 -> 2.53 ms) */
                   }
                   dep = v.w > 0xffffu ? 0xffffu : v.w;
                   if (k) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
@@ -1374,11 +1375,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   t->liveHistValid = track;
   size_t lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
   { const size_t ldsDedup = (size_t) t->R * 16 + MG_RANK_GROUPS * 4; if (ldsDedup > lds) lds = ldsDedup; }
+  const bool bigR = t->R > MG_DEDUP_PER * 1024u;       /* R = 8192: the dedup kernel's threads take eight slots each */
+  if (t->R > MG_DEDUP_PER_BIG * 1024u) { mgSetError ("internal: bucket of %u slots", t->R); return MG_ERR_ARG; }
   if (lds > 48 * 1024)
-    { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    {
+#define MG_DEDUP_ATTR(PK, SL, PER) MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<PK, SL, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds))
+      if (bigR) { MG_DEDUP_ATTR (true, true, MG_DEDUP_PER_BIG); MG_DEDUP_ATTR (true, false, MG_DEDUP_PER_BIG); MG_DEDUP_ATTR (false, true, MG_DEDUP_PER_BIG); MG_DEDUP_ATTR (false, false, MG_DEDUP_PER_BIG); }
+      else      { MG_DEDUP_ATTR (true, true, MG_DEDUP_PER); MG_DEDUP_ATTR (true, false, MG_DEDUP_PER); MG_DEDUP_ATTR (false, true, MG_DEDUP_PER); MG_DEDUP_ATTR (false, false, MG_DEDUP_PER); }
+#undef MG_DEDUP_ATTR
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
   static int bThreadsEnv = -1;
@@ -1388,10 +1392,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
   U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
-  if (packed) { if (a.slotShift) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<true, true>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
-                else             MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<true, false>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock); }
-  else        { if (a.slotShift) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<false, true>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock);
-                else             MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<false, false>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock); }
+  if ((U64) bThreads * (bigR ? MG_DEDUP_PER_BIG : MG_DEDUP_PER) < t->R)      /* every slot of the image must belong to a thread of the closing sweep */
+    { mgSetError ("internal: %u threads for a bucket of %u slots", bThreads, t->R); return MG_ERR_ARG; }
+#define MG_DEDUP_LAUNCH(PK, SL, PER) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<PK, SL, PER>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock)
+#define MG_DEDUP_PICK(PER) do { if (packed) { if (a.slotShift) MG_DEDUP_LAUNCH (true, true, PER); else MG_DEDUP_LAUNCH (true, false, PER); } \
+                                else        { if (a.slotShift) MG_DEDUP_LAUNCH (false, true, PER); else MG_DEDUP_LAUNCH (false, false, PER); } } while (0)
+  if (bigR) MG_DEDUP_PICK (MG_DEDUP_PER_BIG); else MG_DEDUP_PICK (MG_DEDUP_PER);
+#undef MG_DEDUP_PICK
+#undef MG_DEDUP_LAUNCH
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
   if (segSrc)
@@ -1446,7 +1454,7 @@ MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dInde
   if (waves > nRows) waves = nRows;
   const U64 rowsPerWave = (nRows + waves - 1) / waves;
   waves = (nRows + rowsPerWave - 1) / rowsPerWave;
-  MG_LAUNCH (MG_K_TABLE_FIND, st, mgTableFindSegKernel, dim3 ((unsigned) ((waves + 3) / 4)), dim3 (256), 0, st, t->slots, mgGeomOf (t), src, n, rowsPerWave, dIndexOut);
+  MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgTableFindSegKernel, dim3 ((unsigned) ((waves + 3) / 4)), dim3 (256), 0, st, t->slots, mgGeomOf (t), src, n, rowsPerWave, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -1551,11 +1559,11 @@ static void mgSetGeometry (MgTable *t, int log2Slots)
 {
   t->nSlots = (U64) 1 << log2Slots;
   U32 R = t->wantR ? t->wantR : 4096;
-  if (R > 4096) R = 4096;                        /* the dedup kernel's threads hold MG_DEDUP_PER slots each */
+  if (R > 8192) R = 8192;                        /* the dedup kernel's threads hold MG_DEDUP_PER (R <= 4096) or MG_DEDUP_PER_BIG slots each */
   int lgR = mgLog2 (R); R = (U32) 1 << lgR;
   if (lgR > log2Slots) { lgR = log2Slots; R = (U32) 1 << lgR; }
   int lgNB = log2Slots - lgR;
-  while (lgNB > 18) { ++lgR; R <<= 1; --lgNB; }      /* at most 2^18 buckets (two 9-bit partition passes) */
+  while (lgNB > 18) { ++lgR; R <<= 1; --lgNB; }      /* at most 2^18 buckets (two 9-bit partition passes): R = 8192 for the 2^31 slots of table bits 32 */
   t->R = R; t->log2NB = lgNB;
 }
 

@@ -58,6 +58,7 @@ def merge_modsets_in_rank_order(ms, lib):
                     dist.send(t, dst=0)
             dist.barrier()
         return None
+    failed = None                                             # a failed merge is reported after the last round: the other ranks sit in the per-round barriers
     for r in range(1, world):
         nr = int(counts[r])
         v = torch.empty(nr + 1, dtype=torch.int64, device=dev)
@@ -68,9 +69,10 @@ def merge_modsets_in_rank_order(ms, lib):
         hv = np.ascontiguousarray(v.cpu().numpy().view(np.uint64))
         hd = np.ascontiguousarray(d.cpu().numpy().view(np.uint16))
         hi = np.ascontiguousarray(i.cpu().numpy())
-        ok = lib.mgModsetMergeArrays(ms, hv.ctypes.data, hd.ctypes.data, hi.ctypes.data, nr)
+        if failed is None and not lib.mgModsetMergeArrays(ms, hv.ctypes.data, hd.ctypes.data, hi.ctypes.data, nr):
+            failed = r
         del v, d, i
         dist.barrier()
-        if not ok:
-            raise RuntimeError("modsets of different hashers cannot be merged")
+    if failed is not None:
+        raise RuntimeError("modsets of different hashers cannot be merged (rank %d's)" % failed)
     return ms

@@ -251,3 +251,19 @@ def test_config3_full_size_reference_and_queries(tmp_path):
     L.modsetDestroy(ms)
     for d in (d_g, d_r, d_s, d_of, d_st, d_ix, d_ps, d_rd):
         d.free()
+
+
+@pytest.mark.parametrize("variant", ["auto", "flipped"])
+@pytest.mark.parametrize("config", ["c2", "c4", "c5"])
+def test_whole_value_and_depth_arrays_at_full_size(config, variant):
+    """EVERY index of value[] / depth[] at BASELINE size (1.03e8 entries of config 2, 1.65e8 of a config-4 block, 3.3e7 of
+    config 5): the GPU scan's ordered modimizer stream — pinned to the oracle on reads sampled across the whole batch —
+    gives, by a host-side sort (first-occurrence order, counts saturated at 65 535: modset.c:57, modutils.c:26), the arrays
+    the build must produce; compared entirely.  `auto`: the configuration the library selects in steady state (second of
+    two builds: flag polarity and merge-slot choice follow the previous add), the one bench.py times; `flipped`: the other
+    polarity / merge-slot choice forced.  tests/fullsize_whole.py, a fresh process per variant (knobs are read once)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), config, variant],
+                       capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
+    assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -367,3 +367,50 @@ def test_fuzz_small():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "5", "120"], capture_output=True, text=True, cwd=root)
     assert r.returncode == 0, r.stderr[-500:]
     assert "120 trials, 0 mismatches" in r.stdout, r.stdout[-500:]
+
+
+def _iterate_arrays(sh, bases):
+    """modRCiterator / modRCnext over one read without a Python loop per modimizer: the replay block behind hashBuf
+    (mg_host.c) is {n, n k-mers, n words pos | isF << 31}"""
+    L = mg.lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    it = L.modRCiterator(sh, bases.ctypes.data, len(bases))
+    addr = it.contents.hashBuf                                                  # a void * in the binding
+    n = int(C.cast(C.c_void_p(addr), C.POINTER(C.c_uint64))[0])
+    km = np.ctypeslib.as_array(C.cast(C.c_void_p(addr + 8), C.POINTER(C.c_uint64)), (max(n, 1),))[:n].copy()
+    pf = np.ctypeslib.as_array(C.cast(C.c_void_p(addr + 8 * (n + 1)), C.POINTER(C.c_uint32)), (max(n, 1),))[:n].copy()
+    # and the public face of it, for the first few
+    u = C.c_uint64(); p = C.c_int(); f = C.c_bool()
+    for i in range(min(n, 5)):
+        assert L.modRCnext(it, C.byref(u), C.byref(p), C.byref(f))
+        assert u.value == int(km[i]) and p.value == int(pf[i] & mg.MG_POS_MASK) and bool(f.value) == bool(pf[i] >> 31)
+    L.mgSeqhashRCiteratorDestroy(it)
+    return km, (pf & np.uint32(mg.MG_POS_MASK)).astype(np.int32), (pf >> 31).astype(np.uint8)
+
+
+@pytest.mark.parametrize("k,w", [(21, 64), (31, 4), (19, 31), (5, 1), (17, 8)])
+def test_iterator_one_launch_kernel_edges(k, w):
+    """modRCiterator (seqhash.c:154-196) = ONE kernel launch per read up to 64 tiles (mgIterScanKernel: eight workers, the
+    replay block written into pinned host memory), the batch scan beyond: lengths around k, around the tile edge, around the
+    points where the number of tiles per worker changes (8 and 16 tiles), at the one-launch limit and past it; w = 1 makes
+    every start a modimizer, so the first launch's output estimate is too small and the call retries with the size the
+    kernel reported."""
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(k + w)
+    lens = [0, 1, k - 1, k, k + 1, 100, TILE - 1, TILE, TILE + 1, TILE + k - 2, TILE + k - 1, TILE + k, 3 * TILE + 7,
+            8 * TILE - 1, 8 * TILE, 8 * TILE + k - 1, 8 * TILE + k, 9 * TILE + 3, 16 * TILE + k, 20011,
+            64 * TILE - 1, 64 * TILE, 64 * TILE + 1, 64 * TILE + k - 1, 70 * TILE + 5]
+    for n in lens:
+        b = rng.integers(0, 4, n).astype(np.uint8)
+        if n >= 4 * k:
+            b[n // 2:n // 2 + 2 * k] = 0                                  # a homopolymer run: hashF == hashR ties inside
+        a, p, f = _iterate_arrays(sh, b)
+        ek, ep, ef = oh.scan(b)
+        assert np.array_equal(a, ek) and np.array_equal(p, ep) and np.array_equal(f, ef), (k, w, n)
+    # many reads in a row through the same scratch (flag sequence numbers, output growth), alternating sizes
+    for i in range(300):
+        n = int(rng.integers(0, 3 * TILE)) if i % 7 else int(rng.integers(60 * TILE, 66 * TILE))
+        b = rng.integers(0, 4, n).astype(np.uint8)
+        a, p, f = _iterate_arrays(sh, b)
+        ek, ep, ef = oh.scan(b)
+        assert np.array_equal(a, ek) and np.array_equal(p, ep) and np.array_equal(f, ef), (k, w, n, i)
