@@ -134,6 +134,9 @@ uint64_t orcXorshiftBases (uint64_t state, uint8_t *out, int64_t n);   /* SURVEY
 
 /* Timed CPU baseline helper: scan (+ optional modset add) over nReads reads laid out by
  * offsets[nReads+1] in bases[]; returns total modimizers. Single thread. */
+/* first occurrences and counts of a k-mer stream (what modset.c:56-57 + modutils.c:26 make of it), multi-threaded:
+   flag[i] = 1 at first occurrences, cntAt[i] = occurrences of km[i] (at first occurrences); both zeroed by the caller */
+int64_t orcFirstOccurrences (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt);
 int64_t orcScanMany (const OrcHasher *h, const uint8_t *bases, const int64_t *offsets, int64_t nReads,
                      OrcModset *msOrNull);
 

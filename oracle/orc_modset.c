@@ -400,3 +400,57 @@ int64_t orcQueryRead (OrcReference *ref, const char *readName, const uint8_t *s,
   free (km); free (ps); free (six); free (spos);
   return n;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * First occurrences and counts of a stream of k-mers: what sequential modsetIndexFind (..., true) + ++depth over the
+ * stream produce (modset.c:56-57: entry ++max at first sight; modutils.c:26), stated without a table layout: flag[i] = 1
+ * where km[i] has not occurred before, and cntAt[i] = number of occurrences of km[i] in the whole stream (written at first
+ * occurrences only).  Then value[1..] = km[flag] in order, depth[1..] = min (65535, cntAt[flag]).  The full-size parity
+ * tests use it to pin every entry of a 1e8-entry modset in seconds: nThreads threads each own the k-mers of one hash
+ * class (all read the whole stream; no sharing, no locks). */
+#include <pthread.h>
+typedef struct { const uint64_t *km; uint64_t n; int t, T; uint8_t *flag; uint32_t *cntAt; int ok; } OrcFoJob;
+
+static inline uint64_t orcFoMix (uint64_t x)
+{ x ^= x >> 31; x *= 0x7fb5d329728ea185ull; x ^= x >> 27; x *= 0x81dadef4bc2dd44dull; x ^= x >> 33; return x; }
+
+static void *orcFoWorker (void *arg)
+{
+  OrcFoJob *j = (OrcFoJob *) arg;
+  uint64_t mine = 0;
+  for (uint64_t i = 0 ; i < j->n ; ++i) if (orcFoMix (j->km[i]) % (uint64_t) j->T == (uint64_t) j->t) ++mine;
+  uint64_t cap = 1024; while (cap * 7 < mine * 10 + 10) cap <<= 1;       /* load <= 0.7 even if every one of them is distinct */
+  uint64_t *key = (uint64_t *) malloc (cap * 8);
+  uint64_t *first = (uint64_t *) malloc (cap * 8);      /* index of the first occurrence + 1; 0 = empty slot */
+  if (!key || !first) { free (key); free (first); j->ok = 0; return 0; }
+  memset (first, 0, cap * 8);
+  for (uint64_t i = 0 ; i < j->n ; ++i)
+    { const uint64_t x = j->km[i], h = orcFoMix (x);
+      if (h % (uint64_t) j->T != (uint64_t) j->t) continue;
+      uint64_t s = (h / (uint64_t) j->T) & (cap - 1);
+      while (first[s] && key[s] != x) s = (s + 1) & (cap - 1);
+      if (!first[s]) { first[s] = i + 1; key[s] = x; j->flag[i] = 1; j->cntAt[i] = 1; }
+      else ++j->cntAt[first[s] - 1];
+    }
+  free (key); free (first);
+  j->ok = 1;
+  return 0;
+}
+
+/* flag[n] and cntAt[n] must be zeroed by the caller; returns the number of distinct k-mers, -1 on allocation failure */
+int64_t orcFirstOccurrences (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt)
+{
+  if (nThreads < 1) nThreads = 1;
+  if (nThreads > 64) nThreads = 64;
+  OrcFoJob job[64]; pthread_t th[64];
+  for (int t = 0 ; t < nThreads ; ++t)
+    { job[t].km = km; job[t].n = n; job[t].t = t; job[t].T = nThreads; job[t].flag = flag; job[t].cntAt = cntAt; job[t].ok = 0;
+      if (pthread_create (&th[t], 0, orcFoWorker, &job[t])) { orcFoWorker (&job[t]); th[t] = 0; }
+    }
+  int ok = 1;
+  for (int t = 0 ; t < nThreads ; ++t) { if (th[t]) pthread_join (th[t], 0); ok &= job[t].ok; }
+  if (!ok) return -1;
+  int64_t u = 0;
+  for (uint64_t i = 0 ; i < n ; ++i) u += flag[i];
+  return u;
+}

@@ -35,6 +35,22 @@ CONFIGS = {
 }
 
 
+def first_occurrence_arrays(km):
+    """value[1..] / depth[1..] that sequential insertion of the stream km produces: the distinct k-mers in order of first
+    occurrence and their occurrence counts saturated at 65 535 (oracle/orc_modset.c orcFirstOccurrences: threads by hash class)"""
+    from oracle import pyoracle as po
+    OL = po.lib()
+    OL.orcFirstOccurrences.restype = C.c_int64
+    OL.orcFirstOccurrences.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    n = len(km)
+    flag = np.zeros(n, np.uint8); cnt = np.zeros(n, np.uint32)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    u = OL.orcFirstOccurrences(km.ctypes.data, n, threads, flag.ctypes.data, cnt.ctypes.data)
+    assert u >= 0, "orcFirstOccurrences: allocation failed"
+    f = flag.view(np.bool_)
+    return km[f], np.minimum(cnt[f], 65535).astype(np.uint16)
+
+
 def main():
     name = sys.argv[1]
     variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
@@ -130,11 +146,8 @@ def main():
     t_scan = time.time() - t0 - t_build
 
     # ---- first-occurrence order and counts of the whole stream, on the host ------------------------------------------
-    uniq, first_idx, counts = np.unique(km, return_index=True, return_counts=True)
-    assert len(uniq) == U, ("distinct modimizers", len(uniq), "entries", U)
-    order = np.argsort(first_idx, kind="stable")
-    want_value = uniq[order]
-    want_depth = np.minimum(counts[order], 65535).astype(np.uint16)
+    want_value, want_depth = first_occurrence_arrays(km)
+    assert len(want_value) == U, ("distinct modimizers", len(want_value), "entries", U)
     bad = np.flatnonzero(want_value != value)
     assert bad.size == 0, ("value[] differs from first-occurrence order at", bad[:5] + 1, "of", U)
     bad = np.flatnonzero(want_depth != depth)

@@ -224,3 +224,28 @@ def test_vs_reference_depth_saturation():
     po.ref_add_sequence(rms, b); oms.add_sequence(b)
     assert oms.max == 1 and rms.contents.max == 1
     assert oms.depths()[1] == 65535 == rms.contents.depth[1]
+
+
+def test_first_occurrences_helper_matches_numpy():
+    """oracle/orc_modset.c orcFirstOccurrences (the full-size parity tests' host-side reconstruction of value[] / depth[])
+    against the sort-based definition and against sequential orcModsetFind inserts"""
+    import ctypes as C
+    sys_path_fullsize = os.path.join(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fullsize_whole", os.path.join(sys_path_fullsize, "fullsize_whole.py"))
+    fw = importlib.util.module_from_spec(spec); spec.loader.exec_module(fw)
+    rng = np.random.default_rng(5)
+    for n, distinct in ((0, 1), (1, 1), (1000, 7), (300_000, 40_000), (300_000, 10**12)):
+        km = (rng.integers(0, distinct, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64((1 << 42) - 1)
+        v, d = fw.first_occurrence_arrays(km)
+        uq, fi, ct = np.unique(km, return_index=True, return_counts=True)
+        order = np.argsort(fi, kind="stable")
+        assert np.array_equal(v, uq[order]) and np.array_equal(d, np.minimum(ct[order], 65535).astype(np.uint16))
+    # saturation, and the oracle's own modset on the same stream
+    km = np.concatenate([np.full(70_000, 5, np.uint64), rng.integers(0, 50, 5000).astype(np.uint64)])
+    v, d = fw.first_occurrence_arrays(km)
+    assert d[0] == 65535
+    oh = po.Hasher(21, 64, 17); oms = po.Modset(oh, 20)
+    for x in km:
+        ix = oms.find(int(x), True)
+    assert oms.max == len(v) and np.array_equal(oms.values()[1:], v)
