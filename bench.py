@@ -422,6 +422,33 @@ def gpu_rank(args):
         out["collective"] = {"what": "all_reduce(SUM) of the 65536 x int64 depth histogram (512 KiB) over RCCL",
                              "allreduce_ms": round(ar_ms, 4), "histogram_entries": int(hist.sum().item()),
                              "entries_all_ranks": int(sums[1].item()), "matches_local_sums": ok}
+        # every rank checks its own block's result (outside the timed region): the modset of the first ~20 Mbp of the block,
+        # built on its own by mgAddReadsDevice, must be the PREFIX of the block's modset -- same k-mers at the same indices
+        # (indices are handed out in order of first occurrence: modset.c:57), depths no larger -- and the block's depths must
+        # add up to its modimizer count.  (The bit-exactness of a build against the oracle is what tests/ pins; this ties every
+        # rank's full-size result to it on the GPU it ran on.)
+        par = rank_parity(cx, ms, reads, d_offsets, offsets, n_reads, S, k, d, seed)
+        flags = torch.tensor([1 if par["ok"] else 0], dtype=torch.int64, device=cx.dev)
+        dist.all_reduce(flags)
+        out["per_rank_parity"] = bool(int(flags.item()) == world)
+        out["per_rank_parity_rank0"] = par
+        # what ONE GPU does on this workload with the others idle (rank 0's block, no all-reduce in the step): the figure a
+        # scaling efficiency is to be read against
+        torch.cuda.synchronize(); dist.barrier()
+        if rank == 0:
+            def step1():
+                mg.check(L.mgModsetClear(ms, stream))
+                mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads, C.byref(n_hash), stream))
+                hist.zero_()
+                mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), stream))
+            step1(); torch.cuda.synchronize()
+            k1 = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(k1):
+                step1()
+            torch.cuda.synchronize()
+            out["single_gpu_block_gbps"] = round(total * k1 / (time.perf_counter() - t0) / 1e9, 2)
+        dist.barrier()
 
     # ---- CPU baseline (rank 0, N=1 only): the compiled reference on a bounded sample ---------
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -447,6 +474,13 @@ def gpu_rank(args):
                 other[name] = {"error": str(e)[:300]}
         out["other_configs"] = other
 
+    if multi and not args.no_other:
+        # north_star's other sharding (query reads over replicated modsets), every rank taking part
+        try:
+            c3s = bench_c3(cx, args, shard=(rank, world))
+        except Exception as e:
+            c3s = {"error": str(e)[:300]}
+        out["other_configs"] = {"c3_sharded": c3s}
     if multi:
         dist.barrier()                    # every rank is done (and silent) before the line goes out
         C.CDLL(None).fflush(None)
@@ -454,6 +488,28 @@ def gpu_rank(args):
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+
+
+def rank_parity(cx, ms, reads, d_offsets, offsets, n_reads, S, k, d, seed):
+    """see the call site: prefix property of this rank's block on this rank's GPU"""
+    import numpy as np
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    m = max(1, min(int(np.searchsorted(offsets, 20_000_000, side="right")) - 1, n_reads))
+    nb = int(offsets[m])
+    sh = mg.seqhashCreate(k, d, seed)
+    ms2 = mg.modsetCreate(sh, 24)
+    n2 = C.c_uint64(0)
+    mg.check(L.mgAddReadsDevice(ms2, reads.data_ptr(), nb, d_offsets.data_ptr(), m, C.byref(n2), cx.stream))
+    mg.check(L.modsetSyncToHost(ms2, 0)); mg.check(L.modsetSyncToHost(ms, 0))
+    u2, u = ms2.contents.max, ms.contents.max
+    v2 = np.ctypeslib.as_array(ms2.contents.value, (u2 + 1,)); d2 = np.ctypeslib.as_array(ms2.contents.depth, (u2 + 1,))
+    v = np.ctypeslib.as_array(ms.contents.value, (u + 1,)); dd = np.ctypeslib.as_array(ms.contents.depth, (u + 1,))
+    ok = bool(0 < u2 <= u and np.array_equal(v[1:u2 + 1], v2[1:]) and np.all(dd[1:u2 + 1] >= d2[1:])
+              and int(d2[1:].astype(np.int64).sum()) == n2.value
+              and (int(dd[1:].astype(np.int64).sum()) == S or int(dd.max()) == 65535))
+    res = {"ok": ok, "prefix_bases": nb, "prefix_entries": int(u2), "block_entries": int(u)}
+    L.modsetDestroy(ms2)
+    return res
 
 
 # ------------------------------------------------------------------------------------------------
@@ -541,8 +597,11 @@ def bench_c5(cx, args):
     return res
 
 
-def bench_c3(cx, args):
-    """configs[2]: modmap — a 3 Gbp synthetic reference (24 sequences of 125 Mbp, table bits 28, modmap.c:93-134 insert
+def bench_c3(cx, args, shard=None):
+    """shard = (rank, world) at N > 1: north_star's query sharding -- the reference modset replicated (every rank builds it from the
+    same genome), the 90 Gbp of reads split into `world` contiguous shares of whole batches, no collective on the data path; the
+    timed region is bracketed by barriers and the MAX over ranks is taken.
+    configs[2]: modmap — a 3 Gbp synthetic reference (24 sequences of 125 Mbp, table bits 28, modmap.c:93-134 insert
     loop) queried with 30x = 90 Gbp of ONT-like reads in batches of 10 Gbp (modmap.c:197-206 lookup loop: one seed
     (index,pos) per modimizer incl. misses).  Timed: the query batches (scan + lookup), reads resident in HBM."""
     import numpy as np
@@ -554,6 +613,14 @@ def bench_c3(cx, args):
     genome_bases = n_seq * seq_len
     batch = int(float(os.environ.get("MODGPU_BENCH_C3_BATCH_GBP", "10")) * 1e9 * min(scale * 4, 1.0))
     n_batches = int(os.environ.get("MODGPU_BENCH_C3_BATCHES", "9"))
+    rank, world = shard if shard else (0, 1)
+    first_batch = 0
+    if shard:                                          # 90 Gbp / world per rank, in batches of at most 10 Gbp (the shares are whole numbers of equal batches)
+        share = n_batches * batch // world
+        per = -(-share // batch)                       # batches per rank
+        batch = share // per // 16 * 16
+        n_batches = per
+        first_batch = rank * per
     genome = make_genome(cx, genome_bases, 333)
     ref_off = torch.arange(0, n_seq + 1, dtype=torch.int64, device=cx.dev) * seq_len
     sh = mg.seqhashCreate(k, d, 17)
@@ -580,7 +647,7 @@ def bench_c3(cx, args):
     # streaming caller would: nothing else touches the GPU or keeps the host busy between two timed calls
     batches = []
     for b in range(n_batches):
-        reads, d_offsets, offsets, n_reads = make_reads(cx, batch, genome, genome_bases, 4000 + b, 0.05, 5000 + b)
+        reads, d_offsets, offsets, n_reads = make_reads(cx, batch, genome, genome_bases, 4000 + first_batch + b, 0.05, 5000 + first_batch + b)
         batches.append((reads, d_offsets, n_reads, torch.empty(qcap, dtype=torch.int32, device=cx.dev)))
     L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
     reads, d_offsets, n_reads, q_idx = batches[0]                # warm-up of the arena and the kernels, untimed
@@ -591,6 +658,8 @@ def bench_c3(cx, args):
     tot_bases = tot_seeds = tot_hits = 0
     per, seeds_each = [], []
     torch.cuda.synchronize()
+    if shard:
+        cx.dist.barrier()
     t_all = time.perf_counter()
     for reads, d_offsets, n_reads, q_idx in batches:
         t0 = time.perf_counter()
@@ -600,9 +669,15 @@ def bench_c3(cx, args):
         seeds_each.append(n_seeds.value)
         tot_bases += batch; tot_seeds += n_seeds.value
     torch.cuda.synchronize()
+    if shard:
+        cx.dist.barrier()
     t_query = time.perf_counter() - t_all
     for (reads, d_offsets, n_reads, q_idx), ns in zip(batches, seeds_each):
         tot_hits += int((q_idx[:ns] != 0).sum().item())
+    if shard:                                          # whole job: all ranks' bases over the slowest rank's time
+        tm = torch.tensor([t_query], dtype=torch.float64, device=cx.dev); cx.dist.all_reduce(tm, op=cx.dist.ReduceOp.MAX)
+        tot = torch.tensor([tot_bases, tot_seeds, tot_hits], dtype=torch.int64, device=cx.dev); cx.dist.all_reduce(tot)
+        t_job = float(tm.item()); job_bases, job_seeds, job_hits = (int(x) for x in tot.tolist())
     del batches, reads, d_offsets, q_idx
     table = read_profile(L, mg)
     L.mgProfileEnable(0)
@@ -612,6 +687,17 @@ def bench_c3(cx, args):
     alg["mgScanKernel"] = (0.25 + 16.0 / d) * batch              # this path writes kmer 8 + pos 4 + read 4 per modimizer
     alg["mgSegCompactKernel"] = 16.0 * S                         # pos + read, 4 bytes each, read and written (the lookups read the k-mers from the segments)
     kern = {kname: (v[0], v[1], v[2]) for kname, v in table.items()}
+    if shard:
+        res = {"workload": "BASELINE config 3 sharded over %d GPUs (north_star: reads shard, modset replicated): every rank builds the reference "
+                           "%d x %d Mbp (table bits %d, %d modset entries) and queries its %d batches of %.3f Gbp (scan + lookup, seeds out); "
+                           "no data-path collective" % (world, n_seq, seq_len // 1_000_000, bits, ref_entries, n_batches, batch / 1e9),
+               "value": round(job_bases / t_job / 1e9, 2), "unit": "Gbp/s", "n_gpus": world, "query_bases": job_bases, "seeds": job_seeds,
+               "seed_hit_fraction": round(job_hits / max(job_seeds, 1), 4), "ms_each_batch_rank0": per,
+               "rank0_Gbp_per_s": round(tot_bases / t_query / 1e9, 2), "reference_build_s": round(t_ref, 3)}
+        L.modsetDestroy(ms)
+        del genome, q_pos, q_rd
+        torch.cuda.empty_cache()
+        return res
     res = {"workload": "BASELINE config 3: modmap, reference %d x %d Mbp = %.1f Gbp (table bits %d, %d occurrences, %d modset entries), "
                        "%d query batches of %g Gbp ONT-like reads from it (5%% subs): scan + lookup, seeds (index,pos,read) out"
                        % (n_seq, seq_len // 1_000_000, genome_bases / 1e9, bits, ref_occ, ref_entries, n_batches, batch / 1e9),

@@ -183,8 +183,7 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_MODE_ANY   0      /* any d: exact test in phase A via modular inverse */
 #define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
 #define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
-#define MG_CAND_CAP   256    /* candidate list entries per round (LDS, per wavefront) */
-#define MG_CAND_ITERS (MG_CAND_CAP / 64)
+#define MG_CAND_CAP   320    /* candidate list entries (LDS, per wavefront): up to 63 waiting from the tile before + a pass of this tile's */
 #define MG_WAVES      (MG_SCAN_THREADS / 64)
 #ifdef MG_ABLATE
 #define MG_ABLATE_AND(x) && (x)
@@ -264,6 +263,7 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
     }
 
   int buf = 0;
+  U32 qCount = 0, qOld = 0;                          /* the candidate queue: entries waiting, and how many of them are of the previous tile (uniform) */
   while (tile < tileEnd)
     { U32 *sWords = sWordsW[buf]; buf ^= 1;
       *reinterpret_cast<uint4 *> (&sWords[4 * lane]) = curV;
@@ -384,7 +384,6 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
       const U32 incl = mgWaveInclusiveSum (cnt);
       const U32 nc = (U32) __builtin_amdgcn_readlane ((int) incl, 63);
       const U32 myFirst = incl - cnt;                        /* ordinal of this lane's first candidate */
-      const U32 nRounds = (nc + MG_CAND_CAP - 1) / MG_CAND_CAP;
 #ifdef MG_ABLATE
       if (a.debug & 1)                                      /* phases A+B only (output meaningless) */
         { tile = nextTile; curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
@@ -392,52 +391,61 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
           continue;
         }
 #endif
-
-      /* ---- Phase C, MG_CAND_CAP candidates per round ---- */
-      for (U32 rd = 0 ; rd < nRounds ; ++rd)
-        { const U32 lo = rd * MG_CAND_CAP;
-          if (rd) MG_WAVE_SYNC ();                           /* previous round done with sCand */
-          /* the lane's candidates, low half of the mask then high half: 32-bit bit tricks, one LDS store each.
-             o is the slot in this round's list; it wraps below lo, so "o < CAP" alone selects the round's entries
-             (a loop condition on o costs more than it saves when there is one round, the usual case). */
-          if (nRounds == 1)                                  /* the usual case: every candidate has its slot, nothing to clamp */
-            { unsigned short *pp = sCand + myFirst;
+      /* The candidate list is a queue (sCand[0 .. qCount)): a tile's candidates are appended, in order, and evaluated 64 at
+         a time from the front.  When only the k-mers are wanted (the modset build) what is left of a tile, fewer than 64,
+         waits for the next tile's candidates instead of costing a round of its own with most lanes idle -- an entry says which
+         of the two tile buffers it points into, and the previous tile's is intact until the tile after this one is staged; so
+         entries of the previous tile (qOld of them, at the front) must be gone when this tile is done.  A tile with more
+         candidates than the list holds (small d) lists them in passes. */
+      const bool wantWhere = a.segPosF || a.segRead;             /* uniform: the modset build wants the k-mers alone */
+      const bool lastTile = nextTile >= tileEnd;
+      const U32 bufTag = (U32) (buf ^ 1) << 12;                  /* the buffer this tile was staged in */
+      U32 listed = 0;                                            /* candidates of this tile in the list or done with */
+      do
+        { const U32 room = MG_CAND_CAP - qCount;
+          const U32 take = nc - listed < room ? nc - listed : room;
+          const U32 lo = listed, hi = listed + take;             /* this pass lists the tile's candidates lo .. hi-1 */
+          /* the lane's candidates, low half of the mask then high half: 32-bit bit tricks, one LDS store each */
+          if (lo == 0 && hi == nc)                               /* the usual case: every candidate has its slot, nothing to clamp */
+            { unsigned short *pp = sCand + qCount + myFirst;
 #pragma unroll
               for (int half = 0 ; half < 2 ; ++half)
                 { U32 c = half ? (U32) (cand >> 32) : (U32) cand;
-                  const U32 base = (U32) lane * MG_POS_PER_THREAD + 32u * half;
+                  const U32 base = bufTag | ((U32) lane * MG_POS_PER_THREAD + 32u * half);
                   while (c)
                     { *pp++ = (unsigned short) (base | (U32) __builtin_ctz (c));
                       c &= c - 1;
                     }
                 }
             }
-          else if (myFirst < lo + MG_CAND_CAP && myFirst + cnt > lo)
-            { U32 o = myFirst - lo;
+          else if (take && myFirst < hi && myFirst + cnt > lo)
+            { U32 o = myFirst - lo;                              /* place in this pass; wraps below lo, so "o < take" alone selects the pass's entries */
 #pragma unroll
               for (int half = 0 ; half < 2 ; ++half)
                 { U32 c = half ? (U32) (cand >> 32) : (U32) cand;
-                  const U32 base = (U32) lane * MG_POS_PER_THREAD + 32u * half;
+                  const U32 base = bufTag | ((U32) lane * MG_POS_PER_THREAD + 32u * half);
                   while (c)
                     { const U32 t = (U32) __builtin_ctz (c);
                       c &= c - 1;
-                      sCand[o < MG_CAND_CAP ? o : MG_CAND_CAP] = (unsigned short) (base + t);   /* no branch in the loop */
+                      sCand[o < take ? qCount + o : MG_CAND_CAP] = (unsigned short) (base | t);   /* [MG_CAND_CAP]: where other passes' entries land; no branch in the loop */
                       ++o;
                     }
                 }
             }
           MG_WAVE_SYNC ();                                                       /* candidates listed */
-          const U32 nHere = (nc - lo < MG_CAND_CAP) ? nc - lo : MG_CAND_CAP;
+          qCount += take; listed = hi;
+          U32 nEval = qCount & ~63u;                                             /* whole rounds ... */
+          if (listed == nc && (wantWhere || lastTile || qOld > nEval)) nEval = qCount;   /* ... or everything: pos / read come from this tile's state; nothing may outlive its tile buffer */
           U32 waveRun = 0;
 #pragma unroll 1
-          for (int it = 0 ; it < MG_CAND_ITERS ; ++it)
-            { if ((U32) it * 64 >= nHere) break;                                  /* uniform */
-              const U32 i = (U32) it * 64 + lane;
+          for (U32 i0 = 0 ; i0 < nEval ; i0 += 64)
+            { const U32 i = i0 + (U32) lane;
               bool surv = false, fwd = false;
               U64 F = 0; U32 q = 0;
-              if (i < nHere MG_ABLATE_AND (!(a.debug & 4)))
-                { q = sCand[i];
-                  F = mgKmerAt (sWords, q, sh1);
+              if (i < nEval MG_ABLATE_AND (!(a.debug & 4)))
+                { const U32 e = sCand[i];
+                  q = e & (MG_TILE_BASES - 1);
+                  F = mgKmerAt (sWordsW[e >> 12], q, sh1);
                   U64 R = mgRevComp (F, sh1);
                   if (MODE == MG_MODE_FAST)
                     { /* hashes compared and tested where they sit in the products: no 64-bit shifts.  hash = P >> sh1,
@@ -460,12 +468,11 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
                   if (!fwd) F = R;
                 }
               const U64 bs = __ballot (surv);
-              const bool wantWhere = a.segPosF || a.segRead;              /* uniform: the modset build wants the k-mers alone */
               U32 r = 0;
               if (wantWhere && (!oneRead || a.segRead)) r = (U32) __shfl ((int) rFirst, (int) (q >> 6));   /* first read of the owner lane's starts */
               if (surv)
                 { const U64 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
-                  const U64 pos = tile0 + q;
+                  const U64 pos = tile0 + q;                               /* (with pos / read wanted every entry is of this tile) */
                   U64 rs = ti.start;
                   if (!oneRead && wantWhere)
                     { if (offInLds) { while (sOff[r + 1 - ti.firstRead] <= pos) ++r; rs = sOff[r - ti.firstRead]; }
@@ -481,7 +488,19 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
               waveRun += (U32) __popcll (bs);
             }
           found += waveRun;
+          /* what was not evaluated moves to the front */
+          const U32 rem = qCount - nEval;
+          if (rem && nEval)
+            { const U32 v = (U32) lane < rem ? sCand[nEval + lane] : 0u;
+              MG_WAVE_SYNC ();
+              if ((U32) lane < rem) sCand[lane] = (unsigned short) v;
+            }
+          if (nEval) MG_WAVE_SYNC ();                                            /* the list may be written again */
+          qOld = qOld > nEval ? qOld - nEval : 0;
+          qCount = rem;
         }
+      while (listed < nc);
+      qOld = qCount;                                     /* what waits now is of this tile: the previous one for the next */
       tile = nextTile;
       curV = nextV; curHalo = nextHalo; ti = tiNext; nextFirstRead = nextNextFirst;
     }

@@ -39,6 +39,15 @@
 #include "mg_common.h"
 
 #define MG_ASSIGNED 0x80000000u
+/* -DMG_BUILD_PRIO: the build's kernels raise their waves' issue priority (s_setprio 3).  An experiment of round 3 for running
+ * them beside the instruction-bound scan of the next batch on a second stream ("scan || build"): with it the
+ * co-run gains 9 % over no priority, but it still takes 93 % of the sum of the two (the build's kernels need the wave slots the
+ * scan holds), and alone the partition scatter loses 9 % and the merge 5 % to it -- so it is off. */
+#ifdef MG_BUILD_PRIO
+#define MG_BUILD_PRIO() __builtin_amdgcn_s_setprio (3)
+#else
+#define MG_BUILD_PRIO() do { } while (0)
+#endif
 #ifdef MG_ABLATE
 #define MG_ABLATE_AND(x) && (x)
 #else
@@ -105,6 +114,7 @@ void mgDirectFlagKernel (const MgSlot *__restrict__ slots, const U32 *__restrict
 __global__ __launch_bounds__ (256)
 void mgRankCountKernel (const unsigned char *__restrict__ flags, U64 n, U64 rowsPerUnit, U64 *__restrict__ unitCount)
 {
+  MG_BUILD_PRIO ();
   const int lane = threadIdx.x & 63;
   const U64 unit = (U64) blockIdx.x * 4 + (threadIdx.x >> 6);
   const U64 nRows = (n + 63) / 64;
@@ -218,6 +228,7 @@ void mgRankAssignKernel (const unsigned char *__restrict__ flags, const U64 *__r
                          U64 *__restrict__ value, MgSlot *__restrict__ slots, const U32 *__restrict__ slotId,
                          MgRankGrp *__restrict__ grp)
 {
+  MG_BUILD_PRIO ();
   const int lane = threadIdx.x & 63;
   const U64 unit = (U64) blockIdx.x * 4 + (U32) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
   const U64 nRows = (n + 63) / 64;
@@ -292,6 +303,7 @@ __global__ __launch_bounds__ (256)
 void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, MgGeom g,
                         const U64 *__restrict__ kmer, U64 n, U32 *__restrict__ out)
 {
+  MG_BUILD_PRIO ();
   const U64 stride = (U64) gridDim.x * blockDim.x;
   for (U64 o0 = (U64) blockIdx.x * blockDim.x + threadIdx.x ; o0 < n ; o0 += stride * MG_FIND_PER)
     { U64 km[MG_FIND_PER], key[MG_FIND_PER], base[MG_FIND_PER]; U32 at[MG_FIND_PER], res[MG_FIND_PER]; bool live[MG_FIND_PER];
@@ -332,6 +344,7 @@ void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict_
 __global__ __launch_bounds__ (256)
 void mgTableFindSegKernel (const MgSlot *__restrict__ slots, MgGeom g, const MgSegSrc src, U64 n, U64 rowsPerWave, U32 *__restrict__ out)
 {
+  MG_BUILD_PRIO ();
   const int lane = threadIdx.x & 63;
   const U64 wave = (U64) blockIdx.x * 4 + (U32) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
   const U64 nRows = (n + 63) / 64;
@@ -570,6 +583,7 @@ void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, MgPartFmt f, int s
                        const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                        U32 *__restrict__ binCount)
 {
+  MG_BUILD_PRIO ();
   __shared__ U32 sH[MG_PART_MAXBINS];
   /* a workgroup takes a contiguous run of chunks and adds its LDS counts to the global ones only when the
      segment changes (one workgroup per chunk meant thousands of atomics on each of a few hundred addresses) */
@@ -673,6 +687,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
                           unsigned long long *__restrict__ cursor, U32 cstride, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
 {
+  MG_BUILD_PRIO ();
   constexpr bool WIDE = !PACKOUT;
   __shared__ U64 stK[MG_PART_SUB];
   __shared__ U32 stT[WIDE ? MG_PART_SUB : 1];
@@ -864,6 +879,7 @@ template <bool PACKED, bool SLOT, int PER>       /* SLOT: a.slotShift != 0; PER:
 __global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (PER == MG_DEDUP_PER ? 8 : 4)))      /* 64 registers: two workgroups per CU */
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
+  MG_BUILD_PRIO ();
   const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
   unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
   U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
@@ -991,6 +1007,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 __global__ __launch_bounds__ (1024)
 void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
+  MG_BUILD_PRIO ();
   const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
   unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
   U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
@@ -1107,6 +1124,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 __global__ __launch_bounds__ (256)
 void mgRankLookupKernel (const MgBucketArgs a, U32 groupsPerSlice)
 {
+  MG_BUILD_PRIO ();
   const int lane = threadIdx.x & 63;
   const U32 blocksPerSlice = (groupsPerSlice + 3) / 4;
   const U32 xcd = blockIdx.x & 7, k = blockIdx.x >> 3;

@@ -166,10 +166,11 @@ def test_bench_gpus_n_starts_n_ranks():
 def test_bench_multi_rank_path_on_one_gpu():
     """the N > 1 code path of bench.py (RCCL process group, per-step histogram + all-reduce, barriers, collective
     timing) at world size 1: the all-reduced histogram is the rank's own modsetDepthHistogramDevice result"""
-    env = dict(os.environ, MODGPU_BENCH_FORCE_DIST="1", MODGPU_BENCH_GBP="0.3", MASTER_PORT=str(_free_port()))
+    env = dict(os.environ, MODGPU_BENCH_FORCE_DIST="1", MODGPU_BENCH_GBP="0.3", MASTER_PORT=str(_free_port()),
+               MODGPU_BENCH_C3_SCALE="0.02", MODGPU_BENCH_C3_BATCHES="2")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-other"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -177,3 +178,38 @@ def test_bench_multi_rank_path_on_one_gpu():
     c = j["collective"]
     assert c["matches_local_sums"] is True and c["histogram_entries"] == j["config"]["modset_entries"] > 0
     assert j["roofline"]["kernel"] and j["roofline"]["alu"]["floor_ms"] > 0
+    # every rank's block checked on its own GPU (prefix property), the single-GPU figure of the same workload, and the
+    # query sharding (north_star: reads shard, modset replicated) at this world size
+    assert j["per_rank_parity"] is True and j["per_rank_parity_rank0"]["prefix_entries"] > 0
+    assert j["single_gpu_block_gbps"] > 0
+    c3 = j["other_configs"]["c3_sharded"]
+    assert "error" not in c3 and c3["n_gpus"] == 1 and c3["value"] > 0 and 0.25 < c3["seed_hit_fraction"] < 0.45
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", sorted({2, max(2, _gpu_count())}))
+def test_bench_on_every_gpu_of_the_box(n):
+    """`python bench.py --gpus N` on a box that has N > 1 GPUs (skipped on a one-GPU box, so an 8-GPU run of this suite covers
+    the RCCL leg by itself): one rank per GPU, block r of config 4 on rank r, the histogram all-reduce; the summed histogram
+    holds every rank's entries, every rank's block passes its prefix check, and N GPUs do at least 0.8 x N x what one does
+    alone on the same workload.  Reference: SURVEY §8(e), north_star (reads shard, modset per GPU)."""
+    if _gpu_count() < n:
+        pytest.skip("needs %d GPUs, this box has %d" % (n, _gpu_count()))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == n and j["scaling"] == "weak"
+    assert j["collective"]["matches_local_sums"] is True and j["per_rank_parity"] is True
+    assert j["value"] >= 0.8 * n * j["single_gpu_block_gbps"], (j["value"], j["single_gpu_block_gbps"])
+    c3 = j["other_configs"]["c3_sharded"]
+    assert "error" not in c3 and c3["n_gpus"] == n and c3["value"] > 0
