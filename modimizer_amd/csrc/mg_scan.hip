@@ -156,11 +156,14 @@ __device__ __forceinline__ U64 mgValidMask (const U64 *off, U32 rBase, U32 nRead
   return valid;
 }
 
-__device__ __forceinline__ uint4 mgLoadTileWords (const MgScanArgs &a, U64 tile, int tid)
+/* a tile's 1 KiB: one 16-byte load per lane.  Only a batch's last tiles can reach past the allocation (the stream is followed
+ * by MG_PACK_PAD zero words, a tile with its halo reads MG_TILE_WORDS + 8): `inside` (uniform) says this one does not. */
+__device__ __forceinline__ bool mgTileInside (const MgScanArgs &a, U64 tile) { return (tile + 1) * MG_TILE_WORDS + 8 <= a.nWordsAlloc; }
+__device__ __forceinline__ uint4 mgLoadTileWords (const MgScanArgs &a, U64 tile, int tid, bool inside)
 {
   U64 g = tile * MG_TILE_WORDS + 4 * (U64) tid;
   uint4 v;
-  if (g + 4 <= a.nWordsAlloc) v = *reinterpret_cast<const uint4 *> (a.packed + g);
+  if (inside || g + 4 <= a.nWordsAlloc) v = *reinterpret_cast<const uint4 *> (a.packed + g);
   else
     { v.x = g     < a.nWordsAlloc ? a.packed[g]     : 0;
       v.y = g + 1 < a.nWordsAlloc ? a.packed[g + 1] : 0;
@@ -168,6 +171,12 @@ __device__ __forceinline__ uint4 mgLoadTileWords (const MgScanArgs &a, U64 tile,
       v.w = 0;
     }
   return v;
+}
+__device__ __forceinline__ U32 mgLoadTileHalo (const MgScanArgs &a, U64 tile, int lane, bool inside)
+{
+  U32 h = 0;
+  if (lane < 8) { const U64 gh = tile * MG_TILE_WORDS + MG_TILE_WORDS + lane; h = (inside || gh < a.nWordsAlloc) ? a.packed[gh] : 0; }
+  return h;
 }
 
 /* k-mer (forward strand) starting at position q of the tile staged in sWords */
@@ -183,6 +192,7 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_MODE_ANY   0      /* any d: exact test in phase A via modular inverse */
 #define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
 #define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
+#define MG_LIST_UNROLL 4     /* candidates per half of a lane's mask listed by straight-line code */
 #define MG_CAND_CAP   320    /* candidate list entries (LDS, per wavefront): up to 63 waiting from the tile before + a pass of this tile's */
 #define MG_WAVES      (MG_SCAN_THREADS / 64)
 #ifdef MG_ABLATE
@@ -238,7 +248,7 @@ __device__ __forceinline__ void mgScanHistDone (const MgScanArgs &a, U32 *sHist,
 /* the work of one worker (wavefront): its tiles, its segment; returns the number of modimizers it found (uniform).
  * SINGLE: the batch is one read [0, totalBases) (the per-read iterator facade): no per-tile metadata array, every tile's
  * first read is read 0. */
-template <int MODE, bool SINGLE>
+template <int MODE, bool SINGLE, bool WHERE>        /* WHERE: pos / read of the modimizers are wanted, not the k-mers alone (the modset build) */
 __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 worker, const int lane,
                                              U32 (*sWordsW)[MG_TILE_WORDS + 8], unsigned short *sCand, U64 *sOff, U32 *sHist)
 {
@@ -250,14 +260,17 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
   U64 tile = a.tileBegin + worker * a.tilesPerWorker;
   U64 tileEnd = tile + a.tilesPerWorker; if (tileEnd > a.tileLimit) tileEnd = a.tileLimit;
   const U64 segBase = worker * a.segCap;
-  U64 found = 0;                                   /* modimizers this worker has found so far (uniform) */
+  U32 found = 0;                                   /* modimizers this worker has found so far (uniform; a worker's tiles hold fewer than 2^32 starts) */
+  const U32 segCap32 = a.segCap > 0xffffffffull ? 0xffffffffu : (U32) a.segCap;
+  U64 *const segK = a.segKmer + segBase;
   uint4 curV = make_uint4 (0, 0, 0, 0); U32 curHalo = 0;
   MgTileInfo ti, tiNext;
   ti.start = ti.end = 0; ti.firstRead = 0; tiNext = ti;
   U32 nextFirstRead = 0;
   if (tile < tileEnd)
-    { curV = mgLoadTileWords (a, tile, lane);
-      if (lane < 8) { U64 gh = tile * MG_TILE_WORDS + MG_TILE_WORDS + lane; curHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
+    { const bool inside = mgTileInside (a, tile);
+      curV = mgLoadTileWords (a, tile, lane, inside);
+      curHalo = mgLoadTileHalo (a, tile, lane, inside);
       if (SINGLE) { ti.start = 0; ti.end = a.totalBases; ti.firstRead = 0; }
       else { ti = a.tileInfo[tile]; nextFirstRead = a.tileInfo[tile + 1].firstRead; }
     }
@@ -300,8 +313,9 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
       const U64 nextTile = tile + 1;
       uint4 nextV = make_uint4 (0, 0, 0, 0); U32 nextHalo = 0; U32 nextNextFirst = 0;
       if (nextTile < tileEnd)
-        { nextV = mgLoadTileWords (a, nextTile, lane);
-          if (lane < 8) { U64 gh = nextTile * MG_TILE_WORDS + MG_TILE_WORDS + lane; nextHalo = gh < a.nWordsAlloc ? a.packed[gh] : 0; }
+        { const bool inside = mgTileInside (a, nextTile);
+          nextV = mgLoadTileWords (a, nextTile, lane, inside);
+          nextHalo = mgLoadTileHalo (a, nextTile, lane, inside);
           if (SINGLE) tiNext = ti;
           else { tiNext = a.tileInfo[nextTile]; nextNextFirst = a.tileInfo[nextTile + 1].firstRead; }
         }
@@ -318,7 +332,7 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
           U32 fw[6], rw[6];
           const int c2 = 2 * (k - 16);                         /* 2..30 */
 #pragma unroll
-          for (int j = 0 ; j < 5 ; ++j) fw[j] = __funnelshift_l (w[j + 1], w[j], c2);
+          for (int j = 0 ; j < 5 ; ++j) fw[j] = __builtin_amdgcn_alignbit (w[j], w[j + 1], 32 - c2);   /* = funnelshift_l (w[j + 1], w[j], c2): c2 is never 0 here, so one v_alignbit */
           fw[5] = w[5] << c2;
 #pragma unroll
           for (int j = 0 ; j < 6 ; ++j) rw[j] = mgRevComp16 (w[j]);
@@ -380,7 +394,8 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
       cand &= valid;
 
       /* ---- Phase B: order the candidates ---- */
-      const U32 cnt = (U32) __popcll (cand);
+      const U32 cntLo = (U32) __popc ((U32) cand);
+      const U32 cnt = cntLo + (U32) __popc ((U32) (cand >> 32));
       const U32 incl = mgWaveInclusiveSum (cnt);
       const U32 nc = (U32) __builtin_amdgcn_readlane ((int) incl, 63);
       const U32 myFirst = incl - cnt;                        /* ordinal of this lane's first candidate */
@@ -397,7 +412,8 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
          of the two tile buffers it points into, and the previous tile's is intact until the tile after this one is staged; so
          entries of the previous tile (qOld of them, at the front) must be gone when this tile is done.  A tile with more
          candidates than the list holds (small d) lists them in passes. */
-      const bool wantWhere = a.segPosF || a.segRead;             /* uniform: the modset build wants the k-mers alone */
+      constexpr bool wantWhere = WHERE;
+      constexpr int LIST_UNROLL = WHERE ? 0 : MG_LIST_UNROLL;    /* (with pos / read wanted the kernel has no scalar registers to spare for the straight-line form's lane masks) */
       const bool lastTile = nextTile >= tileEnd;
       const U32 bufTag = (U32) (buf ^ 1) << 12;                  /* the buffer this tile was staged in */
       U32 listed = 0;                                            /* candidates of this tile in the list or done with */
@@ -412,10 +428,19 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
               for (int half = 0 ; half < 2 ; ++half)
                 { U32 c = half ? (U32) (cand >> 32) : (U32) cand;
                   const U32 base = bufTag | ((U32) lane * MG_POS_PER_THREAD + 32u * half);
-                  while (c)
-                    { *pp++ = (unsigned short) (base | (U32) __builtin_ctz (c));
+                  /* the first few candidates of the half as straight-line code -- constant store offsets, no pointer to
+                     carry round a loop: the fullest of 64 lanes holds 4 or 5 -- then the rare rest */
+#pragma unroll
+                  for (int j = 0 ; j < LIST_UNROLL ; ++j)
+                    { if (!c) break;
+                      pp[j] = (unsigned short) (base | (U32) __builtin_ctz (c));
                       c &= c - 1;
                     }
+                  if (c)
+                    { unsigned short *qq = pp + LIST_UNROLL;
+                      do { *qq++ = (unsigned short) (base | (U32) __builtin_ctz (c)); c &= c - 1; } while (c);
+                    }
+                  if (!half) pp += cntLo;
                 }
             }
           else if (take && myFirst < hi && myFirst + cnt > lo)
@@ -440,38 +465,39 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
 #pragma unroll 1
           for (U32 i0 = 0 ; i0 < nEval ; i0 += 64)
             { const U32 i = i0 + (U32) lane;
-              bool surv = false, fwd = false;
-              U64 F = 0; U32 q = 0;
-              if (i < nEval MG_ABLATE_AND (!(a.debug & 4)))
-                { const U32 e = sCand[i];
-                  q = e & (MG_TILE_BASES - 1);
-                  F = mgKmerAt (sWordsW[e >> 12], q, sh1);
-                  U64 R = mgRevComp (F, sh1);
-                  if (MODE == MG_MODE_FAST)
-                    { /* hashes compared and tested where they sit in the products: no 64-bit shifts.  hash = P >> sh1,
-                         so hF < hR <=> (PF with its low sh1 bits cleared) < (PR likewise), and hash % 2^m == 0 <=>
-                         bits [sh1, sh1+m) of P are zero -- all inside the low word because sh1 + m <= 32 */
-                      const U64 PF = F * f1, PR = R * f1;
-                      const U32 keep = ~((1u << sh1) - 1u);
-                      const U64 cF = (PF & 0xffffffff00000000ull) | ((U32) PF & keep), cR = (PR & 0xffffffff00000000ull) | ((U32) PR & keep);
-                      fwd = cF < cR;
-                      const U32 lowWord = (U32) (fwd ? PF : PR);
-                      surv = (lowWord & ((U32) dMask << sh1)) == 0;
-                    }
-                  else
-                    { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
-                      fwd = hF < hR;
-                      U64 h = fwd ? hF : hR;
-                      if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
-                      else                     surv = (h & dMask) == 0;
-                    }
-                  if (!fwd) F = R;
-                }
+              /* every lane evaluates what its list slot holds (a stale entry in the slots past the queue's end: any
+                 position of either tile buffer is readable) and is masked afterwards: no divergent region, no values to merge */
+              const U32 e = sCand[i];
+              const U32 q = e & (MG_TILE_BASES - 1);
+              U64 F = mgKmerAt (sWordsW[(e >> 12) & 1], q, sh1);
+              bool surv, fwd;
+              { const U64 R = mgRevComp (F, sh1);
+                if (MODE == MG_MODE_FAST)
+                  { /* hashes compared and tested where they sit in the products: no 64-bit shifts.  hash = P >> sh1,
+                       so hF < hR <=> (PF with its low sh1 bits cleared) < (PR likewise), and hash % 2^m == 0 <=>
+                       bits [sh1, sh1+m) of P are zero -- all inside the low word because sh1 + m <= 32 */
+                    const U64 PF = F * f1, PR = R * f1;
+                    const U32 keep = ~((1u << sh1) - 1u);
+                    const U64 cF = (PF & 0xffffffff00000000ull) | ((U32) PF & keep), cR = (PR & 0xffffffff00000000ull) | ((U32) PR & keep);
+                    fwd = cF < cR;
+                    const U32 lowWord = (U32) (fwd ? PF : PR);
+                    surv = (lowWord & ((U32) dMask << sh1)) == 0;
+                  }
+                else
+                  { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
+                    fwd = hF < hR;
+                    U64 h = fwd ? hF : hR;
+                    if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
+                    else                     surv = (h & dMask) == 0;
+                  }
+                if (!fwd) F = R;
+              }
+              surv = surv && i < nEval MG_ABLATE_AND (!(a.debug & 4));
               const U64 bs = __ballot (surv);
               U32 r = 0;
               if (wantWhere && (!oneRead || a.segRead)) r = (U32) __shfl ((int) rFirst, (int) (q >> 6));   /* first read of the owner lane's starts */
               if (surv)
-                { const U64 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
+                { const U32 o = found + waveRun + (U32) __popcll (bs & (((U64) 1 << lane) - 1));
                   const U64 pos = tile0 + q;                               /* (with pos / read wanted every entry is of this tile) */
                   U64 rs = ti.start;
                   if (!oneRead && wantWhere)
@@ -479,10 +505,10 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
                       else { while (a.readOff[r + 1] <= pos) ++r; rs = a.readOff[r]; }
                     }
                   if (a.histCount) atomicAdd (&sHist[mgMixTopOfKmer (F, a.histKbits, a.histHiB)], 1u);
-                  if (o < a.segCap MG_ABLATE_AND (!(a.debug & 2)))
-                    { a.segKmer[segBase + o] = F;
-                      if (a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
-                      if (a.segRead) a.segRead[segBase + o] = r;
+                  if (o < segCap32 MG_ABLATE_AND (!(a.debug & 2)))
+                    { segK[o] = F;
+                      if (WHERE && a.segPosF) a.segPosF[segBase + o] = (U32) (pos - rs) | (fwd ? MG_FWD_BIT : 0u);
+                      if (WHERE && a.segRead) a.segRead[segBase + o] = r;
                     }
                 }
               waveRun += (U32) __popcll (bs);
@@ -507,7 +533,7 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
   return found;
 }
 
-template <int MODE>
+template <int MODE, bool WHERE>
 __global__ __launch_bounds__ (MG_SCAN_THREADS)
 void mgScanKernel (const MgScanArgs a)
 {
@@ -525,7 +551,7 @@ void mgScanKernel (const MgScanArgs a)
       __syncthreads ();
     }
   if (worker >= a.nWorkers) { if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane); return; }
-  const U64 found = mgScanWorker<MODE, false> (a, worker, lane, sWordsAll[wave], sCandAll[wave], sOffAll[wave], sHist);
+  const U64 found = mgScanWorker<MODE, false, WHERE> (a, worker, lane, sWordsAll[wave], sCandAll[wave], sOffAll[wave], sHist);
   if (lane == 0) a.blockCount[worker] = found;
   if (a.histCount) mgScanHistDone (a, sHist, &sDone, lane);
 }
@@ -550,7 +576,7 @@ void mgIterScanKernel (const MgScanArgs a, const MgIterOut o)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
   U64 found = 0;
-  if ((U64) wave < a.nWorkers) found = mgScanWorker<MODE, true> (a, (U64) wave, lane, sWordsAll[wave], sCandAll[wave], sOffAll[wave], (U32 *) 0);
+  if ((U64) wave < a.nWorkers) found = mgScanWorker<MODE, true, true> (a, (U64) wave, lane, sWordsAll[wave], sCandAll[wave], sOffAll[wave], (U32 *) 0);
   if (lane == 0) sFound[wave] = found;
   __syncthreads ();                                   /* the segments (global memory, written by this workgroup) and the counts are in */
   U64 before = 0, total = 0;
@@ -796,9 +822,11 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
 #endif
   const unsigned grid = (g.nBlocks + MG_WAVES - 1) / MG_WAVES;
   const int mode = mgScanMode (p, &a);
-  if (mode == MG_MODE_FAST)      MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_FAST>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
-  else if (mode == MG_MODE_POW2) MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_POW2>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
-  else                           MG_LAUNCH (MG_K_SCAN, st, mgScanKernel<MG_MODE_ANY>, dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a);
+  const bool where = a.segPosF || a.segRead;
+#define MG_SCAN_LAUNCH(M) do { if (where) MG_LAUNCH (MG_K_SCAN, st, (mgScanKernel<M, true>), dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a); \
+                               else       MG_LAUNCH (MG_K_SCAN, st, (mgScanKernel<M, false>), dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a); } while (0)
+  if (mode == MG_MODE_FAST) MG_SCAN_LAUNCH (MG_MODE_FAST); else if (mode == MG_MODE_POW2) MG_SCAN_LAUNCH (MG_MODE_POW2); else MG_SCAN_LAUNCH (MG_MODE_ANY);
+#undef MG_SCAN_LAUNCH
   MG_HIP (hipGetLastError ());
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
   MG_HIP (hipGetLastError ());

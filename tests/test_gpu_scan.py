@@ -51,8 +51,8 @@ def test_random_ragged_batches(k, w, seed):
 
 
 def test_tile_boundaries():
-    """reads that start / end exactly at, just before and just after the 4096-base tile edges, and whose last
-    k-mer (start len-k) falls on either side of an edge: 4096-1, 4096, 4096+1, 4096+k-1 and neighbours"""
+    """reads that start / end exactly at, just before and just after the tile edges (TILE bases), and whose last
+    k-mer (start len-k) falls on either side of an edge: TILE-1, TILE, TILE+1, TILE+k-1 and neighbours"""
     k, w = 21, 8
     sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
     rng = np.random.default_rng(1)
