@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-other", action="store_true", help="skip configs 3 and 5 (other_configs)")
+    ap.add_argument("--only", default="", help="run ONE of the other configs (c3, c5, c4_block) without the headline workload and print its JSON: for profiler passes")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch path only: gloo ranks, a tiny host-side modset each, the histogram all-reduce (no GPU)")
     return ap.parse_args()
@@ -311,6 +312,11 @@ def gpu_rank(args):
         torch.cuda.synchronize()
         C.CDLL(None).fflush(None)
 
+    cx.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if args.only:                                     # a profiler pass over one of the other configs (N = 1)
+        fn = {"c3": bench_c3, "c5": bench_c5, "c4_block": bench_c4_block}[args.only]
+        print(json.dumps({"only": args.only, "result": fn(cx, args)}), flush=True)
+        return
     k, d, seed, bits = 21, 64, 17, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
     # config 2 at N = 1; one 12.5 Gbp block of config 4's 100 Gbp set per GPU otherwise
     gbp = float(os.environ.get("MODGPU_BENCH_GBP", "12.5" if multi else "10"))

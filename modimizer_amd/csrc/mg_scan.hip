@@ -294,7 +294,8 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
       const bool offInLds = !oneRead && nextFirstRead - ti.firstRead + 2 <= 64;
       if (offInLds)
         { const U32 r = ti.firstRead + (U32) lane;
-          sOff[lane] = r <= a.nReads ? a.readOff[r] : ~0ull;
+          if (SINGLE) sOff[lane] = lane == 0 ? 0ull : (lane == 1 ? a.totalBases : ~0ull);      /* one read [0, totalBases): nothing to fetch (for the iterator the offsets would come over PCIe) */
+          else sOff[lane] = r <= a.nReads ? a.readOff[r] : ~0ull;
         }
       MG_WAVE_SYNC ();                                                           /* tile (and offsets) staged */
       if (oneRead) valid = ~0ull;

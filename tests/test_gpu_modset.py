@@ -430,6 +430,14 @@ print("slices ok", n)
         env = dict(os.environ, MODGPU_RANK_SLICE_SHIFT=shift, MODGPU_TABLE_PATH="bucket", PYTHONPATH=root)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "slices ok" in r.stdout, (shift, r.stderr[-1500:])
+    # buckets of 8192 slots -- the geometry a table of 2^31 slots takes (table bits 32 with more than 6.4e8 entries: at most
+    # 2^18 buckets) -- forced on this small table: the dedup kernel's threads then hold eight slots each (its second instance),
+    # in both flag polarities and with the merge kernel taking the dedup kernel's slots; and smaller buckets (256-thread shape)
+    for knobs in ({"MODGPU_BUCKET_R": "8192"}, {"MODGPU_BUCKET_R": "8192", "MODGPU_FLAG_POLARITY": "1", "MODGPU_MERGE_SLOTS": "1"},
+                  {"MODGPU_BUCKET_R": "8192", "MODGPU_PART_PACKED": "0"}, {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"}):
+        env = dict(os.environ, MODGPU_TABLE_PATH="bucket", PYTHONPATH=root, **knobs)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "slices ok" in r.stdout, (knobs, r.stderr[-1500:])
 
 
 def test_large_table_bits_geometry():

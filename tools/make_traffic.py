@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json and profiles/scan_issue.json from the summaries tools/prof_round.sh leaves under
+gpurun_out/prof_<tag>_{c2,c3,c5}/ (also copies the summaries and kernel_stats into profiles/<tag>_<config>_*).
+usage: tools/make_traffic.py r03"""
+import json, os, shutil, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+tags = {"c2": "10", "c3": "c3", "c5": "c5"}           # the keys bench.py's roofline_of() looks a kernel's traffic up under
+out = {"_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units) of bench.py: key '10' = the headline "
+                "workload (config 2, 10 Gbp), 'c3' / 'c5' = bench.py --only c3 / c5.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 counts wide "
+                "coalesced streaming reads at half) ONLY for the kernels whose reads are such streams ('x2'); for gather-dominated kernels (random rank "
+                "records, random flag bytes, bucket probes) the raw counter is used ('raw').  Values are PER-LAUNCH averages: mgPartScatterKernel runs "
+                "twice per step (both passes together: twice its value).",
+       "_from": "profiles/%s_{c2,c3,c5}_pmc_summary.txt" % tag}
+for cfg, key in tags.items():
+    d = os.path.join(R, "gpurun_out", "prof_%s_%s" % (tag, cfg))
+    j = json.load(open(os.path.join(d, "summary.json")))
+    shutil.copy(os.path.join(d, "summary.txt"), os.path.join(R, "profiles", "%s_%s_pmc_summary.txt" % (tag, cfg)))
+    if os.path.exists(os.path.join(d, "kernel_stats.csv")):
+        shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(R, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
+    for k, v in j.items():
+        if "hbm_bytes" in v:
+            e = out.setdefault(k, {})
+            e[key] = v["hbm_bytes"]
+            e["fetch"] = "x2" if v.get("fetch_correction", "").startswith("x2") else "raw"
+    if cfg == "c2":
+        s = j["mgScanKernel"]
+        starts = 1e10
+        old = {}
+        try: old = json.load(open(os.path.join(R, "profiles", "scan_issue.json")))
+        except Exception: pass
+        si = {"_from": "profiles/%s_c2_pmc_summary.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ... on bench.py, 10 Gbp) and profiles/r02_ubench_valu_rates.txt (tools/ubench.hip)" % tag,
+              "kernel": "mgScanKernel<FAST, k-mers only>", "starts_per_launch": starts}
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
+            if c in s: si[c] = s[c]
+        si["valu_per_start"] = round(s["SQ_INSTS_VALU"] * 64 / starts, 3)
+        si["salu_per_start"] = round(s["SQ_INSTS_SALU"] * 64 / starts, 3)
+        si["measured_int_valu_peak_lane_ops_per_s"] = old.get("measured_int_valu_peak_lane_ops_per_s", 37.6e12)
+        si["measured_int_valu_peak_wave_insts_per_s"] = old.get("measured_int_valu_peak_wave_insts_per_s", 587.5e9)
+        si["avg_ms_under_trace"] = s.get("avg_ms")
+        si["history"] = {"round 1": 13.2, "round 2": 11.87, "round 3": si["valu_per_start"]}
+        json.dump(si, open(os.path.join(R, "profiles", "scan_issue.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "profiles", "traffic.json"), "w"), indent=1)
+print("wrote profiles/traffic.json, profiles/scan_issue.json;", {k: v for k, v in out.items() if k in ("mgScanKernel", "mgTableFindSegKernel", "mgPartScatterKernel")})
