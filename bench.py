@@ -240,6 +240,16 @@ def time_steps(cx, step, steps, warmup, multi):
     return dt, kern, table
 
 
+def best_of_two(cx, step, steps):
+    """the other configs (never the headline `value`): two timed regions of `steps` steps each, the faster one reported and both
+    listed -- after host-heavy legs (CPU baseline, drop-in programs) the first kernel of a call is now and then dispatched tens of
+    milliseconds late on some boxes, which a single region of ten steps shows as a 20 % slower config"""
+    a = time_steps(cx, step, steps, 1, False)
+    b = time_steps(cx, step, steps, 1, False)
+    best = a if a[0] <= b[0] else b
+    return best[0], best[1], best[2], [round(a[0] / steps * 1e3, 3), round(b[0] / steps * 1e3, 3)]
+
+
 def roofline_of(kern, table, alg_bytes, tag, extra=None, units=None):
     """units: {kernel: work items per launch in the unit of the kernel's real bound} for bound_actual"""
     if not kern:
@@ -545,10 +555,11 @@ def bench_c4_block(cx, args):
         mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), cx.stream))
 
     steps = max(3, min(args.steps, 10))
-    dt, kern, table = time_steps(cx, step, steps, 1, False)
+    dt, kern, table, regions = best_of_two(cx, step, steps)
     S, entries = n_hash.value, ms.contents.max
     alg = alg_bytes_table(total, S, entries, d, float(L.mgModsetDeviceSlots(ms)))
-    res = {"workload": "one GPU's share of BASELINE config 4 on this GPU alone: block 0 of 8 (12.5 Gbp of reads from the %d Mbp genome), "
+    res = {"timed_regions_ms_per_step": regions,
+           "workload": "one GPU's share of BASELINE config 4 on this GPU alone: block 0 of 8 (12.5 Gbp of reads from the %d Mbp genome), "
                        "k=21 d=64, table bits %d: seqhash scan + modset build + depth histogram (no all-reduce)" % (genome_bases // 1_000_000, bits),
            "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "bases": total, "modimizers": S, "modset_entries": entries, "histogram_entries": int(hist.sum().item()),
@@ -584,11 +595,12 @@ def bench_c5(cx, args):
         mg.check(L.modsetDepthHistogramDevice(ms, hist.data_ptr(), cx.stream))
 
     steps = max(3, min(args.steps, 10))
-    dt, kern, table = time_steps(cx, step, steps, 1, False)
+    dt, kern, table, regions = best_of_two(cx, step, steps)
     S, entries = n_hash.value, ms.contents.max
     alg = alg_bytes_table(total, S, entries, d, float(L.mgModsetDeviceSlots(ms)), k)
     h = hist.cpu().numpy()
-    res = {"workload": "BASELINE config 5: %d x 150 b reads (50x of a %d Mbp genome, 0.5%% subs), k=31 d=4 seed=17, table bits %d: "
+    res = {"timed_regions_ms_per_step": regions,
+           "workload": "BASELINE config 5: %d x 150 b reads (50x of a %d Mbp genome, 0.5%% subs), k=31 d=4 seed=17, table bits %d: "
                        "seqhash scan + modset build + depth histogram" % (n_reads, genome_bases // 1_000_000, bits),
            "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "bases": total, "modimizers": S, "modset_entries": entries,
