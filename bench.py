@@ -240,6 +240,29 @@ def time_steps(cx, step, steps, warmup, multi):
     return dt, kern, table
 
 
+def scan_alu(starts, scan_ms):
+    """the integer-issue bound of mgScanKernel<FAST> (k=21 d=64): VALU instructions per start from the round's --pmc pass
+    (profiles/scan_issue.json), the issue peak measured by tools/ubench.hip, the fraction of it this run's scan time means"""
+    if not scan_ms:
+        return None
+    ipath = os.path.join(HERE, "profiles", "scan_issue.json")     # SQ_INSTS_VALU etc. of mgScanKernel from a --pmc pass
+    valu_per_start, src, peak = None, None, VALU_WAVE_INSTS_PER_S
+    if os.path.exists(ipath):
+        try:
+            ij = json.load(open(ipath)); valu_per_start = ij.get("valu_per_start"); src = ij.get("_from")
+            peak = ij.get("measured_int_valu_peak_wave_insts_per_s", peak)     # tools/ubench.hip: 37.6 T integer lane-ops/s
+        except Exception:
+            pass
+    floor7 = 7.0 * starts / 64 / peak * 1e3                        # the 7-instruction candidate filter alone
+    return {"valu_per_start": valu_per_start, "valu_per_start_from": src,
+            "filter_floor_valu_per_start": 7, "floor_ms": round(floor7, 3),
+            "issue_peak_wave_insts_per_s": peak,
+            "issue_peak_from": "measured integer VALU rate (v_mul_lo_u32 / v_alignbit / v_min / v_add chains, tools/ubench.hip); "
+                               "the fp32 datasheet rate would be %.3g" % VALU_WAVE_INSTS_PER_S,
+            "issue_frac": (round(valu_per_start * starts / 64 / peak / (scan_ms * 1e-3), 3) if valu_per_start else None),
+            "scan_ms": round(scan_ms, 4)}
+
+
 def best_of_two(cx, step, steps):
     """the other configs (never the headline `value`): two timed regions of `steps` steps each, the faster one reported and both
     listed -- after host-heavy legs (CPU baseline, drop-in programs) the first kernel of a call is now and then dispatched tens of
@@ -367,24 +390,7 @@ def gpu_rank(args):
     # the scan's two bounds (SURVEY §8(d) asks for both): HBM bytes and integer issue
     scan_ms = table.get("mgScanKernel", (0, 1))[0] / max(table.get("mgScanKernel", (0, 1))[1], 1)
     starts = float(total)
-    alu = None
-    if scan_ms:
-        ipath = os.path.join(HERE, "profiles", "scan_issue.json")     # SQ_INSTS_VALU etc. of mgScanKernel from a --pmc pass
-        valu_per_start, src, peak = None, None, VALU_WAVE_INSTS_PER_S
-        if os.path.exists(ipath):
-            try:
-                ij = json.load(open(ipath)); valu_per_start = ij.get("valu_per_start"); src = ij.get("_from")
-                peak = ij.get("measured_int_valu_peak_wave_insts_per_s", peak)     # tools/ubench.hip: 37.6 T integer lane-ops/s
-            except Exception:
-                pass
-        floor7 = 7.0 * starts / 64 / peak * 1e3                        # the 7-instruction candidate filter alone
-        alu = {"valu_per_start": valu_per_start, "valu_per_start_from": src,
-               "filter_floor_valu_per_start": 7, "floor_ms": round(floor7, 3),
-               "issue_peak_wave_insts_per_s": peak,
-               "issue_peak_from": "measured integer VALU rate (v_mul_lo_u32 / v_alignbit / v_min / v_add chains, tools/ubench.hip); "
-                                  "the fp32 datasheet rate would be %.3g" % VALU_WAVE_INSTS_PER_S,
-               "issue_frac": (round(valu_per_start * starts / 64 / peak / (scan_ms * 1e-3), 3) if valu_per_start else None),
-               "scan_ms": round(scan_ms, 4)}
+    alu = scan_alu(starts, scan_ms)
     extra = {"alu": alu,
              "scan_bytes": {"this_path_8B_per_modimizer": alg["mgScanKernel"],
                             "survey_12B_per_modimizer": (0.25 + 12.0 / d) * total,
@@ -563,7 +569,8 @@ def bench_c4_block(cx, args):
                        "k=21 d=64, table bits %d: seqhash scan + modset build + depth histogram (no all-reduce)" % (genome_bases // 1_000_000, bits),
            "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "bases": total, "modimizers": S, "modset_entries": entries, "histogram_entries": int(hist.sum().item()),
-           "roofline": roofline_of(kern, table, alg, "12.5", units={"mgRankLookupKernel": float(entries)})}
+           "roofline": roofline_of(kern, table, alg, "12.5", {"alu": scan_alu(float(total), table.get("mgScanKernel", (0, 1))[0] / max(table.get("mgScanKernel", (0, 1))[1], 1))},
+                                   units={"mgScanKernel": float(total), "mgRankLookupKernel": float(entries)})}
     L.modsetDestroy(ms)
     del reads, d_offsets
     torch.cuda.empty_cache()

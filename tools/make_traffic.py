@@ -5,15 +5,17 @@ usage: tools/make_traffic.py r03"""
 import json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-tags = {"c2": "10", "c3": "c3", "c5": "c5"}           # the keys bench.py's roofline_of() looks a kernel's traffic up under
+tags = {"c2": "10", "c3": "c3", "c5": "c5", "c4": "12.5"}           # the keys bench.py's roofline_of() looks a kernel's traffic up under
 out = {"_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units) of bench.py: key '10' = the headline "
-                "workload (config 2, 10 Gbp), 'c3' / 'c5' = bench.py --only c3 / c5.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 counts wide "
+                "workload (config 2, 10 Gbp), 'c3' / 'c5' / '12.5' = bench.py --only c3 / c5 / c4_block.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 counts wide "
                 "coalesced streaming reads at half) ONLY for the kernels whose reads are such streams ('x2'); for gather-dominated kernels (random rank "
                 "records, random flag bytes, bucket probes) the raw counter is used ('raw').  Values are PER-LAUNCH averages: mgPartScatterKernel runs "
                 "twice per step (both passes together: twice its value).",
        "_from": "profiles/%s_{c2,c3,c5}_pmc_summary.txt" % tag}
 for cfg, key in tags.items():
     d = os.path.join(R, "gpurun_out", "prof_%s_%s" % (tag, cfg))
+    if not os.path.exists(os.path.join(d, "summary.json")):
+        continue
     j = json.load(open(os.path.join(d, "summary.json")))
     shutil.copy(os.path.join(d, "summary.txt"), os.path.join(R, "profiles", "%s_%s_pmc_summary.txt" % (tag, cfg)))
     if os.path.exists(os.path.join(d, "kernel_stats.csv")):

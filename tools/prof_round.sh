@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/prof_round.sh <round tag, e.g. r03> — the round's profiles: kernel-trace stats + separate --pmc passes (as
 # MI355X_MICROARCH.md prescribes: counters in their own runs, --pmc with nothing else) of bench.py for the headline workload
-# (config 2) and, with --only, for configs 3 and 5.  Results: gpurun_out/prof_<tag>_{c2,c3,c5}/summary.txt
+# (config 2) and, with --only, for configs 3, 5 and one block of config 4.  Results: gpurun_out/prof_<tag>_{c2,c3,c5,c4}/summary.txt
 TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -27,3 +27,4 @@ prof () {   # name, bench args...
 prof c2 --steps 5 --warmup 1 --no-cpu --no-other
 prof c3 --only c3 --steps 3
 prof c5 --only c5 --steps 5
+prof c4 --only c4_block --steps 3

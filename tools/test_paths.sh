@@ -3,7 +3,15 @@
 for p in direct bucket auto; do
   for pk in 1 0; do
     echo "== MODGPU_TABLE_PATH=$p MODGPU_PART_PACKED=$pk"
-    MODGPU_TABLE_PATH=$p MODGPU_PART_PACKED=$pk python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+    MODGPU_TABLE_PATH=$p MODGPU_PART_PACKED=$pk python -m pytest tests -q -m gpu -x --deselect tests/test_gpu_fullsize.py 2>&1 | tail -3
     MODGPU_TABLE_PATH=$p MODGPU_PART_PACKED=$pk python tests/fuzz_gpu.py $((7 + pk)) 150 2>&1 | tail -2
   done
 done
+# the scan's worker geometry: few workers (many tiles per worker: the candidate queue carries across tiles all the time), and the exact-mode kernel for everything
+for g in 3 50; do
+  echo "== MODGPU_SCAN_GRID=$g"
+  MODGPU_SCAN_GRID=$g python -m pytest tests/test_gpu_scan.py tests/test_gpu_modset.py -q -x 2>&1 | tail -2
+  MODGPU_SCAN_GRID=$g python tests/fuzz_gpu.py 11 150 2>&1 | tail -2
+done
+echo "== MODGPU_SCAN_GENERIC=1"
+MODGPU_SCAN_GENERIC=1 python -m pytest tests/test_gpu_scan.py tests/test_gpu_modset.py -q -x 2>&1 | tail -2
