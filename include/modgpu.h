@@ -270,6 +270,12 @@ void mgSeqBatchFree (MgSeqBatch *b) ;
 void mgSeqClose (MgSeqReader *r) ;
 void mgSeqReleaseBuffers (void) ;	/* the readers keep their two largest buffers for the next file (unmapping and touching gigabytes again costs as much as parsing them); this gives them back -- a no-op while a reader is open; also run when the library is unloaded */
 void mgReleaseBuffers (void) ;	/* everything the library caches between calls: the readers' buffers (mgSeqReleaseBuffers), the device buffers and pinned staging of the host-buffer entry points (mgAddSequenceBatch, mgUploadPack: they live on the device the last call ran on and are re-made by themselves when the caller moves to another one), the calling thread's iterator scratch (modRCiterator) */
+/* A plain FASTA file parsed ON THE DEVICE (the host only moves the bytes: parallel pread into pinned memory, the text as it is
+ * across PCIe, record starts / headers / bases found by three small kernels per window): mgAddSequenceFile takes this path by
+ * itself for plain FASTA text and falls back to the reader above for gzip, FASTQ, a file that does not end in a newline.
+ * This entry returns the parser's records as host arrays (bases 0..3 one per byte, offsets[nSeq + 1]; free () both): 0 = done,
+ * -1 = error, -2 = not a file for the device parser. */
+int  mgTextParseFileDevice (const char *filename, char **bases, int64_t **offsets, int64_t *nSeq) ;
 /* the callers' per-file loops: parsing of the next batch overlaps the GPU work on the current one */
 int  mgAddSequenceFile (Modset *ms, const char *filename, FILE *out) ;                        /* modutils.c:33-51 */
 int  mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out) ;   /* modmap.c:93-134 */

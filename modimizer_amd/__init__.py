@@ -74,7 +74,7 @@ EXPORTS = [
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
-    "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
+    "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
     "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
@@ -159,6 +159,7 @@ def lib():
     sig("mgReadsetStats", None, RS, vp); sig("mgReadsetWrite", None, RS, C.c_char_p); sig("mgReadsetLoad", RS, C.c_char_p)
     sig("mgSeqOpen", vp, C.c_char_p); sig("mgSeqNextBatch", i32, vp, C.c_int64, C.POINTER(MgSeqBatch))
     sig("mgSeqBatchFree", None, C.POINTER(MgSeqBatch)); sig("mgSeqClose", None, vp); sig("mgSeqReleaseBuffers", None); sig("mgReleaseBuffers", None)
+    sig("mgTextParseFileDevice", i32, C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64))
     sig("mgAddSequenceFile", i32, MS, C.c_char_p, vp); sig("mgReferenceFastaRead", i32, vp, C.c_char_p, C.c_bool, vp)
     sig("mgQueryFile", i32, vp, C.c_char_p, vp)
     sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)

@@ -1195,6 +1195,7 @@ extern "C" void mgSeqReleaseBuffers (void);
 extern "C" void mgReleaseBuffers (void)
 {
   mgSeqReleaseBuffers ();
+  mgTextReleaseBuffers ();
   mgHostBatchRelease ();
   mgIterReleaseBuffers ();
   std::lock_guard<std::mutex> g (gUp.lock);

@@ -19,6 +19,10 @@ int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **blk);
 void mgIterReleaseBuffers (void);                  /* the calling thread's iterator scratch (pinned buffers, stream) */
 /* the same for the minimizer iterator: *rec = malloc()ed {U64 hash[n]; U32 posF[n]} */
 int  mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
+/* the file front end on the device (mg_textgpu.hip): plain FASTA parsed by the GPU.  0 = done, -1 = error, -2 = not a file for this path (the host parser takes it) */
+int  mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash);
+int  mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **offsetsOut, int64_t *nSeqOut);   /* test hook: the parser's records as host arrays (malloc) */
+void mgTextReleaseBuffers (void);
 /* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */
 #define MG_HIDDEN __attribute__ ((visibility ("hidden")))
 typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } MgDevBatch;     /* host bytes -> 2-bit words in HBM */

@@ -30,6 +30,7 @@
 #include <zlib.h>
 #include <time.h>
 #include "modgpu.h"
+#include "mg_internal.h"
 static double nowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 static double gPhase[8]; static const char *gPhaseName[8];
 #define TIMING(slot, tag) do { double t_ = nowS (); gPhase[slot] += t_ - tLast; gPhaseName[slot] = tag; tLast = t_; } while (0)
@@ -1025,7 +1026,11 @@ static int addBatch (MgSeqBatch *b, void *v)
 int mgAddSequenceFile (Modset *ms, const char *filename, FILE *out)            /* modutils.c:33-51 */
 {
   AddCtx c; memset (&c, 0, sizeof (c)); c.ms = ms;
-  int rc = forEachBatch (filename, addBatch, &c);
+  /* plain FASTA text: the device parses it (mg_textgpu.hip), the host only moves the bytes; everything else -- gzip, FASTQ,
+     an unfinished last line -- through the host parser below */
+  int rc = mgAddSequenceFileDevice (ms, filename, &c.nSeq, &c.totLen, &c.totHash);
+  if (rc == -1) return -1;
+  if (rc == -2) rc = forEachBatch (filename, addBatch, &c);
   if (rc) return rc;
   fprintf (out, "added %llu sequences total length %llu total hashes %llu, new max %u\n",
            (unsigned long long) c.nSeq, (unsigned long long) c.totLen, (unsigned long long) c.totHash, ms->max);

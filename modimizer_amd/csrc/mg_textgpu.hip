@@ -1,0 +1,605 @@
+/* mg_textgpu.hip — the file front end on the device: plain FASTA text -> 2-bit packed reads, parsed by the GPU.
+ *
+ * What the reference's callers get from seqIOread for FASTA (seqio.c:302-323 with dna2indexConv after the N -> 0 patch,
+ * modutils.c:39): a record starts at a '>' that is the first byte of a line, its header runs to the end of that line, its
+ * sequence is every A/a C/c G/g T/t N/n (0 1 2 3 0) up to the next record start, all other bytes dropped.  The host parser
+ * (mg_seqio.c) does that with a pool of threads at about 19 GB/s of text on the box's 16 allowed CPUs, which is what bounds
+ * mgAddSequenceFile (12-14 Gbp/s file -> modset) under kernels that take 1 Tbp/s.  Here the host only moves bytes: the
+ * file is read window by window straight into pinned memory (parallel pread: the copy out of the page cache), the window
+ * goes across PCIe as it is, and three small kernels per window do the parsing:
+ *
+ *   "\n>" is a record start whatever came before (a header ends at its newline, so after a newline the state is always
+ *   "sequence"); a byte lies in a header iff the LAST EVENT before it -- record start or newline -- is a record start.
+ *   Events carry their position, so "last event" is a running maximum:
+ *     K1  per tile of 4 KiB: the code (position << 1 | isStart) of its last event;
+ *     K2  one workgroup: running maximum over the tiles (+ the state the previous window ended in) -> the state at every
+ *         tile's first byte;
+ *     K3  per tile: the bytes again, the running maximum inside the tile, per thread the bases and record starts of its
+ *         16 bytes -> the tile's counts;
+ *     K4  one workgroup: prefix sums of the counts, on top of what the batch holds already (device-resident totals);
+ *     K5  per tile: the bytes a third time; bases (one byte each) and record offsets written where the sums say.
+ *   The bases of complete records are packed to 2 bits (mgLaunchPack) and handed to mgAddReadsDevice a batch at a time; the
+ *   record the batch ends in the middle of is carried to the front of the next batch on the device.
+ *
+ * Not handled here, and left to the host parser by returning -2 ("not applicable"): gzip / blocked gzip, FASTQ, a file whose
+ * last byte is not a newline (the reference reports the unfinished record, seqio.c:213-217), anything that is not a regular
+ * file.  Record ids are not extracted (addSequenceFile ignores them, modutils.c:35).
+ */
+#include <fcntl.h>
+#include <pthread.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sched.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "mg_common.h"
+#include "mg_internal.h"
+
+#define TX_THREADS 256
+#define TX_PER     16                                   /* bytes per thread: one 16-byte load */
+#define TX_TILE    (TX_THREADS * TX_PER)                 /* 4 KiB of text per workgroup */
+
+struct TxState {                                         /* device resident, carried from window to window */
+  U64 lastEvent;        /* code of the last event of the text so far: bit 0 = it was a record start (we are in a header) */
+  U64 accBases;         /* bases in the batch accumulator */
+  U64 accRecs;          /* record starts in the batch accumulator */
+};
+/* per window, from the host: the file offset of its first byte (event codes carry file positions) and the byte before it (a
+   newline before the file's first byte) */
+
+/* base code of a text byte, 4 = not a base (seqio.c:643-652 + N -> 0): branch-free on the letter */
+__device__ __forceinline__ U32 txCode (U32 c)
+{
+  const U32 u = c & 0xdfu;                                /* upper case */
+  U32 code = 4;
+  code = u == 'A' ? 0u : code; code = u == 'C' ? 1u : code; code = u == 'G' ? 2u : code; code = u == 'T' ? 3u : code; code = u == 'N' ? 0u : code;
+  return code;
+}
+
+/* a thread's 16 bytes and the byte before them */
+__device__ __forceinline__ void txLoad (const unsigned char *text, U64 n, U64 at, U32 prevByte, unsigned char *b, U32 *prev)
+{
+  uint4 v = make_uint4 (0, 0, 0, 0);
+  if (at + 16 <= n) v = *reinterpret_cast<const uint4 *> (text + at);
+  else { unsigned char t[16]; for (int j = 0 ; j < 16 ; ++j) t[j] = at + j < n ? text[at + j] : 0; memcpy (&v, t, 16); }
+  memcpy (b, &v, 16);
+  *prev = at ? text[at - 1] : prevByte;
+}
+
+/* the event code of byte i of the window (0: no event): newline -> even, record start -> odd; a later event has a larger code */
+__device__ __forceinline__ U64 txEvent (U32 c, U32 prev, U64 filePos)
+{
+  if (c == '\n') return (filePos + 1) << 1;
+  if (c == '>' && prev == '\n') return ((filePos + 1) << 1) | 1;
+  return 0;
+}
+
+__device__ __forceinline__ U64 txBlockMax (U64 v, U64 *sRed)
+{
+  for (int off = 32 ; off ; off >>= 1)
+    { const U64 o = ((U64) (U32) __shfl_xor ((int) (U32) (v >> 32), off) << 32) | (U32) __shfl_xor ((int) (U32) v, off);
+      if (o > v) v = o;
+    }
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
+  __syncthreads ();
+  U64 m = 0;
+  for (int w = 0 ; w < TX_THREADS / 64 ; ++w) if (sRed[w] > m) m = sRed[w];
+  __syncthreads ();
+  return m;
+}
+
+/* K1: the last event of every tile */
+__global__ __launch_bounds__ (TX_THREADS)
+void mgTextEventKernel (const unsigned char *__restrict__ text, U64 n, U64 textBase, U32 prevByte, U64 *__restrict__ tileEvent)
+{
+  __shared__ U64 sRed[TX_THREADS / 64];
+  const U64 at = ((U64) blockIdx.x * TX_THREADS + threadIdx.x) * TX_PER;
+  unsigned char b[16]; U32 prev = 0;
+  U64 last = 0;
+  if (at < n)
+    { txLoad (text, n, at, prevByte, b, &prev);
+      const U64 base = textBase + at;
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j)
+        { if (at + j < n) { const U64 e = txEvent (b[j], prev, base + j); if (e) last = e; }
+          prev = b[j];
+        }
+    }
+  const U64 m = txBlockMax (last, sRed);
+  if (threadIdx.x == 0) tileEvent[blockIdx.x] = m;
+}
+
+/* K2 / K4 helper: one workgroup scans nTiles values (inclusive), running maximum or running sum, with a carry-in */
+template <bool MAX>
+__device__ __forceinline__ void txScanTiles (U64 *v, U64 nTiles, U64 carryIn, U64 *totalOut)
+{
+  __shared__ U64 sPart[1024];
+  const int tid = threadIdx.x;
+  const U64 per = (nTiles + 1023) / 1024;
+  const U64 lo = (U64) tid * per, hi = lo + per < nTiles ? lo + per : nTiles;
+  U64 acc = 0;
+  for (U64 i = lo ; i < hi ; ++i) { const U64 x = v[i]; acc = MAX ? (x > acc ? x : acc) : acc + x; }
+  sPart[tid] = acc;
+  __syncthreads ();
+  for (int off = 1 ; off < 1024 ; off <<= 1)
+    { const U64 o = tid >= off ? sPart[tid - off] : 0;
+      __syncthreads ();
+      sPart[tid] = MAX ? (o > sPart[tid] ? o : sPart[tid]) : sPart[tid] + o;
+      __syncthreads ();
+    }
+  U64 run = tid ? sPart[tid - 1] : 0;                     /* exclusive over the threads' pieces */
+  run = MAX ? (carryIn > run ? carryIn : run) : run + carryIn;
+  for (U64 i = lo ; i < hi ; ++i)                          /* v[i] becomes the EXCLUSIVE value: what holds at the tile's first byte */
+    { const U64 x = v[i]; v[i] = run; run = MAX ? (x > run ? x : run) : run + x; }
+  if (tid == 1023) { const U64 t = sPart[1023]; *totalOut = MAX ? (carryIn > t ? carryIn : t) : t + carryIn; }
+}
+
+__global__ __launch_bounds__ (1024)
+void mgTextStateScanKernel (U64 *tileEvent, U64 nTiles, TxState *st)
+{
+  __shared__ U64 total;
+  txScanTiles<true> (tileEvent, nTiles, st->lastEvent, &total);
+  __syncthreads ();
+  if (threadIdx.x == 0) st->lastEvent = total;            /* the state the next window starts in */
+}
+
+/* the per-thread walk shared by K3 and K5: state at the thread's first byte from the tile's incoming event and the events of
+ * the threads before it in the tile */
+__device__ __forceinline__ U64 txIncoming (U64 myLast, U64 tileIn, U64 *sScan)
+{
+  /* exclusive running maximum over the threads of the workgroup */
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  U64 v = myLast;
+  for (int off = 1 ; off < 64 ; off <<= 1)
+    { const U64 o = ((U64) (U32) __shfl_up ((int) (U32) (v >> 32), off) << 32) | (U32) __shfl_up ((int) (U32) v, off);
+      if (lane >= off && o > v) v = o;
+    }
+  if (lane == 63) sScan[wave] = v;
+  __syncthreads ();
+  U64 before = tileIn;
+  for (int w = 0 ; w < wave ; ++w) if (sScan[w] > before) before = sScan[w];
+  U64 excl = ((U64) (U32) __shfl_up ((int) (U32) (v >> 32), 1) << 32) | (U32) __shfl_up ((int) (U32) v, 1);
+  if (lane == 0) excl = 0;
+  __syncthreads ();
+  return excl > before ? excl : before;
+}
+
+/* K3: bases and record starts of every tile */
+__global__ __launch_bounds__ (TX_THREADS)
+void mgTextCountKernel (const unsigned char *__restrict__ text, U64 n, U64 textBase, U32 prevByte, const U64 *__restrict__ tileIn,
+                        U32 *__restrict__ tileBases, U32 *__restrict__ tileStarts)
+{
+  __shared__ U64 sScan[TX_THREADS / 64];
+  __shared__ U32 sB[TX_THREADS / 64], sS[TX_THREADS / 64];
+  const U64 at = ((U64) blockIdx.x * TX_THREADS + threadIdx.x) * TX_PER;
+  unsigned char b[16]; U32 prev0 = 0;
+  U64 last = 0;
+  if (at < n)
+    { txLoad (text, n, at, prevByte, b, &prev0);
+      U32 prev = prev0;
+      const U64 base = textBase + at;
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j) { if (at + j < n) { const U64 e = txEvent (b[j], prev, base + j); if (e) last = e; } prev = b[j]; }
+    }
+  const U64 in = txIncoming (last, tileIn[blockIdx.x], sScan);
+  U32 nb = 0, ns = 0;
+  if (at < n)
+    { bool header = (in & 1) != 0;
+      U32 prev = prev0;
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j)
+        { if (at + j < n)
+            { const U32 c = b[j];
+              if (c == '>' && prev == '\n') { header = true; ++ns; }
+              else if (c == '\n') header = false;
+              else if (!header && txCode (c) < 4) ++nb;
+            }
+          prev = b[j];
+        }
+    }
+  for (int off = 32 ; off ; off >>= 1) { nb += __shfl_xor (nb, off); ns += __shfl_xor (ns, off); }
+  if ((threadIdx.x & 63) == 0) { sB[threadIdx.x >> 6] = nb; sS[threadIdx.x >> 6] = ns; }
+  __syncthreads ();
+  if (threadIdx.x == 0)
+    { U32 tb = 0, ts = 0;
+      for (int w = 0 ; w < TX_THREADS / 64 ; ++w) { tb += sB[w]; ts += sS[w]; }
+      tileBases[blockIdx.x] = tb; tileStarts[blockIdx.x] = ts;
+    }
+}
+
+/* K4: where every tile's bases and record offsets go in the batch accumulator; the new totals */
+__global__ __launch_bounds__ (1024)
+void mgTextOffsetScanKernel (const U32 *__restrict__ tileBases, const U32 *__restrict__ tileStarts, U64 nTiles,
+                             U64 *__restrict__ tileBaseOff, U64 *__restrict__ tileStartOff, TxState *st, U64 *hostCounts)
+{
+  __shared__ U64 totB, totS;
+  for (U64 i = threadIdx.x ; i < nTiles ; i += 1024) { tileBaseOff[i] = tileBases[i]; tileStartOff[i] = tileStarts[i]; }
+  __syncthreads ();
+  txScanTiles<false> (tileBaseOff, nTiles, st->accBases, &totB);
+  __syncthreads ();
+  txScanTiles<false> (tileStartOff, nTiles, st->accRecs, &totS);
+  __syncthreads ();
+  if (threadIdx.x == 0)
+    { st->accBases = totB; st->accRecs = totS;
+      hostCounts[0] = totB; hostCounts[1] = totS;           /* pinned host words: the host decides about the batch from them */
+    }
+}
+
+/* K5: the bases (one byte each) and the record offsets, written where the sums say */
+__global__ __launch_bounds__ (TX_THREADS)
+void mgTextEmitKernel (const unsigned char *__restrict__ text, U64 n, U64 textBase, U32 prevByte,
+                       const U64 *__restrict__ tileIn, const U64 *__restrict__ tileBaseOff, const U64 *__restrict__ tileStartOff,
+                       unsigned char *__restrict__ bases, U64 basesCap, U64 *__restrict__ recOff, U64 recCap, U32 *__restrict__ overflow)
+{
+  __shared__ U64 sScan[TX_THREADS / 64];
+  __shared__ U32 sB[TX_THREADS / 64], sS[TX_THREADS / 64];
+  const U64 at = ((U64) blockIdx.x * TX_THREADS + threadIdx.x) * TX_PER;
+  unsigned char b[16]; U32 prev0 = 0;
+  U64 last = 0;
+  if (at < n)
+    { txLoad (text, n, at, prevByte, b, &prev0);
+      U32 prev = prev0;
+      const U64 base = textBase + at;
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j) { if (at + j < n) { const U64 e = txEvent (b[j], prev, base + j); if (e) last = e; } prev = b[j]; }
+    }
+  const U64 in = txIncoming (last, tileIn[blockIdx.x], sScan);
+  /* the thread's counts (its place inside the tile), then the walk that writes */
+  U32 nb = 0, ns = 0;
+  if (at < n)
+    { bool header = (in & 1) != 0;
+      U32 prev = prev0;
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j)
+        { if (at + j < n)
+            { const U32 c = b[j];
+              if (c == '>' && prev == '\n') { header = true; ++ns; }
+              else if (c == '\n') header = false;
+              else if (!header && txCode (c) < 4) ++nb;
+            }
+          prev = b[j];
+        }
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  U32 ib = nb, is = ns;
+  for (int off = 1 ; off < 64 ; off <<= 1)
+    { const U32 ob = __shfl_up (ib, off), os = __shfl_up (is, off);
+      if (lane >= off) { ib += ob; is += os; }
+    }
+  if (lane == 63) { sB[wave] = ib; sS[wave] = is; }
+  __syncthreads ();
+  U32 wb = 0, ws = 0;
+  for (int w = 0 ; w < wave ; ++w) { wb += sB[w]; ws += sS[w]; }
+  U64 myB = tileBaseOff[blockIdx.x] + wb + ib - nb;
+  U64 myS = tileStartOff[blockIdx.x] + ws + is - ns;
+  if (!nb && !ns) return;
+  if (myB + nb > basesCap || myS + ns > recCap) { *overflow = 1; return; }
+  bool header = (in & 1) != 0;
+  U32 prev = prev0;
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j)
+    { if (at + j < n)
+        { const U32 c = b[j];
+          if (c == '>' && prev == '\n') { header = true; recOff[myS++] = myB; }      /* a record's offset: the bases before its '>' */
+          else if (c == '\n') header = false;
+          else if (!header) { const U32 code = txCode (c); if (code < 4) bases[myB++] = (unsigned char) code; }
+        }
+      prev = b[j];
+    }
+}
+
+/* the carried record moves to the front of the accumulator (regions may overlap: chunks in order, one workgroup) */
+__global__ __launch_bounds__ (1024)
+void mgTextCarryKernel (unsigned char *bases, U64 from, U64 count)
+{
+  for (U64 i0 = 0 ; i0 < count ; i0 += 1024)
+    { const U64 i = i0 + threadIdx.x;
+      unsigned char v = 0;
+      if (i < count) v = bases[from + i];
+      __syncthreads ();
+      if (i < count) bases[i] = v;
+      __syncthreads ();
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* host side                                                                                  */
+
+static inline size_t txAl (size_t n) { return (n + 255) & ~(size_t) 255; }
+
+struct TxBufs {
+  int dev = -1;
+  size_t window = 0;
+  unsigned char *hPin[2] = { 0, 0 }; hipEvent_t h2dDone[2];
+  unsigned char *dText[2] = { 0, 0 };
+  U64 *hCounts = 0;                    /* pinned: {accBases, accRecs} after the last window's K4 */
+  TxState *dState = 0; U32 *dOverflow = 0;
+  U64 *dTileEvent = 0, *dTileBaseOff = 0, *dTileStartOff = 0; U32 *dTileBases = 0, *dTileStarts = 0; size_t tilesCap = 0;
+  unsigned char *dBases = 0; size_t basesCap = 0;
+  U64 *dRecOff = 0; size_t recCap = 0;
+  U32 *dPacked = 0; size_t packedWords = 0;
+  hipStream_t copy = 0;
+  std::mutex lock;
+  void release ()
+  { for (int i = 0 ; i < 2 ; ++i) { if (hPin[i]) { (void) hipHostFree (hPin[i]); (void) hipEventDestroy (h2dDone[i]); } (void) hipFree (dText[i]); hPin[i] = 0; dText[i] = 0; }
+    if (hCounts) (void) hipHostFree (hCounts);
+    (void) hipFree (dState); (void) hipFree (dOverflow); (void) hipFree (dTileEvent); (void) hipFree (dTileBaseOff); (void) hipFree (dTileStartOff);
+    (void) hipFree (dTileBases); (void) hipFree (dTileStarts); (void) hipFree (dBases); (void) hipFree (dRecOff); (void) hipFree (dPacked);
+    if (copy) (void) hipStreamDestroy (copy);
+    hCounts = 0; dState = 0; dOverflow = 0; dTileEvent = dTileBaseOff = dTileStartOff = 0; dTileBases = dTileStarts = 0; dBases = 0; dRecOff = 0; dPacked = 0;
+    tilesCap = basesCap = recCap = packedWords = window = 0; copy = 0; dev = -1;
+  }
+};
+static TxBufs gTx;
+extern "C" void mgTextReleaseBuffers (void) { std::lock_guard<std::mutex> g (gTx.lock); if (gTx.dev >= 0) gTx.release (); }
+
+/* text per window: 128 MiB (two pinned and two device buffers of that size are kept between calls; 64 MiB windows: 31.6 Gbp/s on a
+   4 Gbp file, 256 MiB: 34.8), less for a file that is smaller */
+static size_t txWindowBytes (size_t fileSize)
+{
+  const char *e = getenv ("MODGPU_TEXT_WINDOW_KB");          /* test knob: small windows put window and batch edges everywhere */
+  long kb = e ? atol (e) : 0;
+  size_t w = kb > 0 ? (size_t) kb << 10 : (size_t) 128 << 20;
+  if (kb <= 0) while (w > ((size_t) 1 << 20) && w / 2 >= fileSize) w /= 2;
+  return (w + TX_TILE - 1) / TX_TILE * TX_TILE;
+}
+static U64 txBatchBases (void)
+{
+  const char *e = getenv ("MODGPU_FILE_BATCH_MBP");
+  long mbp = e ? atol (e) : 1024;
+  if (mbp < 1) mbp = 1;
+  U64 b = (U64) mbp * 1000000;
+  const char *x = getenv ("MODGPU_FILE_BATCH_BASES");        /* test knob (as in mg_seqio.c) */
+  if (x && atol (x) > 0) b = (U64) atol (x);
+  return b;
+}
+
+static int txReserve (TxBufs &t, size_t window, U64 basesNeed, U64 recsNeed)
+{
+  int dev = 0; if (hipGetDevice (&dev) != hipSuccess) return -1;
+  if (t.dev >= 0 && (t.dev != dev || t.window < window)) t.release ();      /* (buffers made for a larger window serve a smaller one) */
+  if (t.dev < 0)
+    { for (int i = 0 ; i < 2 ; ++i)
+        { if (hipHostMalloc ((void **) &t.hPin[i], window + 64, hipHostMallocDefault) != hipSuccess) return -1;
+          if (hipEventCreateWithFlags (&t.h2dDone[i], hipEventDisableTiming) != hipSuccess) return -1;
+          if (hipMalloc ((void **) &t.dText[i], window + 64) != hipSuccess) return -1;
+        }
+      if (hipHostMalloc ((void **) &t.hCounts, 64, hipHostMallocDefault) != hipSuccess) return -1;
+      if (hipMalloc ((void **) &t.dState, sizeof (TxState)) != hipSuccess || hipMalloc ((void **) &t.dOverflow, 4) != hipSuccess) return -1;
+      const size_t tiles = window / TX_TILE + 2;
+      if (hipMalloc ((void **) &t.dTileEvent, tiles * 8) != hipSuccess || hipMalloc ((void **) &t.dTileBaseOff, tiles * 8) != hipSuccess
+          || hipMalloc ((void **) &t.dTileStartOff, tiles * 8) != hipSuccess || hipMalloc ((void **) &t.dTileBases, tiles * 4) != hipSuccess
+          || hipMalloc ((void **) &t.dTileStarts, tiles * 4) != hipSuccess) return -1;
+      t.tilesCap = tiles;
+      if (hipStreamCreateWithFlags (&t.copy, hipStreamNonBlocking) != hipSuccess) return -1;
+      t.dev = dev; t.window = window;
+    }
+  if (basesNeed > t.basesCap)
+    { unsigned char *nb = 0; const size_t cap = (size_t) (basesNeed + basesNeed / 4 + (1 << 20));
+      if (hipMalloc ((void **) &nb, cap) != hipSuccess) return -1;
+      if (t.dBases) { (void) hipMemcpy (nb, t.dBases, t.basesCap, hipMemcpyDeviceToDevice); (void) hipFree (t.dBases); }
+      t.dBases = nb; t.basesCap = cap;
+    }
+  if (recsNeed > t.recCap)
+    { U64 *nr = 0; const size_t cap = (size_t) (recsNeed + recsNeed / 4 + 4096);
+      if (hipMalloc ((void **) &nr, cap * 8) != hipSuccess) return -1;
+      if (t.dRecOff) { (void) hipMemcpy (nr, t.dRecOff, t.recCap * 8, hipMemcpyDeviceToDevice); (void) hipFree (t.dRecOff); }
+      t.dRecOff = nr; t.recCap = cap;
+    }
+  return 0;
+}
+
+/* [off, off + n) of the file into dst, by a team of threads (the copy out of the page cache is the cost) */
+static bool txReadParallel (int fd, unsigned char *dst, size_t n, off_t off, int nThreads)
+{
+  if (nThreads < 1) nThreads = 1;
+  const size_t slice = ((n + nThreads - 1) / nThreads + 4095) & ~(size_t) 4095;
+  volatile int bad = 0;
+  auto work = [&] (int t)
+    { size_t a = slice * (size_t) t, b = a + slice < n ? a + slice : n;
+      while (a < b)
+        { ssize_t g = pread (fd, dst + a, b - a, off + (off_t) a);
+          if (g <= 0) { bad = 1; return; }
+          a += (size_t) g;
+        }
+    };
+  std::vector<std::thread> th;
+  int started = 1;
+  try { for (int t = 1 ; t < nThreads && slice * (size_t) t < n ; ++t) { th.emplace_back (work, t); ++started; } }
+  catch (...) { }
+  work (0);
+  for (auto &x : th) x.join ();
+  for (int t = started ; t < nThreads && slice * (size_t) t < n ; ++t) work (t);      /* threads that could not be started */
+  return !bad;
+}
+
+static int txHostThreads (void)
+{
+  const char *e = getenv ("MODGPU_PARSE_THREADS");
+  long v = e ? atol (e) : 0;
+  if (v <= 0)
+    { v = sysconf (_SC_NPROCESSORS_ONLN);
+      cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
+      FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");
+      if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < v) v = c; } fclose (q); }
+    }
+  if (v < 1) v = 1;
+  if (v > 32) v = 32;
+  return (int) v;
+}
+
+struct TxSink {                                            /* what is done with a batch of complete records */
+  int (*fn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, hipStream_t st);
+  void *ctx;
+};
+
+/* one batch: records [0, nRec) of the accumulator, bases [0, total); dRecOff[nRec] == total.  Returns 0 or an error */
+static int txFlush (TxBufs &t, const TxSink &sink, U64 total, U64 nRec, hipStream_t st)
+{
+  if (!nRec) return 0;
+  const size_t nw = mgPackedWords (total);
+  if (nw > t.packedWords)
+    { (void) hipFree (t.dPacked); t.dPacked = 0; t.packedWords = 0;
+      if (hipMalloc ((void **) &t.dPacked, (nw + nw / 4) * 4) != hipSuccess) return -1;
+      t.packedWords = nw + nw / 4;
+    }
+  if (mgLaunchPack (t.dBases, total, t.dPacked, st)) return -1;
+  return sink.fn (sink.ctx, t.dPacked, total, t.dRecOff, (U32) nRec, st);
+}
+
+/* the file through the device parser; every batch of complete records goes to sink.  Returns 0, -1 (error: mgLastError), or -2
+ * (not a file this path takes: the caller uses the host parser).  *nSeqOut / *totLenOut: records and bases of the file. */
+static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut)
+{
+  if (mgEnsureDevice ()) return -2;
+  { const char *e = getenv ("MODGPU_TEXT_HOST"); if (e && *e == '1') return -2; }      /* test knob: the host parser */
+  int fd = open (filename, O_RDONLY);
+  if (fd < 0) return -2;
+  struct stat sb;
+  if (fstat (fd, &sb) || !S_ISREG (sb.st_mode) || sb.st_size < 2) { close (fd); return -2; }
+  const size_t fileSize = (size_t) sb.st_size;
+  unsigned char first = 0, lastc = 0;
+  if (pread (fd, &first, 1, 0) != 1 || pread (fd, &lastc, 1, (off_t) fileSize - 1) != 1 || first != '>' || lastc != '\n') { close (fd); return -2; }
+
+  TxBufs &t = gTx;
+  std::lock_guard<std::mutex> g (t.lock);
+  const size_t window = txWindowBytes (fileSize);
+  const U64 batch = txBatchBases ();
+  hipStream_t st = 0;
+  int rc = -1;
+  U64 nSeq = 0, totLen = 0;
+  do {
+    if (txReserve (t, window, batch + 2 * (U64) window, window / 2 + 4096)) { mgSetError ("device text parser: allocation failed"); break; }
+    TxState init; init.lastEvent = 0; init.accBases = 0; init.accRecs = 0;
+    if (hipMemcpy (t.dState, &init, sizeof (init), hipMemcpyHostToDevice) != hipSuccess || hipMemset (t.dOverflow, 0, 4) != hipSuccess) break;
+    const int nThreads = txHostThreads ();
+    U64 accBases = 0, accRecs = 0;                          /* the accumulator as of the last synchronised window */
+    size_t off = 0; int w = 0;
+    U32 prevByte = '\n';
+    size_t nCur = fileSize < window ? fileSize : window;
+    if (!txReadParallel (fd, t.hPin[0], nCur, 0, nThreads)) { mgSetError ("device text parser: read failed"); break; }
+    bool failed = false;
+    while (nCur)
+      { const int cur = w & 1, oth = cur ^ 1;
+        /* room for what this window can add (a base per byte, a record per two bytes) */
+        if (accBases + nCur + 64 > t.basesCap || accRecs + nCur / 2 + 2 > t.recCap)
+          if (txReserve (t, window, accBases + nCur + 64, accRecs + nCur / 2 + 2)) { mgSetError ("device text parser: allocation failed"); failed = true; break; }
+        /* the window crosses the link and is parsed ... */
+        const U64 nTiles = (nCur + TX_TILE - 1) / TX_TILE;
+        if (hipMemcpyAsync (t.dText[cur], t.hPin[cur], nCur, hipMemcpyHostToDevice, st) != hipSuccess
+            || hipEventRecord (t.h2dDone[cur], st) != hipSuccess) { failed = true; break; }
+        hipLaunchKernelGGL (mgTextEventKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevByte, t.dTileEvent);
+        hipLaunchKernelGGL (mgTextStateScanKernel, dim3 (1), dim3 (1024), 0, st, t.dTileEvent, nTiles, t.dState);
+        hipLaunchKernelGGL (mgTextCountKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevByte,
+                            t.dTileEvent, t.dTileBases, t.dTileStarts);
+        hipLaunchKernelGGL (mgTextOffsetScanKernel, dim3 (1), dim3 (1024), 0, st, t.dTileBases, t.dTileStarts, nTiles, t.dTileBaseOff, t.dTileStartOff, t.dState, t.hCounts);
+        hipLaunchKernelGGL (mgTextEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevByte,
+                            t.dTileEvent, t.dTileBaseOff, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, (U64) t.recCap, t.dOverflow);
+        if (hipGetLastError () != hipSuccess) { failed = true; break; }
+        prevByte = t.hPin[cur][nCur - 1];
+        /* ... while the host reads the next one into the other pinned buffer (whose last copy to the device must be over) */
+        const size_t offNext = off + nCur;
+        size_t nNext = fileSize - offNext < window ? fileSize - offNext : window;
+        if (nNext)
+          { if (w >= 1 && hipEventSynchronize (t.h2dDone[oth]) != hipSuccess) { failed = true; break; }
+            if (!txReadParallel (fd, t.hPin[oth], nNext, (off_t) offNext, nThreads)) { mgSetError ("device text parser: read failed"); failed = true; break; }
+          }
+        if (hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        accBases = t.hCounts[0]; accRecs = t.hCounts[1];
+        const bool eof = !nNext;
+        if (eof || accBases >= batch)
+          { /* complete records: all of them at the end of the file, otherwise all but the one still open */
+            U64 nRec = eof ? accRecs : accRecs - 1, total = accBases;
+            if (!eof && hipMemcpy (&total, t.dRecOff + nRec, 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+            if (eof && hipMemcpy (t.dRecOff + nRec, &total, 8, hipMemcpyHostToDevice) != hipSuccess) { failed = true; break; }
+            U32 ov = 0; if (hipMemcpy (&ov, t.dOverflow, 4, hipMemcpyDeviceToHost) != hipSuccess || ov) { mgSetError ("device text parser: accumulator overflow"); failed = true; break; }
+            if (nRec)
+              { if (txFlush (t, sink, total, nRec, st)) { failed = true; break; }
+                nSeq += nRec; totLen += total;
+                /* the open record's bases move to the front; it becomes record 0 of the next batch */
+                const U64 carry = accBases - total;
+                if (!eof)
+                  { if (carry) hipLaunchKernelGGL (mgTextCarryKernel, dim3 (1), dim3 (1024), 0, st, t.dBases, total, carry);
+                    TxState ns; ns.lastEvent = 0; ns.accBases = carry; ns.accRecs = 1;
+                    U64 zero = 0;
+                    /* (lastEvent stays what it is on the device: only the two counters change) */
+                    if (hipMemcpyAsync ((char *) t.dState + offsetof (TxState, accBases), &ns.accBases, 16, hipMemcpyHostToDevice, st) != hipSuccess
+                        || hipMemcpyAsync (t.dRecOff, &zero, 8, hipMemcpyHostToDevice, st) != hipSuccess
+                        || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+                    accBases = carry; accRecs = 1;
+                  }
+              }
+          }
+        off = offNext; nCur = nNext; ++w;
+      }
+    if (failed) { if (!mgLastError ()[0]) mgSetError ("device text parser: HIP failure (%s)", hipGetErrorString (hipGetLastError ())); break; }
+    rc = 0;
+  } while (0);
+  close (fd);
+  if (nSeqOut) *nSeqOut = nSeq;
+  if (totLenOut) *totLenOut = totLen;
+  return rc;
+}
+
+/* ---- sinks ---- */
+
+struct TxAddCtx { Modset *ms; U64 totHash; };
+static int txAddSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, hipStream_t st)
+{
+  TxAddCtx *c = (TxAddCtx *) v;
+  U64 nHash = 0;
+  if (mgAddReadsDevice (c->ms, dPacked, total, dOff, nReads, &nHash, (void *) st) != MG_OK) return -1;
+  c->totHash += nHash;
+  return 0;
+}
+
+/* modutils.c:33-51 with the text parsed on the device.  0: done (counts filled in); -1: error; -2: not a file for this path */
+extern "C" int mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash)
+{
+  TxAddCtx c; c.ms = ms; c.totHash = 0;
+  TxSink sink; sink.fn = txAddSink; sink.ctx = &c;
+  const int rc = txParseFile (filename, sink, nSeq, totLen);
+  if (totHash) *totHash = c.totHash;
+  return rc;
+}
+
+/* test hook: the device parser's records as host arrays (bases 0..3 one per byte, offsets[nSeq + 1]), malloc()ed */
+struct TxHostCtx { std::vector<unsigned char> bases; std::vector<int64_t> offs; };
+static int txHostSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, hipStream_t st)
+{
+  TxHostCtx *c = (TxHostCtx *) v;
+  std::vector<U64> o ((size_t) nReads + 1);
+  if (hipMemcpy (o.data (), dOff, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  unsigned char *dB = 0;
+  if (hipMalloc ((void **) &dB, total ? total : 16) != hipSuccess) return -1;
+  int rc = -1;
+  if (mgLaunchUnpack (dPacked, total, dB, st) == MG_OK && hipStreamSynchronize (st) == hipSuccess)
+    { const size_t at = c->bases.size ();
+      c->bases.resize (at + total);
+      if (!total || hipMemcpy (c->bases.data () + at, dB, total, hipMemcpyDeviceToHost) == hipSuccess)
+        { if (c->offs.empty ()) c->offs.push_back (0);
+          for (U32 r = 1 ; r <= nReads ; ++r) c->offs.push_back ((int64_t) (at + o[r]));
+          rc = 0;
+        }
+    }
+  (void) hipFree (dB);
+  return rc;
+}
+extern "C" int mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **offsetsOut, int64_t *nSeqOut)
+{
+  TxHostCtx c;
+  TxSink sink; sink.fn = txHostSink; sink.ctx = &c;
+  U64 nSeq = 0, totLen = 0;
+  const int rc = txParseFile (filename, sink, &nSeq, &totLen);
+  if (rc) return rc;
+  if (c.offs.empty ()) c.offs.push_back (0);
+  char *b = (char *) malloc (c.bases.size () + 1); int64_t *o = (int64_t *) malloc (c.offs.size () * sizeof (int64_t));
+  if (!b || !o) { free (b); free (o); return -1; }
+  memcpy (b, c.bases.data (), c.bases.size ()); memcpy (o, c.offs.data (), c.offs.size () * sizeof (int64_t));
+  *basesOut = b; *offsetsOut = o; *nSeqOut = (int64_t) nSeq;
+  return 0;
+}

@@ -29,7 +29,7 @@ with open(path, "wb") as f:
         done += L; i += 1
 size = os.path.getsize(path)
 L = mg.lib()
-for threads in (1, 4, 16):
+for threads in (16,):
     os.environ["MODGPU_PARSE_THREADS"] = str(threads)
     t0 = time.time()
     r = L.mgSeqOpen(path.encode()); b = mg.MgSeqBatch(); tot = 0
@@ -41,11 +41,12 @@ for threads in (1, 4, 16):
 del os.environ["MODGPU_PARSE_THREADS"]
 if L.mgDeviceCount() > 0:
     sh = mg.seqhashCreate(21, 64, 17); ms = mg.modsetCreate(sh, 28)
-    for rep in range(2):
+    for host in ("1", "0", "0", "1", "0"):
+        os.environ["MODGPU_TEXT_HOST"] = host                      # 1: the host parser; 0: plain FASTA parsed on the device (read per call)
         L.mgModsetClear(ms, None)
         t0 = time.time()
         with mg.CFile("/dev/null", "w") as f:
             assert L.mgAddSequenceFile(ms, path.encode(), f) == 0
         dt = time.time() - t0
-        print("file -> modset: %.2f s  %.2f Gbp/s  (max %d)" % (dt, n / dt / 1e9, ms.contents.max))
+        print("file -> modset (%s parser): %.3f s  %.2f Gbp/s  (max %d)" % ("host" if host == "1" else "device", dt, n / dt / 1e9, ms.contents.max))
 os.remove(path)
