@@ -19,8 +19,10 @@ int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **blk);
 void mgIterReleaseBuffers (void);                  /* the calling thread's iterator scratch (pinned buffers, stream) */
 /* the same for the minimizer iterator: *rec = malloc()ed {U64 hash[n]; U32 posF[n]} */
 int  mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
-/* the file front end on the device (mg_textgpu.hip): plain FASTA parsed by the GPU.  0 = done, -1 = error, -2 = not a file for this path (the host parser takes it) */
-int  mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash);
+/* the file front end on the device (mg_textgpu.hip): plain FASTA / FASTQ text parsed by the GPU.  0 = done, -1 = error, -2 = not a
+   file for this path (the host parser takes it), -3 = FASTQ text this parser leaves to the host parser from byte *resumeOff (a
+   record start, line *resumeLine of the file; the counts are those of the records added so far) */
+int  mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash, U64 *resumeOff, U64 *resumeLine);
 int  mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **offsetsOut, int64_t *nSeqOut);   /* test hook: the parser's records as host arrays (malloc) */
 void mgTextReleaseBuffers (void);
 /* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */

@@ -299,7 +299,10 @@ static size_t readParallel (MgSeqReader *r, char *dst, size_t n)
 
 static void closeInput (MgSeqReader *r) { if (r->gz) gzclose (r->gz); else close (r->fd); free (r->cbuf); r->cbuf = 0; }
 
-MgSeqReader *mgSeqOpen (const char *filename)
+/* startOff / startLine / startSeq: a reader that takes a plain regular file up from a record that starts at byte startOff, which
+   is line startLine of the file and record startSeq + 1 (the device text parser hands a file over like this when it meets text
+   it leaves to this parser: mg_textgpu.hip); 0 / 1 / 0 for a whole file */
+static MgSeqReader *seqOpenAt (const char *filename, size_t startOff, U64 startLine, U64 startSeq)
 {
   pthread_once (&convOnce, convInit);
   /* the reference reads everything through gzread (seqio.c:33-40), which passes plain text through;
@@ -324,6 +327,10 @@ MgSeqReader *mgSeqOpen (const char *filename)
   { struct stat st;                                              /* plain file: the window it will need is known */
     if (!gz && !bgzf && fstat (fd, &st) == 0 && S_ISREG (st.st_mode)) r->fileSize = (size_t) st.st_size;
   }
+  if (startOff)
+    { if (!r->fileSize || startOff >= r->fileSize || lseek (fd, (off_t) startOff, SEEK_SET) < 0) { closeInput (r); free (r); bigFlush (); return 0; }
+      r->consumed = startOff;
+    }
   r->buf = (char *) bigAlloc (r->cap);
   r->len = readSome (r, r->buf, r->cap);
   if (!r->len)
@@ -338,10 +345,12 @@ MgSeqReader *mgSeqOpen (const char *filename)
       closeInput (r); bigFree (r->buf, r->cap); free (r); bigFlush ();
       return 0;
     }
-  r->line = 1;
+  r->line = startLine; r->nSeq = startSeq;
   r->nThreads = threadCount ();
   return r;
 }
+
+MgSeqReader *mgSeqOpen (const char *filename) { return seqOpenAt (filename, 0, 1, 0); }
 
 void mgSeqClose (MgSeqReader *r)
 {
@@ -989,9 +998,9 @@ static int64_t batchBases (void)
 }
 
 /* every batch of the file through fn, the next batch being parsed while fn works on this one */
-static int forEachBatch (const char *filename, int (*fn) (MgSeqBatch *, void *), void *ctx)
+static int forEachBatchFrom (const char *filename, size_t startOff, U64 startLine, U64 startSeq, int (*fn) (MgSeqBatch *, void *), void *ctx)
 {
-  MgSeqReader *r = mgSeqOpen (filename);
+  MgSeqReader *r = seqOpenAt (filename, startOff, startLine, startSeq);
   if (!r) return -1;
   Prefetch p; memset (&p, 0, sizeof (p)); p.r = r; p.maxBases = batchBases ();
   prefetchMain (&p);
@@ -1013,6 +1022,9 @@ static int forEachBatch (const char *filename, int (*fn) (MgSeqBatch *, void *),
   return rc;
 }
 
+static int forEachBatch (const char *filename, int (*fn) (MgSeqBatch *, void *), void *ctx)
+{ return forEachBatchFrom (filename, 0, 1, 0, fn, ctx); }
+
 typedef struct { Modset *ms; U64 nSeq, totLen, totHash; } AddCtx;
 static int addBatch (MgSeqBatch *b, void *v)
 {
@@ -1026,11 +1038,13 @@ static int addBatch (MgSeqBatch *b, void *v)
 int mgAddSequenceFile (Modset *ms, const char *filename, FILE *out)            /* modutils.c:33-51 */
 {
   AddCtx c; memset (&c, 0, sizeof (c)); c.ms = ms;
-  /* plain FASTA text: the device parses it (mg_textgpu.hip), the host only moves the bytes; everything else -- gzip, FASTQ,
-     an unfinished last line -- through the host parser below */
-  int rc = mgAddSequenceFileDevice (ms, filename, &c.nSeq, &c.totLen, &c.totHash);
+  /* plain FASTA / FASTQ text: the device parses it (mg_textgpu.hip), the host only moves the bytes; everything else -- gzip, a
+     last line without its newline -- through the host parser below */
+  U64 resumeOff = 0, resumeLine = 1;
+  int rc = mgAddSequenceFileDevice (ms, filename, &c.nSeq, &c.totLen, &c.totHash, &resumeOff, &resumeLine);
   if (rc == -1) return -1;
   if (rc == -2) rc = forEachBatch (filename, addBatch, &c);
+  else if (rc == -3) rc = forEachBatchFrom (filename, (size_t) resumeOff, resumeLine, c.nSeq, addBatch, &c);   /* the device parser met FASTQ text it leaves to this one (a record that breaks the rules, an unfinished one): from the first record it has not added */
   if (rc) return rc;
   fprintf (out, "added %llu sequences total length %llu total hashes %llu, new max %u\n",
            (unsigned long long) c.nSeq, (unsigned long long) c.totLen, (unsigned long long) c.totHash, ms->max);

@@ -306,10 +306,182 @@ void mgTextCarryKernel (unsigned char *bases, U64 from, U64 count)
     }
 }
 
+/* ======================================================================================== */
+/* FASTQ: four lines a record (seqio.c:325-339).  The line a byte belongs to is the number of newlines before it, a prefix
+ * sum; line mod 4 says what the byte is: 0 header ('@' first), 1 sequence (EVERY byte but the newline is a base: A/a C/c G/g
+ * T/t N/n as in FASTA, anything else stays in the sequence as (char) -2, i.e. 2 once packed -- as the host parser and the
+ * reference leave it), 2 the '+' line, 3 qualities (as many bytes as the sequence line).  A record is complete at its fourth
+ * newline; there the kernels note the bases and the quality bytes counted so far and the newline's file position: the first
+ * gives the read offsets, the first two the length check, the third where the host parser would take over.  The rules
+ * ('@', '+', equal lengths, whole records at the end of the file) are CHECKED here and never judged: any breach, and the file
+ * goes back to the host parser from the first record not yet added, which then says what the reference says. */
+struct TqState {
+  U64 nlCount;          /* newlines of the file so far */
+  U64 accBases, accQual, accRecs;      /* of the batch accumulator: bases, quality bytes, completed records */
+  U64 bad;              /* != 0: a rule was broken somewhere in the accumulator's text */
+};
+
+__device__ __forceinline__ U32 tqBlockSum (U32 v, U32 *sRed)
+{
+  for (int off = 32 ; off ; off >>= 1) v += __shfl_xor (v, off);
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
+  __syncthreads ();
+  U32 t = 0;
+  for (int w = 0 ; w < TX_THREADS / 64 ; ++w) t += sRed[w];
+  __syncthreads ();
+  return t;
+}
+/* exclusive prefix of v over the workgroup's threads */
+__device__ __forceinline__ U32 tqBlockExcl (U32 v, U32 *sScan)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  U32 incl = v;
+  for (int off = 1 ; off < 64 ; off <<= 1) { const U32 o = __shfl_up (incl, off); if (lane >= off) incl += o; }
+  if (lane == 63) sScan[wave] = incl;
+  __syncthreads ();
+  U32 before = 0;
+  for (int w = 0 ; w < wave ; ++w) before += sScan[w];
+  __syncthreads ();
+  return before + incl - v;
+}
+
+/* Kq1: newlines per tile */
+__global__ __launch_bounds__ (TX_THREADS)
+void mgTextNewlineKernel (const unsigned char *__restrict__ text, U64 n, U64 *__restrict__ tileNL)
+{
+  __shared__ U32 sRed[TX_THREADS / 64];
+  const U64 at = ((U64) blockIdx.x * TX_THREADS + threadIdx.x) * TX_PER;
+  unsigned char b[16]; U32 prev = 0; U32 c = 0;
+  if (at < n)
+    { txLoad (text, n, at, 0, b, &prev);
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j) c += (at + j < n && b[j] == '\n') ? 1u : 0u;
+    }
+  const U32 t = tqBlockSum (c, sRed);
+  if (threadIdx.x == 0) tileNL[blockIdx.x] = t;
+}
+
+/* Kq2: the line number at every tile's first byte */
+__global__ __launch_bounds__ (1024)
+void mgTextLineScanKernel (U64 *tileNL, U64 nTiles, TqState *st)
+{
+  __shared__ U64 total;
+  txScanTiles<false> (tileNL, nTiles, st->nlCount, &total);
+  __syncthreads ();
+  if (threadIdx.x == 0) st->nlCount = total;
+}
+
+/* the walk over a thread's 16 bytes, shared by Kq3 (counts) and Kq5 (writes): EMIT = false counts only */
+template <bool EMIT>
+__device__ __forceinline__ void tqWalk (const unsigned char *b, U64 at, U64 n, U32 prev, U64 line, U64 filePos,
+                                        U32 *nb, U32 *nq, U32 *ne, U32 *bad,
+                                        unsigned char *bases, U64 myB, U64 myQ, U64 *endB, U64 *endQ, U64 *endP, U64 myE)
+{
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j)
+    { if (at + j < n)
+        { const U32 c = b[j];
+          const U32 phase = (U32) line & 3u;
+          if (prev == '\n' && ((phase == 0 && c != '@') || (phase == 2 && c != '+'))) *bad = 1;     /* seqio.c:326,333 */
+          if (c == '\n')
+            { if (phase == 3)
+                { if (EMIT) { endB[myE] = myB; endQ[myE] = myQ; endP[myE] = filePos + (U64) j; ++myE; }
+                  ++*ne;
+                }
+              ++line;
+            }
+          else if (phase == 1) { if (EMIT) { const U32 code = txCode (c); bases[myB++] = (unsigned char) (code < 4 ? code : 2u); } ++*nb; }
+          else if (phase == 3) { if (EMIT) ++myQ; ++*nq; }
+        }
+      prev = b[j];
+    }
+}
+
+/* Kq3: bases, quality bytes and completed records of every tile; rule checks at the line starts */
+__global__ __launch_bounds__ (TX_THREADS)
+void mgTextFastqCountKernel (const unsigned char *__restrict__ text, U64 n, U32 prevByte, const U64 *__restrict__ tileLine,
+                             U32 *__restrict__ tileBases, U32 *__restrict__ tileQual, U32 *__restrict__ tileEnds, TqState *st)
+{
+  __shared__ U32 sScan[TX_THREADS / 64], sRed[TX_THREADS / 64];
+  const U64 at = ((U64) blockIdx.x * TX_THREADS + threadIdx.x) * TX_PER;
+  unsigned char b[16]; U32 prev = 0; U32 nl = 0;
+  if (at < n)
+    { txLoad (text, n, at, prevByte, b, &prev);
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j) nl += (at + j < n && b[j] == '\n') ? 1u : 0u;
+    }
+  const U64 line = tileLine[blockIdx.x] + tqBlockExcl (nl, sScan);
+  U32 nb = 0, nq = 0, ne = 0, bad = 0;
+  if (at < n) tqWalk<false> (b, at, n, prev, line, 0, &nb, &nq, &ne, &bad, 0, 0, 0, 0, 0, 0, 0);
+  if (bad) st->bad = 1;
+  const U32 tb = tqBlockSum (nb, sRed), tq = tqBlockSum (nq, sRed), te = tqBlockSum (ne, sRed);
+  if (threadIdx.x == 0) { tileBases[blockIdx.x] = tb; tileQual[blockIdx.x] = tq; tileEnds[blockIdx.x] = te; }
+}
+
+/* Kq4: where the tiles' bases / quality counts / record ends go; the new totals */
+__global__ __launch_bounds__ (1024)
+void mgTextFastqOffsetKernel (const U32 *__restrict__ tileBases, const U32 *__restrict__ tileQual, const U32 *__restrict__ tileEnds, U64 nTiles,
+                              U64 *__restrict__ offB, U64 *__restrict__ offQ, U64 *__restrict__ offE, TqState *st, U64 *hostCounts)
+{
+  __shared__ U64 totB, totQ, totE;
+  for (U64 i = threadIdx.x ; i < nTiles ; i += 1024) { offB[i] = tileBases[i]; offQ[i] = tileQual[i]; offE[i] = tileEnds[i]; }
+  __syncthreads ();
+  txScanTiles<false> (offB, nTiles, st->accBases, &totB);
+  __syncthreads ();
+  txScanTiles<false> (offQ, nTiles, st->accQual, &totQ);
+  __syncthreads ();
+  txScanTiles<false> (offE, nTiles, st->accRecs, &totE);
+  __syncthreads ();
+  if (threadIdx.x == 0)
+    { st->accBases = totB; st->accQual = totQ; st->accRecs = totE;
+      hostCounts[0] = totB; hostCounts[1] = totE; hostCounts[2] = totQ; hostCounts[3] = st->nlCount; hostCounts[4] = st->bad;
+    }
+}
+
+/* Kq5: the bases, and at every record's last newline the three running values (entries 1 .. of endB / endQ / endP; entry 0 is
+ * what held when the accumulator was started) */
+__global__ __launch_bounds__ (TX_THREADS)
+void mgTextFastqEmitKernel (const unsigned char *__restrict__ text, U64 n, U64 textBase, U32 prevByte, const U64 *__restrict__ tileLine,
+                            const U64 *__restrict__ offB, const U64 *__restrict__ offQ, const U64 *__restrict__ offE,
+                            unsigned char *__restrict__ bases, U64 basesCap, U64 *__restrict__ endB, U64 *__restrict__ endQ, U64 *__restrict__ endP, U64 recCap,
+                            U32 *__restrict__ overflow)
+{
+  __shared__ U32 sScan[TX_THREADS / 64];
+  const U64 at = ((U64) blockIdx.x * TX_THREADS + threadIdx.x) * TX_PER;
+  unsigned char b[16]; U32 prev = 0; U32 nl = 0;
+  if (at < n)
+    { txLoad (text, n, at, prevByte, b, &prev);
+#pragma unroll
+      for (int j = 0 ; j < 16 ; ++j) nl += (at + j < n && b[j] == '\n') ? 1u : 0u;
+    }
+  const U64 line = tileLine[blockIdx.x] + tqBlockExcl (nl, sScan);
+  U32 nb = 0, nq = 0, ne = 0, bad = 0;
+  if (at < n) tqWalk<false> (b, at, n, prev, line, 0, &nb, &nq, &ne, &bad, 0, 0, 0, 0, 0, 0, 0);
+  const U64 myB = offB[blockIdx.x] + tqBlockExcl (nb, sScan);
+  const U64 myQ = offQ[blockIdx.x] + tqBlockExcl (nq, sScan);
+  const U64 myE = offE[blockIdx.x] + tqBlockExcl (ne, sScan) + 1;                     /* entry 0 is the accumulator's start */
+  if (at >= n || (!nb && !ne)) return;
+  if (myB + nb > basesCap || myE + ne > recCap) { *overflow = 1; return; }
+  U32 x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+  tqWalk<true> (b, at, n, prev, line, textBase + at, &x0, &x1, &x2, &x3, bases, myB, myQ, endB, endQ, endP, myE);
+}
+
+/* Kq6: a record's sequence line and quality line are of one length (seqio.c:339), for the records completed in [first, last] */
+__global__ void mgTextFastqCheckKernel (const U64 *__restrict__ endB, const U64 *__restrict__ endQ, U64 first, U64 last, TqState *st)
+{
+  const U64 r = first + (U64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > last) return;
+  if (endB[r] - endB[r - 1] != endQ[r] - endQ[r - 1]) st->bad = 1;
+}
+
 /* ---------------------------------------------------------------------------------------- */
 /* host side                                                                                  */
 
 static inline size_t txAl (size_t n) { return (n + 255) & ~(size_t) 255; }
+#include <time.h>
+static double txNow (void) { struct timespec ts; clock_gettime (CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static bool txTiming (void) { static int v = -1; if (v < 0) { const char *e = getenv ("MODGPU_TEXT_TIMING"); v = e && *e == '1'; } return v != 0; }   /* dev knob */
+struct TxClock { double reserve = 0, read = 0, wait = 0, flush = 0, t0 = 0; void lap (double &slot) { const double n = txNow (); slot += n - t0; t0 = n; } };
 
 struct TxBufs {
   int dev = -1;
@@ -319,6 +491,8 @@ struct TxBufs {
   U64 *hCounts = 0;                    /* pinned: {accBases, accRecs} after the last window's K4 */
   TxState *dState = 0; U32 *dOverflow = 0;
   U64 *dTileEvent = 0, *dTileBaseOff = 0, *dTileStartOff = 0; U32 *dTileBases = 0, *dTileStarts = 0; size_t tilesCap = 0;
+  U64 *dTileOffQ = 0; U32 *dTileQual = 0; TqState *dTq = 0;      /* FASTQ: the third counted quantity */
+  U64 *dEndQ = 0, *dEndP = 0;                                    /* FASTQ: per completed record (dRecOff is the first of the three) */
   unsigned char *dBases = 0; size_t basesCap = 0;
   U64 *dRecOff = 0; size_t recCap = 0;
   U32 *dPacked = 0; size_t packedWords = 0;
@@ -329,6 +503,8 @@ struct TxBufs {
     if (hCounts) (void) hipHostFree (hCounts);
     (void) hipFree (dState); (void) hipFree (dOverflow); (void) hipFree (dTileEvent); (void) hipFree (dTileBaseOff); (void) hipFree (dTileStartOff);
     (void) hipFree (dTileBases); (void) hipFree (dTileStarts); (void) hipFree (dBases); (void) hipFree (dRecOff); (void) hipFree (dPacked);
+    (void) hipFree (dTileOffQ); (void) hipFree (dTileQual); (void) hipFree (dTq); (void) hipFree (dEndQ); (void) hipFree (dEndP);
+    dTileOffQ = 0; dTileQual = 0; dTq = 0; dEndQ = 0; dEndP = 0;
     if (copy) (void) hipStreamDestroy (copy);
     hCounts = 0; dState = 0; dOverflow = 0; dTileEvent = dTileBaseOff = dTileStartOff = 0; dTileBases = dTileStarts = 0; dBases = 0; dRecOff = 0; dPacked = 0;
     tilesCap = basesCap = recCap = packedWords = window = 0; copy = 0; dev = -1;
@@ -373,22 +549,29 @@ static int txReserve (TxBufs &t, size_t window, U64 basesNeed, U64 recsNeed)
       const size_t tiles = window / TX_TILE + 2;
       if (hipMalloc ((void **) &t.dTileEvent, tiles * 8) != hipSuccess || hipMalloc ((void **) &t.dTileBaseOff, tiles * 8) != hipSuccess
           || hipMalloc ((void **) &t.dTileStartOff, tiles * 8) != hipSuccess || hipMalloc ((void **) &t.dTileBases, tiles * 4) != hipSuccess
-          || hipMalloc ((void **) &t.dTileStarts, tiles * 4) != hipSuccess) return -1;
+          || hipMalloc ((void **) &t.dTileStarts, tiles * 4) != hipSuccess
+          || hipMalloc ((void **) &t.dTileOffQ, tiles * 8) != hipSuccess || hipMalloc ((void **) &t.dTileQual, tiles * 4) != hipSuccess
+          || hipMalloc ((void **) &t.dTq, sizeof (TqState)) != hipSuccess) return -1;
       t.tilesCap = tiles;
       if (hipStreamCreateWithFlags (&t.copy, hipStreamNonBlocking) != hipSuccess) return -1;
       t.dev = dev; t.window = window;
     }
   if (basesNeed > t.basesCap)
-    { unsigned char *nb = 0; const size_t cap = (size_t) (basesNeed + basesNeed / 4 + (1 << 20));
+    { unsigned char *nb = 0; size_t cap = (size_t) (basesNeed + basesNeed / 4 + (1 << 20)); if (cap < 2 * t.basesCap) cap = 2 * t.basesCap;
       if (hipMalloc ((void **) &nb, cap) != hipSuccess) return -1;
       if (t.dBases) { (void) hipMemcpy (nb, t.dBases, t.basesCap, hipMemcpyDeviceToDevice); (void) hipFree (t.dBases); }
       t.dBases = nb; t.basesCap = cap;
     }
   if (recsNeed > t.recCap)
-    { U64 *nr = 0; const size_t cap = (size_t) (recsNeed + recsNeed / 4 + 4096);
-      if (hipMalloc ((void **) &nr, cap * 8) != hipSuccess) return -1;
-      if (t.dRecOff) { (void) hipMemcpy (nr, t.dRecOff, t.recCap * 8, hipMemcpyDeviceToDevice); (void) hipFree (t.dRecOff); }
-      t.dRecOff = nr; t.recCap = cap;
+    { size_t cap = (size_t) (recsNeed + recsNeed / 4 + 4096); if (cap < 2 * t.recCap) cap = 2 * t.recCap;
+      U64 **arr[3] = { &t.dRecOff, &t.dEndQ, &t.dEndP };
+      for (int i = 0 ; i < 3 ; ++i)
+        { U64 *nr = 0;
+          if (hipMalloc ((void **) &nr, cap * 8) != hipSuccess) return -1;
+          if (*arr[i]) { (void) hipMemcpy (nr, *arr[i], t.recCap * 8, hipMemcpyDeviceToDevice); (void) hipFree (*arr[i]); }
+          *arr[i] = nr;
+        }
+      t.recCap = cap;
     }
   return 0;
 }
@@ -451,9 +634,11 @@ static int txFlush (TxBufs &t, const TxSink &sink, U64 total, U64 nRec, hipStrea
   return sink.fn (sink.ctx, t.dPacked, total, t.dRecOff, (U32) nRec, st);
 }
 
+static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff, U64 *resumeLine);
+
 /* the file through the device parser; every batch of complete records goes to sink.  Returns 0, -1 (error: mgLastError), or -2
  * (not a file this path takes: the caller uses the host parser).  *nSeqOut / *totLenOut: records and bases of the file. */
-static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut)
+static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff = 0, U64 *resumeLine = 0)
 {
   if (mgEnsureDevice ()) return -2;
   { const char *e = getenv ("MODGPU_TEXT_HOST"); if (e && *e == '1') return -2; }      /* test knob: the host parser */
@@ -463,17 +648,24 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
   if (fstat (fd, &sb) || !S_ISREG (sb.st_mode) || sb.st_size < 2) { close (fd); return -2; }
   const size_t fileSize = (size_t) sb.st_size;
   unsigned char first = 0, lastc = 0;
-  if (pread (fd, &first, 1, 0) != 1 || pread (fd, &lastc, 1, (off_t) fileSize - 1) != 1 || first != '>' || lastc != '\n') { close (fd); return -2; }
+  if (pread (fd, &first, 1, 0) != 1 || pread (fd, &lastc, 1, (off_t) fileSize - 1) != 1 || (first != '>' && first != '@') || lastc != '\n') { close (fd); return -2; }
 
   TxBufs &t = gTx;
   std::lock_guard<std::mutex> g (t.lock);
+  if (first == '@')
+    { const int rq = txParseFastq (fd, fileSize, t, sink, nSeqOut, totLenOut, resumeOff, resumeLine);
+      close (fd);
+      return rq;
+    }
   const size_t window = txWindowBytes (fileSize);
   const U64 batch = txBatchBases ();
   hipStream_t st = 0;
   int rc = -1;
   U64 nSeq = 0, totLen = 0;
   do {
-    if (txReserve (t, window, batch + 2 * (U64) window, window / 2 + 4096)) { mgSetError ("device text parser: allocation failed"); break; }
+    TxClock ck; ck.t0 = txNow ();
+    if (txReserve (t, window, 1 << 20, 4096)) { mgSetError ("device text parser: allocation failed"); break; }      /* the accumulators grow to what the windows' counts ask for */
+    ck.lap (ck.reserve);
     TxState init; init.lastEvent = 0; init.accBases = 0; init.accRecs = 0;
     if (hipMemcpy (t.dState, &init, sizeof (init), hipMemcpyHostToDevice) != hipSuccess || hipMemset (t.dOverflow, 0, 4) != hipSuccess) break;
     const int nThreads = txHostThreads ();
@@ -481,35 +673,45 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
     size_t off = 0; int w = 0;
     U32 prevByte = '\n';
     size_t nCur = fileSize < window ? fileSize : window;
+    ck.lap (ck.flush);
     if (!txReadParallel (fd, t.hPin[0], nCur, 0, nThreads)) { mgSetError ("device text parser: read failed"); break; }
+    ck.lap (ck.read);
+    if (hipMemcpyAsync (t.dText[0], t.hPin[0], nCur, hipMemcpyHostToDevice, t.copy) != hipSuccess || hipEventRecord (t.h2dDone[0], t.copy) != hipSuccess) break;
     bool failed = false;
     while (nCur)
       { const int cur = w & 1, oth = cur ^ 1;
-        /* room for what this window can add (a base per byte, a record per two bytes) */
-        if (accBases + nCur + 64 > t.basesCap || accRecs + nCur / 2 + 2 > t.recCap)
-          if (txReserve (t, window, accBases + nCur + 64, accRecs + nCur / 2 + 2)) { mgSetError ("device text parser: allocation failed"); failed = true; break; }
         /* the window crosses the link and is parsed ... */
         const U64 nTiles = (nCur + TX_TILE - 1) / TX_TILE;
-        if (hipMemcpyAsync (t.dText[cur], t.hPin[cur], nCur, hipMemcpyHostToDevice, st) != hipSuccess
-            || hipEventRecord (t.h2dDone[cur], st) != hipSuccess) { failed = true; break; }
+        if (hipStreamWaitEvent (st, t.h2dDone[cur], 0) != hipSuccess) { failed = true; break; }      /* the window's copy was started as soon as it was read (copy stream) */
         hipLaunchKernelGGL (mgTextEventKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevByte, t.dTileEvent);
         hipLaunchKernelGGL (mgTextStateScanKernel, dim3 (1), dim3 (1024), 0, st, t.dTileEvent, nTiles, t.dState);
         hipLaunchKernelGGL (mgTextCountKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevByte,
                             t.dTileEvent, t.dTileBases, t.dTileStarts);
         hipLaunchKernelGGL (mgTextOffsetScanKernel, dim3 (1), dim3 (1024), 0, st, t.dTileBases, t.dTileStarts, nTiles, t.dTileBaseOff, t.dTileStartOff, t.dState, t.hCounts);
-        hipLaunchKernelGGL (mgTextEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevByte,
-                            t.dTileEvent, t.dTileBaseOff, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, (U64) t.recCap, t.dOverflow);
         if (hipGetLastError () != hipSuccess) { failed = true; break; }
+        const U32 prevOfWindow = prevByte;
         prevByte = t.hPin[cur][nCur - 1];
         /* ... while the host reads the next one into the other pinned buffer (whose last copy to the device must be over) */
         const size_t offNext = off + nCur;
         size_t nNext = fileSize - offNext < window ? fileSize - offNext : window;
         if (nNext)
           { if (w >= 1 && hipEventSynchronize (t.h2dDone[oth]) != hipSuccess) { failed = true; break; }
+            ck.lap (ck.flush);
             if (!txReadParallel (fd, t.hPin[oth], nNext, (off_t) offNext, nThreads)) { mgSetError ("device text parser: read failed"); failed = true; break; }
+            ck.lap (ck.read);
+            /* across the link at once, beside this window's kernels (the other device buffer is free: its window's kernels were waited for) */
+            if (hipMemcpyAsync (t.dText[oth], t.hPin[oth], nNext, hipMemcpyHostToDevice, t.copy) != hipSuccess
+                || hipEventRecord (t.h2dDone[oth], t.copy) != hipSuccess) { failed = true; break; }
           }
+        /* the counts are in: room for exactly what this window adds, then the bases and the offsets are written */
         if (hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
         accBases = t.hCounts[0]; accRecs = t.hCounts[1];
+        ck.lap (ck.wait);
+        if (accBases + 64 > t.basesCap || accRecs + 2 > t.recCap)
+          if (txReserve (t, window, accBases + 64, accRecs + 2)) { mgSetError ("device text parser: allocation failed"); failed = true; break; }
+        hipLaunchKernelGGL (mgTextEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevOfWindow,
+                            t.dTileEvent, t.dTileBaseOff, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, (U64) t.recCap, t.dOverflow);
+        if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
         const bool eof = !nNext;
         if (eof || accBases >= batch)
           { /* complete records: all of them at the end of the file, otherwise all but the one still open */
@@ -536,12 +738,119 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
           }
         off = offNext; nCur = nNext; ++w;
       }
+    ck.lap (ck.flush);
+    if (txTiming ()) fprintf (stderr, "  [device text] FASTA: reserve %.3f s, read %.3f, wait for the device %.3f, emit + flush + rest %.3f\n", ck.reserve, ck.read, ck.wait, ck.flush);
     if (failed) { if (!mgLastError ()[0]) mgSetError ("device text parser: HIP failure (%s)", hipGetErrorString (hipGetLastError ())); break; }
     rc = 0;
   } while (0);
   close (fd);
   if (nSeqOut) *nSeqOut = nSeq;
   if (totLenOut) *totLenOut = totLen;
+  return rc;
+}
+
+/* the FASTQ file through the device parser.  0 = the whole file; -1 = error; -3 = the text from byte *resumeOff on (a record start,
+ * line *resumeLine) is left to the host parser: a rule of the format is broken somewhere after it, or the file ends in the middle of
+ * a record -- the host parser then reports what the reference reports (seqio.c:213-217,326-339) */
+static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff, U64 *resumeLine)
+{
+  const size_t window = txWindowBytes (fileSize);
+  const U64 batch = txBatchBases ();
+  hipStream_t st = 0;
+  int rc = -1;
+  U64 nSeq = 0, totLen = 0, resume = 0;
+  do {
+    TxClock ck; ck.t0 = txNow ();
+    if (txReserve (t, window, 1 << 20, 4096)) { mgSetError ("device text parser: allocation failed"); break; }
+    ck.lap (ck.reserve);
+    TqState init; memset (&init, 0, sizeof (init));
+    U64 zero = 0;
+    if (hipMemcpy (t.dTq, &init, sizeof (init), hipMemcpyHostToDevice) != hipSuccess || hipMemset (t.dOverflow, 0, 4) != hipSuccess
+        || hipMemcpy (t.dRecOff, &zero, 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy (t.dEndQ, &zero, 8, hipMemcpyHostToDevice) != hipSuccess) break;
+    const int nThreads = txHostThreads ();
+    U64 accBases = 0, accRecs = 0, accQual = 0;
+    size_t off = 0; int w = 0;
+    U32 prevByte = '\n';
+    size_t nCur = fileSize < window ? fileSize : window;
+    ck.lap (ck.flush);
+    if (!txReadParallel (fd, t.hPin[0], nCur, 0, nThreads)) { mgSetError ("device text parser: read failed"); break; }
+    ck.lap (ck.read);
+    if (hipMemcpyAsync (t.dText[0], t.hPin[0], nCur, hipMemcpyHostToDevice, t.copy) != hipSuccess || hipEventRecord (t.h2dDone[0], t.copy) != hipSuccess) break;
+    bool failed = false, handOver = false;
+    while (nCur)
+      { const int cur = w & 1, oth = cur ^ 1;
+        const U64 nTiles = (nCur + TX_TILE - 1) / TX_TILE;
+        if (hipStreamWaitEvent (st, t.h2dDone[cur], 0) != hipSuccess) { failed = true; break; }      /* the window's copy was started as soon as it was read (copy stream) */
+        hipLaunchKernelGGL (mgTextNewlineKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, t.dTileEvent);
+        hipLaunchKernelGGL (mgTextLineScanKernel, dim3 (1), dim3 (1024), 0, st, t.dTileEvent, nTiles, t.dTq);
+        hipLaunchKernelGGL (mgTextFastqCountKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, prevByte, t.dTileEvent,
+                            t.dTileBases, t.dTileQual, t.dTileStarts, t.dTq);
+        hipLaunchKernelGGL (mgTextFastqOffsetKernel, dim3 (1), dim3 (1024), 0, st, t.dTileBases, t.dTileQual, t.dTileStarts, nTiles,
+                            t.dTileBaseOff, t.dTileOffQ, t.dTileStartOff, t.dTq, t.hCounts);
+        if (hipGetLastError () != hipSuccess) { failed = true; break; }
+        const U32 prevOfWindow = prevByte;
+        prevByte = t.hPin[cur][nCur - 1];
+        const size_t offNext = off + nCur;
+        size_t nNext = fileSize - offNext < window ? fileSize - offNext : window;
+        if (nNext)
+          { if (w >= 1 && hipEventSynchronize (t.h2dDone[oth]) != hipSuccess) { failed = true; break; }
+            ck.lap (ck.flush);
+            if (!txReadParallel (fd, t.hPin[oth], nNext, (off_t) offNext, nThreads)) { mgSetError ("device text parser: read failed"); failed = true; break; }
+            ck.lap (ck.read);
+            /* across the link at once, beside this window's kernels (the other device buffer is free: its window's kernels were waited for) */
+            if (hipMemcpyAsync (t.dText[oth], t.hPin[oth], nNext, hipMemcpyHostToDevice, t.copy) != hipSuccess
+                || hipEventRecord (t.h2dDone[oth], t.copy) != hipSuccess) { failed = true; break; }
+          }
+        if (hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        const U64 recsBefore = accRecs;
+        accBases = t.hCounts[0]; accRecs = t.hCounts[1]; accQual = t.hCounts[2];
+        ck.lap (ck.wait);
+        if (accBases + 64 > t.basesCap || accRecs + 3 > t.recCap)
+          if (txReserve (t, window, accBases + 64, accRecs + 3)) { mgSetError ("device text parser: allocation failed"); failed = true; break; }
+        hipLaunchKernelGGL (mgTextFastqEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevOfWindow, t.dTileEvent,
+                            t.dTileBaseOff, t.dTileOffQ, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, t.dEndQ, t.dEndP, (U64) t.recCap, t.dOverflow);
+        if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        const U64 nlCount = t.hCounts[3];
+        bool bad = t.hCounts[4] != 0;
+        if (!bad && accRecs > recsBefore)                  /* the records this window completed: sequence and quality lines of one length? */
+          { const U64 nNew = accRecs - recsBefore;
+            hipLaunchKernelGGL (mgTextFastqCheckKernel, dim3 ((unsigned) ((nNew + 255) / 256)), dim3 (256), 0, st, t.dRecOff, t.dEndQ, recsBefore + 1, accRecs, t.dTq);
+            TqState now;
+            if (hipMemcpy (&now, t.dTq, sizeof (now), hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+            bad = now.bad != 0;
+          }
+        U32 ov = 0; if (hipMemcpy (&ov, t.dOverflow, 4, hipMemcpyDeviceToHost) != hipSuccess || ov) { mgSetError ("device text parser: accumulator overflow"); failed = true; break; }
+        const bool eof = !nNext;
+        U64 tail[3] = { 0, 0, 0 };                         /* bases, quality bytes, file position at the end of the last completed record */
+        if (accRecs && (hipMemcpy (&tail[0], t.dRecOff + accRecs, 8, hipMemcpyDeviceToHost) != hipSuccess
+                        || hipMemcpy (&tail[1], t.dEndQ + accRecs, 8, hipMemcpyDeviceToHost) != hipSuccess
+                        || hipMemcpy (&tail[2], t.dEndP + accRecs, 8, hipMemcpyDeviceToHost) != hipSuccess)) { failed = true; break; }
+        if (bad || (eof && ((nlCount & 3) || accBases != (accRecs ? tail[0] : 0) || accQual != (accRecs ? tail[1] : 0))))
+          { handOver = true; break; }                      /* nothing of the accumulator has been added: the host parser starts at its first record */
+        if ((eof || accBases >= batch) && accRecs)
+          { if (txFlush (t, sink, tail[0], accRecs, st)) { failed = true; break; }
+            nSeq += accRecs; totLen += tail[0];
+            resume = tail[2] + 1;
+            if (!eof)
+              { const U64 carry = accBases - tail[0];
+                if (carry) hipLaunchKernelGGL (mgTextCarryKernel, dim3 (1), dim3 (1024), 0, st, t.dBases, tail[0], carry);
+                U64 counters[3] = { carry, accQual - tail[1], 0 };               /* accBases, accQual, accRecs */
+                if (hipMemcpyAsync ((char *) t.dTq + offsetof (TqState, accBases), counters, 24, hipMemcpyHostToDevice, st) != hipSuccess
+                    || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+                accBases = carry; accQual -= tail[1]; accRecs = 0;
+              }
+          }
+        off = offNext; nCur = nNext; ++w;
+      }
+    ck.lap (ck.flush);
+    if (txTiming ()) fprintf (stderr, "  [device text] FASTQ: reserve %.3f s, read %.3f, wait for the device %.3f, emit + flush + rest %.3f\n", ck.reserve, ck.read, ck.wait, ck.flush);
+    if (failed) { if (!mgLastError ()[0]) mgSetError ("device text parser: HIP failure (%s)", hipGetErrorString (hipGetLastError ())); break; }
+    rc = handOver ? -3 : 0;
+  } while (0);
+  if (nSeqOut) *nSeqOut = nSeq;
+  if (totLenOut) *totLenOut = totLen;
+  if (resumeOff) *resumeOff = resume;
+  if (resumeLine) *resumeLine = 4 * nSeq + 1;
   return rc;
 }
 
@@ -558,11 +867,11 @@ static int txAddSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U
 }
 
 /* modutils.c:33-51 with the text parsed on the device.  0: done (counts filled in); -1: error; -2: not a file for this path */
-extern "C" int mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash)
+extern "C" int mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash, U64 *resumeOff, U64 *resumeLine)
 {
   TxAddCtx c; c.ms = ms; c.totHash = 0;
   TxSink sink; sink.fn = txAddSink; sink.ctx = &c;
-  const int rc = txParseFile (filename, sink, nSeq, totLen);
+  const int rc = txParseFile (filename, sink, nSeq, totLen, resumeOff, resumeLine);
   if (totHash) *totHash = c.totHash;
   return rc;
 }

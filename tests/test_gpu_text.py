@@ -78,9 +78,97 @@ def test_device_parser_equals_host_parser(kind, n_rec, seed, window_kb, batch_ba
         assert np.array_equal(a, b), (i, len(a), len(b))
 
 
+def crafted_fastq(rng, n_rec, crlf=False, max_len=300):
+    """valid FASTQ that tries the parser: quality lines that start with '@' or '+', empty reads, lower case, N and junk bytes in the
+    sequence line (kept, as (char) -2: seqio.c:328-331), optionally CR LF line ends (the CR then counts as a base and as a quality)"""
+    letters = np.frombuffer(b"ACGTacgtNnRYx*.", np.uint8)
+    wt = np.array([20, 20, 20, 20, 5, 5, 5, 5, 2, 1, 1, 1, 1, 1, 1], float); wt /= wt.sum()
+    qual = np.frombuffer(b"@+!5IFHJ#>", np.uint8)
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for r in range(n_rec):
+        n = int(rng.integers(0, max_len)) if rng.random() > 0.05 else 0
+        out.append(b"@read%d/1 extra" % r + eol)
+        out.append(letters[rng.choice(len(letters), n, p=wt)].tobytes() + eol)
+        out.append((b"+" if r % 3 else b"+read%d/1 extra" % r) + eol)
+        out.append(qual[rng.integers(0, len(qual), n)].tobytes() + eol)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("n_rec,seed,crlf", [(2000, 1, False), (500, 2, True), (1, 3, False), (30000, 4, False)])
+@pytest.mark.parametrize("window_kb,batch_bases", [(0, 0), (4, 0), (8, 3000), (64, 100000)])
+def test_device_fastq_parser_equals_host_parser(n_rec, seed, crlf, window_kb, batch_bases, tmp_path):
+    path = str(tmp_path / "t.fq")
+    open(path, "wb").write(crafted_fastq(np.random.default_rng(seed), n_rec, crlf, 40 if n_rec > 10000 else 300))
+    _, want = parse_file(path, 1 << 40, 4)
+    env = {}
+    if window_kb:
+        env["MODGPU_TEXT_WINDOW_KB"] = str(window_kb)
+    if batch_bases:
+        env["MODGPU_FILE_BATCH_BASES"] = str(batch_bases)
+    os.environ.update(env)
+    try:
+        rc, got = device_records(path)
+    finally:
+        for k in env:
+            del os.environ[k]
+    assert rc == 0, mg.lib().mgLastError()
+    assert len(got) == len(want) == n_rec
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a & 3, b & 3), (i, len(a), len(b))           # the host parser's batch keeps (char) -2 for other bytes: 2 once packed
+
+
+BROKEN = {
+    "no_plus": lambda recs: recs[:700] + [recs[700].replace(b"\n+", b"\n-", 1)] + recs[701:],
+    "no_at": lambda recs: recs[:901] + [b"#" + recs[901][1:]] + recs[902:],
+    "short_qual": lambda recs: recs[:650] + [recs[650][:-2] + b"\n"] + recs[651:],
+    "truncated": lambda recs: recs[:1200] + [b"\n".join(recs[1200].split(b"\n")[:2]) + b"\n"],
+    "three_lines_more": lambda recs: recs + [b"@last\nACGT\n+\n"],
+}
+
+
+@pytest.mark.parametrize("kind", list(BROKEN))
+def test_fastq_that_breaks_the_rules_goes_to_the_host_parser(kind, tmp_path):
+    """a record without its '+', without its '@', with a quality line of another length; a file that ends in the middle of a record:
+    the device parser adds what comes before (whole batches), then the host parser takes over at the first record not yet added and says
+    what the reference says, with the reference's line number (seqio.c:213-217,326-339).  Same stderr, exit code, "added" line and
+    modset as with the host parser from the start."""
+    rng = np.random.default_rng(9)
+    text = crafted_fastq(rng, 1500)
+    lines = text.split(b"\n")[:-1]
+    recs = [b"\n".join(lines[4 * i:4 * i + 4]) + b"\n" for i in range(len(lines) // 4)]
+    for r in (650, 700, 901, 1200):                                                 # records the breakages touch: give them bases and plain lines
+        recs[r] = b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % r
+    path = str(tmp_path / "bad.fq")
+    open(path, "wb").write(b"".join(BROKEN[kind](recs)))
+    code = r"""
+import sys, numpy as np
+import modimizer_amd as mg
+L = mg.lib()
+sh = mg.seqhashCreate(15, 4, 17); ms = mg.modsetCreate(sh, 20)
+with mg.CFile(sys.argv[2], "w") as f:
+    rc = L.mgAddSequenceFile(ms, sys.argv[1].encode(), f)
+mg.check(L.modsetSyncToHost(ms, 0))
+v, d, _ = mg.modset_arrays(ms)
+print("rc", rc, "max", ms.contents.max, "sum", int(v[1:].sum() % (1 << 61)), int(d[1:].astype(np.int64).sum()))
+"""
+    res = []
+    for host in ("1", "0"):
+        env = dict(os.environ, MODGPU_TEXT_HOST=host, MODGPU_TEXT_WINDOW_KB="8", MODGPU_FILE_BATCH_BASES="5000", PYTHONPATH=util.ROOT)
+        line = str(tmp_path / ("l%s.txt" % host))
+        r = subprocess.run([sys.executable, "-c", code, path, line], capture_output=True, text=True, env=env)
+        err = "\n".join(l for l in r.stderr.splitlines() if "amdgpu.ids" not in l)
+        res.append((r.returncode, r.stdout, err, open(line).read() if os.path.exists(line) else ""))
+    assert res[0] == res[1], res
+    if kind in ("no_plus", "no_at", "short_qual"):
+        assert res[0][0] != 0 and "FATAL ERROR" in res[0][2] and "line" in res[0][2]
+    else:
+        assert res[0][0] == 0 and "incomplete sequence record" in res[0][2]
+
+
 def test_device_parser_declines_what_it_does_not_take(golden_dir, tmp_path):
-    """gzip, FASTQ, an unterminated last line, a missing file: -2, so that mgAddSequenceFile goes to the host parser"""
-    for name in ("mixed.fa.gz", "mixed.fq", "unterminated.fa"):
+    """gzip, an unterminated last line, a missing file: -2, so that mgAddSequenceFile goes to the host parser"""
+    for name in ("mixed.fa.gz", "unterminated.fa"):
         rc, _ = device_records(os.path.join(golden_dir, name))
         assert rc == -2, name
     rc, _ = device_records(str(tmp_path / "nope.fa"))

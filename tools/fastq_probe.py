@@ -14,7 +14,7 @@ hdr = np.frombuffer(b"@r\n", np.uint8); plus = np.frombuffer(b"\n+\n", np.uint8)
 block = np.concatenate([np.tile(hdr, (n_reads, 1)), seqs, np.tile(plus, (n_reads, 1)), q, nl], axis=1)
 block.tofile(path); size = os.path.getsize(path); del block, seqs, q
 L = mg.lib()
-for threads in (1, 16):
+for threads in (16,):
     os.environ["MODGPU_PARSE_THREADS"] = str(threads)
     t0 = time.time(); r = L.mgSeqOpen(path.encode()); b = mg.MgSeqBatch(); tot = 0
     while L.mgSeqNextBatch(r, 512_000_000, C.byref(b)):
@@ -24,13 +24,14 @@ for threads in (1, 16):
 del os.environ["MODGPU_PARSE_THREADS"]
 if L.mgDeviceCount() > 0:
     sh = mg.seqhashCreate(31, 4, 17); ms = mg.modsetCreate(sh, 32)
-    for rep in range(2):
+    for host in ("1", "0", "0", "1", "0"):
+        os.environ["MODGPU_TEXT_HOST"] = host                      # 1: the host parser; 0: the text parsed on the device
         L.mgModsetClear(ms, None); t0 = time.time()
         with mg.CFile("/dev/null", "w") as f:
             rc = L.mgAddSequenceFile(ms, path.encode(), f)
             assert rc == 0, L.mgLastError().decode()
         dt = time.time() - t0
-        print("FASTQ file -> modset: %.2f s  %.2f Gbp/s (max %d)" % (dt, n_reads * rec / dt / 1e9, ms.contents.max))
+        print("FASTQ file -> modset (%s parser): %.3f s  %.2f Gbp/s (max %d)" % ("host" if host == "1" else "device", dt, n_reads * rec / dt / 1e9, ms.contents.max))
 # the same text as ordinary gzip (one zlib stream, the reference's path) and as blocked gzip (inflated by the pool)
 import gzip, struct, zlib
 raw = open(path, "rb").read()[: 300 * (1 << 20)]
