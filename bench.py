@@ -18,7 +18,8 @@ Launch: python bench.py [--gpus N --steps K --warmup W]
   --gpus N > 1 without WORLD_SIZE in the environment: this process starts N ranks (torch.distributed.run, one per GPU)
   BEFORE anything touches the GPU and passes their output through; under torch.distributed.run it is a rank itself.
 Environment overrides (for quick runs): MODGPU_BENCH_GBP, MODGPU_BENCH_BITS, MODGPU_CPU_SAMPLE_MBP,
-MODGPU_BENCH_FORCE_DIST=1 (run the N>1 code path at whatever world size, even 1).
+MODGPU_BENCH_FORCE_DIST=1 (run the N>1 code path at whatever world size, even 1); MODGPU_BENCH_ONE_GPU=1 (all ranks on cuda:0,
+gloo: the world > 1 code path on a one-GPU box, rates meaningless).
 """
 import argparse
 import ctypes as C
@@ -326,6 +327,11 @@ def gpu_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # MODGPU_BENCH_ONE_GPU=1: every rank on cuda:0 with the gloo backend (RCCL refuses two ranks on one device) — the
+    # world > 1 code path (shares, rank != 0 branches, barriers, collectives) checked on a one-GPU box; its rates mean nothing
+    one_gpu = os.environ.get("MODGPU_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     cx = Ctx()
     cx.torch, cx.dist, cx.mg, cx.synth = torch, dist, mg, synth
@@ -338,7 +344,10 @@ def gpu_rank(args):
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=cx.dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=cx.dev)
         # RCCL writes its version banner to stdout (C stdio, block-buffered on a pipe) when the communicator
         # comes up: bring it up and push the banner out now, so that rank 0's JSON line is the last line of stdout
         dist.barrier()

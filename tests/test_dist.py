@@ -186,6 +186,28 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert "error" not in c3 and c3["n_gpus"] == 1 and c3["value"] > 0 and 0.25 < c3["seed_hit_fraction"] < 0.45
 
 
+@pytest.mark.gpu
+def test_bench_world2_code_path_on_one_gpu():
+    """`python bench.py --gpus 2` with both ranks on cuda:0 (MODGPU_BENCH_ONE_GPU=1: gloo instead of RCCL, which refuses two
+    ranks on one device): the world > 1 branches a one-GPU box cannot otherwise reach -- block r on rank r, the summed histogram
+    holding both ranks' entries, the parity flag all-reduced over both, rank 1 waiting out rank 0's single-GPU leg, the query
+    reads split into two shares over replicated modsets.  The rates of such a run mean nothing and are not looked at."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MODGPU_BENCH_ONE_GPU="1", MODGPU_BENCH_GBP="0.3", MODGPU_BENCH_C3_SCALE="0.02", MODGPU_BENCH_C3_BATCHES="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                 # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "block r on rank r" in j["config"]["workload"]
+    c = j["collective"]
+    assert c["matches_local_sums"] is True and c["histogram_entries"] == c["entries_all_ranks"] > j["config"]["modset_entries"]
+    assert j["per_rank_parity"] is True and j["single_gpu_block_gbps"] > 0
+    c3 = j["other_configs"]["c3_sharded"]
+    assert "error" not in c3 and c3["n_gpus"] == 2 and c3["value"] > 0 and 0.25 < c3["seed_hit_fraction"] < 0.45
+
+
 def _gpu_count():
     try:
         import torch
