@@ -89,6 +89,15 @@ __device__ __forceinline__ U32 mgWaveInclusiveSum (U32 v)
 struct MgGeom { U32 R, rMask; int log2NB; int kbits; };      /* kbits = 2k */
 __device__ __forceinline__ U64 mgMixBits (U64 x, int b)        /* murmur-style bijection of b-bit values */
 {
+  if (b <= 32)                                                  /* the same function in 32-bit arithmetic: modulo 2^b only the multipliers' low words count */
+    { U32 y = (U32) x;
+      const U32 m32 = b >= 32 ? ~0u : (((U32) 1 << b) - 1);
+      const int h32 = (b + 1) >> 1;
+      y ^= y >> h32; y = (y * 0xed558ccdu) & m32;
+      y ^= y >> h32; y = (y * 0x1a85ec53u) & m32;
+      y ^= y >> h32;
+      return y;
+    }
   const U64 mask = b >= 64 ? ~0ull : (((U64) 1 << b) - 1);
   const int h = (b + 1) >> 1;
   x ^= x >> h; x = (x * 0xff51afd7ed558ccdull) & mask;
@@ -101,7 +110,7 @@ __device__ __forceinline__ U64 mgMixBits (U64 x, int b)        /* murmur-style b
  * the way (a full mix there would be two 64-bit multiplies in an instruction-bound kernel).  With x = (A : L), A the top
  * MG_MIX_TOP bits:  mix = (A ^ g(L)) : mixBits (L),  g(L) = top bits of a 32-bit multiplicative hash of L's low word.
  * A bijection: L comes back from its own mix, then A from the top part. */
-#define MG_MIX_TOP 9
+#define MG_MIX_TOP 10
 #define MG_MIX_MUL 0x9E3779B1u
 __device__ __forceinline__ U64 mgMixK (U64 x, int b)
 {
