@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""dev: a longer randomised run of tests/test_gpu_text.py's comparisons (device parser against host parser): random record counts,
+kinds, line ends, window and batch sizes.  usage: fuzz_text.py [seed] [trials]"""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests.test_gpu_text import crafted_fasta, crafted_fastq, device_records
+from tests.test_seqio import parse_file
+import modimizer_amd as mg
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+trials = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+rng = np.random.default_rng(seed)
+bad = 0
+with tempfile.TemporaryDirectory() as d:
+    for t in range(trials):
+        fq = rng.random() < 0.5
+        n_rec = int(rng.choice([1, 2, 7, 100, 1000, 5000]))
+        if fq:
+            crlf = bool(rng.random() < 0.3)
+            text = crafted_fastq(rng, n_rec, crlf, int(rng.choice([5, 40, 300, 3000])))
+        else:
+            text = crafted_fasta(rng, n_rec, str(rng.choice(["mixed", "tiny", "long"])))
+        path = os.path.join(d, "t.fq" if fq else "t.fa")
+        open(path, "wb").write(text)
+        _, want = parse_file(path, 1 << 40, 4)
+        env = {}
+        w = int(rng.choice([0, 4, 8, 12, 64, 1024])); b = int(rng.choice([0, 1, 500, 3000, 100000]))
+        if w: env["MODGPU_TEXT_WINDOW_KB"] = str(w)
+        if b: env["MODGPU_FILE_BATCH_BASES"] = str(b)
+        os.environ.update(env)
+        try:
+            rc, got = device_records(path)
+        finally:
+            for k in env: del os.environ[k]
+        ok = rc == 0 and len(got) == len(want) and all(np.array_equal(a & 3, c & 3) if fq else np.array_equal(a, c) for a, c in zip(got, want))
+        if not ok:
+            bad += 1
+            keep = "/tmp/fuzz_text_fail_%d_%d.%s" % (seed, t, "fq" if fq else "fa")
+            open(keep, "wb").write(text)
+            print("MISMATCH trial %d: %s n_rec %d window %d batch %d rc %d (%s) -> %s" % (t, "fastq" if fq else "fasta", n_rec, w, b, rc, mg.lib().mgLastError(), keep))
+print("fuzz_text seed %d: %d trials, %d mismatches" % (seed, trials, bad))
+sys.exit(1 if bad else 0)
