@@ -842,6 +842,9 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
 #ifndef MG_MERGE_PREFETCH
 #define MG_MERGE_PREFETCH 2          /* uniques per thread of the merge kernel fetched one bucket ahead */
 #endif
+#ifndef MG_HOT_DEPTH
+#define MG_HOT_DEPTH 4                /* occurrences per thread and turn of the dedup kernel's loop over what was not fetched ahead */
+#endif
 #define MG_RANK_GROUPS 64            /* most groups a bucket's list is cut into: slices of the ordinal range + 1 */
 #define MG_SLOT_SHIFT 48             /* a list entry's slot sits above this bit of its mixed k-mer (when 2k <= 48) */
 #define MG_DEDUP_PER 4               /* slots of the LDS image per thread of the dedup kernel: R <= 4 x threads ... */
@@ -873,6 +876,41 @@ __device__ __forceinline__ void mgDedupCount (const MgBucketArgs &a, U32 *sOrd, 
     }
   else atomicMax (&sOrd[at], tok);
   atomicAdd (&sCnt[at], 1u);
+}
+/* the largest value over the 64 lanes of a wave (DPP, as mgWaveInclusiveSum; every lane must be active) */
+__device__ __forceinline__ U32 mgWaveMax (U32 v)
+{
+#define MG_MAX_DPP(ctrl, rows) do { const U32 o_ = (U32) __builtin_amdgcn_update_dpp (0, (int) v, ctrl, rows, 0xf, false); v = o_ > v ? o_ : v; } while (0)
+  MG_MAX_DPP (0x111, 0xf); MG_MAX_DPP (0x112, 0xf); MG_MAX_DPP (0x114, 0xf); MG_MAX_DPP (0x118, 0xf); MG_MAX_DPP (0x142, 0xa); MG_MAX_DPP (0x143, 0xc);
+#undef MG_MAX_DPP
+  return (U32) __builtin_amdgcn_readlane ((int) v, 63);
+}
+/* A bucket's occurrences beyond the ones fetched ahead -- only a bucket with a k-mer of very many copies has any (a poly-A
+ * 21-mer is a modimizer at k = 21, d = 64, seed 17, and a human read set holds millions of them): a wave takes 64 of them at a
+ * time, and the lanes that landed in the same slot as its first lane are counted as ONE occurrence with their number -- the
+ * earliest of them stands for all at the slot's token, the others are not first occurrences (markDup: their flags are
+ * cleared) -- instead of 64 atomics queueing on one LDS word (1.7 ns per occurrence: 1.7 s for a batch of nothing but poly-A).
+ * Every lane of the wave calls this, `live` or not. */
+__device__ __forceinline__ void mgDedupCountWave (const MgBucketArgs &a, U32 *sOrd, U32 *sCnt, U32 R, bool live, U32 at, U32 ord)
+{
+  live = live && at < R;
+  const U32 at0 = (U32) __builtin_amdgcn_readfirstlane ((int) at);
+  const bool mine = live && at == at0;
+  const U32 n = (U32) __popcll (__ballot (mine));
+  if (n > 1)                                                   /* (uniform) */
+    { const U32 tok = mgToken (ord);
+      const U32 best = mgWaveMax (mine ? tok : 0u);
+      if (mine)
+        { if (tok == best)
+            { const U32 old = atomicMax (&sOrd[at], tok);
+              if (a.markDup) { const U32 loser = old > tok ? tok : old; if (loser) a.flags[0x7fffffffu - loser] = 0; }
+              atomicAdd (&sCnt[at], n);
+            }
+          else if (a.markDup) a.flags[ord] = 0;
+        }
+      else if (live) mgDedupCount (a, sOrd, sCnt, at, ord);
+    }
+  else if (live) mgDedupCount (a, sOrd, sCnt, at, ord);
 }
 
 template <bool PACKED, bool SLOT, int PER>       /* SLOT: a.slotShift != 0; PER: slots of the image per thread, R <= PER x threads */
@@ -939,18 +977,70 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #endif
                 else { mgDedupCount (a, sOrd, sCnt, at, ord); }
               }
-          for (U64 i = lo + (U64) MG_BUCKET_PREFETCH * T + tid ; i < hi ; i += T)
-            { U64 m; U32 ord; mgOccurrence<PACKED> (a, b, a.pK[i], PACKED ? 0u : a.pT[i], &m, &ord);
-              U32 at;
+          /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies), MG_HOT_DEPTH x T at a time; every
+             lane stays in the loop: the wave works together */
+          for (U64 i0 = lo + (U64) MG_BUCKET_PREFETCH * T ; i0 < hi ; i0 += (U64) MG_HOT_DEPTH * T)
+            { U64 x[MG_HOT_DEPTH]; U32 tx[MG_HOT_DEPTH]; bool live[MG_HOT_DEPTH];
+#pragma unroll
+              for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
+                { const U64 i = i0 + (U64) j * T + tid;
+                  live[j] = i < hi;
+                  x[j] = live[j] ? a.pK[i] : 0; tx[j] = (!PACKED && live[j]) ? a.pT[i] : 0;
+                }
+              /* all of the wave's elements one k-mer (that of its first lane)?  Then one claim, one token, one count for all of them */
+              const int kShift = PACKED ? a.f.ordBits : 0;
+              const U64 x0 = mgUniform64 (x[0]); const U32 tx0 = (U32) __builtin_amdgcn_readfirstlane ((int) tx[0]);
+              bool same = true;
+#pragma unroll
+              for (int j = 0 ; j < MG_HOT_DEPTH ; ++j) if (live[j] && (x[j] >> kShift) != (x0 >> kShift)) same = false;
+              const bool first = __builtin_amdgcn_readfirstlane ((int) live[0]) != 0;
+              bool done = false;
+              if (first && __ballot (!same) == 0 MG_ABLATE_AND (!(a.debug & 6)))                     /* (uniform) */
+                { U64 m; U32 o0; mgOccurrence<PACKED> (a, b, x0, tx0, &m, &o0);
+                  const U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);          /* (every lane claims the same slot with the same key) */
+                  if (at < R)
+                    { U32 tok[MG_HOT_DEPTH], tmax = 0, cnt = 0;
+#pragma unroll
+                      for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
+                        { const U32 ord = PACKED ? (U32) (x[j] & (((U64) 1 << a.f.ordBits) - 1)) : tx[j];
+                          tok[j] = live[j] ? mgToken (ord) : 0u;
+                          if (tok[j] > tmax) tmax = tok[j];
+                          cnt += live[j] ? 1u : 0u;
+                        }
+                      const U32 best = mgWaveMax (tmax);
+                      const U32 total = (U32) __builtin_amdgcn_readlane ((int) mgWaveInclusiveSum (cnt), 63);
+                      if (cnt && tmax == best)                                                        /* (one lane: tokens are all different) */
+                        { const U32 old = atomicMax (&sOrd[at], best);
+                          if (a.markDup) { const U32 loser = old > best ? best : old; if (loser) a.flags[0x7fffffffu - loser] = 0; }
+                          atomicAdd (&sCnt[at], total);
+                        }
+                      if (a.markDup)
+                        {
+#pragma unroll
+                          for (int j = 0 ; j < MG_HOT_DEPTH ; ++j) if (live[j] && tok[j] != best) a.flags[0x7fffffffu - tok[j]] = 0;
+                        }
+                      done = true;
+                    }
+                }
+              if (!done)                                                                              /* (uniform) */
+                {
+#pragma unroll
+                  for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
+                    { U64 m = 0; U32 ord = 0, at = R;
+                      if (live[j])
+                        { mgOccurrence<PACKED> (a, b, x[j], tx[j], &m, &ord);
 #ifdef MG_ABLATE
-              if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
+                          if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
 #endif
-              at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
-              if (at == R) { a.counters[1] = 1; continue; }
+                          at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+                          if (at == R) a.counters[1] = 1;
+                        }
 #ifdef MG_ABLATE
-              if (a.debug & 2) { sOrd[at] = mgToken (ord); sCnt[at] = 1; continue; }
+                      if (a.debug & 2) { if (live[j] && at < R) { sOrd[at] = mgToken (ord); sCnt[at] = 1; } continue; }
 #endif
-              mgDedupCount (a, sOrd, sCnt, at, ord);
+                      mgDedupCountWave (a, sOrd, sCnt, R, live[j], at, ord);
+                    }
+                }
             }
           __syncthreads ();
           /* the uniques leave grouped (see MgBucketArgs).  Every thread takes its slots of the image into registers

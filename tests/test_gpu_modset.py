@@ -590,3 +590,48 @@ def test_histogram_kept_by_the_build(tmp_path):
     mg.check(L.modsetDepthHistogramDevice(ms, d_h.ptr, None))
     assert np.array_equal(d_h.to_numpy(np.uint64, 65536), want)
     L.modsetDestroy(ms); oms.close()
+
+
+def test_kmers_with_very_many_copies():
+    """bucketed path, the dedup kernel's loop over what was not fetched ahead (mg_table.hip, mgDedupCountWave / MG_HOT_DEPTH): buckets with
+    far more occurrences than a workgroup fetches ahead (3 per thread) -- thousands of copies of one read (whole waves of one k-mer),
+    poly-A stretches (every start a modimizer of one k-mer when it is one), and ordinary reads in between so that waves mix k-mers;
+    both flag polarities, both element formats, two batches (the second finds the hot k-mers already in the table).  Against the oracle:
+    value[], depth[] (saturating at 65 535: modutils.c:26) and index[]."""
+    import subprocess, sys, os
+    code = r"""
+import numpy as np, modimizer_amd as mg
+from oracle import pyoracle as po
+k, d = 21, 64
+sh = mg.seqhashCreate(k, d, 17); oh = po.Hasher(k, d, 17)
+rng = np.random.default_rng(9)
+hot = rng.integers(0, 4, 400).astype(np.uint8)
+reads = []
+for r in range(9000):
+    u = rng.random()
+    if u < 0.55: reads.append(hot)                                                     # one read, thousands of times
+    elif u < 0.75: reads.append(np.concatenate([rng.integers(0, 4, 30).astype(np.uint8), np.zeros(int(rng.integers(25, 400)), np.uint8), rng.integers(0, 4, 30).astype(np.uint8)]))   # poly-A inside a read
+    elif u < 0.80: reads.append(3 - hot[::-1])                                         # its reverse complement: the same k-mers
+    else: reads.append(rng.integers(0, 4, int(rng.integers(21, 800))).astype(np.uint8))
+offs = np.concatenate([[0], np.cumsum([len(x) for x in reads])]).astype(np.int64)
+b = np.concatenate(reads)
+bits = 20
+ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
+half = len(reads) // 2
+n = mg.add_sequence_batch(ms, b[:int(offs[half])], offs[:half + 1])
+n += mg.add_sequence_batch(ms, b, offs)
+t = sum(oms.add_sequence(x) for x in reads[:half]) + sum(oms.add_sequence(x) for x in reads)
+mg.check(mg.lib().modsetSyncToHost(ms, 1))
+v, dep, _ = mg.modset_arrays(ms)
+assert n == t and ms.contents.max == oms.max, (n, t, ms.contents.max, oms.max)
+assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(dep[1:], oms.depths()[1:])
+assert int(dep[1:].max()) == 65535                                                     # the hot k-mers saturate
+assert np.array_equal(np.ctypeslib.as_array(ms.contents.index, (1 << bits,)), oms.index_table())
+print("hot ok", n, oms.max)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knobs in ({}, {"MODGPU_FLAG_POLARITY": "0"}, {"MODGPU_FLAG_POLARITY": "1"}, {"MODGPU_PART_PACKED": "0", "MODGPU_FLAG_POLARITY": "1"},
+                  {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"}):
+        env = dict(os.environ, MODGPU_TABLE_PATH="bucket", PYTHONPATH=root, **knobs)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "hot ok" in r.stdout, (knobs, r.stdout[-300:], r.stderr[-1500:])
