@@ -87,7 +87,15 @@ __global__ void mgTableInsertKernel (MgSlot *__restrict__ slots, MgGeom g, const
       U32 v = slots[s].ord;                        /* tokens only grow: a stale read is only ever too small */
       U32 tok = mgToken (o);
       if (v < tok) atomicMax (&slots[s].ord, tok); /* an assigned index (bit 31) is never below a token */
-      if (withDepth) atomicAdd (&slots[s].cnt, 1u);
+      if (withDepth)
+        { /* the lanes of the wave that sit in the same slot as its first one add their number once: a run of one k-mer (64 consecutive
+             modimizers of a poly-A stretch are one) would otherwise queue 64 atomics on one word -- 12 ns per occurrence */
+          const U64 s0 = ((U64) (U32) __builtin_amdgcn_readfirstlane ((int) (U32) (s >> 32)) << 32) | (U32) __builtin_amdgcn_readfirstlane ((int) (U32) s);
+          const bool mine = s == s0;
+          const U64 grp = __ballot (mine);
+          if (!mine) atomicAdd (&slots[s].cnt, 1u);
+          else if ((threadIdx.x & 63) == (U32) __builtin_ctzll (grp)) atomicAdd (&slots[s].cnt, (U32) __popcll (grp));
+        }
       slotId[o] = (U32) s;
     }
 }

@@ -593,7 +593,7 @@ def test_histogram_kept_by_the_build(tmp_path):
 
 
 def test_kmers_with_very_many_copies():
-    """bucketed path, the dedup kernel's loop over what was not fetched ahead (mg_table.hip, mgDedupCountWave / MG_HOT_DEPTH): buckets with
+    """bucketed path (and, last, the atomic one), the dedup kernel's loop over what was not fetched ahead (mg_table.hip, mgDedupCountWave / MG_HOT_DEPTH): buckets with
     far more occurrences than a workgroup fetches ahead (3 per thread) -- thousands of copies of one read (whole waves of one k-mer),
     poly-A stretches (every start a modimizer of one k-mer when it is one), and ordinary reads in between so that waves mix k-mers;
     both flag polarities, both element formats, two batches (the second finds the hot k-mers already in the table).  Against the oracle:
@@ -631,7 +631,8 @@ print("hot ok", n, oms.max)
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for knobs in ({}, {"MODGPU_FLAG_POLARITY": "0"}, {"MODGPU_FLAG_POLARITY": "1"}, {"MODGPU_PART_PACKED": "0", "MODGPU_FLAG_POLARITY": "1"},
-                  {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"}):
-        env = dict(os.environ, MODGPU_TABLE_PATH="bucket", PYTHONPATH=root, **knobs)
+                  {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"},
+                  {"MODGPU_TABLE_PATH": "direct"}):            # the atomic path: a wave's lanes in one slot add their number once (mgTableInsertKernel)
+        env = dict(os.environ, PYTHONPATH=root, **dict({"MODGPU_TABLE_PATH": "bucket"}, **knobs))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "hot ok" in r.stdout, (knobs, r.stdout[-300:], r.stderr[-1500:])
