@@ -730,9 +730,13 @@ static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
   if (!want) want = 1;
   g.tilesPerBlock = (g.nTiles + want - 1) / want; if (!g.tilesPerBlock) g.tilesPerBlock = 1;
   g.nBlocks = (U32) ((g.nTiles + g.tilesPerBlock - 1) / g.tilesPerBlock); if (!g.nBlocks) g.nBlocks = 1;
-  /* a block's fair share of the caller's capacity plus slack, never more than its k-mer starts */
+  /* a block's fair share of the caller's capacity three times over, never more than its k-mer starts.  The room costs memory only
+     (a segment is read up to its count), and a worker's range is about one long read: reads from a satellite array whose monomer
+     is rich in modimizers, or with a long homopolymer, hold two or three times the average -- with an eighth of slack every real
+     batch had a worker that overflowed, and an overflow means the whole scan again with more room (tools/realistic_probe.py:
+     the scan 0.72 instead of 0.36 ms per Gbp) */
   U64 share = capacity / g.nBlocks;
-  U64 seg = share + share / 8 + 64;
+  U64 seg = 3 * share + 64;
   U64 most = g.tilesPerBlock * (U64) MG_TILE_BASES;
   g.segCap = seg < most ? seg : most;
   return g;
