@@ -37,6 +37,7 @@
  */
 #include <stdlib.h>
 #include "mg_common.h"
+#include <type_traits>
 
 #define MG_ASSIGNED 0x80000000u
 /* -DMG_BUILD_PRIO: the build's kernels raise their waves' issue priority (s_setprio 3).  An experiment of round 3 for running
@@ -518,7 +519,7 @@ __global__ void mgIndexFinishKernel (U32 *__restrict__ index, U64 n)
 /* ======================================================================================== */
 /* bucketed path, step 1: radix partition of (kmer, ordinal) by bucket id                     */
 
-#define MG_PART_CHUNK (2 * MG_PART_SUB)          /* elements per workgroup pass */
+#define MG_PART_CHUNK (2 * MG_PART_SUB)          /* elements per workgroup pass, at least (a pass with larger sub-chunks takes two of those) */
 #define MG_PART_MAXBINS 512
 
 /* What a partition pass reads and writes.  The first pass reads the dense k-mers (an element's ordinal is its
@@ -547,24 +548,24 @@ __device__ __forceinline__ U32 mgDigitOf (U64 x, const MgGeom &g, const MgPartFm
  * chunkBase[nSeg] = number of chunks, and behind that table (at MG_CHUNK_SEG_AT) the segment of every chunk, so
  * that a workgroup moving to its next chunk does two rounds of loads, not a binary search of dependent ones */
 #define MG_CHUNK_SEG_AT (MG_PART_MAXBINS + 2)
-__device__ __forceinline__ bool mgChunkRange (const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
+__device__ __forceinline__ bool mgChunkRange (const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg, U32 chunkElems,
                                               U32 chunk, U32 *seg, U64 *lo, U64 *hi)
 {
   if (chunk >= chunkBase[nSeg]) return false;
   const U32 a = chunkBase[MG_CHUNK_SEG_AT + chunk];
   *seg = a;
-  *lo = segStart[a] + (U64) (chunk - chunkBase[a]) * MG_PART_CHUNK;
+  *lo = segStart[a] + (U64) (chunk - chunkBase[a]) * chunkElems;
   U64 e = segStart[a + 1];
-  *hi = *lo + MG_PART_CHUNK < e ? *lo + MG_PART_CHUNK : e;
+  *hi = *lo + chunkElems < e ? *lo + chunkElems : e;
   return true;
 }
 
 __global__ __launch_bounds__ (MG_PART_MAXBINS)
-void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 *__restrict__ chunkBase)
+void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 chunkElems, U32 *__restrict__ chunkBase)
 {
   __shared__ U32 sS[MG_PART_MAXBINS];
   const U32 t = threadIdx.x;
-  U32 c = t < nSeg ? (U32) ((segStart[t + 1] - segStart[t] + MG_PART_CHUNK - 1) / MG_PART_CHUNK) : 0;
+  U32 c = t < nSeg ? (U32) ((segStart[t + 1] - segStart[t] + chunkElems - 1) / chunkElems) : 0;
   sS[t] = c;
   __syncthreads ();
   for (int off = 1 ; off < MG_PART_MAXBINS ; off <<= 1)
@@ -588,7 +589,7 @@ void mgPartChunksKernel (const U64 *__restrict__ segStart, U32 nSeg, U32 *__rest
 template <int MODE>
 __global__ __launch_bounds__ (256)
 void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, MgPartFmt f, int shift, U32 nBins,
-                       const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
+                       const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg, U32 chunkElems,
                        U32 *__restrict__ binCount)
 {
   MG_BUILD_PRIO ();
@@ -605,7 +606,7 @@ void mgPartHistKernel (const U64 *__restrict__ kIn, MgGeom g, MgPartFmt f, int s
   U32 curSeg = 0xffffffffu;
   for ( ; c < cEnd ; ++c)
     { U32 seg; U64 lo, hi;
-      if (!mgChunkRange (segStart, chunkBase, nSeg, c, &seg, &lo, &hi)) break;
+      if (!mgChunkRange (segStart, chunkBase, nSeg, chunkElems, c, &seg, &lo, &hi)) break;
       if (seg != curSeg && curSeg != 0xffffffffu)
         { __syncthreads ();
           for (U32 b = threadIdx.x ; b < nBins ; b += 256) { U32 v = sH[b]; if (v) { atomicAdd (&binCount[(U64) curSeg * nBins + b], v); sH[b] = 0; } }
@@ -659,9 +660,13 @@ void mgPartScanKernel (const U32 *__restrict__ binCount, U32 nBins, const U64 *_
 #ifndef MG_PART_THREADS
 #define MG_PART_THREADS 1024
 #endif
-#define MG_PART_PER_THREAD (MG_PART_SUB / MG_PART_THREADS)
+/* Sub-chunks of MG_PART_SUB_BIG elements where they fit the LDS -- one packed 8-byte word per element, at most 256 bins, so that a staged
+ * element's digit is one byte: 152 KB.  A bin's run is then 64 elements (512 bytes) instead of 32, and the barriers, the scan of the
+ * counts and the reservations are paid once per 16384 elements: the two passes 1.335 -> 1.235 ms at config 2. */
+#define MG_PART_SUB_BIG (2 * MG_PART_SUB)
+#define MG_PART_BIG_BINS 256
 /* the elements [sub, subHi) of a sub-chunk into registers, MG_PART_THREADS apart */
-template <int INMODE>
+template <int INMODE, int SUB>
 __device__ __forceinline__ void mgPartFetch (U64 *km, U32 *tk, const U64 *__restrict__ kIn, const U32 *__restrict__ tIn,
                                              const MgSegSrc &src, const MgSubSeg *__restrict__ subSeg, U64 sub, U64 subHi, int tid)
 {
@@ -671,7 +676,7 @@ __device__ __forceinline__ void mgPartFetch (U64 *km, U32 *tk, const U64 *__rest
       MgSegCursor cur;
       mgSegCursorFrom (subSeg, sub / MG_PART_SUB, &cur);            /* the first partition pass has one segment [0, n): sub is a multiple of MG_PART_SUB */
 #pragma unroll
-      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+      for (int j = 0 ; j < SUB / MG_PART_THREADS ; ++j)
         { const U64 o0 = sub + (U64) j * MG_PART_THREADS + (U64) wave * 64;
           if (o0 >= subHi) break;                                     /* uniform */
           mgSegCursorSeek (src, &cur, o0);
@@ -682,26 +687,31 @@ __device__ __forceinline__ void mgPartFetch (U64 *km, U32 *tk, const U64 *__rest
       return;
     }
 #pragma unroll
-  for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+  for (int j = 0 ; j < SUB / MG_PART_THREADS ; ++j)
     { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
       if (i < subHi) { km[j] = kIn[i]; if (INMODE == MG_EL_WIDE) tk[j] = tIn[i]; }
     }
 }
 
-template <int INMODE, bool PACKOUT>     /* INMODE: what kIn holds; PACKOUT: one packed word out, otherwise (mixed k-mer, ordinal) */
+template <int INMODE, bool PACKOUT, int SUB>     /* INMODE: what kIn holds; PACKOUT: one packed word out, otherwise (mixed k-mer, ordinal); SUB: elements of a sub-chunk */
 __global__ __launch_bounds__ (MG_PART_THREADS)
 void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, const MgSegSrc src, const MgSubSeg *__restrict__ subSeg,
                           MgGeom g, MgPartFmt f, int shift, U32 nBins,
-                          const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg,
+                          const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg, U32 chunkElems,
                           unsigned long long *__restrict__ cursor, U32 cstride, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
 {
   MG_BUILD_PRIO ();
   constexpr bool WIDE = !PACKOUT;
-  __shared__ U64 stK[MG_PART_SUB];
-  __shared__ U32 stT[WIDE ? MG_PART_SUB : 1];
-  __shared__ unsigned short stB[MG_PART_SUB];
-  __shared__ U32 sH[MG_PART_MAXBINS], sOff[MG_PART_MAXBINS];
-  __shared__ unsigned long long sBase[MG_PART_MAXBINS];
+  constexpr bool BIG = SUB > MG_PART_SUB;
+  constexpr int PER = SUB / MG_PART_THREADS;
+  constexpr int BINS = BIG ? MG_PART_BIG_BINS : MG_PART_MAXBINS;
+  static_assert (!BIG || PACKOUT, "large sub-chunks: packed elements only");
+  typedef typename std::conditional<BIG, unsigned char, unsigned short>::type Digit;
+  __shared__ U64 stK[SUB];
+  __shared__ U32 stT[WIDE ? SUB : 1];
+  __shared__ Digit stB[SUB];
+  __shared__ U32 sH[BINS], sOff[BINS];
+  __shared__ unsigned long long sBase[BINS];
   __shared__ U32 sWave[MG_PART_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const U64 remMask = f.remBits >= 64 ? ~0ull : (((U64) 1 << f.remBits) - 1);
@@ -709,26 +719,26 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
      of the next sub-chunk are already on their way into registers while the current one is written out (one
      workgroup fills a CU's LDS, so nothing else would hide that latency). */
   U32 c = blockIdx.x, seg; U64 lo, hi;
-  bool have = mgChunkRange (segStart, chunkBase, nSeg, c, &seg, &lo, &hi);
+  bool have = mgChunkRange (segStart, chunkBase, nSeg, chunkElems, c, &seg, &lo, &hi);
   U64 sub = have ? lo : 0;
-  U64 km[MG_PART_PER_THREAD]; U32 tk[MG_PART_PER_THREAD];
+  U64 km[PER]; U32 tk[PER];
 #pragma unroll
-  for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j) { km[j] = 0; tk[j] = 0; }
+  for (int j = 0 ; j < PER ; ++j) { km[j] = 0; tk[j] = 0; }
   if (have)
-    { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
-      mgPartFetch<INMODE> (km, tk, kIn, tIn, src, subSeg, sub, subHi, tid);
+    { const U64 subHi = sub + SUB < hi ? sub + SUB : hi;
+      mgPartFetch<INMODE, SUB> (km, tk, kIn, tIn, src, subSeg, sub, subHi, tid);
     }
   while (have)
-    { const U64 subHi = sub + MG_PART_SUB < hi ? sub + MG_PART_SUB : hi;
+    { const U64 subHi = sub + SUB < hi ? sub + SUB : hi;
       const U32 cnt = (U32) (subHi - sub);
       /* what comes after this sub-chunk */
-      U32 nc = c, nseg = seg; U64 nlo = lo, nhi = hi, nsub = sub + MG_PART_SUB; bool nhave = true;
-      if (nsub >= hi) { nc = c + gridDim.x; nhave = mgChunkRange (segStart, chunkBase, nSeg, nc, &nseg, &nlo, &nhi); nsub = nlo; }
+      U32 nc = c, nseg = seg; U64 nlo = lo, nhi = hi, nsub = sub + SUB; bool nhave = true;
+      if (nsub >= hi) { nc = c + gridDim.x; nhave = mgChunkRange (segStart, chunkBase, nSeg, chunkElems, nc, &nseg, &nlo, &nhi); nsub = nlo; }
       for (U32 b = tid ; b < nBins ; b += MG_PART_THREADS) sH[b] = 0;
       __syncthreads ();
-      U32 dr[MG_PART_PER_THREAD];
+      U32 dr[PER];
 #pragma unroll
-      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+      for (int j = 0 ; j < PER ; ++j)
         { U64 i = sub + (U64) j * MG_PART_THREADS + tid;
           dr[j] = 0xffffffffu;
           if (i < subHi)
@@ -764,17 +774,17 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
       }
       __syncthreads ();
 #pragma unroll
-      for (int j = 0 ; j < MG_PART_PER_THREAD ; ++j)
+      for (int j = 0 ; j < PER ; ++j)
         if (dr[j] != 0xffffffffu)
           { U32 d = dr[j] >> 16, p = sOff[d] + (dr[j] & 0xffffu);
-            stK[p] = km[j]; if (WIDE) stT[p] = tk[j]; stB[p] = (unsigned short) d;
+            stK[p] = km[j]; if (WIDE) stT[p] = tk[j]; stB[p] = (Digit) d;
           }
       if ((U32) (2 * tid) < nBins) sBase[2 * tid] = base0;
       if ((U32) (2 * tid + 1) < nBins) sBase[2 * tid + 1] = base1;
       /* the registers are free: fetch the next sub-chunk */
       if (nhave)
-        { const U64 nsubHi = nsub + MG_PART_SUB < nhi ? nsub + MG_PART_SUB : nhi;
-          mgPartFetch<INMODE> (km, tk, kIn, tIn, src, subSeg, nsub, nsubHi, tid);
+        { const U64 nsubHi = nsub + SUB < nhi ? nsub + SUB : nhi;
+          mgPartFetch<INMODE, SUB> (km, tk, kIn, tIn, src, subSeg, nsub, nsubHi, tid);
         }
       __syncthreads ();
       for (U32 p = tid ; p < cnt ; p += MG_PART_THREADS)
@@ -1348,29 +1358,35 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
     }
   if (counted) MG_HIP (hipMemcpy2DAsync (binCount, sizeof (U32), counted, MG_HIST_STRIDE * sizeof (U32), sizeof (U32), nBins, hipMemcpyDeviceToDevice, st));   /* the scan counted them */
   else MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
-  MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkBase);
-  unsigned maxChunks = (unsigned) (n / MG_PART_CHUNK + nSeg + 1);
+  /* large sub-chunks where the kernel has them: packed elements, at most 256 bins */
+  static int bigEnv = -1; if (bigEnv < 0) { const char *e = getenv ("MODGPU_PART_BIG"); bigEnv = e ? atoi (e) : 1; }      /* test knob: 0 = sub-chunks of MG_PART_SUB everywhere */
+  const bool big = bigEnv && packed && nBins <= MG_PART_BIG_BINS && MG_PART_THREADS == 1024;
+  const U32 chunkElems = 2u * (U32) (big ? MG_PART_SUB_BIG : MG_PART_SUB);
+  MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkElems, chunkBase);
+  unsigned maxChunks = (unsigned) (n / chunkElems + nSeg + 1);
   static int sgEnv = -1; if (sgEnv < 0) { const char *e = getenv ("MODGPU_SCATTER_GRID"); sgEnv = e ? atoi (e) : 0; }   /* dev knob */
   unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
   const dim3 hg (maxChunks < 4096 ? maxChunks : 4096), sg (scatterGrid);
   if (!counted)
     { if (inMode == MG_EL_DENSE)
-        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_DENSE>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, binCount);
+        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_DENSE>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, binCount);
       else if (inMode == MG_EL_WIDE)
-        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_WIDE>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, binCount);
+        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_WIDE>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, binCount);
       else
-        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_PACKED>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, binCount);
+        MG_LAUNCH (MG_K_PART_HIST, st, mgPartHistKernel<MG_EL_PACKED>, hg, dim3 (256), 0, st, kIn, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, binCount);
     }
   /* one segment (the first pass): every workgroup reserves in the same few hundred cursors -- one cache line each
      (scatter 0.88 -> 0.73 ms: returning atomics on cursors that share a line queue behind each other) */
   const U32 cstride = nSeg == 1 ? 16u : 1u;                  /* (the second pass's 65536 cursors: no gain from padding) */
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, cstride, nSeg, n);
-#define MG_SCATTER(IN, PK) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK>), sg, dim3 (MG_PART_THREADS), 0, st, \
-                                      kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, cursor, cstride, kOut, tOut)
-  if (inMode == MG_EL_DENSE) { if (packed) MG_SCATTER (MG_EL_DENSE, true); else MG_SCATTER (MG_EL_DENSE, false); }
-  else if (inMode == MG_EL_SEG) { if (packed) MG_SCATTER (MG_EL_SEG, true); else MG_SCATTER (MG_EL_SEG, false); }
-  else if (inMode == MG_EL_WIDE) MG_SCATTER (MG_EL_WIDE, false);
-  else MG_SCATTER (MG_EL_PACKED, true);
+#define MG_SCATTER(IN, PK, SUB) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK, SUB>), sg, dim3 (MG_PART_THREADS), 0, st, \
+                                           kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, cursor, cstride, kOut, tOut)
+#define MG_SCATTER_P(IN) do { if (big) MG_SCATTER (IN, true, MG_PART_SUB_BIG); else MG_SCATTER (IN, true, MG_PART_SUB); } while (0)
+  if (inMode == MG_EL_DENSE) { if (packed) MG_SCATTER_P (MG_EL_DENSE); else MG_SCATTER (MG_EL_DENSE, false, MG_PART_SUB); }
+  else if (inMode == MG_EL_SEG) { if (packed) MG_SCATTER_P (MG_EL_SEG); else MG_SCATTER (MG_EL_SEG, false, MG_PART_SUB); }
+  else if (inMode == MG_EL_WIDE) MG_SCATTER (MG_EL_WIDE, false, MG_PART_SUB);
+  else MG_SCATTER_P (MG_EL_PACKED);
+#undef MG_SCATTER_P
 #undef MG_SCATTER
   MG_HIP (hipGetLastError ());
   return MG_OK;

@@ -434,7 +434,8 @@ print("slices ok", n)
     # 2^18 buckets) -- forced on this small table: the dedup kernel's threads then hold eight slots each (its second instance),
     # in both flag polarities and with the merge kernel taking the dedup kernel's slots; and smaller buckets (256-thread shape)
     for knobs in ({"MODGPU_BUCKET_R": "8192"}, {"MODGPU_BUCKET_R": "8192", "MODGPU_FLAG_POLARITY": "1", "MODGPU_MERGE_SLOTS": "1"},
-                  {"MODGPU_BUCKET_R": "8192", "MODGPU_PART_PACKED": "0"}, {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"}):
+                  {"MODGPU_BUCKET_R": "8192", "MODGPU_PART_PACKED": "0"}, {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"},
+                  {"MODGPU_PART_BIG": "0"}):                     # the partition passes with sub-chunks of 8192 elements where they would take 16384
         env = dict(os.environ, MODGPU_TABLE_PATH="bucket", PYTHONPATH=root, **knobs)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "slices ok" in r.stdout, (knobs, r.stderr[-1500:])

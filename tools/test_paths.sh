@@ -15,3 +15,6 @@ for g in 3 50; do
 done
 echo "== MODGPU_SCAN_GENERIC=1"
 MODGPU_SCAN_GENERIC=1 python -m pytest tests/test_gpu_scan.py tests/test_gpu_modset.py -q -x 2>&1 | tail -2
+echo "== MODGPU_PART_BIG=0"
+MODGPU_PART_BIG=0 MODGPU_TABLE_PATH=bucket python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
+MODGPU_PART_BIG=0 MODGPU_TABLE_PATH=bucket python tests/fuzz_gpu.py 13 150 2>&1 | tail -2
