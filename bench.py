@@ -852,8 +852,11 @@ def dropin_unmodified(h, shm):
     if not all(os.path.exists(p) for p in progs.values()):
         return {"skipped": "oracle/_ref programs not present (built where the reference tree is)"}
     letters = np.frombuffer(b"ACGT", np.uint8)
-    out = {"what": "whole-program wall clock, `modutils -c 26 21 64 17 -a <file>`; Mbp/s = marginal (big file minus small file)"}
-    for tag, rl, mbp in (("reads_10kb", 10000, 200), ("reads_150b", 150, 30)):
+    out = {"what": "whole-program wall clock, `modutils -c 26 21 64 17 -a <file>`; Mbp/s = marginal (big file minus small file)",
+           "iterator_crossover_bases": int(__import__("modimizer_amd").lib().mgIterHostBelow(-1)),
+           "crossover_note": "modRCiterator scans reads shorter than this with the library's own scalar loop (a synchronous call cannot hide "
+                             "the 13-15 us of a kernel launch + poll), longer ones with one kernel launch (mg_host.c)"}
+    for tag, rl, mbp in (("reads_10kb", 10000, 400), ("reads_150b", 150, 400)):
         paths = []
         for frac in (20, 1):
             nb = min(len(h), int(mbp * 1e6) // frac) // rl * rl

@@ -75,7 +75,7 @@ EXPORTS = [
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
-    "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgIterScanHost", "mgIterHostBelow", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
@@ -118,6 +118,7 @@ def lib():
     sig("modRCiterator", IT, SH, vp, i32)
     sig("modRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
     sig("minimizerRCiterator", IT, SH, vp, i32)
+    sig("mgIterScanHost", vp, SH, vp, i32); sig("mgIterHostBelow", i32, i32)
     sig("minimizerRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
     sig("seqString", C.c_char_p, u64, i32)
     sig("mgSeqhashDestroy", None, SH); sig("mgSeqhashRCiteratorDestroy", None, IT)

@@ -1189,6 +1189,8 @@ extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **blkOut)
   return -1;
 }
 
+extern "C" int mgIterRequireDevice (void) { return mgEnsureDevice () ? -1 : 0; }
+
 extern "C" void mgIterReleaseBuffers (void) { if (gIt.dev >= 0) gIt.release (); }
 
 extern "C" void mgSeqReleaseBuffers (void);

@@ -98,11 +98,91 @@ static SeqhashRCiterator *iterAlloc (Seqhash *sh, char *s, int len)
   return si;
 }
 
+/* The latency switch of the per-read facade.  A synchronous call cannot hide a kernel launch: launch + poll of the
+ * one-launch iterator kernel cost 13-15 us whatever the read's length, and a read shorter than the crossover is
+ * scanned in less than that by one host core.  Reads below the crossover are therefore scanned right here, by the
+ * library's own scalar loop -- the semantics of seqhash.c:60-79,154-196 restated: roll the forward k-mer and its
+ * reverse complement, hash both (seqhash.h:58), the smaller hash picks the strand (ties -> reverse, seqhash.c:66-67),
+ * keep the start when hash % w == 0 (seqhash.c:170,190) -- into the same replay block the kernel writes.  Bases are
+ * taken modulo 4, as the packer takes them (mg_pack.c).  This is a dispatch by latency inside the scalar facade, not
+ * a fallback: modRCiterator still needs a HIP device (mgIterRequireDevice) and every batch entry point runs on it. */
+#define MG_ITER_HOST_BELOW_DEFAULT 4096
+static int gIterHostBelow = -1;
+static int iterHostBelow (void)
+{
+  if (gIterHostBelow < 0)
+    { const char *e = getenv ("MODGPU_ITER_HOST_BELOW");     /* tuning knob: 0 = every read through the kernel */
+      int v = e ? atoi (e) : MG_ITER_HOST_BELOW_DEFAULT;
+      gIterHostBelow = v < 0 ? 0 : v;
+    }
+  return gIterHostBelow;
+}
+
+/* the crossover in bases; below < 0 only asks.  Returns the value in force before the call. */
+int mgIterHostBelow (int below)
+{
+  const int was = iterHostBelow ();
+  if (below >= 0) gIterHostBelow = below;
+  return was;
+}
+
+/* the replay block {n, n k-mers, n pos | isF << 31} of one read; malloc()ed, exact size */
+U64 *mgIterScanHost (const Seqhash *sh, const char *s, int len)
+{
+  const int k = sh->k;
+  if (len < k)
+    { U64 *blk = (U64 *) xalloc (16, 0); blk[0] = 0; return blk; }
+  const U64 f1 = sh->factor1, mask = sh->mask;
+  const int shift1 = sh->shift1, topShift = 2 * (k - 1);
+  const U64 w = (U64) sh->w;
+  /* w = wOdd << wShift: hash % w == 0 iff the low wShift bits are zero and (hash >> wShift) * wOdd^-1 mod 2^64
+     is at most (2^64 - 1) / wOdd -- exact, no division in the loop */
+  int wShift = 0; U64 wOdd = w;
+  while (!(wOdd & 1)) { wOdd >>= 1; ++wShift; }
+  U64 inv = wOdd;                                        /* Newton: five steps double 3 correct bits to 64 and more */
+  for (int i = 0 ; i < 5 ; ++i) inv *= 2 - wOdd * inv;
+  const U64 lim = ~(U64) 0 / wOdd, lowMask = ((U64) 1 << wShift) - 1;
+  const size_t cap = (size_t) (len - k + 1);
+  U64 *blk = (U64 *) xalloc ((cap + 1) * 8 + cap * 4 + 8, 0);
+  U64 *km = blk + 1;
+  U32 stackPf[1024];
+  U32 *pf = cap <= 1024 ? stackPf : (U32 *) xalloc (cap * 4, 0);
+  const unsigned char *b = (const unsigned char *) s;
+  U64 h = 0, r = 0;
+  for (int i = 0 ; i < k - 1 ; ++i)
+    { const U64 x = b[i] & 3;
+      h = (h << 2) | x;
+      r = (r >> 2) | ((3 - x) << topShift);
+    }
+  size_t n = 0;
+  for (int i = k - 1 ; i < len ; ++i)
+    { const U64 x = b[i] & 3;
+      h = ((h << 2) & mask) | x;
+      r = (r >> 2) | ((3 - x) << topShift);
+      const U64 hF = (h * f1) >> shift1, hR = (r * f1) >> shift1;
+      const int isF = hF < hR;
+      const U64 hash = isF ? hF : hR;
+      if (!(hash & lowMask) && ((hash >> wShift) * inv) <= lim)
+        { km[n] = isF ? h : r;
+          pf[n] = (U32) (i - k + 1) | (isF ? MG_FWD_BIT : 0);
+          ++n;
+        }
+    }
+  blk[0] = n;
+  memcpy (km + n, pf, n * 4);
+  if (pf != stackPf) free (pf);
+  return blk;
+}
+
 SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len)
 {
   SeqhashRCiterator *si = iterAlloc (sh, s, len);
   U64 *blk = 0;
-  if (mgIterScan (sh, s, len, &blk)) die ("modRCiterator: GPU scan failed: %s", mgLastError ());
+  if (len < iterHostBelow ())
+    { if (mgIterRequireDevice ()) die ("modRCiterator: %s", mgLastError ());
+      blk = mgIterScanHost (sh, s, len);
+    }
+  else if (mgIterScan (sh, s, len, &blk)) die ("modRCiterator: GPU scan failed: %s", mgLastError ());
   si->hashBuf = blk;                       /* the replay block as the scan wrote it: no second copy */
   si->iMin = 0;
   si->isDone = (blk[0] == 0);

@@ -16,6 +16,7 @@ int  mgHookMergeDevice (Modset *ms1, Modset *ms2);   /* modsetMerge with ms1 on 
 int  mgHookPruneDevice (Modset *ms, int lo, int hi);  /* modsetDepthPrune on the device; 0 = done */
 /* one GPU scan of one read for the iterator facade: *blk = malloc()ed replay block {U64 n; U64 kmer[n]; U32 posF[n]} */
 int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **blk);
+int  mgIterRequireDevice (void);                   /* 0 when a HIP device is usable (cached); else the error is set */
 void mgIterReleaseBuffers (void);                  /* the calling thread's iterator scratch (pinned buffers, stream) */
 /* the same for the minimizer iterator: *rec = malloc()ed {U64 hash[n]; U32 posF[n]} */
 int  mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);

@@ -77,11 +77,13 @@ def test_batch_path_fails_loudly_without_device():
 
 
 @no_gpu
-def test_iterator_dies_without_device():
-    """modRCiterator is a GPU scan; with no device it die()s like every reference error (utils.c:19-30)"""
+@pytest.mark.parametrize("n", [100, 10000])
+def test_iterator_dies_without_device(n):
+    """modRCiterator needs a HIP device whichever leg a read's length selects (the scalar loop below the launch-latency
+    crossover, one kernel launch above it): with no device it die()s like every reference error (utils.c:19-30)"""
     code = ("import numpy as np, modimizer_amd as mg\n"
             "sh = mg.seqhashCreate(21, 64, 17)\n"
-            "mg.iterate(sh, np.zeros(100, np.uint8))\n")
+            "mg.iterate(sh, np.zeros(%d, np.uint8))\n" % n)
     env = dict(os.environ, MODGPU_NO_TORCH="1", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-    assert r.returncode != 0 and "FATAL ERROR" in r.stderr and "GPU scan failed" in r.stderr
+    assert r.returncode != 0 and "FATAL ERROR" in r.stderr and "modRCiterator" in r.stderr and "no HIP device" in r.stderr

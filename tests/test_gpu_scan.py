@@ -12,6 +12,7 @@ import util
 
 pytestmark = pytest.mark.gpu
 TILE = 4096            # MG_TILE_BASES (mg_common.h): k-mer starts per tile = one wavefront-worker's unit
+DEFAULT_BELOW = mg.lib().mgIterHostBelow(-1)     # modRCiterator's crossover in force at start-up (mg_host.c)
 
 
 def assert_batch_equal(sh, oh, reads):
@@ -34,9 +35,12 @@ def test_golden_vectors_batch_and_iterator(ci):
     for r, (name, b, gk, gp, gf) in enumerate(cases):
         s, e = st[r], st[r + 1]
         assert np.array_equal(km[s:e], gk) and np.array_equal(pos[s:e], gp) and np.array_equal(isf[s:e], gf), (ci, name)
-        # the per-read facade the reference callers use (modRCiterator/modRCnext)
-        a, p, f = mg.iterate(sh, b)
-        assert np.array_equal(a, gk) and np.array_equal(p, gp) and np.array_equal(f, gf), (ci, name, "iterator")
+        # the per-read facade the reference callers use (modRCiterator/modRCnext), both legs: every read through the
+        # kernel (crossover 0) and short reads through the scalar loop (the default crossover)
+        for below in (0, DEFAULT_BELOW):
+            mg.lib().mgIterHostBelow(below)
+            a, p, f = mg.iterate(sh, b)
+            assert np.array_equal(a, gk) and np.array_equal(p, gp) and np.array_equal(f, gf), (ci, name, "iterator", below)
 
 
 @pytest.mark.parametrize("k,w,seed", [(21, 64, 17), (31, 4, 17), (19, 31, 17), (16, 32, 0), (11, 1, 3),
@@ -369,10 +373,11 @@ def test_fuzz_small():
     assert "120 trials, 0 mismatches" in r.stdout, r.stdout[-500:]
 
 
-def _iterate_arrays(sh, bases):
+def _iterate_arrays(sh, bases, below=0):
     """modRCiterator / modRCnext over one read without a Python loop per modimizer: the replay block behind hashBuf
     (mg_host.c) is {n, n k-mers, n words pos | isF << 31}"""
     L = mg.lib()
+    L.mgIterHostBelow(below)                                                    # 0: every read through the kernel
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     it = L.modRCiterator(sh, bases.ctypes.data, len(bases))
     addr = it.contents.hashBuf                                                  # a void * in the binding
@@ -385,6 +390,7 @@ def _iterate_arrays(sh, bases):
         assert L.modRCnext(it, C.byref(u), C.byref(p), C.byref(f))
         assert u.value == int(km[i]) and p.value == int(pf[i] & mg.MG_POS_MASK) and bool(f.value) == bool(pf[i] >> 31)
     L.mgSeqhashRCiteratorDestroy(it)
+    L.mgIterHostBelow(DEFAULT_BELOW)
     return km, (pf & np.uint32(mg.MG_POS_MASK)).astype(np.int32), (pf >> 31).astype(np.uint8)
 
 
@@ -414,3 +420,29 @@ def test_iterator_one_launch_kernel_edges(k, w):
         a, p, f = _iterate_arrays(sh, b)
         ek, ep, ef = oh.scan(b)
         assert np.array_equal(a, ek) and np.array_equal(p, ep) and np.array_equal(f, ef), (k, w, n, i)
+
+
+@pytest.mark.parametrize("k,w", [(21, 64), (31, 4), (19, 31)])
+def test_iterator_latency_switch(k, w):
+    """modRCiterator picks its leg by length (mg_host.c): reads below the crossover take the library's scalar loop, the
+    others one kernel launch.  Lengths on both sides of several crossovers, both legs against the oracle and each other;
+    FASTQ-style bytes above 3 go modulo 4 on both legs."""
+    L = mg.lib()
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    rng = np.random.default_rng(k * 3 + w)
+    assert DEFAULT_BELOW > 0
+    for below in (DEFAULT_BELOW, 1, 151, 70000):
+        for n in sorted({0, k - 1, k, 150, 151, below - 1, below, below + 1, 5000, 9000}):
+            if n < 0:
+                continue
+            b = rng.integers(0, 4, n).astype(np.uint8)
+            ek, ep, ef = oh.scan(b)
+            for leg in (below, 0):
+                a, p, f = _iterate_arrays(sh, b, leg)
+                assert np.array_equal(a, ek) and np.array_equal(p, ep) and np.array_equal(f, ef), (k, w, n, below, leg)
+    b = rng.integers(0, 4, 6000).astype(np.uint8)
+    junk = b.copy(); junk[::5] |= 0xFC
+    ref = _iterate_arrays(sh, b, 0)
+    for leg in (0, 1 << 20):
+        assert all(np.array_equal(x, y) for x, y in zip(ref, _iterate_arrays(sh, junk, leg)))
+    assert L.mgIterHostBelow(-1) == DEFAULT_BELOW
