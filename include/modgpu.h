@@ -70,13 +70,13 @@ const char *mgVersion (void) ;
 
 /* The per-read facade's latency switch (seqhash.c:154-196 behind modRCiterator).  A synchronous per-read call cannot
  * hide a kernel launch (13-15 us launch + poll whatever the length), so modRCiterator scans reads shorter than
- * MODGPU_ITER_HOST_BELOW bases (default 4096; 0 = every read through the kernel) with the library's own scalar loop and
+ * MODGPU_ITER_HOST_BELOW bases (default: the measured crossover, 12288, or 8192 where w < 16; 0 = every read through the kernel) with the library's own scalar loop and
  * longer ones with one kernel launch; both write the same replay block.  mgIterScanHost is that scalar loop by itself
  * (tests pin it to the golden vectors, the oracle and the compiled reference without a GPU): the malloc()ed block
  * {U64 n; U64 kmer[n]; U32 pos | isF << 31 [n]} of one read.  It is not a fallback: modRCiterator die()s without a HIP
  * device whatever the read's length, and no batch entry point ever takes it. */
 U64 *mgIterScanHost (const Seqhash *sh, const char *s, int len) ;
-int  mgIterHostBelow (int below) ;          /* sets the crossover in bases (below < 0: only asks); returns the one in force before */
+int  mgIterHostBelow (int below) ;          /* sets the crossover in bases (below < 0: only asks; 1 << 30: back to the defaults by w); returns the one in force before */
 
 /* Device memory helpers so a host language needs no other HIP binding. */
 MgStatus mgDeviceAlloc (void **dptr, size_t bytes) ;

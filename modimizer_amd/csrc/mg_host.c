@@ -106,23 +106,33 @@ static SeqhashRCiterator *iterAlloc (Seqhash *sh, char *s, int len)
  * keep the start when hash % w == 0 (seqhash.c:170,190) -- into the same replay block the kernel writes.  Bases are
  * taken modulo 4, as the packer takes them (mg_pack.c).  This is a dispatch by latency inside the scalar facade, not
  * a fallback: modRCiterator still needs a HIP device (mgIterRequireDevice) and every batch entry point runs on it. */
-#define MG_ITER_HOST_BELOW_DEFAULT 4096
-static int gIterHostBelow = -1;
-static int iterHostBelow (void)
+/* measured on the MI355X box (tools/iter_probe.c, profiles/r04_iter_probe.txt; us per call, host leg / kernel leg):
+ *   k=21 w=64:  150 b 0.28 / 12.7   4 kb 4.4 / 13.7   12 kb 12.9 / 14.2   16 kb 17.3 / 14.4   64 kb 69 / 22   250 kb 267 / 53
+ *   k=31 w=4:   150 b 0.63 / 15.9   4 kb 16 / 29      8 kb 31.7 / 32.1    12 kb 47.7 / 34.5   250 kb 1010 / 326
+ *   k=19 w=31:  12 kb 19.2 / 19.7   16 kb 25.6 / 20.1
+ * (the reference's own iterator: 0.71 us at 150 b, 56 us at 12 kb, 1144 us at 250 kb).  Dense selections (w < 16) cost the
+ * scalar loop more per base (stores, mispredicted branches), so their crossover is lower. */
+#define MG_ITER_HOST_BELOW_DEFAULT 12288
+#define MG_ITER_HOST_BELOW_DENSE    8192
+static int gIterHostBelow = -1;           /* -1: not looked up yet, -2: the defaults by w, >= 0: set (knob or mgIterHostBelow) */
+static int iterHostBelow (const Seqhash *sh)
 {
-  if (gIterHostBelow < 0)
+  if (gIterHostBelow == -1)
     { const char *e = getenv ("MODGPU_ITER_HOST_BELOW");     /* tuning knob: 0 = every read through the kernel */
-      int v = e ? atoi (e) : MG_ITER_HOST_BELOW_DEFAULT;
-      gIterHostBelow = v < 0 ? 0 : v;
+      gIterHostBelow = e ? (atoi (e) < 0 ? 0 : atoi (e)) : -2;
     }
-  return gIterHostBelow;
+  if (gIterHostBelow >= 0) return gIterHostBelow;
+  return sh && sh->w < 16 ? MG_ITER_HOST_BELOW_DENSE : MG_ITER_HOST_BELOW_DEFAULT;
 }
 
-/* the crossover in bases; below < 0 only asks.  Returns the value in force before the call. */
+/* the crossover in bases; below < 0 asks (the value for sparse selections when the defaults are in force), below >= 0
+   sets it for every hasher, MG_ITER_BELOW_DEFAULTS (1 << 30 and above) puts the defaults by w back.  Returns the value in
+   force before the call. */
 int mgIterHostBelow (int below)
 {
-  const int was = iterHostBelow ();
-  if (below >= 0) gIterHostBelow = below;
+  const int was = iterHostBelow (0);
+  if (below >= (1 << 30)) gIterHostBelow = -2;
+  else if (below >= 0) gIterHostBelow = below;
   return was;
 }
 
@@ -178,7 +188,7 @@ SeqhashRCiterator *modRCiterator (Seqhash *sh, char *s, int len)
 {
   SeqhashRCiterator *si = iterAlloc (sh, s, len);
   U64 *blk = 0;
-  if (len < iterHostBelow ())
+  if (len < iterHostBelow (sh))
     { if (mgIterRequireDevice ()) die ("modRCiterator: %s", mgLastError ());
       blk = mgIterScanHost (sh, s, len);
     }

@@ -172,3 +172,77 @@ const char *orcSeqString (uint64_t kmer, int len)
   for (int i = len - 1 ; i >= 0 ; --i) { buf[i] = acgt[kmer & 3]; kmer >>= 2; }
   return buf;
 }
+
+/* Whole-stream check for the full-size parity runs (tests/fullsize_whole.py): the reads of one piece of a batch
+ * (bases[], offsets[nReads + 1] relative to bases[0]) are scanned by orcScanRead's loop on nThreads threads and compared,
+ * modimizer by modimizer, with a stream given as arrays: read r's modimizers are km / posF [first[r], first[r + 1])
+ * (posF = pos | isF << 31).  Nothing is sampled.  Returns the number of reads that differ; *firstBad = the lowest such
+ * read (or -1), *nChecked = modimizers compared. */
+#include <pthread.h>
+typedef struct
+{ const OrcHasher *h; const uint8_t *bases; const int64_t *offsets; int64_t nReads;
+  const int64_t *first; const uint64_t *km; const uint32_t *posF;
+  int64_t *next; int64_t bad, firstBad, checked;
+} OrcCheckJob;
+
+static int64_t checkRead (const OrcHasher *h, const uint8_t *s, int64_t len, const uint64_t *km, const uint32_t *posF, int64_t want)
+{
+  int64_t n = 0;
+  if (len >= h->k)
+    { const uint64_t w = (uint64_t) h->w;
+      Pair p = firstPair (h, s);
+      for (int64_t i = 0 ; ; ++i)
+        { uint64_t hF = orcHash (h, p.F), hR = orcHash (h, p.R);
+          int fwd = hF < hR;
+          uint64_t hash = fwd ? hF : hR;
+          if (hash % w == 0)
+            { if (n >= want) return -1;
+              if (km[n] != (fwd ? p.F : p.R) || posF[n] != ((uint32_t) i | ((uint32_t) fwd << 31))) return -1;
+              ++n;
+            }
+          if (i + h->k >= len) break;
+          p = nextPair (h, p, s[i + h->k]);
+        }
+    }
+  return n == want ? n : -1;
+}
+
+static void *checkWorker (void *arg)
+{
+  OrcCheckJob *j = (OrcCheckJob *) arg;
+  for (;;)
+    { int64_t lo = __atomic_fetch_add (j->next, 64, __ATOMIC_RELAXED);
+      if (lo >= j->nReads) break;
+      int64_t hi = lo + 64 < j->nReads ? lo + 64 : j->nReads;
+      for (int64_t r = lo ; r < hi ; ++r)
+        { int64_t n = checkRead (j->h, j->bases + j->offsets[r], j->offsets[r + 1] - j->offsets[r],
+                                 j->km + j->first[r], j->posF + j->first[r], j->first[r + 1] - j->first[r]);
+          if (n < 0) { ++j->bad; if (j->firstBad < 0 || r < j->firstBad) j->firstBad = r; }
+          else j->checked += n;
+        }
+    }
+  return 0;
+}
+
+int64_t orcScanCheckMany (const OrcHasher *h, const uint8_t *bases, const int64_t *offsets, int64_t nReads,
+                          const int64_t *first, const uint64_t *km, const uint32_t *posF, int nThreads,
+                          int64_t *firstBad, int64_t *nChecked)
+{
+  if (nThreads < 1) nThreads = 1;
+  if (nThreads > 64) nThreads = 64;
+  OrcCheckJob job[64]; pthread_t th[64];
+  int64_t next = 0;
+  for (int t = 0 ; t < nThreads ; ++t)
+    { job[t] = (OrcCheckJob) { h, bases, offsets, nReads, first, km, posF, &next, 0, -1, 0 };
+      pthread_create (&th[t], 0, checkWorker, &job[t]);
+    }
+  int64_t bad = 0, fb = -1, chk = 0;
+  for (int t = 0 ; t < nThreads ; ++t)
+    { pthread_join (th[t], 0);
+      bad += job[t].bad; chk += job[t].checked;
+      if (job[t].firstBad >= 0 && (fb < 0 || job[t].firstBad < fb)) fb = job[t].firstBad;
+    }
+  if (firstBad) *firstBad = fb;
+  if (nChecked) *nChecked = chk;
+  return bad;
+}

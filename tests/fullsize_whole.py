@@ -6,8 +6,10 @@ What the reference defines (modset.c:45-62, modutils.c:19-31): entry i of value[
 (read,pos)-ordered modimizer stream (`++ms->max` at first sight), depth[i] the number of its occurrences, saturating at
 65 535 (modutils.c:26).  So, given the ordered stream, the whole of value[1..max] / depth[1..max] follows by sorting:
 np.unique(..., return_index, return_counts), entries ordered by first index.  The stream itself is the GPU scan's
-(seqhashScanBatchDevice: k-mer, pos|isF, read of every modimizer), and it is pinned to the oracle on reads sampled over
-the WHOLE batch plus whole-stream properties (reads non-decreasing, positions increasing inside a read).  The modset is
+(seqhashScanBatchDevice: k-mer, pos|isF, read of every modimizer), and it is pinned to the oracle ENTIRELY: the batch is
+unpacked to host bytes piece by piece and oracle/orc_seqhash.c orcScanCheckMany scans every read on the host's cores and
+compares every k-mer, position and strand (round 4; before: 1000 sampled reads), plus the whole-stream order properties
+(reads non-decreasing, positions increasing inside a read).  The modset is
 built by mgAddReadsDevice twice (clear in between): the second build runs in the configuration the library selects for
 itself in steady state (flag polarity and merge-slot choice follow what the previous add saw), which is the one bench.py
 times.  `flipped` forces the opposite polarity / merge-slot choice through the test knobs.
@@ -15,6 +17,11 @@ times.  `flipped` forces the opposite polarity / merge-slot choice through the t
 configs:  c2  BASELINE config 2 (10 Gbp ONT-like, k=21 d=64, table bits 30)
           c4  one GPU's block of config 4 (12.5 Gbp of the 100 Gbp set, 3.33 Gbp genome)
           c5  BASELINE config 5 (6 666 667 x 150 b, k=31 d=4, table bits 28)
+          c3ref  BASELINE config 3's reference: 24 x 125 Mbp built by mgReferenceRead (modmap.c:93-134, referencePack :74-91):
+                 value[], info copy classes, ref->index / offset / id of every occurrence, ref->depth, loc[] and rev[] -- all
+                 rebuilt on the host from the oracle-pinned stream and compared entirely
+          refdef the reference's default parameters (modmap.c:314-317, modutils.c:140: k=19, w=31, seed 17 -- the MG_MODE_ANY
+                 scan) on config 2's reads
 MODGPU_FULLSIZE_SCALE=<f> shrinks the workload (development on small boxes).
 """
 import ctypes as C
@@ -32,10 +39,11 @@ CONFIGS = {
     "c2": (21, 64, 30, 10_000_000_000, 333_333_333, 0.05, "ont", (4241, 4242, 4243)),
     "c4": (21, 64, 30, 12_500_000_000, 3_333_333_333, 0.05, "ont", (4241, 4242, 4243)),
     "c5": (31, 4, 28, 6_666_667 * 150, 20_000_000, 0.005, "fixed150", (555, 556, 557)),
+    "refdef": (19, 31, 30, 10_000_000_000, 333_333_333, 0.05, "ont", (4241, 4242, 4243)),
 }
 
 
-def first_occurrence_arrays(km):
+def first_occurrence_arrays(km, saturate=True):
     """value[1..] / depth[1..] that sequential insertion of the stream km produces: the distinct k-mers in order of first
     occurrence and their occurrence counts saturated at 65 535 (oracle/orc_modset.c orcFirstOccurrences: threads by hash class)"""
     from oracle import pyoracle as po
@@ -48,11 +56,130 @@ def first_occurrence_arrays(km):
     u = OL.orcFirstOccurrences(km.ctypes.data, n, threads, flag.ctypes.data, cnt.ctypes.data)
     assert u >= 0, "orcFirstOccurrences: allocation failed"
     f = flag.view(np.bool_)
-    return km[f], np.minimum(cnt[f], 65535).astype(np.uint16)
+    return km[f], (np.minimum(cnt[f], 65535).astype(np.uint16) if saturate else cnt[f])
+
+
+def check_whole_stream(L, mg, po, oh, d_r, offs64, n_reads, km, pf, first):
+    """the GPU's ordered modimizer stream (km, pf = pos | isF << 31; read r's are [first[r], first[r + 1])) against the
+    oracle's scan of EVERY read of the batch held packed at d_r; returns (modimizers compared, pieces)"""
+    OL = po.lib()
+    OL.orcScanCheckMany.restype = C.c_int64
+    OL.orcScanCheckMany.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    piece = int(float(os.environ.get("MODGPU_FULLSIZE_PIECE_GBP", "2")) * 1e9)
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    first64 = np.ascontiguousarray(first, dtype=np.int64)
+    km = np.ascontiguousarray(km); pf = np.ascontiguousarray(pf)
+    d_b = None
+    checked = pieces = 0
+    r0 = 0
+    while r0 < n_reads:
+        a = int(offs64[r0]); a16 = a - a % 16
+        r1 = int(np.searchsorted(offs64, a16 + piece, side="right")) - 1
+        r1 = min(max(r1, r0 + 1), n_reads)
+        nb = int(offs64[r1]) - a16
+        if d_b is None or nb > d_b.nbytes:
+            if d_b is not None:
+                d_b.free()
+            d_b = mg.DeviceBuffer(nb + nb // 8 + 4096)
+        mg.check(L.mgUnpackDevice(C.c_void_p(d_r.ptr.value + a16 // 4), nb, d_b.ptr, None))
+        bases = d_b.to_numpy(np.uint8, nb)
+        rel = np.ascontiguousarray(offs64[r0:r1 + 1] - a16)
+        fb = C.c_int64(-1); nchk = C.c_int64(0)
+        bad = OL.orcScanCheckMany(C.byref(oh.c), bases.ctypes.data, rel.ctypes.data, r1 - r0, first64[r0:].ctypes.data,
+                                  km.ctypes.data, pf.ctypes.data, threads, C.byref(fb), C.byref(nchk))
+        assert bad == 0, ("reads whose modimizers differ from the oracle's", int(bad), "first", r0 + int(fb.value))
+        checked += int(nchk.value); pieces += 1
+        del bases
+        r0 = r1
+    if d_b is not None:
+        d_b.free()
+    return checked, pieces
+
+
+def main_c3ref():
+    """config 3's reference at full size, every array"""
+    import modimizer_amd as mg
+    from oracle import pyoracle as po
+    L = mg.lib()
+    mg.check(L.mgSetDevice(0))
+    scale = float(os.environ.get("MODGPU_FULLSIZE_SCALE", "1"))
+    k, w, bits = 21, 64, 28
+    n_seq, seq_len = 24, int(125_000_000 * scale)
+    G = n_seq * seq_len
+    t0 = time.time()
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    d_g = mg.DeviceBuffer(L.mgPackedWords(G) * 4)
+    mg.check(L.mgSynthGenome(d_g.ptr, G, 333, None))
+    d_b = mg.DeviceBuffer(G)
+    mg.check(L.mgUnpackDevice(d_g.ptr, G, d_b.ptr, None))
+    genome = d_b.to_numpy(np.uint8, G); d_b.free()
+    ref_off = np.arange(n_seq + 1, dtype=np.int64) * seq_len
+    names = (C.c_char_p * n_seq)(*[b"chr%d" % (i + 1) for i in range(n_seq)])
+    ref = L.mgReferenceCreate(ms, 1 << 26)                              # modmap.c:363
+    with mg.CFile(os.devnull, "w") as f:
+        assert L.mgReferenceRead(ref, genome.ctypes.data, ref_off.ctypes.data, n_seq, names, True, f) == 0
+    R = C.cast(ref, C.POINTER(mg.MgReference)).contents
+    U, occ = ms.contents.max, R.max
+    t_build = time.time() - t0
+    # ---- the ordered stream of the 24 sequences from the scan entry point, pinned ENTIRELY to the oracle ------------
+    d_of = mg.DeviceBuffer.from_numpy(ref_off.astype(np.uint64))
+    cap = occ + 4096
+    d_k = mg.DeviceBuffer(cap * 8); d_p = mg.DeviceBuffer(cap * 4); d_i = mg.DeviceBuffer(cap * 4)
+    d_c = mg.DeviceBuffer(64); d_w = mg.DeviceBuffer(L.mgScanWorkBytes(G, n_seq, cap))
+    mg.check(L.seqhashScanBatchDevice(sh, d_g.ptr, G, d_of.ptr, n_seq, d_k.ptr, d_p.ptr, d_i.ptr, cap, d_c.ptr, d_w.ptr, None))
+    cnt = d_c.to_numpy(np.uint64, 4)
+    assert int(cnt[0]) == occ and int(cnt[1]) == 0, ("scan entry point and reference build disagree", cnt, occ)
+    km = d_k.to_numpy(np.uint64, occ); pf = d_p.to_numpy(np.uint32, occ); rd = d_i.to_numpy(np.uint32, occ)
+    for d in (d_k, d_p, d_i, d_c, d_w, d_of, d_g):
+        d.free()
+    first = np.searchsorted(rd, np.arange(n_seq + 1, dtype=np.uint32)).astype(np.int64)
+    OL = po.lib()
+    OL.orcScanCheckMany.restype = C.c_int64
+    OL.orcScanCheckMany.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    fb = C.c_int64(-1); nchk = C.c_int64(0)
+    bad = OL.orcScanCheckMany(C.byref(oh.c), genome.ctypes.data, ref_off.ctypes.data, n_seq, first.ctypes.data, km.ctypes.data,
+                              pf.ctypes.data, max(1, min(32, len(os.sched_getaffinity(0)))), C.byref(fb), C.byref(nchk))
+    assert bad == 0 and nchk.value == occ, ("sequences whose modimizers differ from the oracle's", int(bad), int(fb.value), nchk.value, occ)
+    del genome
+    t_scan = time.time() - t0 - t_build
+    # ---- what referenceFastaRead + referencePack make of that stream (modmap.c:106-133, 74-91), on the host ------------
+    want_value, want_cnt = first_occurrence_arrays(km, saturate=False)
+    assert len(want_value) == U, ("distinct modimizers", len(want_value), "entries", U)
+    as_np = lambda p, n, : np.ctypeslib.as_array(p, (n,))
+    assert np.array_equal(as_np(ms.contents.value, U + 1)[1:], want_value), "value[]"
+    order = np.argsort(want_value, kind="stable")
+    at = np.searchsorted(want_value[order], km)
+    occ_index = (order[at] + 1).astype(np.uint32)                        # modsetIndexFind's answer for every occurrence
+    assert np.array_equal(want_value[occ_index - 1], km)
+    assert np.array_equal(as_np(R.index, occ), occ_index), "ref->index"
+    assert np.array_equal(as_np(R.offset, occ), pf & np.uint32(mg.MG_POS_MASK)), "ref->offset"
+    assert np.array_equal(as_np(R.id, occ), rd), "ref->id"
+    depth = np.zeros(U + 1, np.uint32); depth[1:] = want_cnt
+    assert np.array_equal(as_np(R.depth, U + 1), depth), "ref->depth"
+    info = as_np(ms.contents.info, U + 1)[1:] & 3
+    assert np.array_equal(info, np.minimum(want_cnt, 3).astype(np.uint8)), "info copy classes (modmap.c:125-129)"
+    assert not as_np(ms.contents.depth, U + 1).any(), "ms->depth is not touched by referenceFastaRead"
+    loc = np.zeros(U + 1, np.uint32); loc[1:] = np.cumsum(depth[:-1], dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(as_np(R.loc, U + 1), loc), "loc[] (modmap.c:82-84)"
+    rev = np.argsort(occ_index, kind="stable").astype(np.uint32)          # occurrences grouped by index, in occurrence order
+    assert np.array_equal(as_np(R.rev, occ), rev), "rev[] (modmap.c:86-90)"
+    assert R.size == occ and ms.contents.size == U + 1                  # referencePack / modsetPack
+    n1, n2, nM = int((want_cnt == 1).sum()), int((want_cnt == 2).sum()), int((want_cnt > 2).sum())
+    L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+    print("fullsize_whole c3ref: %d bases in %d sequences, %d occurrences, %d entries (%d copy 1, %d copy 2, %d multiple): the whole "
+          "stream == oracle; value[], info, ref->index / offset / id / depth, loc[], rev[] pinned entirely; build %.1f s, "
+          "scan + oracle check %.1f s, host reconstruction %.1f s"
+          % (G, n_seq, occ, U, n1, n2, nM, t_build, t_scan, time.time() - t0 - t_build - t_scan))
+    print("FULLSIZE_WHOLE_OK")
 
 
 def main():
     name = sys.argv[1]
+    if name == "c3ref":
+        return main_c3ref()
     variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
     k, w, bits, total, G, err, kind, (sg, sp, se) = CONFIGS[name]
     scale = float(os.environ.get("MODGPU_FULLSIZE_SCALE", "1"))
@@ -119,29 +246,14 @@ def main():
     assert np.all(pos[1:][same] > pos[:-1][same])
     del same
     first = np.searchsorted(rd, np.arange(n_reads + 1, dtype=np.uint32))
-    # reads sampled over the WHOLE batch against the oracle: k-mers, positions, strands
-    rng = np.random.default_rng(11)
-    n_sample = 1000 if kind == "ont" else 20000
-    sample = np.unique(np.concatenate([[0, n_reads - 1], rng.integers(0, n_reads, n_sample - 2)]))
+    # EVERY read against the oracle: k-mers, positions, strands of the whole stream (round 4; it was a sample of 1000 reads).
+    # The batch is unpacked to host bytes in pieces of whole reads (<= MODGPU_FULLSIZE_PIECE_GBP, default 2 Gbp) and
+    # oracle/orc_seqhash.c orcScanCheckMany scans every read of a piece on all allowed cores and compares in place.
     oh = po.Hasher(k, w, 17)
     offs64 = offs.astype(np.int64)
-    d_b = mg.DeviceBuffer(1 << 20)
-    checked = 0
-    for r in sample:
-        a, b = int(offs64[r]), int(offs64[r + 1])
-        a16 = a - a % 16
-        nb = b - a16
-        if nb > d_b.nbytes:
-            d_b.free(); d_b = mg.DeviceBuffer(2 * nb)
-        mg.check(L.mgUnpackDevice(C.c_void_p(d_r.ptr.value + a16 // 4), nb, d_b.ptr, None))
-        bases = d_b.to_numpy(np.uint8, nb)[a - a16:]
-        ek, ep, ef = oh.scan(bases)
-        lo, hi = int(first[r]), int(first[r + 1])
-        assert hi - lo == len(ek), ("read", int(r), hi - lo, len(ek))
-        assert np.array_equal(km[lo:hi], ek) and np.array_equal(pos[lo:hi], ep.astype(np.uint32)) \
-            and np.array_equal((pf[lo:hi] >> 31).astype(np.uint8), ef), ("read", int(r))
-        checked += hi - lo
-    d_b.free(); d_r.free(); d_of.free()
+    checked, n_pieces = check_whole_stream(L, mg, po, oh, d_r, offs64, n_reads, km, pf, first)
+    assert checked == S, ("modimizers compared with the oracle", checked, "of", S)
+    d_r.free(); d_of.free()
     del pf, rd, pos, first
     t_scan = time.time() - t0 - t_build
 
@@ -153,8 +265,8 @@ def main():
     bad = np.flatnonzero(want_depth != depth)
     assert bad.size == 0, ("depth[] differs at", bad[:5] + 1, "of", U)
     print("fullsize_whole %s %s: %d bases, %d reads, %d modimizers, %d entries: value[] and depth[] pinned entirely; "
-          "%d sampled reads (%d modimizers) == oracle; build %.1f s, scan+sample %.1f s, host reconstruction %.1f s"
-          % (name, variant, total, n_reads, S, U, len(sample), checked, t_build, t_scan, time.time() - t0 - t_build - t_scan))
+          "ALL %d reads (%d modimizers, %d pieces) == oracle; build %.1f s, scan + oracle check %.1f s, host reconstruction %.1f s"
+          % (name, variant, total, n_reads, S, U, n_reads, checked, n_pieces, t_build, t_scan, time.time() - t0 - t_build - t_scan))
     print("FULLSIZE_WHOLE_OK")
 
 

@@ -257,7 +257,8 @@ def test_config3_full_size_reference_and_queries(tmp_path):
 @pytest.mark.parametrize("config", ["c2", "c4", "c5"])
 def test_whole_value_and_depth_arrays_at_full_size(config, variant):
     """EVERY index of value[] / depth[] at BASELINE size (1.03e8 entries of config 2, 1.65e8 of a config-4 block, 3.3e7 of
-    config 5): the GPU scan's ordered modimizer stream — pinned to the oracle on reads sampled across the whole batch —
+    config 5): the GPU scan's ordered modimizer stream — pinned to the oracle ENTIRELY (every read of the batch scanned by
+    oracle/orc_seqhash.c orcScanCheckMany on the host's cores and compared in place) —
     gives, by a host-side sort (first-occurrence order, counts saturated at 65 535: modset.c:57, modutils.c:26), the arrays
     the build must produce; compared entirely.  `auto`: the configuration the library selects in steady state (second of
     two builds: flag polarity and merge-slot choice follow the previous add), the one bench.py times; `flipped`: the other
@@ -265,5 +266,27 @@ def test_whole_value_and_depth_arrays_at_full_size(config, variant):
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), config, variant],
+                       capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
+    assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_config3_reference_arrays_whole_at_full_size():
+    """config 3's 3 Gbp reference (24 x 125 Mbp, mgReferenceRead = referenceFastaRead + referencePack, modmap.c:74-134): the
+    whole modimizer stream of the 24 sequences against the oracle, then value[], the info copy classes, ref->index / offset /
+    id of all 4.7e7 occurrences, ref->depth, loc[] and rev[] rebuilt on the host from that stream and compared entirely
+    (tests/fullsize_whole.py c3ref)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), "c3ref"],
+                       capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
+    assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_reference_default_parameters_whole_at_full_size():
+    """the reference's own defaults (modmap.c:314-317, modutils.c:140: k = 19, w = 31, seed 17 -- a non-power-of-two d, the
+    MG_MODE_ANY scan) on config 2's 10 Gbp of reads: whole stream against the oracle, whole value[] / depth[]"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), "refdef", "auto"],
                        capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
     assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

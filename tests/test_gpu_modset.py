@@ -637,3 +637,99 @@ print("hot ok", n, oms.max)
         env = dict(os.environ, PYTHONPATH=root, **dict({"MODGPU_TABLE_PATH": "bucket"}, **knobs))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "hot ok" in r.stdout, (knobs, r.stdout[-300:], r.stderr[-1500:])
+
+
+def _revcomp(b):
+    return (3 - b[::-1]).astype(np.uint8)
+
+
+def _mutate(rng, b, rate):
+    b = b.copy()
+    hit = rng.random(len(b)) < rate
+    b[hit] = (b[hit] + rng.integers(1, 4, int(hit.sum()))) % 4
+    return b
+
+
+@pytest.mark.parametrize("k,w,seed", [(15, 8, 17), (21, 64, 17), (19, 31, 17), (13, 4, 5), (17, 16, 17), (25, 11, 3)])
+def test_modmap_randomized_vs_oracle(k, w, seed, tmp_path):
+    """queryProcess (modmap.c:188-281) on randomized references and reads against the ORACLE's restatement of it
+    (oracle/orc_modset.c orcQueryRead, itself pinned to the reference program's golden Q / M lines), byte for byte: references
+    with duplicated and triplicated segments (copy-2 / copy-M classes, the second-copy retry of modmap.c:242-254), forward
+    and reverse-strand reads, substitutions, chimeric reads, reads stitched from up to 60 pieces (more M blocks than the
+    device chain kernel keeps per read: the overflow path), reads that hit nothing, reads shorter than k, empty reads.
+    6 parameter sets x 6 references x 7-9 reads = about 290 reads; the reference build's own report lines and arrays
+    (index / offset / id / depth / loc / rev, modmap.c:74-134) are compared on the way."""
+    L = mg.lib()
+    rng = np.random.default_rng(1000 * k + w)
+    n_reads_total = n_m_lines = n_overflow = 0
+    for trial in range(6):
+        # ---- a reference of 1-3 sequences with copies of segments inside and across sequences -----------------------
+        n_seq = int(rng.integers(1, 4))
+        seqs = [rng.integers(0, 4, int(rng.integers(30_000, 90_000))).astype(np.uint8) for _ in range(n_seq)]
+        for _ in range(int(rng.integers(2, 6))):
+            src = seqs[int(rng.integers(0, n_seq))]
+            ln = int(rng.integers(300, 6000))
+            a = int(rng.integers(0, len(src) - ln))
+            piece = src[a:a + ln].copy()
+            if rng.random() < 0.4:
+                piece = _revcomp(piece)
+            for _copy in range(int(rng.integers(1, 3))):               # one or two extra copies: copy 2 / copy M
+                dst = seqs[int(rng.integers(0, n_seq))]
+                b = int(rng.integers(0, len(dst) - ln))
+                dst[b:b + ln] = _mutate(rng, piece, 0.002 * rng.random())
+        names = ["s%d_%d" % (trial, i) for i in range(n_seq)]
+        g = np.concatenate(seqs)
+        # ---- reads --------------------------------------------------------------------------------------------------
+        def cut(ln):
+            s = seqs[int(rng.integers(0, n_seq))]
+            ln = min(ln, len(s) - 1)
+            a = int(rng.integers(0, len(s) - ln))
+            r = s[a:a + ln]
+            return _revcomp(r) if rng.random() < 0.5 else r.copy()
+        reads = [cut(int(rng.integers(2000, 20000))),                                        # plain
+                 _mutate(rng, cut(int(rng.integers(3000, 15000))), 0.03),                       # substitutions
+                 np.concatenate([cut(int(rng.integers(1500, 6000))) for _ in range(int(rng.integers(2, 5)))]),   # chimeric
+                 np.concatenate([cut(int(rng.integers(700, 2500))) for _ in range(int(rng.integers(20, 61)))]),  # > 16 blocks
+                 rng.integers(0, 4, int(rng.integers(500, 5000))).astype(np.uint8),           # hits nothing
+                 cut(k - 1) if trial % 2 else np.zeros(0, np.uint8),                           # shorter than k / empty
+                 np.concatenate([cut(4000), rng.integers(0, 4, 800).astype(np.uint8), cut(4000)])]               # a gap of junk
+        if trial % 3 == 0:
+            reads.append(_mutate(rng, np.concatenate([cut(900) for _ in range(25)]), 0.01))
+            reads.append(np.zeros(3000, np.uint8))                                             # poly-A
+        rnames = ["q%d_%d" % (trial, i) for i in range(len(reads))]
+        # ---- oracle -------------------------------------------------------------------------------------------------
+        oh = po.Hasher(k, w, seed); oms = po.Modset(oh, 20); oref = po.Reference(oms)
+        for nm, s in zip(names, seqs):
+            oref.add_sequence(nm, s)
+        oref.finish()
+        want = "".join(oref.query(nm, r, str(tmp_path / "o.txt"))[0] for nm, r in zip(rnames, reads))
+        oa = oref.arrays()
+        # ---- the library --------------------------------------------------------------------------------------------
+        sh = mg.seqhashCreate(k, w, seed); ms = mg.modsetCreate(sh, 20)
+        ref = L.mgReferenceCreate(ms, 1 << 26)
+        offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+        cn = (C.c_char_p * n_seq)(*[n.encode() for n in names])
+        with mg.CFile(str(tmp_path / "r.txt"), "w") as f:
+            assert L.mgReferenceRead(ref, g.ctypes.data, offs.ctypes.data, n_seq, cn, True, f) == 0
+        R = C.cast(ref, C.POINTER(mg.MgReference)).contents
+        U, occ = ms.contents.max, R.max
+        assert U == oms.max and occ == len(oa["index"])
+        as_np = lambda p, n: np.ctypeslib.as_array(p, (max(n, 1),))[:n]
+        for key, n in (("index", occ), ("offset", occ), ("id", occ), ("rev", occ), ("depth", U + 1), ("loc", U + 1)):
+            assert np.array_equal(as_np(getattr(R, key), n), oa[key]), (trial, key)
+        assert np.array_equal(as_np(ms.contents.value, U + 1)[1:], oms.values()[1:])
+        assert np.array_equal(as_np(ms.contents.info, U + 1)[1:], oms.infos()[1:])           # copy classes, modmap.c:125-129
+        qb, qo = util.concat_reads(reads)
+        cq = (C.c_char_p * len(reads))(*[n.encode() for n in rnames])
+        out = str(tmp_path / "q.txt")
+        with mg.CFile(out, "w") as f:
+            assert L.mgQueryProcess(ref, qb.ctypes.data, qo.ctypes.data, len(reads), cq, f) == 0
+        got = open(out).read()
+        assert got == want, (k, w, trial, [x for x in zip(got.splitlines(), want.splitlines()) if x[0] != x[1]][:3])
+        n_reads_total += len(reads)
+        n_m_lines += sum(l.startswith("M\t") for l in want.splitlines())
+        n_overflow += sum(sum(l.startswith("M\t%s\t" % nm) for l in want.splitlines()) > 16 for nm in rnames)
+        L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+        oref.close()
+    assert n_reads_total >= 42 and n_m_lines > 20
+    assert n_overflow >= 1 or w >= 31, "no read with more than 16 M blocks: the overflow path was not exercised"

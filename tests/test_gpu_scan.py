@@ -37,8 +37,8 @@ def test_golden_vectors_batch_and_iterator(ci):
         assert np.array_equal(km[s:e], gk) and np.array_equal(pos[s:e], gp) and np.array_equal(isf[s:e], gf), (ci, name)
         # the per-read facade the reference callers use (modRCiterator/modRCnext), both legs: every read through the
         # kernel (crossover 0) and short reads through the scalar loop (the default crossover)
-        for below in (0, DEFAULT_BELOW):
-            mg.lib().mgIterHostBelow(below)
+        for below in (0, 1 << 30):
+            mg.lib().mgIterHostBelow(below)                                 # 1 << 30: the defaults
             a, p, f = mg.iterate(sh, b)
             assert np.array_equal(a, gk) and np.array_equal(p, gp) and np.array_equal(f, gf), (ci, name, "iterator", below)
 
@@ -390,7 +390,7 @@ def _iterate_arrays(sh, bases, below=0):
         assert L.modRCnext(it, C.byref(u), C.byref(p), C.byref(f))
         assert u.value == int(km[i]) and p.value == int(pf[i] & mg.MG_POS_MASK) and bool(f.value) == bool(pf[i] >> 31)
     L.mgSeqhashRCiteratorDestroy(it)
-    L.mgIterHostBelow(DEFAULT_BELOW)
+    L.mgIterHostBelow(1 << 30)                                                  # back to the defaults by w
     return km, (pf & np.uint32(mg.MG_POS_MASK)).astype(np.int32), (pf >> 31).astype(np.uint8)
 
 
@@ -432,7 +432,7 @@ def test_iterator_latency_switch(k, w):
     rng = np.random.default_rng(k * 3 + w)
     assert DEFAULT_BELOW > 0
     for below in (DEFAULT_BELOW, 1, 151, 70000):
-        for n in sorted({0, k - 1, k, 150, 151, below - 1, below, below + 1, 5000, 9000}):
+        for n in sorted({0, k - 1, k, 150, 151, below - 1, below, below + 1, 5000, 9000, 8191, 8192, 12287, 12288}):
             if n < 0:
                 continue
             b = rng.integers(0, 4, n).astype(np.uint8)

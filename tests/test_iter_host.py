@@ -89,7 +89,7 @@ def test_crossover_setter():
     was = L.mgIterHostBelow(-1)
     assert was >= 0
     assert L.mgIterHostBelow(123) == was and L.mgIterHostBelow(-1) == 123
-    assert L.mgIterHostBelow(was) == 123 and L.mgIterHostBelow(-1) == was
+    assert L.mgIterHostBelow(1 << 30) == 123 and L.mgIterHostBelow(-1) == was      # 1 << 30: the defaults by w again
 
 
 needs_ref = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (reference tree absent)")

@@ -45,7 +45,7 @@ int main (int argc, char **argv)
       for (size_t j = 0 ; j < (size_t) len * nReads ; ++j) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; bases[j] = (char) (x >> 62); }
       U64 s1 = 0, s2 = 0, s3 = 0; double tH = -1, tK = -1, tR = -1;
       if (haveGpu)
-        { mgIterHostBelow (1 << 30); loop (modRCiterator, modRCnext, sh, bases, len, nReads > 100 ? 100 : nReads, &s1); s1 = 0;
+        { mgIterHostBelow ((1 << 30) - 1); loop (modRCiterator, modRCnext, sh, bases, len, nReads > 100 ? 100 : nReads, &s1); s1 = 0;
           tH = loop (modRCiterator, modRCnext, sh, bases, len, nReads, &s1);
           mgIterHostBelow (0); loop (modRCiterator, modRCnext, sh, bases, len, nReads > 100 ? 100 : nReads, &s2); s2 = 0;
           int nk = nReads > 4000 ? 4000 : nReads;
