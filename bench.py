@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-other", action="store_true", help="skip configs 3 and 5 (other_configs)")
-    ap.add_argument("--only", default="", help="run ONE of the other configs (c3, c5, c4_block) without the headline workload and print its JSON: for profiler passes")
+    ap.add_argument("--only", default="", help="run ONE of the other configs (c3, c5, c4_block, ref_default, realistic) without the headline workload and print its JSON: for profiler passes")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch path only: gloo ranks, a tiny host-side modset each, the histogram all-reduce (no GPU)")
     return ap.parse_args()
@@ -356,7 +356,7 @@ def gpu_rank(args):
 
     cx.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if args.only:                                     # a profiler pass over one of the other configs (N = 1)
-        fn = {"c3": bench_c3, "c5": bench_c5, "c4_block": bench_c4_block}[args.only]
+        fn = {"c3": bench_c3, "c5": bench_c5, "c4_block": bench_c4_block, "ref_default": bench_ref_default, "realistic": bench_realistic}[args.only]
         print(json.dumps({"only": args.only, "result": fn(cx, args)}), flush=True)
         return
     k, d, seed, bits = 21, 64, 17, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
@@ -496,8 +496,8 @@ def gpu_rank(args):
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not multi and not args.no_other:
         other = {}
-        for name, fn in (("c4_block", bench_c4_block), ("c5", bench_c5), ("c3", bench_c3)):
-            if name not in os.environ.get("MODGPU_BENCH_OTHER", "c4_block,c5,c3").split(","):      # dev: run a subset
+        for name, fn in (("c4_block", bench_c4_block), ("c5", bench_c5), ("c3", bench_c3), ("ref_default", bench_ref_default), ("realistic", bench_realistic)):
+            if name not in os.environ.get("MODGPU_BENCH_OTHER", "c4_block,c5,c3,ref_default,realistic").split(","):      # dev: run a subset
                 continue
             try:
                 other[name] = fn(cx, args)
@@ -628,6 +628,97 @@ def bench_c5(cx, args):
     L.modsetDestroy(ms)
     del reads, d_offsets
     torch.cuda.empty_cache()
+    return res
+
+
+def bench_ref_default(cx, args):
+    """The reference's OWN default parameters (modmap.c:314-317, modutils.c:140: k = 19, w = 31, seed 17) on config 2's reads:
+    w is not a power of two, so the scan is the exact-mode kernel (mgScanKernel<MG_MODE_ANY>: both 64-bit hashes at every
+    start, divisibility by 31 without a division).  Step = clear + scan + build, as the headline."""
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    k, w, bits = 19, 31, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
+    total = int(float(os.environ.get("MODGPU_BENCH_GBP", "10")) * 1e9)
+    genome_bases = max(total // 30, 1_000_000)
+    genome = make_genome(cx, genome_bases, 12345)
+    reads, d_offsets, offsets, n_reads = make_reads(cx, total, genome, genome_bases, 1000, 0.05, 777)     # the headline's reads
+    del genome
+    sh = mg.seqhashCreate(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    n_hash = C.c_uint64(0)
+
+    def step():
+        mg.check(L.mgModsetClear(ms, cx.stream))
+        mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads, C.byref(n_hash), cx.stream))
+
+    steps = max(3, min(args.steps, 10))
+    dt, kern, table, regions = best_of_two(cx, step, steps)
+    S, entries = n_hash.value, ms.contents.max
+    alg = alg_bytes_table(total, S, entries, w, float(L.mgModsetDeviceSlots(ms)), k)
+    scan_ms = table.get("mgScanKernel", (0, 1))[0] / max(table.get("mgScanKernel", (0, 1))[1], 1)
+    alu = scan_alu(float(total), scan_ms)
+    try:
+        pm = json.load(open(os.path.join(HERE, "profiles", "scan_issue.json"))).get("ref_default")
+        if pm and scan_ms:
+            alu = dict(alu, valu_per_start=pm["valu_per_start"], valu_per_start_from=pm["from"],
+                       wave_valu_per_s=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3), 1),
+                       issue_frac=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3) / VALU_ISSUE_PEAK, 4))
+    except Exception:
+        pass
+    res = {"timed_regions_ms_per_step": regions,
+           "workload": "the reference's default parameters (modmap.c:314-317: k=19 w=31 seed=17; exact-mode scan, w not a power of two) on "
+                       "BASELINE config 2's reads (%.1f Gbp ONT-like, N50 20 kb, 5%% subs, 30x of a %d Mbp genome), table bits %d: "
+                       "seqhash scan + modset build" % (total / 1e9, genome_bases // 1_000_000, bits),
+           "value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "bases": total, "modimizers": S, "modset_entries": entries,
+           "whole_step": {"bytes_per_base": 0.25 + 28.0 / w, "GBps": round((0.25 + 28.0 / w) * total * steps / dt / 1e9, 1),
+                          "frac": round((0.25 + 28.0 / w) * total * steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+           "roofline": roofline_of(kern, table, alg, "ref_default", {"alu": alu}, units={"mgScanKernel": float(total), "mgRankLookupKernel": float(entries)})}
+    L.modsetDestroy(ms)
+    del reads, d_offsets
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_realistic(cx, args):
+    """What repeats cost: 1 Gbp of ONT-like reads (N50 20 kb, 5 % subs, 10x) from a 100 Mbp genome with the repeat
+    structure of a real one (synth.repeat_genome: an Alu-like family with poly-A tails, satellite arrays, (CA)n) beside the same
+    from an iid genome, and 0.5 Gbp of nothing but poly-A -- every start a modimizer of ONE k-mer at k=21 d=64 seed 17.  A
+    k-mer's occurrences all fall into one table bucket; buckets beyond 32768 occurrences are reduced chunk by chunk by many
+    workgroups first (mgHotReduceKernel).  Step = clear + scan + build, k=21 d=64, table bits 28."""
+    import numpy as np
+    torch, L, mg, synth = cx.torch, cx.L, cx.mg, cx.synth
+    k, d, bits = 21, 64, 28
+    G = int(float(os.environ.get("MODGPU_BENCH_REALISTIC_GENOME_MBP", "100")) * 1e6)
+    res = {"workload": "1 Gbp ONT-like reads (N50 20 kb, 5% subs) from a 100 Mbp genome: iid / with 10% Alu-like + poly-A tails, 3% satellite arrays, "
+                       "1% (CA)n; and 0.5 Gbp of poly-A; k=21 d=64 seed=17, table bits 28: seqhash scan + modset build"}
+    sh = mg.seqhashCreate(k, d, 17)
+    steps = max(3, min(args.steps, 5))
+    for name, host_genome, total in (("iid_genome", np.random.default_rng(11).integers(0, 4, G).astype(np.uint8), 1_000_000_000),
+                                     ("repeat_genome", synth.repeat_genome(G, 12), 1_000_000_000),
+                                     ("poly_a", np.zeros(1_000_000, np.uint8), 500_000_000)):
+        gb = len(host_genome)
+        words = np.zeros(L.mgPackedWords(gb), np.uint32)
+        L.mgPackHost(host_genome.ctypes.data, gb, words.ctypes.data)
+        genome = torch.from_numpy(words.view(np.int32)).to(cx.dev)
+        reads, d_offsets, offsets, n_reads = make_reads(cx, total, genome, gb, 21, 0.05 if name != "poly_a" else 0.0, 22)
+        del genome, host_genome
+        ms = mg.modsetCreate(sh, bits)
+        n_hash = C.c_uint64(0)
+
+        def step():
+            mg.check(L.mgModsetClear(ms, cx.stream))
+            mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_offsets.data_ptr(), n_reads, C.byref(n_hash), cx.stream))
+        dt, kern, table, regions = best_of_two(cx, step, steps)
+        per = {kn.replace("Kernel", "").replace("mg", ""): round(v[0], 3) for kn, v in sorted(table.items(), key=lambda kv: -kv[1][0])[:7]}
+        mg.check(L.modsetSyncToHost(ms, 0))
+        dep = np.ctypeslib.as_array(ms.contents.depth, (ms.contents.max + 1,))[1:]
+        res[name] = {"value": round(total * steps / dt / 1e9, 2), "unit": "Gbp/s", "ms_per_Gbp": round(dt / steps * 1e3 / (total / 1e9), 3),
+                     "bases": total, "modimizers": n_hash.value, "modset_entries": ms.contents.max,
+                     "saturated_entries": int((dep == 65535).sum()), "kernels_ms_per_step": per}
+        L.modsetDestroy(ms)
+        del reads, d_offsets
+        torch.cuda.empty_cache()
+    res["repeats_cost"] = round(res["repeat_genome"]["ms_per_Gbp"] / res["iid_genome"]["ms_per_Gbp"], 3)
     return res
 
 

@@ -36,6 +36,7 @@
  *           unique k-mers into its LDS copy of the table bucket and streams it back.
  */
 #include <stdlib.h>
+#include <string.h>
 #include "mg_common.h"
 #include <type_traits>
 
@@ -825,6 +826,12 @@ struct MgBucketArgs {
                                       store per duplicate: fewer when most of a batch's modimizers are new k-mers) */
   int withDepth;
   U64 *counters;
+  /* oversize buckets (a k-mer with very many copies: poly-A, satellite monomers): a bucket of more than hotSplit occurrences is
+     cut into chunks of mgHotChunkLen () occurrences, mgHotReduceKernel -- a workgroup per chunk -- reduces every chunk in place
+     to weighted entries (one per distinct k-mer: its earliest ordinal in the chunk, its count in pC; pC = 0 ends a chunk's
+     list), and the bucket's own workgroup in the dedup kernel walks the chunks' lists instead of the occurrences */
+  U32 hotSplit, hotChunk;
+  U64 *hotItems; unsigned long long *hotCount;     /* the chunks to reduce: (bucket << 32 | chunk), and how many */
 #ifdef MG_ABLATE
   int debug;                       /* ablation builds only (MODGPU_BUCKET_DEBUG): dedup: 1 no flag stores, 2 plain stores for max/add, 4 no claim loop, 8 no list stores; merge: 32 no claim loop, 64 no image stores; lookup: 16 no rank gathers, 128 no index stores, 256 no ordinal loads; results are wrong */
 #endif
@@ -931,6 +938,177 @@ __device__ __forceinline__ void mgDedupCountWave (const MgBucketArgs &a, U32 *sO
   else if (live) mgDedupCount (a, sOrd, sCnt, at, ord);
 }
 
+/* A run [from, hi) of occurrences of bucket b into the LDS image, MG_HOT_DEPTH x T at a time; every lane stays in the
+ * loop: the wave works together (see mgDedupCountWave).  Used by the dedup kernel for what it did not fetch ahead and by
+ * mgHotReduceKernel for a chunk of an oversize bucket. */
+template <bool PACKED>
+__device__ __forceinline__ void mgDedupRun (const MgBucketArgs &a, U32 b, unsigned long long *sKey, U32 *sOrd, U32 *sCnt,
+                                            U32 R, U32 T, U32 tid, U64 from, U64 hi)
+{
+  /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies), MG_HOT_DEPTH x T at a time; every
+     lane stays in the loop: the wave works together */
+  for (U64 i0 = from ; i0 < hi ; i0 += (U64) MG_HOT_DEPTH * T)
+    { U64 x[MG_HOT_DEPTH]; U32 tx[MG_HOT_DEPTH]; bool live[MG_HOT_DEPTH];
+#pragma unroll
+      for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
+        { const U64 i = i0 + (U64) j * T + tid;
+          live[j] = i < hi;
+          x[j] = live[j] ? a.pK[i] : 0; tx[j] = (!PACKED && live[j]) ? a.pT[i] : 0;
+        }
+      /* all of the wave's elements one k-mer (that of its first lane)?  Then one claim, one token, one count for all of them */
+      const int kShift = PACKED ? a.f.ordBits : 0;
+      const U64 x0 = mgUniform64 (x[0]); const U32 tx0 = (U32) __builtin_amdgcn_readfirstlane ((int) tx[0]);
+      bool same = true;
+#pragma unroll
+      for (int j = 0 ; j < MG_HOT_DEPTH ; ++j) if (live[j] && (x[j] >> kShift) != (x0 >> kShift)) same = false;
+      const bool first = __builtin_amdgcn_readfirstlane ((int) live[0]) != 0;
+      bool done = false;
+      if (first && __ballot (!same) == 0 MG_ABLATE_AND (!(a.debug & 6)))                     /* (uniform) */
+        { U64 m; U32 o0; mgOccurrence<PACKED> (a, b, x0, tx0, &m, &o0);
+          const U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);          /* (every lane claims the same slot with the same key) */
+          if (at < R)
+            { U32 tok[MG_HOT_DEPTH], tmax = 0, cnt = 0;
+#pragma unroll
+              for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
+                { const U32 ord = PACKED ? (U32) (x[j] & (((U64) 1 << a.f.ordBits) - 1)) : tx[j];
+                  tok[j] = live[j] ? mgToken (ord) : 0u;
+                  if (tok[j] > tmax) tmax = tok[j];
+                  cnt += live[j] ? 1u : 0u;
+                }
+              const U32 best = mgWaveMax (tmax);
+              const U32 total = (U32) __builtin_amdgcn_readlane ((int) mgWaveInclusiveSum (cnt), 63);
+              if (cnt && tmax == best)                                                        /* (one lane: tokens are all different) */
+                { const U32 old = atomicMax (&sOrd[at], best);
+                  if (a.markDup) { const U32 loser = old > best ? best : old; if (loser) a.flags[0x7fffffffu - loser] = 0; }
+                  atomicAdd (&sCnt[at], total);
+                }
+              if (a.markDup)
+                {
+#pragma unroll
+                  for (int j = 0 ; j < MG_HOT_DEPTH ; ++j) if (live[j] && tok[j] != best) a.flags[0x7fffffffu - tok[j]] = 0;
+                }
+              done = true;
+            }
+        }
+      if (!done)                                                                              /* (uniform) */
+        {
+#pragma unroll
+          for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
+            { U64 m = 0; U32 ord = 0, at = R;
+              if (live[j])
+                { mgOccurrence<PACKED> (a, b, x[j], tx[j], &m, &ord);
+#ifdef MG_ABLATE
+                  if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
+#endif
+                  at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+                  if (at == R) a.counters[1] = 1;
+                }
+#ifdef MG_ABLATE
+              if (a.debug & 2) { if (live[j] && at < R) { sOrd[at] = mgToken (ord); sCnt[at] = 1; } continue; }
+#endif
+              mgDedupCountWave (a, sOrd, sCnt, R, live[j], at, ord);
+            }
+        }
+    }
+}
+
+#define MG_HOT_SPLIT_DEFAULT 32768u  /* occurrences above which a bucket is reduced chunk by chunk first (a bucket of config 2 holds 2400) */
+#define MG_HOT_CHUNK_DEFAULT 8192u   /* occurrences of a chunk, at least */
+#define MG_HOT_MAXCHUNKS 1024u       /* chunks of a bucket, at most: a bucket of 1e9 occurrences is 1024 chunks of 1e6 */
+__host__ __device__ __forceinline__ U64 mgHotChunkLen (U64 cnt, U32 minChunk)
+{ const U64 L = (cnt + MG_HOT_MAXCHUNKS - 1) / MG_HOT_MAXCHUNKS; return L < minChunk ? minChunk : L; }
+
+/* the chunks of every oversize bucket, listed for mgHotReduceKernel */
+__global__ __launch_bounds__ (256)
+void mgHotPlanKernel (const MgBucketArgs a)
+{
+  const U32 b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.nBuckets) return;
+  const U64 cnt = a.bucketStart[b + 1] - a.bucketStart[b];
+  if (cnt <= a.hotSplit) return;
+  const U64 L = mgHotChunkLen (cnt, a.hotChunk);
+  const U32 nCh = (U32) ((cnt + L - 1) / L);
+  const U64 at = atomicAdd (a.hotCount, (unsigned long long) nCh);
+  for (U32 j = 0 ; j < nCh ; ++j) a.hotItems[at + j] = ((U64) b << 32) | j;
+}
+
+/* one chunk of an oversize bucket -> its distinct k-mers as weighted entries, in place at the chunk's start.  The LDS image
+ * is the dedup kernel's (keys of ONE bucket: at most R distinct, or the bucket overflows there too); it starts empty, so a
+ * k-mer's token here is its earliest ordinal within the chunk, and with markDup every other occurrence of the chunk has its
+ * flag cleared right here -- none of them can be a first occurrence. */
+template <bool PACKED>
+__global__ __launch_bounds__ (1024)
+void mgHotReduceKernel (const MgBucketArgs a)
+{
+  const U32 R = a.g.R, T = blockDim.x, tid = threadIdx.x;
+  unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
+  U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
+  U32 *sCnt = sOrd + R;
+  U32 *sN = sCnt + R;
+  const U64 nItems = *a.hotCount;
+  if (blockIdx.x >= nItems) return;
+  for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+  if (tid == 0) sN[0] = 0;
+  __syncthreads ();
+  for (U64 w = blockIdx.x ; w < nItems ; w += gridDim.x)
+    { const U64 item = a.hotItems[w];
+      const U32 b = (U32) (item >> 32), j = (U32) item;
+      const U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
+      const U64 L = mgHotChunkLen (hi - lo, a.hotChunk);
+      const U64 cs = lo + (U64) j * L, ce = cs + L < hi ? cs + L : hi;
+      mgDedupRun<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, cs, ce);
+      __syncthreads ();
+      for (U32 i = tid ; i < R ; i += T)
+        { const unsigned long long key = sKey[i];
+          if (key)
+            { const U32 tok = sOrd[i], c = sCnt[i];
+              sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0;
+              const U32 at = atomicAdd (&sN[0], 1u);
+              const U32 ord = 0x7fffffffu - tok;
+              if (PACKED) a.pK[cs + at] = (((key - 1) & (((U64) 1 << a.f.remBits) - 1)) << a.f.ordBits) | ord;
+              else { a.pK[cs + at] = key - 1; a.pT[cs + at] = ord; }
+              a.pC[cs + at] = c;
+            }
+        }
+      __syncthreads ();
+      if (tid == 0) { const U32 nc = sN[0]; if (cs + nc < ce) a.pC[cs + nc] = 0; sN[0] = 0; }
+      __syncthreads ();
+    }
+}
+
+/* the dedup kernel's side of it: the weighted entries of an oversize bucket's chunks into the bucket's image; a wave takes
+ * chunks w, w + T / 64, ... and reads a chunk's list 64 entries at a time up to its end (pC = 0, or the chunk's end) */
+template <bool PACKED>
+__device__ __forceinline__ void mgDedupHotBucket (const MgBucketArgs &a, U32 b, unsigned long long *sKey, U32 *sOrd, U32 *sCnt,
+                                                  U32 R, U32 T, U32 tid, U64 lo, U64 hi)
+{
+  const U64 L = mgHotChunkLen (hi - lo, a.hotChunk);
+  const U32 nCh = (U32) ((hi - lo + L - 1) / L);
+  const U32 lane = tid & 63;
+  for (U32 j = tid >> 6 ; j < nCh ; j += T >> 6)
+    { const U64 cs = lo + (U64) j * L, ce = cs + L < hi ? cs + L : hi;
+      for (U64 base = cs ; base < ce ; base += 64)
+        { const U64 i = base + lane;
+          const U32 c = i < ce ? a.pC[i] : 0u;
+          const unsigned long long ended = __ballot (c == 0);
+          const bool live = c != 0 && (ended == 0 || lane < (U32) __builtin_ctzll (ended));
+          if (live)
+            { U64 m; U32 ord;
+              mgOccurrence<PACKED> (a, b, a.pK[i], PACKED ? 0u : a.pT[i], &m, &ord);
+              const U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+              if (at == R) a.counters[1] = 1;
+              else
+                { const U32 tok = mgToken (ord);
+                  const U32 old = atomicMax (&sOrd[at], tok);
+                  if (a.markDup) { const U32 loser = old > tok ? tok : old; if (loser) a.flags[0x7fffffffu - loser] = 0; }
+                  atomicAdd (&sCnt[at], c);
+                }
+            }
+          if (ended) break;
+        }
+    }
+}
+
 template <bool PACKED, bool SLOT, int PER>       /* SLOT: a.slotShift != 0; PER: slots of the image per thread, R <= PER x threads */
 __global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (PER == MG_DEDUP_PER ? 8 : 4)))      /* 64 registers: two workgroups per CU */
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
@@ -980,6 +1158,9 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 }
               __syncthreads ();
             }
+          if (hi - lo > a.hotSplit) mgDedupHotBucket<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo, hi);   /* (uniform) reduced to weighted entries by mgHotReduceKernel */
+          else
+          {
 #pragma unroll
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
             if (lo + (U64) j * T + tid < hi)
@@ -995,71 +1176,9 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #endif
                 else { mgDedupCount (a, sOrd, sCnt, at, ord); }
               }
-          /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies), MG_HOT_DEPTH x T at a time; every
-             lane stays in the loop: the wave works together */
-          for (U64 i0 = lo + (U64) MG_BUCKET_PREFETCH * T ; i0 < hi ; i0 += (U64) MG_HOT_DEPTH * T)
-            { U64 x[MG_HOT_DEPTH]; U32 tx[MG_HOT_DEPTH]; bool live[MG_HOT_DEPTH];
-#pragma unroll
-              for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
-                { const U64 i = i0 + (U64) j * T + tid;
-                  live[j] = i < hi;
-                  x[j] = live[j] ? a.pK[i] : 0; tx[j] = (!PACKED && live[j]) ? a.pT[i] : 0;
-                }
-              /* all of the wave's elements one k-mer (that of its first lane)?  Then one claim, one token, one count for all of them */
-              const int kShift = PACKED ? a.f.ordBits : 0;
-              const U64 x0 = mgUniform64 (x[0]); const U32 tx0 = (U32) __builtin_amdgcn_readfirstlane ((int) tx[0]);
-              bool same = true;
-#pragma unroll
-              for (int j = 0 ; j < MG_HOT_DEPTH ; ++j) if (live[j] && (x[j] >> kShift) != (x0 >> kShift)) same = false;
-              const bool first = __builtin_amdgcn_readfirstlane ((int) live[0]) != 0;
-              bool done = false;
-              if (first && __ballot (!same) == 0 MG_ABLATE_AND (!(a.debug & 6)))                     /* (uniform) */
-                { U64 m; U32 o0; mgOccurrence<PACKED> (a, b, x0, tx0, &m, &o0);
-                  const U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);          /* (every lane claims the same slot with the same key) */
-                  if (at < R)
-                    { U32 tok[MG_HOT_DEPTH], tmax = 0, cnt = 0;
-#pragma unroll
-                      for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
-                        { const U32 ord = PACKED ? (U32) (x[j] & (((U64) 1 << a.f.ordBits) - 1)) : tx[j];
-                          tok[j] = live[j] ? mgToken (ord) : 0u;
-                          if (tok[j] > tmax) tmax = tok[j];
-                          cnt += live[j] ? 1u : 0u;
-                        }
-                      const U32 best = mgWaveMax (tmax);
-                      const U32 total = (U32) __builtin_amdgcn_readlane ((int) mgWaveInclusiveSum (cnt), 63);
-                      if (cnt && tmax == best)                                                        /* (one lane: tokens are all different) */
-                        { const U32 old = atomicMax (&sOrd[at], best);
-                          if (a.markDup) { const U32 loser = old > best ? best : old; if (loser) a.flags[0x7fffffffu - loser] = 0; }
-                          atomicAdd (&sCnt[at], total);
-                        }
-                      if (a.markDup)
-                        {
-#pragma unroll
-                          for (int j = 0 ; j < MG_HOT_DEPTH ; ++j) if (live[j] && tok[j] != best) a.flags[0x7fffffffu - tok[j]] = 0;
-                        }
-                      done = true;
-                    }
-                }
-              if (!done)                                                                              /* (uniform) */
-                {
-#pragma unroll
-                  for (int j = 0 ; j < MG_HOT_DEPTH ; ++j)
-                    { U64 m = 0; U32 ord = 0, at = R;
-                      if (live[j])
-                        { mgOccurrence<PACKED> (a, b, x[j], tx[j], &m, &ord);
-#ifdef MG_ABLATE
-                          if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
-#endif
-                          at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
-                          if (at == R) a.counters[1] = 1;
-                        }
-#ifdef MG_ABLATE
-                      if (a.debug & 2) { if (live[j] && at < R) { sOrd[at] = mgToken (ord); sCnt[at] = 1; } continue; }
-#endif
-                      mgDedupCountWave (a, sOrd, sCnt, R, live[j], at, ord);
-                    }
-                }
-            }
+          /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies) */
+          mgDedupRun<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo + (U64) MG_BUCKET_PREFETCH * T, hi);
+          }
           __syncthreads ();
           /* the uniques leave grouped (see MgBucketArgs).  Every thread takes its slots of the image into registers
              (clearing them for the next bucket) and counts the groups' members -- a unique's place inside its group is
@@ -1300,6 +1419,22 @@ static inline U64 mgRankRowsPerUnit (U64 n, U32 *nBlocks)
   return per;
 }
 
+/* the split of oversize buckets: occurrences above which a bucket is split, occurrences of a chunk at least */
+static void mgHotKnobs (U32 *split, U32 *chunk)
+{
+  static U32 sp = 0, ch = 0;
+  if (!sp)
+    { const char *e = getenv ("MODGPU_HOT_SPLIT");          /* test knob "split,chunk": small values send ordinary buckets through the split path */
+      U32 a = MG_HOT_SPLIT_DEFAULT, b = MG_HOT_CHUNK_DEFAULT;
+      if (e) { a = (U32) atoi (e); const char *c = strchr (e, ','); b = c ? (U32) atoi (c + 1) : a / 4; }
+      if (b < 64) b = 64;
+      if (a < b) a = b;
+      ch = b; sp = a;
+    }
+  *split = sp; *chunk = ch;
+}
+static U64 mgHotItemsCap (U64 n) { U32 sp, ch; mgHotKnobs (&sp, &ch); return n / ch + n / sp + 16; }
+
 /* scratch needed by mgTableAdd for a batch of n */
 size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
 {
@@ -1310,7 +1445,8 @@ size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
   size_t part = 2 * (mgAl (n * 8) + mgAl (n * 4)) + mgAl (n * 4)
               + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3 + 2 * mgAl ((U64) MG_PART_MAXBINS * 16 * 8 + 4096)
               + mgAl ((MG_PART_MAXBINS + 2) * 4) + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4)
-              + mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short)) + mgAl ((n / MG_PART_SUB + 2) * 24);
+              + mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short)) + mgAl ((n / MG_PART_SUB + 2) * 24)
+              + mgAl (mgHotItemsCap (n) * 8) + 256;
   return rank + (direct > part ? direct : part) + 4096;
 }
 
@@ -1443,6 +1579,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   U32 *chunkBase = (U32 *) wb;                wb += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);   /* + the segment of every chunk */
   unsigned short *sliceOff = (unsigned short *) wb;   wb += mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short));
   MgSubSeg *subSeg = (MgSubSeg *) wb;         wb += mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg));
+  U64 *hotItems = (U64 *) wb;                 wb += mgAl (mgHotItemsCap (n) * 8);
+  unsigned long long *hotCount = (unsigned long long *) wb; wb += 256;
   (void) spare64;
 
   /* split the bucket-id bits into a coarse digit (high) and a fine digit (low), each <= 9 bits */
@@ -1526,6 +1664,18 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
   if ((U64) bThreads * (bigR ? MG_DEDUP_PER_BIG : MG_DEDUP_PER) < t->R)      /* every slot of the image must belong to a thread of the closing sweep */
     { mgSetError ("internal: %u threads for a bucket of %u slots", bThreads, t->R); return MG_ERR_ARG; }
+  /* oversize buckets first: their chunks reduced to weighted entries by a workgroup each (nothing to do on ordinary data:
+     the plan finds no bucket and the reduce kernel's workgroups leave at once) */
+  mgHotKnobs (&a.hotSplit, &a.hotChunk);
+  a.hotItems = hotItems; a.hotCount = hotCount;
+  MG_HIP (hipMemsetAsync (hotCount, 0, 8, st));
+  MG_LAUNCH (MG_K_HOT_REDUCE, st, mgHotPlanKernel, dim3 ((unsigned) ((NB + 255) / 256)), dim3 (256), 0, st, a);
+  { const size_t ldsHot = (size_t) t->R * 16 + 16;
+    if (packed) { if (ldsHot > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgHotReduceKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsHot));
+                  MG_LAUNCH (MG_K_HOT_REDUCE, st, mgHotReduceKernel<true>, dim3 (1024), dim3 (bThreads), ldsHot, st, a); }
+    else        { if (ldsHot > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgHotReduceKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsHot));
+                  MG_LAUNCH (MG_K_HOT_REDUCE, st, mgHotReduceKernel<false>, dim3 (1024), dim3 (bThreads), ldsHot, st, a); }
+  }
 #define MG_DEDUP_LAUNCH(PK, SL, PER) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<PK, SL, PER>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock)
 #define MG_DEDUP_PICK(PER) do { if (packed) { if (a.slotShift) MG_DEDUP_LAUNCH (true, true, PER); else MG_DEDUP_LAUNCH (true, false, PER); } \
                                 else        { if (a.slotShift) MG_DEDUP_LAUNCH (false, true, PER); else MG_DEDUP_LAUNCH (false, false, PER); } } while (0)

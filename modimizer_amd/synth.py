@@ -95,3 +95,34 @@ def reads_from_genome(genome, starts, offsets, strands, err_rate, seed):
     sub = ((u & np.uint64(0xFFFF)) % np.uint64(3)).astype(np.uint8)
     out[hit] = (out[hit] + 1 + sub[hit]) & 3
     return out
+
+
+def repeat_genome(n_bases, seed, alu=0.10, satellite=0.03, ca=0.01):
+    """A genome with the repeat structure real ones have, by share of its length: an Alu-like family (300 b, 10 % divergence
+    between copies) each copy with a poly-A tail of 15-45 bases, satellite arrays (200-3000 copies of a 171-base monomer, 2 %
+    divergence), (CA)n microsatellites, unique sequence in between.  Not from the reference: the workload behind
+    bench.py's other_configs.realistic (poly-A and monomer k-mers with 1e5-1e6 copies: one table bucket each)."""
+    rng = np.random.default_rng(seed)
+
+    def mutate(x, rate):
+        x = x.copy(); m = rng.random(len(x)) < rate
+        x[m] = (x[m] + rng.integers(1, 4, int(m.sum()))) & 3
+        return x
+    alu_seq = rng.integers(0, 4, 300).astype(np.uint8); mono = rng.integers(0, 4, 171).astype(np.uint8)
+    share = {"alu": alu, "sat": satellite, "ca": ca}
+    have = dict.fromkeys(share, 0)
+    parts, n = [], 0
+    while n < n_bases:
+        kind = next((k for k in share if have[k] < share[k] * n), None) if n else None
+        if kind == "alu":
+            p = np.concatenate([mutate(alu_seq, 0.10), np.zeros(int(rng.integers(15, 45)), np.uint8)])
+        elif kind == "sat":
+            p = np.concatenate([mutate(mono, 0.02) for _ in range(int(rng.integers(200, 3000)))])
+        elif kind == "ca":
+            p = np.tile(np.array([1, 0], np.uint8), int(rng.integers(10, 60)))
+        else:
+            p = rng.integers(0, 4, int(rng.integers(200, 6000))).astype(np.uint8)
+        if kind:
+            have[kind] += len(p)
+        parts.append(p); n += len(p)
+    return np.concatenate(parts)[:n_bases]

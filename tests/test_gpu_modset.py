@@ -633,6 +633,13 @@ print("hot ok", n, oms.max)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for knobs in ({}, {"MODGPU_FLAG_POLARITY": "0"}, {"MODGPU_FLAG_POLARITY": "1"}, {"MODGPU_PART_PACKED": "0", "MODGPU_FLAG_POLARITY": "1"},
                   {"MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"},
+                  # the split of oversize buckets (mgHotPlanKernel / mgHotReduceKernel / mgDedupHotBucket): the poly-A k-mer's bucket takes it with
+                  # the defaults above (> 32768 occurrences); "200,64" sends every bucket of more than 200 occurrences through it in chunks of 64,
+                  # both polarities and both element formats; the last switches it off (the single-workgroup path as it was)
+                  {"MODGPU_HOT_SPLIT": "200,64"}, {"MODGPU_HOT_SPLIT": "200,64", "MODGPU_FLAG_POLARITY": "0"},
+                  {"MODGPU_HOT_SPLIT": "200,64", "MODGPU_FLAG_POLARITY": "1", "MODGPU_PART_PACKED": "0"},
+                  {"MODGPU_HOT_SPLIT": "3000,1000", "MODGPU_BUCKET_R": "1024", "MODGPU_BUCKET_T": "256"},
+                  {"MODGPU_HOT_SPLIT": "2000000000"},
                   {"MODGPU_TABLE_PATH": "direct"}):            # the atomic path: a wave's lanes in one slot add their number once (mgTableInsertKernel)
         env = dict(os.environ, PYTHONPATH=root, **dict({"MODGPU_TABLE_PATH": "bucket"}, **knobs))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)

@@ -18,3 +18,8 @@ MODGPU_SCAN_GENERIC=1 python -m pytest tests/test_gpu_scan.py tests/test_gpu_mod
 echo "== MODGPU_PART_BIG=0"
 MODGPU_PART_BIG=0 MODGPU_TABLE_PATH=bucket python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
 MODGPU_PART_BIG=0 MODGPU_TABLE_PATH=bucket python tests/fuzz_gpu.py 13 150 2>&1 | tail -2
+echo "== MODGPU_HOT_SPLIT=200,64 (every bucket beyond 200 occurrences through the chunk-wise reduction)"
+for pk in 1 0; do
+  MODGPU_HOT_SPLIT=200,64 MODGPU_TABLE_PATH=bucket MODGPU_PART_PACKED=$pk python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
+  MODGPU_HOT_SPLIT=200,64 MODGPU_TABLE_PATH=bucket MODGPU_PART_PACKED=$pk python tests/fuzz_gpu.py $((17 + pk)) 150 2>&1 | tail -2
+done
