@@ -886,7 +886,8 @@ def end_to_end(cx, reads, offsets, k, d, seed):
         fb = int(off[m])
 
         def time_file(p_, host_parser):
-            os.environ["MODGPU_TEXT_HOST"] = "1" if host_parser else "0"        # read per call: 1 = the host parser (mg_seqio.c), 0 = plain text parsed on the device (mg_textgpu.hip)
+            os.environ["MODGPU_TEXT_HOST"] = "1" if host_parser else "0"        # 1 = the host parser (mg_seqio.c), 0 = plain text parsed on the device (mg_textgpu.hip)
+            L.mgReloadKnobs()
             best_ = None
             try:
                 for it in range(3):
@@ -901,6 +902,7 @@ def end_to_end(cx, reads, offsets, k, d, seed):
                         best_ = dt if best_ is None else min(best_, dt)
             finally:
                 del os.environ["MODGPU_TEXT_HOST"]
+                L.mgReloadKnobs()
             return best_
         t_dev, t_host = time_file(path, False), time_file(path, True)
         res["fasta_file"] = {"entry": "mgAddSequenceFile", "Gbp_per_s": round(fb / t_dev / 1e9, 2), "Gbp_per_s_host_parser": round(fb / t_host / 1e9, 2),

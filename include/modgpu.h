@@ -76,6 +76,7 @@ const char *mgVersion (void) ;
  * {U64 n; U64 kmer[n]; U32 pos | isF << 31 [n]} of one read.  It is not a fallback: modRCiterator die()s without a HIP
  * device whatever the read's length, and no batch entry point ever takes it. */
 U64 *mgIterScanHost (const Seqhash *sh, const char *s, int len) ;
+void mgReloadKnobs (void) ;                 /* the library reads its MODGPU_* environment knobs once; this reads them again (tests that set one between calls; not while another thread is inside the library) */
 int  mgIterHostBelow (int below) ;          /* sets the crossover in bases (below < 0: only asks; 1 << 30: back to the defaults by w); returns the one in force before */
 
 /* Device memory helpers so a host language needs no other HIP binding. */

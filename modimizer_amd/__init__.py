@@ -4,6 +4,7 @@ This module is a thin ctypes binding over the C ABI declared in include/modgpu.h
 in the HIP library.  There is no CPU fallback: if the library or a HIP device is missing the batch
 entry points raise.
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -75,8 +76,32 @@ EXPORTS = [
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
-    "mgIterScanHost", "mgIterHostBelow", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
+
+
+@contextlib.contextmanager
+def knobs(**kv):
+    """MODGPU_<NAME>=value (None: unset) for the duration of the block.  The library reads its environment knobs once
+    (csrc/mg_knobs.c); mgReloadKnobs makes it read them again, on the way in and on the way out."""
+    old = {}
+    for k, v in kv.items():
+        name = "MODGPU_" + k
+        old[name] = os.environ.get(name)
+        if v is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(v)
+    lib().mgReloadKnobs()
+    try:
+        yield
+    finally:
+        for name, v in old.items():
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = v
+        lib().mgReloadKnobs()
 
 
 def build(force=False):
@@ -118,7 +143,7 @@ def lib():
     sig("modRCiterator", IT, SH, vp, i32)
     sig("modRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
     sig("minimizerRCiterator", IT, SH, vp, i32)
-    sig("mgIterScanHost", vp, SH, vp, i32); sig("mgIterHostBelow", i32, i32)
+    sig("mgIterScanHost", vp, SH, vp, i32); sig("mgIterHostBelow", i32, i32); sig("mgReloadKnobs", None)
     sig("minimizerRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
     sig("seqString", C.c_char_p, u64, i32)
     sig("mgSeqhashDestroy", None, SH); sig("mgSeqhashRCiteratorDestroy", None, IT)

@@ -219,15 +219,15 @@ static int mgHostThreads (void)
 {
   static int n = 0;
   if (n) return n;
-  const char *e = getenv ("MODGPU_PACK_THREADS");
-  long v = e ? atol (e) : 0;
+  const long kv = mgKnobs ()->packThreads;
+  long v = kv != MG_KNOB_UNSET ? kv : 0;
   if (v <= 0)
     { v = sysconf (_SC_NPROCESSORS_ONLN);
       cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
       FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");                 /* a cgroup CPU quota caps what threads can get */
       if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < v) v = c; } fclose (q); }
     }
-  if (!e) v = v / 2;                                   /* measured (16-CPU quota): 8 packers keep the link busy, 16 starve the thread that issues the copies */
+  if (kv == MG_KNOB_UNSET) v = v / 2;                                   /* measured (16-CPU quota): 8 packers keep the link busy, 16 starve the thread that issues the copies */
   if (v < 1) v = 1;
   if (v > 16) v = 16;
   return n = (int) v;
@@ -487,7 +487,7 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
   t.maxLog2Slots = ms->tableBits - 1;                 /* load <= 0.5 at the largest legal fill */
   t.kbits = 2 * ms->hasher->k;
   t.wantR = 4096;                                      /* 64 KiB of LDS per bucket, 1024-thread workgroups (measured best) */
-  { const char *e = getenv ("MODGPU_BUCKET_R"); if (e && atoi (e) >= 256) t.wantR = (U32) atoi (e); }
+  { const long r = mgKnobs ()->bucketR; if (r != MG_KNOB_UNSET && r >= 256) t.wantR = (U32) r; }     /* test knob */
   t.size = ms->size;
   U64 cap = (ms->tableSize >> 2);                      /* device arrays cover the largest legal size */
   MG_HIP (hipMalloc ((void **) &t.value, cap * sizeof (U64)));
@@ -712,8 +712,9 @@ extern "C" int mgHookHasDevice (Modset *ms) { return mgDevLookup (ms) != 0; }
 /* modimizers per insert pass (tokens are 31-bit ordinals); MODGPU_ADD_CHUNK shrinks it for tests */
 static U64 mgAddChunkSize (void)
 {
-  static U64 v = 0;
-  if (!v) { const char *e = getenv ("MODGPU_ADD_CHUNK"); v = e && atoll (e) > 0 ? (U64) atoll (e) : ((U64) 1 << 30); if (v > ((U64) 1 << 30)) v = (U64) 1 << 30; }
+  const long c = mgKnobs ()->addChunk;
+  U64 v = c != MG_KNOB_UNSET && c > 0 ? (U64) c : ((U64) 1 << 30);
+  if (v > ((U64) 1 << 30)) v = (U64) 1 << 30;
   return v;
 }
 #define MG_ADD_CHUNK (mgAddChunkSize ())
@@ -924,7 +925,7 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   MgScanBufs b; U64 n = 0;
   d->t.loadPct = 60;                                   /* lookups follow (or are this call): see MgTable.loadPct */
   if (mode == 0 && d->t.slots && (s = mgTableEnsure (&d->t, 0, st))) return s;
-  static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_SEED_TIMING"); timing = e && *e == '1'; }   /* dev */
+  const int timing = mgKnobs ()->seedTiming == 1;   /* dev */
   struct timespec q0, q1, q2; if (timing) clock_gettime (CLOCK_MONOTONIC, &q0);
   /* lookups read the k-mers from the scan's segments (no dense copy of them); pos / read are compacted as before */
   if ((s = mgScanIntoArena (d, ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, mode ? 4 : 0, &b, &n, st,
@@ -977,7 +978,7 @@ extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int6
 {
   if (mgEnsureDevice ()) return -1;
   if (nReads <= 0) return 0;
-  static int timing = -1; if (timing < 0) { const char *e = getenv ("MODGPU_UPLOAD_TIMING"); timing = e && *e == '1'; }   /* dev */
+  const int timing = mgKnobs ()->uploadTiming == 1;   /* dev */
   { int curDev = 0; if (hipGetDevice (&curDev) != hipSuccess) { mgSetError ("mgAddSequenceBatch: no current device"); return -1; }
     bool moved; { std::lock_guard<std::mutex> g0 (gHb.lock); moved = gHb.dev >= 0 && gHb.dev != curDev; }
     if (moved) mgHostBatchRelease ();                  /* the cached buffers live on the device the previous call ran on */

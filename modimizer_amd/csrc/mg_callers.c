@@ -463,8 +463,7 @@ int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets,
   MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
   MgChainQ *q = (MgChainQ *) malloc ((size_t) nReads * sizeof (MgChainQ));
   MgChainM *m = (MgChainM *) malloc ((size_t) nReads * MG_QUERY_MAXM * sizeof (MgChainM));
-  static int hostChain = -1;
-  if (hostChain < 0) { const char *e = getenv ("MODGPU_QUERY_HOST_CHAIN"); hostChain = (e && *e == '1') ? 1 : 0; }   /* test knob */
+  const int hostChain = mgKnobs ()->queryHostChain == 1;   /* test knob */
   int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, q, m, MG_QUERY_MAXM);
   if (rc < 0) fatal ("query");
   if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);

@@ -1,6 +1,7 @@
 /* mg_common.h — shared declarations for the HIP side of libmodgpu (gfx950 only). */
 #ifndef MG_COMMON_H
 #define MG_COMMON_H
+#include "mg_knobs.h"
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

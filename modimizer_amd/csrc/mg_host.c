@@ -118,8 +118,8 @@ static int gIterHostBelow = -1;           /* -1: not looked up yet, -2: the defa
 static int iterHostBelow (const Seqhash *sh)
 {
   if (gIterHostBelow == -1)
-    { const char *e = getenv ("MODGPU_ITER_HOST_BELOW");     /* tuning knob: 0 = every read through the kernel */
-      gIterHostBelow = e ? (atoi (e) < 0 ? 0 : atoi (e)) : -2;
+    { const long v = mgKnobs ()->iterHostBelow;              /* tuning knob: 0 = every read through the kernel */
+      gIterHostBelow = v != MG_KNOB_UNSET ? (v < 0 ? 0 : (int) v) : -2;
     }
   if (gIterHostBelow >= 0) return gIterHostBelow;
   return sh && sh->w < 16 ? MG_ITER_HOST_BELOW_DENSE : MG_ITER_HOST_BELOW_DEFAULT;

@@ -3,6 +3,7 @@
 #ifndef MG_INTERNAL_H
 #define MG_INTERNAL_H
 #include "modgpu.h"
+#include "mg_knobs.h"
 #ifdef __cplusplus
 extern "C" {
 #endif

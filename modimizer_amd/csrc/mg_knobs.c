@@ -1,0 +1,42 @@
+/* mg_knobs.c — the library's environment knobs, read once (see mg_knobs.h) */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mg_knobs.h"
+
+static MgKnobs gKnobs;
+static pthread_once_t gOnce = PTHREAD_ONCE_INIT;
+
+static long num (const char *name)
+{ const char *e = getenv (name); return e && *e ? atol (e) : MG_KNOB_UNSET; }
+
+static void readAll (void)
+{
+  MgKnobs k;
+  const char *e = getenv ("MODGPU_TABLE_PATH");
+  k.tablePath = e && *e ? (long) e[0] : MG_KNOB_UNSET;
+  k.partPacked = num ("MODGPU_PART_PACKED");       k.partBig = num ("MODGPU_PART_BIG");
+  k.addChunk = num ("MODGPU_ADD_CHUNK");           k.scanGrid = num ("MODGPU_SCAN_GRID");
+  k.scanGeneric = num ("MODGPU_SCAN_GENERIC");     k.scanHist = num ("MODGPU_SCAN_HIST");
+  k.noSegmentInput = num ("MODGPU_NO_SEGMENT_INPUT");
+  k.rankSliceShift = num ("MODGPU_RANK_SLICE_SHIFT");
+  k.flagPolarity = num ("MODGPU_FLAG_POLARITY");   k.mergeSlots = num ("MODGPU_MERGE_SLOTS");
+  k.bucketR = num ("MODGPU_BUCKET_R");             k.bucketT = num ("MODGPU_BUCKET_T");
+  e = getenv ("MODGPU_HOT_SPLIT");
+  k.hotSplit = e && *e ? atol (e) : MG_KNOB_UNSET;
+  { const char *c = e ? strchr (e, ',') : 0; k.hotChunk = c ? atol (c + 1) : MG_KNOB_UNSET; }
+  k.noAvx2 = num ("MODGPU_NO_AVX2");               k.textHost = num ("MODGPU_TEXT_HOST");
+  k.textWindowKb = num ("MODGPU_TEXT_WINDOW_KB");
+  k.fileBatchMbp = num ("MODGPU_FILE_BATCH_MBP");  k.fileBatchBases = num ("MODGPU_FILE_BATCH_BASES");
+  k.queryHostChain = num ("MODGPU_QUERY_HOST_CHAIN");
+  k.iterHostBelow = num ("MODGPU_ITER_HOST_BELOW");
+  k.scatterGrid = num ("MODGPU_SCATTER_GRID");     k.tableLoad = num ("MODGPU_TABLE_LOAD");
+  k.packThreads = num ("MODGPU_PACK_THREADS");     k.parseThreads = num ("MODGPU_PARSE_THREADS");
+  k.seedTiming = num ("MODGPU_SEED_TIMING");       k.uploadTiming = num ("MODGPU_UPLOAD_TIMING");
+  k.textTiming = num ("MODGPU_TEXT_TIMING");       k.parseTiming = getenv ("MODGPU_PARSE_TIMING") ? 1 : MG_KNOB_UNSET;
+  k.scanDebug = num ("MODGPU_SCAN_DEBUG");         k.bucketDebug = num ("MODGPU_BUCKET_DEBUG");
+  gKnobs = k;
+}
+
+const MgKnobs *mgKnobs (void) { pthread_once (&gOnce, readAll); return &gKnobs; }
+void mgReloadKnobs (void) { pthread_once (&gOnce, readAll); readAll (); }

@@ -1,0 +1,50 @@
+/* mg_knobs.h — every environment knob of the library, read ONCE (pthread_once) into one struct.
+ *
+ * None is needed in production.  Test knobs force code paths through the same parity checks (tests/, tools/test_paths.sh);
+ * development knobs serve the sweeps under tools/.  A field holds the variable's value as parsed by atol (), or
+ * MG_KNOB_UNSET when the variable is absent; what an absent or out-of-range value means is decided where the knob is used,
+ * next to the default it replaces.  mgReloadKnobs () reads the environment again -- for tests that set a knob between calls
+ * of one process; not to be called while another thread is inside the library. */
+#ifndef MG_KNOBS_H
+#define MG_KNOBS_H
+#include <limits.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define MG_KNOB_UNSET LONG_MIN
+typedef struct {
+  /* test knobs */
+  long tablePath;          /* MODGPU_TABLE_PATH: 'd' direct atomics, 'b' bucketed (the first letter), else automatic */
+  long partPacked;         /* MODGPU_PART_PACKED: 0 = wide partition elements */
+  long partBig;            /* MODGPU_PART_BIG: 0 = sub-chunks of MG_PART_SUB everywhere */
+  long addChunk;           /* MODGPU_ADD_CHUNK: modimizers per insert pass */
+  long scanGrid;           /* MODGPU_SCAN_GRID: workers per scan launch */
+  long scanGeneric;        /* MODGPU_SCAN_GENERIC: 1 = no filter mode */
+  long scanHist;           /* MODGPU_SCAN_HIST: 0 = the compaction kernel counts the first partition digit */
+  long noSegmentInput;     /* MODGPU_NO_SEGMENT_INPUT: 1 = the build always gets a dense copy */
+  long rankSliceShift;     /* MODGPU_RANK_SLICE_SHIFT */
+  long flagPolarity;       /* MODGPU_FLAG_POLARITY: 0 / 1 force which way round the first-occurrence flags are written */
+  long mergeSlots;         /* MODGPU_MERGE_SLOTS: 0 / 1: the merge kernel probes / takes the dedup kernel's slots */
+  long bucketR, bucketT;   /* MODGPU_BUCKET_R / MODGPU_BUCKET_T: slots per bucket / threads of the bucket kernels */
+  long hotSplit, hotChunk; /* MODGPU_HOT_SPLIT="split[,chunk]": occurrences above which a bucket is reduced chunk-wise first */
+  long noAvx2;             /* MODGPU_NO_AVX2: 1 = portable packer / parser loops */
+  long textHost;           /* MODGPU_TEXT_HOST: 1 = the host parser for every file */
+  long textWindowKb;       /* MODGPU_TEXT_WINDOW_KB: text per window of the device parser */
+  long fileBatchMbp;       /* MODGPU_FILE_BATCH_MBP */
+  long fileBatchBases;     /* MODGPU_FILE_BATCH_BASES: bases per batch of the file entry points */
+  long queryHostChain;     /* MODGPU_QUERY_HOST_CHAIN: 1 = modmap's chaining on the host */
+  long iterHostBelow;      /* MODGPU_ITER_HOST_BELOW: modRCiterator's crossover in bases */
+  /* development knobs */
+  long scatterGrid;        /* MODGPU_SCATTER_GRID */
+  long tableLoad;          /* MODGPU_TABLE_LOAD: per cent */
+  long packThreads;        /* MODGPU_PACK_THREADS */
+  long parseThreads;       /* MODGPU_PARSE_THREADS */
+  long seedTiming, uploadTiming, textTiming, parseTiming;   /* MODGPU_*_TIMING prints */
+  long scanDebug, bucketDebug;                               /* only read by -DMG_ABLATE builds */
+} MgKnobs;
+const MgKnobs *mgKnobs (void);
+void mgReloadKnobs (void);
+#ifdef __cplusplus
+}
+#endif
+#endif

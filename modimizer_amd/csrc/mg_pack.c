@@ -9,6 +9,7 @@
 #include <string.h>
 #include <immintrin.h>
 #include "modgpu.h"
+#include "mg_knobs.h"
 
 static void packScalar (const unsigned char *b, uint64_t nWords, U32 *w)
 {
@@ -46,8 +47,7 @@ static void packAvx2 (const unsigned char *b, uint64_t nWords, U32 *w)
 /* whole words [0, nBases/16) and, zero padded, the partial last word: words[0 .. ceil(nBases/16)) */
 void mgPackWords (const char *bases, U64 nBases, U32 *words)
 {
-  static int haveAvx2 = -1;
-  if (haveAvx2 < 0) { const char *e = getenv ("MODGPU_NO_AVX2"); haveAvx2 = (e && *e == '1') ? 0 : (__builtin_cpu_supports ("avx2") ? 1 : 0); }   /* MODGPU_NO_AVX2=1 (tests): the portable loop */
+  const int haveAvx2 = mgKnobs ()->noAvx2 == 1 ? 0 : (__builtin_cpu_supports ("avx2") ? 1 : 0);   /* MODGPU_NO_AVX2=1 (tests): the portable loop */
   const uint64_t full = nBases / 16;
   if (haveAvx2) packAvx2 ((const unsigned char *) bases, full, words);
   else packScalar ((const unsigned char *) bases, full, words);

@@ -141,9 +141,9 @@ int mgReadsetFileRead (MgReadset *rs, const char *filename)       /* modasm.c:15
   MgSeqReader *r = mgSeqOpen (filename);
   if (!r) return -1;
   readsetBegin (rs);
-  const char *e = getenv ("MODGPU_FILE_BATCH_MBP"), *eb = getenv ("MODGPU_FILE_BATCH_BASES");   /* the second: tests */
-  int64_t maxBases = (int64_t) (e && atol (e) > 0 ? atol (e) : 512) * 1000000;
-  if (eb && atol (eb) > 0) maxBases = atol (eb);
+  const MgKnobs *kn = mgKnobs ();                          /* FILE_BATCH_BASES: tests */
+  int64_t maxBases = (int64_t) (kn->fileBatchMbp != MG_KNOB_UNSET && kn->fileBatchMbp > 0 ? kn->fileBatchMbp : 512) * 1000000;
+  if (kn->fileBatchBases != MG_KNOB_UNSET && kn->fileBatchBases > 0) maxBases = kn->fileBatchBases;
   MgSeqBatch b;
   while (mgSeqNextBatch (r, maxBases, &b) > 0)
     { readsetAddBatch (rs, b.bases, b.offsets, b.nSeq);

@@ -192,6 +192,7 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_MODE_ANY   0      /* any d: exact test in phase A via modular inverse */
 #define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
 #define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
+#define MG_MODE_ODD   3      /* odd d (the reference's default w = 31): the exact test is the inverse's product alone */
 #define MG_LIST_UNROLL 4     /* candidates per half of a lane's mask listed by straight-line code */
 #define MG_CAND_CAP   320    /* candidate list entries (LDS, per wavefront): up to 63 waiting from the tile before + a pass of this tile's */
 #define MG_WAVES      (MG_SCAN_THREADS / 64)
@@ -359,34 +360,37 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
           cand = ((U64) __brev (acc) << 32) | __brev (candLo);
         }
       else
-        { /* incoming-base stream: in[j] holds bases k+16j .. k+16j+15 of the lane's window */
-          U32 in[4];
-          { const bool up = (2 * k) >= 32;
-            const int r = (2 * k) & 31;
-            U32 s0 = up ? w[1] : w[0], s1 = up ? w[2] : w[1], s2 = up ? w[3] : w[2],
-                s3 = up ? w[4] : w[3], s4 = up ? w[5] : w[4];
-            in[0] = __funnelshift_l (s1, s0, r); in[1] = __funnelshift_l (s2, s1, r);
-            in[2] = __funnelshift_l (s3, s2, r); in[3] = __funnelshift_l (s4, s3, r);
-          }
-          U64 F = (((U64) w[0] << 32) | w[1]) >> sh1;
-          U64 R = mgRevComp (F, sh1);
-          const int top = 2 * (k - 1);
+        { /* exact modes: both k-mers of every start straight out of the lane's six words (96 bases: its 64 starts and
+             the k - 1 <= 30 bases after them), two v_alignbit each -- no rolled k-mer, no chain from start to start.
+             Forward: the 64 bits from the start's first base, shifted down to the k-mer (F = W >> shift1).  Reverse: word-wise
+             reverse complements make a little-endian stream X with base n at bits [2n, 2n + 2); R = (X >> 2 start) & mask.
+             (Round 4: the rolled form -- F = ((F << 2) & mask) | b, R = (R >> 2) | (3 - b) << 2(k-1) -- cost 11 instructions a
+             start against 7 here; with the test by the odd part's inverse alone where d is odd, 40.7 -> VALU per start.) */
+          U32 rw[6];
+#pragma unroll
+          for (int j = 0 ; j < 6 ; ++j) rw[j] = mgRevComp16 (w[j]);
+          const U32 maskLo = (U32) p.mask, maskHi = (U32) (p.mask >> 32);
           U32 acc = 0, hitLo = 0;
 #pragma unroll 1
           for (int chunk = 0 ; chunk < 4 ; ++chunk)
-            { const U32 cur = in[0];
-              in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
+            { const U32 f0 = w[0], f1w = w[1], f2 = w[2], r0 = rw[0], r1 = rw[1], r2 = rw[2];
+              w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5];
+              rw[0] = rw[1]; rw[1] = rw[2]; rw[2] = rw[3]; rw[3] = rw[4]; rw[4] = rw[5];
 #pragma unroll
               for (int tt = 0 ; tt < 16 ; ++tt)
-                { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
+                { const U32 wHi = tt ? __builtin_amdgcn_alignbit (f0, f1w, 32 - 2 * tt) : f0;
+                  const U32 wLo = tt ? __builtin_amdgcn_alignbit (f1w, f2, 32 - 2 * tt) : f1w;
+                  const U32 xLo = tt ? __builtin_amdgcn_alignbit (r1, r0, 2 * tt) : r0;
+                  const U32 xHi = tt ? __builtin_amdgcn_alignbit (r2, r1, 2 * tt) : r1;
+                  const U64 F = (((U64) wHi << 32) | wLo) >> sh1;
+                  const U64 R = ((U64) (xHi & maskHi) << 32) | (xLo & maskLo);
+                  U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
                   U64 h = hF < hR ? hF : hR;
                   bool hit;
-                  if (MODE == MG_MODE_POW2) hit = (h & dMask) == 0;
-                  else                      hit = mgDivisible (h, p);
+                  if (MODE == MG_MODE_POW2)     hit = (h & dMask) == 0;
+                  else if (MODE == MG_MODE_ODD) hit = h * p.dOddInv <= p.dOddLim;
+                  else                          hit = mgDivisible (h, p);
                   acc = (acc << 1) | (hit ? 1u : 0u);
-                  U32 b = (cur >> (30 - 2 * tt)) & 3;         /* base k + 16*chunk + tt enters */
-                  F = ((F << 2) & p.mask) | b;
-                  R = (R >> 2) | ((U64) (3 - b) << top);
                 }
               if (chunk == 1) { hitLo = acc; acc = 0; }
             }
@@ -488,8 +492,9 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
                   { U64 hF = (F * f1) >> sh1, hR = (R * f1) >> sh1;
                     fwd = hF < hR;
                     U64 h = fwd ? hF : hR;
-                    if (MODE == MG_MODE_ANY) surv = mgDivisible (h, p);
-                    else                     surv = (h & dMask) == 0;
+                    if (MODE == MG_MODE_POW2)     surv = (h & dMask) == 0;
+                    else if (MODE == MG_MODE_ODD) surv = h * p.dOddInv <= p.dOddLim;
+                    else                          surv = mgDivisible (h, p);
                   }
                 if (!fwd) F = R;
               }
@@ -721,11 +726,8 @@ static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
 {
   MgScanGeom g;
   g.nTiles = nTiles;
-  static long maxBlocks = -1;
-  if (maxBlocks < 0)
-    { const char *e = getenv ("MODGPU_SCAN_GRID");           /* test knob */
-      maxBlocks = e && atol (e) > 0 ? atol (e) : MG_SCAN_MAX_BLOCKS;   /* read once; tests use it to put several tiles in a worker's range */
-    }
+  const long gridKnob = mgKnobs ()->scanGrid;                 /* test knob: several tiles in a worker's range */
+  const long maxBlocks = gridKnob != MG_KNOB_UNSET && gridKnob > 0 ? gridKnob : MG_SCAN_MAX_BLOCKS;
   U64 want = g.nTiles < (U64) maxBlocks ? g.nTiles : (U64) maxBlocks;
   if (!want) want = 1;
   g.tilesPerBlock = (g.nTiles + want - 1) / want; if (!g.tilesPerBlock) g.tilesPerBlock = 1;
@@ -777,8 +779,7 @@ static int mgScanMode (const MgHashParams &p, MgScanArgs *a)
 {
   const bool pow2 = (p.dOddInv == 1 && p.dOddLim == ~0ull);
   const int B = p.shift1 + p.dShift;
-  static int forceGeneric = -1;
-  if (forceGeneric < 0) { const char *e = getenv ("MODGPU_SCAN_GENERIC"); forceGeneric = (e && *e == '1') ? 1 : 0; }
+  const int forceGeneric = mgKnobs ()->scanGeneric == 1;       /* test knob */
   a->fS = 0; a->thresh = 0;
   /* the filter passes 2/d of the starts to the exact evaluation: from d = 8 up that beats computing both full
      hashes everywhere (measured at k=31: d=4 1.80 ms/Gbp exact vs 2.29 filtered) */
@@ -787,7 +788,7 @@ static int mgScanMode (const MgHashParams &p, MgScanArgs *a)
       a->thresh = (U32) 1 << (32 - p.dShift);
       return MG_MODE_FAST;
     }
-  return pow2 ? MG_MODE_POW2 : MG_MODE_ANY;
+  return pow2 ? MG_MODE_POW2 : (p.dShift == 0 ? MG_MODE_ODD : MG_MODE_ANY);
 }
 
 /* scan tiles [tile0, tile1) of the batch: the modimizers of those k-mer starts, dense and in order */
@@ -819,18 +820,19 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   /* the first partition digit, counted by the scan itself when the table hash allows it (2k >= 24); otherwise by the compaction kernel */
   int hHiB = 0, hLoB = 0;
   if (hist && hist->binCount) mgPartSplit (hist->log2NB, &hHiB, &hLoB);
-  static int histEnv = -1; if (histEnv < 0) { const char *e = getenv ("MODGPU_SCAN_HIST"); histEnv = (e && *e == '0') ? 0 : 1; }   /* test knob: 0 = the compaction kernel counts */
+  const int histEnv = mgKnobs ()->scanHist == 0 ? 0 : 1;   /* test knob: 0 = the compaction kernel counts */
   const bool scanCounts = histEnv && hist && hist->binCount && hist->kbits >= 24 && hHiB >= 1 && hHiB <= MG_MIX_TOP && hLoB + hHiB == hist->log2NB;
   a.histCount = scanCounts ? hist->binCount : 0; a.histKbits = hist ? hist->kbits : 64; a.histHiB = hHiB;
 #ifdef MG_ABLATE
-  { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_SCAN_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = (U32) dbg; }
+  { const long dbg = mgKnobs ()->scanDebug; a.debug = dbg != MG_KNOB_UNSET ? (U32) dbg : 0u; }
 #endif
   const unsigned grid = (g.nBlocks + MG_WAVES - 1) / MG_WAVES;
   const int mode = mgScanMode (p, &a);
   const bool where = a.segPosF || a.segRead;
 #define MG_SCAN_LAUNCH(M) do { if (where) MG_LAUNCH (MG_K_SCAN, st, (mgScanKernel<M, true>), dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a); \
                                else       MG_LAUNCH (MG_K_SCAN, st, (mgScanKernel<M, false>), dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a); } while (0)
-  if (mode == MG_MODE_FAST) MG_SCAN_LAUNCH (MG_MODE_FAST); else if (mode == MG_MODE_POW2) MG_SCAN_LAUNCH (MG_MODE_POW2); else MG_SCAN_LAUNCH (MG_MODE_ANY);
+  if (mode == MG_MODE_FAST) MG_SCAN_LAUNCH (MG_MODE_FAST); else if (mode == MG_MODE_POW2) MG_SCAN_LAUNCH (MG_MODE_POW2);
+  else if (mode == MG_MODE_ODD) MG_SCAN_LAUNCH (MG_MODE_ODD); else MG_SCAN_LAUNCH (MG_MODE_ANY);
 #undef MG_SCAN_LAUNCH
   MG_HIP (hipGetLastError ());
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
@@ -901,6 +903,7 @@ MgStatus mgLaunchIterScan (const MgHashParams &p, const U32 *dPacked, U64 totalB
   const int mode = mgScanMode (p, &a);
   if (mode == MG_MODE_FAST)      hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_FAST>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   else if (mode == MG_MODE_POW2) hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_POW2>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
+  else if (mode == MG_MODE_ODD)  hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ODD>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   else                           hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ANY>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   MG_HIP (hipGetLastError ());
   return MG_OK;

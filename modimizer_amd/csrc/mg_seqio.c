@@ -125,7 +125,8 @@ static void dieLine (const char *fmt, U64 line)
 
 static int threadCount (void)
 {
-  const char *e = getenv ("MODGPU_PARSE_THREADS");
+  const long pk = mgKnobs ()->parseThreads;
+  const int e = pk != MG_KNOB_UNSET;
   static long budget = 0;
   if (!e && !budget)                                  /* the CPUs this process may really use: affinity mask and cgroup quota, not what is online */
     { budget = sysconf (_SC_NPROCESSORS_ONLN);
@@ -134,7 +135,7 @@ static int threadCount (void)
       if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < budget) budget = c; } fclose (q); }
       if (budget < 1) budget = 1;
     }
-  long n = e ? atol (e) : budget;
+  long n = e ? pk : budget;
   if (n < 1) n = 1;
   if (n > 32) n = 32;
   return (int) n;
@@ -357,7 +358,7 @@ void mgSeqClose (MgSeqReader *r)
   if (!r) return;
   closeInput (r); bigFree (r->buf, r->cap); free (r);
   bigFlush ();
-  if (getenv ("MODGPU_PARSE_TIMING"))          /* dev: where the parser's time went, summed over the batches */
+  if (mgKnobs ()->parseTiming == 1)          /* dev: where the parser's time went, summed over the batches */
     { for (int i = 0 ; i < 8 ; ++i) if (gPhaseName[i]) { fprintf (stderr, "  [parse] %-8s %.3f s\n", gPhaseName[i], gPhase[i]); gPhase[i] = 0; } }
 }
 
@@ -674,9 +675,7 @@ typedef struct {
 #include <immintrin.h>
 static int haveAvx2 (void)                       /* MODGPU_NO_AVX2=1 (tests): the portable loops */
 {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv ("MODGPU_NO_AVX2"); v = (e && *e == '1') ? 0 : (__builtin_cpu_supports ("avx2") ? 1 : 0); }
-  return v;
+  return mgKnobs ()->noAvx2 == 1 ? 0 : (__builtin_cpu_supports ("avx2") ? 1 : 0);
 }
 static size_t countKept (const unsigned char *s, const unsigned char *e)      /* bytes convTable keeps */
 {
@@ -991,8 +990,8 @@ static void *prefetchMain (void *arg) { Prefetch *p = (Prefetch *) arg; p->n = m
 
 static int64_t batchBases (void)
 {
-  const char *e = getenv ("MODGPU_FILE_BATCH_MBP");
-  long mbp = e ? atol (e) : 512;          /* parse of the next batch overlaps the GPU work on this one */
+  const long fk = mgKnobs ()->fileBatchMbp;
+  long mbp = fk != MG_KNOB_UNSET ? fk : 512;          /* parse of the next batch overlaps the GPU work on this one */
   if (mbp < 1) mbp = 1;
   return (int64_t) mbp * 1000000;
 }

@@ -831,7 +831,8 @@ struct MgBucketArgs {
      to weighted entries (one per distinct k-mer: its earliest ordinal in the chunk, its count in pC; pC = 0 ends a chunk's
      list), and the bucket's own workgroup in the dedup kernel walks the chunks' lists instead of the occurrences */
   U32 hotSplit, hotChunk;
-  U64 *hotItems; unsigned long long *hotCount;     /* the chunks to reduce: (bucket << 32 | chunk), and how many */
+  U64 *hotItems; unsigned long long *hotCount;     /* the chunks to reduce: (bucket << 32 | chunk), and how many ([0]; [1]: oversize buckets) */
+  U32 *hotBuckets;                                 /* the oversize buckets, for the dedup kernel's HOT instance */
 #ifdef MG_ABLATE
   int debug;                       /* ablation builds only (MODGPU_BUCKET_DEBUG): dedup: 1 no flag stores, 2 plain stores for max/add, 4 no claim loop, 8 no list stores; merge: 32 no claim loop, 64 no image stores; lookup: 16 no rank gathers, 128 no index stores, 256 no ordinal loads; results are wrong */
 #endif
@@ -1030,6 +1031,7 @@ void mgHotPlanKernel (const MgBucketArgs a)
   const U32 nCh = (U32) ((cnt + L - 1) / L);
   const U64 at = atomicAdd (a.hotCount, (unsigned long long) nCh);
   for (U32 j = 0 ; j < nCh ; ++j) a.hotItems[at + j] = ((U64) b << 32) | j;
+  a.hotBuckets[atomicAdd (a.hotCount + 1, 1ull)] = b;
 }
 
 /* one chunk of an oversize bucket -> its distinct k-mers as weighted entries, in place at the chunk's start.  The LDS image
@@ -1109,7 +1111,10 @@ __device__ __forceinline__ void mgDedupHotBucket (const MgBucketArgs &a, U32 b, 
     }
 }
 
-template <bool PACKED, bool SLOT, int PER>       /* SLOT: a.slotShift != 0; PER: slots of the image per thread, R <= PER x threads */
+/* HOT = false: every bucket but the oversize ones; HOT = true (its own launch, a few workgroups): the oversize buckets the plan
+   listed, from their chunks' weighted entries -- a second instance so that the ordinary one keeps its registers (with the walk
+   inlined as a branch the dedup of config 2 went from 1.22 to 1.27 ms, as a called function to 3.2) */
+template <bool PACKED, bool SLOT, int PER, bool HOT>       /* SLOT: a.slotShift != 0; PER: slots of the image per thread, R <= PER x threads */
 __global__ __launch_bounds__ (1024) __attribute__ ((amdgpu_waves_per_eu (PER == MG_DEDUP_PER ? 8 : 4)))      /* 64 registers: two workgroups per CU */
 void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 {
@@ -1121,16 +1126,23 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
   U32 *sGrp = sCnt + R;                            /* [MG_RANK_GROUPS] members of each group of the bucket's list */
   const U32 nGrp = a.nSlices + 1;
   U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
-  if (bEnd > a.nBuckets) bEnd = a.nBuckets;
-  if (b >= bEnd) return;
+  U64 hotAt = blockIdx.x; const U64 nHot = HOT ? a.hotCount[1] : 0;
+  if (HOT) { if (hotAt >= nHot) return; }
+  else
+    { if (bEnd > a.nBuckets) bEnd = a.nBuckets;
+      if (b >= bEnd) return;
+    }
   for (U32 i = tid ; i < R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
   if (tid < MG_RANK_GROUPS) sGrp[tid] = 0;
+  for ( ; ; )                                           /* (HOT: one listed bucket per turn; otherwise a single turn over the workgroup's range) */
+  {
+  if (HOT) { b = a.hotBuckets[hotAt]; bEnd = b + 1; }
   U64 lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
   U32 occNow = a.occ[b];                          /* fetched one bucket ahead like the bounds: it gates a branch */
   U64 ck[MG_BUCKET_PREFETCH]; U32 ct[MG_BUCKET_PREFETCH];
 #pragma unroll
   for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (i < hi) { ck[j] = __builtin_nontemporal_load (&a.pK[i]); if (!PACKED) ct[j] = __builtin_nontemporal_load (&a.pT[i]); } }
+    { U64 i = lo + (U64) j * T + tid; ck[j] = 0; ct[j] = 0; if (!HOT && i < hi) { ck[j] = __builtin_nontemporal_load (&a.pK[i]); if (!PACKED) ct[j] = __builtin_nontemporal_load (&a.pT[i]); } }
   __syncthreads ();
   for ( ; b < bEnd ; ++b)
     { /* fetch the next bucket while this one is processed */
@@ -1150,6 +1162,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
         { if (tid == 0) a.uniqCount[b] = 0;
           if (tid < nGrp + 1) a.sliceOff[(U64) b * (nGrp + 1) + tid] = 0;
         }
+      else if (!HOT && hi - lo > a.hotSplit) { }          /* (uniform) an oversize bucket: the other instance's */
       else
         { if (occNow)
             { for (U32 i = tid ; i < R ; i += T)
@@ -1158,7 +1171,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 }
               __syncthreads ();
             }
-          if (hi - lo > a.hotSplit) mgDedupHotBucket<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo, hi);   /* (uniform) reduced to weighted entries by mgHotReduceKernel */
+          if (HOT) mgDedupHotBucket<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo, hi);   /* reduced to weighted entries by mgHotReduceKernel */
           else
           {
 #pragma unroll
@@ -1228,6 +1241,10 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #pragma unroll
       for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j) { ck[j] = nk[j]; ct[j] = nt[j]; }
     }
+  if (!HOT) break;
+  hotAt += gridDim.x;
+  if (hotAt >= nHot) break;
+  }
 }
 
 /* step 4: merge the bucket's uniques into the table bucket and stream it back */
@@ -1422,16 +1439,13 @@ static inline U64 mgRankRowsPerUnit (U64 n, U32 *nBlocks)
 /* the split of oversize buckets: occurrences above which a bucket is split, occurrences of a chunk at least */
 static void mgHotKnobs (U32 *split, U32 *chunk)
 {
-  static U32 sp = 0, ch = 0;
-  if (!sp)
-    { const char *e = getenv ("MODGPU_HOT_SPLIT");          /* test knob "split,chunk": small values send ordinary buckets through the split path */
-      U32 a = MG_HOT_SPLIT_DEFAULT, b = MG_HOT_CHUNK_DEFAULT;
-      if (e) { a = (U32) atoi (e); const char *c = strchr (e, ','); b = c ? (U32) atoi (c + 1) : a / 4; }
-      if (b < 64) b = 64;
-      if (a < b) a = b;
-      ch = b; sp = a;
-    }
-  *split = sp; *chunk = ch;
+  const MgKnobs *k = mgKnobs ();                             /* test knob "split,chunk": small values send ordinary buckets through the split path */
+  U32 a = MG_HOT_SPLIT_DEFAULT, b = MG_HOT_CHUNK_DEFAULT;
+  if (k->hotSplit != MG_KNOB_UNSET && k->hotSplit > 0)
+    { a = (U32) k->hotSplit; b = k->hotChunk != MG_KNOB_UNSET && k->hotChunk > 0 ? (U32) k->hotChunk : a / 4; }
+  if (b < 64) b = 64;
+  if (a < b) a = b;
+  *split = a; *chunk = b;
 }
 static U64 mgHotItemsCap (U64 n) { U32 sp, ch; mgHotKnobs (&sp, &ch); return n / ch + n / sp + 16; }
 
@@ -1446,18 +1460,14 @@ size_t mgTableAddScratchBytes (const MgTable *t, U64 n)
               + mgAl ((NB + 2) * 8) * 3 + mgAl ((NB + 2) * 4) * 2 + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 3 + 2 * mgAl ((U64) MG_PART_MAXBINS * 16 * 8 + 4096)
               + mgAl ((MG_PART_MAXBINS + 2) * 4) + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4)
               + mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short)) + mgAl ((n / MG_PART_SUB + 2) * 24)
-              + mgAl (mgHotItemsCap (n) * 8) + 256;
+              + mgAl (mgHotItemsCap (n) * 8) + mgAl (mgHotItemsCap (n) * 4) + 256;
   return rank + (direct > part ? direct : part) + 4096;
 }
 
 static int mgPathOverride (void)
 {
-  static int v = -1;
-  if (v < 0)
-    { const char *e = getenv ("MODGPU_TABLE_PATH");
-      v = !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0));
-    }
-  return v;
+  const long c = mgKnobs ()->tablePath;                       /* test knob: the first letter of "direct" / "bucket" */
+  return c == 'd' ? 1 : (c == 'b' ? 2 : 0);
 }
 
 bool mgTableUseBuckets (const MgTable *t, U64 n);
@@ -1465,7 +1475,7 @@ bool mgTableUseBuckets (const MgTable *t, U64 n);
    needs the digit counts the scan made for exactly this table geometry */
 bool mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *counted)
 {
-  static int off = -1; if (off < 0) { const char *e = getenv ("MODGPU_NO_SEGMENT_INPUT"); off = (e && *e == '1') ? 1 : 0; }   /* test knob: always compact first */
+  const int off = mgKnobs ()->noSegmentInput == 1;   /* test knob: always compact first */
   return !off && n && mgTableUseBuckets (t, n) && counted && counted->binCount && counted->log2NB == t->log2NB && counted->kbits == t->kbits;
 }
 
@@ -1495,12 +1505,12 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
   if (counted) MG_HIP (hipMemcpy2DAsync (binCount, sizeof (U32), counted, MG_HIST_STRIDE * sizeof (U32), sizeof (U32), nBins, hipMemcpyDeviceToDevice, st));   /* the scan counted them */
   else MG_HIP (hipMemsetAsync (binCount, 0, (size_t) nSeg * nBins * sizeof (U32), st));
   /* large sub-chunks where the kernel has them: packed elements, at most 256 bins */
-  static int bigEnv = -1; if (bigEnv < 0) { const char *e = getenv ("MODGPU_PART_BIG"); bigEnv = e ? atoi (e) : 1; }      /* test knob: 0 = sub-chunks of MG_PART_SUB everywhere */
+  const int bigEnv = mgKnobs ()->partBig == MG_KNOB_UNSET ? 1 : (int) mgKnobs ()->partBig;      /* test knob: 0 = sub-chunks of MG_PART_SUB everywhere */
   const bool big = bigEnv && packed && nBins <= MG_PART_BIG_BINS && MG_PART_THREADS == 1024;
   const U32 chunkElems = 2u * (U32) (big ? MG_PART_SUB_BIG : MG_PART_SUB);
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkElems, chunkBase);
   unsigned maxChunks = (unsigned) (n / chunkElems + nSeg + 1);
-  static int sgEnv = -1; if (sgEnv < 0) { const char *e = getenv ("MODGPU_SCATTER_GRID"); sgEnv = e ? atoi (e) : 0; }   /* dev knob */
+  const int sgEnv = mgKnobs ()->scatterGrid == MG_KNOB_UNSET ? 0 : (int) mgKnobs ()->scatterGrid;   /* dev knob */
   unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
   const dim3 hg (maxChunks < 4096 ? maxChunks : 4096), sg (scatterGrid);
   if (!counted)
@@ -1580,6 +1590,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   unsigned short *sliceOff = (unsigned short *) wb;   wb += mgAl ((size_t) (MG_RANK_GROUPS + 2) * NB * sizeof (unsigned short));
   MgSubSeg *subSeg = (MgSubSeg *) wb;         wb += mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg));
   U64 *hotItems = (U64 *) wb;                 wb += mgAl (mgHotItemsCap (n) * 8);
+  U32 *hotBuckets = (U32 *) wb;               wb += mgAl (mgHotItemsCap (n) * 4);
   unsigned long long *hotCount = (unsigned long long *) wb; wb += 256;
   (void) spare64;
 
@@ -1593,7 +1604,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   /* element format: one packed 8-byte word when the mixed k-mer without its coarse digit and the ordinal fit in 64 bits */
   MgPartFmt f;
   f.ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1; f.remBits = t->kbits - hiB; f.loB = loB;
-  static int packEnv = -1; if (packEnv < 0) { const char *e = getenv ("MODGPU_PART_PACKED"); packEnv = e ? atoi (e) : 1; }   /* test knob: 0 forces the wide format */
+  const int packEnv = mgKnobs ()->partPacked == MG_KNOB_UNSET ? 1 : (int) mgKnobs ()->partPacked;   /* test knob: 0 forces the wide format */
   const bool packed = packEnv && t->kbits >= j + 4 && f.remBits + f.ordBits <= 64;
   MgStatus s;
   const U64 *bucketStart = fineStart;
@@ -1607,14 +1618,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
 
   MgBucketArgs a;
   /* flag polarity from what the previous bucketed add saw (MgTable.newPct: new entries per 100 modimizers) */
-  { static int polEnv = -2; if (polEnv == -2) { const char *e = getenv ("MODGPU_FLAG_POLARITY"); polEnv = e ? atoi (e) : -1; }   /* test knob: 0 / 1 force it */
+  { const int polEnv = mgKnobs ()->flagPolarity == MG_KNOB_UNSET ? -1 : (int) mgKnobs ()->flagPolarity;   /* test knob: 0 / 1 force it */
     a.markDup = polEnv >= 0 ? (polEnv ? 1 : 0) : (t->newPct > 50 ? 1 : 0);
   }
   MG_HIP (hipMemsetAsync (flags, a.markDup ? 1 : 0, n, st));
   /* the merge kernel takes the slots from the dedup kernel when the buckets will be more than half full (there its
      probing costs more than the dedup kernel's extra work: a 12.5 Gbp block at load 0.62 gains 0.4 ms, config 2 at 0.38
      nothing); the load is estimated from the share of new k-mers the previous add saw */
-  { static int slotEnv = -2; if (slotEnv == -2) { const char *e = getenv ("MODGPU_MERGE_SLOTS"); slotEnv = e ? atoi (e) : -1; }   /* test knob: 0 / 1 force it */
+  { const int slotEnv = mgKnobs ()->mergeSlots == MG_KNOB_UNSET ? -1 : (int) mgKnobs ()->mergeSlots;   /* test knob: 0 / 1 force it */
     const U64 expectNew = t->newPct > 0 ? n * (U64) t->newPct / 100 : n;
     const bool dense = ((U64) t->max + expectNew) * 2 > t->nSlots;
     a.slotShift = (t->kbits <= MG_SLOT_SHIFT && (slotEnv >= 0 ? slotEnv != 0 : dense)) ? MG_SLOT_SHIFT : 0;
@@ -1624,7 +1635,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
   /* slices of the ordinal range for the rank lookups: 2^sliceShift ordinals each (2^22: 1 MiB of rank records, and a
      bucket's share of a slice is usually shorter than a wave), at most MG_RANK_GROUPS - 1 of them */
-  { static int shEnv = -1; if (shEnv < 0) { const char *e = getenv ("MODGPU_RANK_SLICE_SHIFT"); shEnv = e ? atoi (e) : 22; }   /* dev knob */
+  { const int shEnv = mgKnobs ()->rankSliceShift == MG_KNOB_UNSET ? 22 : (int) mgKnobs ()->rankSliceShift;   /* dev knob */
     a.sliceShift = shEnv;
     while (((n - 1) >> a.sliceShift) + 1 > (U64) (MG_RANK_GROUPS - 1)) ++a.sliceShift;
     a.nSlices = (U32) (((n - 1) >> a.sliceShift) + 1);
@@ -1632,7 +1643,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   }
   a.counters = t->counters; a.f = f;
 #ifdef MG_ABLATE
-  { static int dbg = -1; if (dbg < 0) { const char *e = getenv ("MODGPU_BUCKET_DEBUG"); dbg = e ? atoi (e) : 0; } a.debug = dbg; }
+  { const long dbg = mgKnobs ()->bucketDebug; a.debug = dbg != MG_KNOB_UNSET ? (int) dbg : 0; }
 #endif
   /* depth histogram on the fly: possible when this add builds the whole set (empty before, no host depths) */
   const bool track = t->max == 0 && t->baseZero;
@@ -1649,14 +1660,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   if (t->R > MG_DEDUP_PER_BIG * 1024u) { mgSetError ("internal: bucket of %u slots", t->R); return MG_ERR_ARG; }
   if (lds > 48 * 1024)
     {
-#define MG_DEDUP_ATTR(PK, SL, PER) MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<PK, SL, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds))
+#define MG_DEDUP_ATTR(PK, SL, PER) do { MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<PK, SL, PER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+                                        MG_HIP (hipFuncSetAttribute ((const void *) mgBucketDedupKernel<PK, SL, PER, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); } while (0)
       if (bigR) { MG_DEDUP_ATTR (true, true, MG_DEDUP_PER_BIG); MG_DEDUP_ATTR (true, false, MG_DEDUP_PER_BIG); MG_DEDUP_ATTR (false, true, MG_DEDUP_PER_BIG); MG_DEDUP_ATTR (false, false, MG_DEDUP_PER_BIG); }
       else      { MG_DEDUP_ATTR (true, true, MG_DEDUP_PER); MG_DEDUP_ATTR (true, false, MG_DEDUP_PER); MG_DEDUP_ATTR (false, true, MG_DEDUP_PER); MG_DEDUP_ATTR (false, false, MG_DEDUP_PER); }
 #undef MG_DEDUP_ATTR
       MG_HIP (hipFuncSetAttribute ((const void *) mgBucketMergeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
-  static int bThreadsEnv = -1;
-  if (bThreadsEnv < 0) { const char *e = getenv ("MODGPU_BUCKET_T"); bThreadsEnv = e ? atoi (e) : 0; }
+  const int bThreadsEnv = mgKnobs ()->bucketT == MG_KNOB_UNSET ? 0 : (int) mgKnobs ()->bucketT;
   unsigned bThreads = bThreadsEnv ? (unsigned) bThreadsEnv : (t->R >= 4096 ? 1024u : (t->R >= 2048 ? 512u : 256u));
   while (bThreads < 1024 && (U64) bThreads * MG_DEDUP_PER < t->R) bThreads *= 2;
   unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
@@ -1667,8 +1678,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   /* oversize buckets first: their chunks reduced to weighted entries by a workgroup each (nothing to do on ordinary data:
      the plan finds no bucket and the reduce kernel's workgroups leave at once) */
   mgHotKnobs (&a.hotSplit, &a.hotChunk);
-  a.hotItems = hotItems; a.hotCount = hotCount;
-  MG_HIP (hipMemsetAsync (hotCount, 0, 8, st));
+  a.hotItems = hotItems; a.hotCount = hotCount; a.hotBuckets = hotBuckets;
+  MG_HIP (hipMemsetAsync (hotCount, 0, 16, st));
   MG_LAUNCH (MG_K_HOT_REDUCE, st, mgHotPlanKernel, dim3 ((unsigned) ((NB + 255) / 256)), dim3 (256), 0, st, a);
   { const size_t ldsHot = (size_t) t->R * 16 + 16;
     if (packed) { if (ldsHot > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgHotReduceKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsHot));
@@ -1676,7 +1687,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
     else        { if (ldsHot > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgHotReduceKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsHot));
                   MG_LAUNCH (MG_K_HOT_REDUCE, st, mgHotReduceKernel<false>, dim3 (1024), dim3 (bThreads), ldsHot, st, a); }
   }
-#define MG_DEDUP_LAUNCH(PK, SL, PER) MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<PK, SL, PER>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock)
+#define MG_DEDUP_LAUNCH(PK, SL, PER) do { MG_LAUNCH (MG_K_BUCKET_DEDUP, st, (mgBucketDedupKernel<PK, SL, PER, false>), dim3 (bGrid), dim3 (bThreads), lds, st, a, perBlock); \
+                                          MG_LAUNCH (MG_K_HOT_REDUCE, st, (mgBucketDedupKernel<PK, SL, PER, true>), dim3 (64), dim3 (bThreads), lds, st, a, perBlock); } while (0)
 #define MG_DEDUP_PICK(PER) do { if (packed) { if (a.slotShift) MG_DEDUP_LAUNCH (true, true, PER); else MG_DEDUP_LAUNCH (true, false, PER); } \
                                 else        { if (a.slotShift) MG_DEDUP_LAUNCH (false, true, PER); else MG_DEDUP_LAUNCH (false, false, PER); } } while (0)
   if (bigR) MG_DEDUP_PICK (MG_DEDUP_PER_BIG); else MG_DEDUP_PICK (MG_DEDUP_PER);
@@ -1879,8 +1891,8 @@ MgStatus mgTableClean (MgTable *t, hipStream_t st)
 /* slots needed so that `entries` fit at load <= 0.6 */
 static int mgLog2SlotsFor (const MgTable *t, U64 entries)
 {
-  static int envPct = -1;
-  if (envPct < 0) { const char *e = getenv ("MODGPU_TABLE_LOAD"); envPct = e && atoi (e) >= 10 && atoi (e) <= 150 ? atoi (e) : 0; }   /* dev knob (above 100: experiments only) */
+  const long lk = mgKnobs ()->tableLoad;
+  const int envPct = lk != MG_KNOB_UNSET && lk >= 10 && lk <= 150 ? (int) lk : 0;   /* dev knob (above 100: experiments only) */
   const int loadPct = envPct ? envPct : (t->loadPct ? t->loadPct : 60);
   U64 need = entries * 100 / (U64) loadPct + 1;      /* entries / 0.6 by default */
   int lg = mgLog2 (need);

@@ -480,7 +480,7 @@ __global__ void mgTextFastqCheckKernel (const U64 *__restrict__ endB, const U64 
 static inline size_t txAl (size_t n) { return (n + 255) & ~(size_t) 255; }
 #include <time.h>
 static double txNow (void) { struct timespec ts; clock_gettime (CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-static bool txTiming (void) { static int v = -1; if (v < 0) { const char *e = getenv ("MODGPU_TEXT_TIMING"); v = e && *e == '1'; } return v != 0; }   /* dev knob */
+static bool txTiming (void) { return mgKnobs ()->textTiming == 1; }   /* dev knob */
 struct TxClock { double reserve = 0, read = 0, wait = 0, flush = 0, t0 = 0; void lap (double &slot) { const double n = txNow (); slot += n - t0; t0 = n; } };
 
 struct TxBufs {
@@ -517,20 +517,19 @@ extern "C" void mgTextReleaseBuffers (void) { std::lock_guard<std::mutex> g (gTx
    4 Gbp file, 256 MiB: 34.8), less for a file that is smaller */
 static size_t txWindowBytes (size_t fileSize)
 {
-  const char *e = getenv ("MODGPU_TEXT_WINDOW_KB");          /* test knob: small windows put window and batch edges everywhere */
-  long kb = e ? atol (e) : 0;
+  const long wk = mgKnobs ()->textWindowKb;                  /* test knob: small windows put window and batch edges everywhere */
+  long kb = wk != MG_KNOB_UNSET ? wk : 0;
   size_t w = kb > 0 ? (size_t) kb << 10 : (size_t) 128 << 20;
   if (kb <= 0) while (w > ((size_t) 1 << 20) && w / 2 >= fileSize) w /= 2;
   return (w + TX_TILE - 1) / TX_TILE * TX_TILE;
 }
 static U64 txBatchBases (void)
 {
-  const char *e = getenv ("MODGPU_FILE_BATCH_MBP");
-  long mbp = e ? atol (e) : 1024;
+  const MgKnobs *kn = mgKnobs ();
+  long mbp = kn->fileBatchMbp != MG_KNOB_UNSET ? kn->fileBatchMbp : 1024;
   if (mbp < 1) mbp = 1;
   U64 b = (U64) mbp * 1000000;
-  const char *x = getenv ("MODGPU_FILE_BATCH_BASES");        /* test knob (as in mg_seqio.c) */
-  if (x && atol (x) > 0) b = (U64) atol (x);
+  if (kn->fileBatchBases != MG_KNOB_UNSET && kn->fileBatchBases > 0) b = (U64) kn->fileBatchBases;        /* test knob (as in mg_seqio.c) */
   return b;
 }
 
@@ -602,8 +601,8 @@ static bool txReadParallel (int fd, unsigned char *dst, size_t n, off_t off, int
 
 static int txHostThreads (void)
 {
-  const char *e = getenv ("MODGPU_PARSE_THREADS");
-  long v = e ? atol (e) : 0;
+  const long pk = mgKnobs ()->parseThreads;
+  long v = pk != MG_KNOB_UNSET ? pk : 0;
   if (v <= 0)
     { v = sysconf (_SC_NPROCESSORS_ONLN);
       cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
@@ -641,7 +640,7 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
 static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff = 0, U64 *resumeLine = 0)
 {
   if (mgEnsureDevice ()) return -2;
-  { const char *e = getenv ("MODGPU_TEXT_HOST"); if (e && *e == '1') return -2; }      /* test knob: the host parser */
+  if (mgKnobs ()->textHost == 1) return -2;      /* test knob: the host parser */
   int fd = open (filename, O_RDONLY);
   if (fd < 0) return -2;
   struct stat sb;

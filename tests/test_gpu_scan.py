@@ -44,7 +44,8 @@ def test_golden_vectors_batch_and_iterator(ci):
 
 
 @pytest.mark.parametrize("k,w,seed", [(21, 64, 17), (31, 4, 17), (19, 31, 17), (16, 32, 0), (11, 1, 3),
-                                      (1, 1, 17), (2, 3, 5), (31, 97, 9), (27, 1024, 17), (5, 2, 17)])
+                                      (1, 1, 17), (2, 3, 5), (31, 97, 9), (27, 1024, 17), (5, 2, 17),
+                                      (21, 96, 17), (13, 6, 5), (31, 12, 2), (17, 1000, 1), (16, 31, 4), (15, 7, 4)])   # even d that is no power of two (MG_MODE_ANY), odd d around k = 16
 def test_random_ragged_batches(k, w, seed):
     sh = mg.seqhashCreate(k, w, seed); oh = po.Hasher(k, w, seed)
     rng = np.random.default_rng(k * 7 + w)

@@ -2,7 +2,7 @@
 seqio.c by tests/test_seqio.py) and against what the reference program prints for the golden text files.
 
 mgAddSequenceFile takes the device parser by itself for plain FASTA text; MODGPU_TEXT_HOST=1 forces the host parser,
-MODGPU_TEXT_WINDOW_KB / MODGPU_FILE_BATCH_BASES put window and batch edges everywhere (knobs are read per call)."""
+MODGPU_TEXT_WINDOW_KB / MODGPU_FILE_BATCH_BASES put window and batch edges everywhere (mg.knobs: the library reads its knobs once, mgReloadKnobs again)."""
 import ctypes as C
 import os
 import subprocess
@@ -63,15 +63,11 @@ def test_device_parser_equals_host_parser(kind, n_rec, seed, window_kb, batch_ba
     _, want = parse_file(path, 1 << 40, 4)
     env = {}
     if window_kb:
-        env["MODGPU_TEXT_WINDOW_KB"] = str(window_kb)
+        env["TEXT_WINDOW_KB"] = window_kb
     if batch_bases:
-        env["MODGPU_FILE_BATCH_BASES"] = str(batch_bases)
-    os.environ.update(env)
-    try:
+        env["FILE_BATCH_BASES"] = batch_bases
+    with mg.knobs(**env):
         rc, got = device_records(path)
-    finally:
-        for k in env:
-            del os.environ[k]
     assert rc == 0, mg.lib().mgLastError()
     assert len(got) == len(want)
     for i, (a, b) in enumerate(zip(got, want)):
@@ -103,15 +99,11 @@ def test_device_fastq_parser_equals_host_parser(n_rec, seed, crlf, window_kb, ba
     _, want = parse_file(path, 1 << 40, 4)
     env = {}
     if window_kb:
-        env["MODGPU_TEXT_WINDOW_KB"] = str(window_kb)
+        env["TEXT_WINDOW_KB"] = window_kb
     if batch_bases:
-        env["MODGPU_FILE_BATCH_BASES"] = str(batch_bases)
-    os.environ.update(env)
-    try:
+        env["FILE_BATCH_BASES"] = batch_bases
+    with mg.knobs(**env):
         rc, got = device_records(path)
-    finally:
-        for k in env:
-            del os.environ[k]
     assert rc == 0, mg.lib().mgLastError()
     assert len(got) == len(want) == n_rec
     for i, (a, b) in enumerate(zip(got, want)):

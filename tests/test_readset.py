@@ -127,11 +127,11 @@ def test_readset_file_read_gpu(tag, golden_dir, tmp_path):
     L = mg.lib()
     ms = load_mod_gz(os.path.join(golden_dir, "asm_%s_src.mod" % tag), str(tmp_path / "src.mod"))
     rs = L.mgReadsetCreate(ms)
-    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"        # several batches: reads2.fa holds 120 kb... one batch; the knob is exercised below
+    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"; L.mgReloadKnobs()        # several batches: reads2.fa holds 120 kb... one batch; the knob is exercised below
     try:
         assert L.mgReadsetFileRead(rs, os.path.join(golden_dir, "reads2.fa").encode()) == 0
     finally:
-        del os.environ["MODGPU_FILE_BATCH_MBP"]
+        del os.environ["MODGPU_FILE_BATCH_MBP"]; L.mgReloadKnobs()
     got = stats_text(rs, str(tmp_path / "s.txt")).splitlines()
     assert got == util.golden_text("asm_%s.stdout.txt" % tag).splitlines()[-len(got):]
     out = str(tmp_path / "gpu")
@@ -175,11 +175,11 @@ def test_readset_vs_oracle_saturation_and_batches(tmp_path):
                 for i, s in enumerate(reads):
                     f.write(">r%d\n%s\n" % (i, "".join("ACGT"[b] for b in s)))
             os.environ["MODGPU_FILE_BATCH_MBP"] = "1"
-            os.environ["MODGPU_FILE_BATCH_BASES"] = "9500"
+            os.environ["MODGPU_FILE_BATCH_BASES"] = "9500"; L.mgReloadKnobs()
             try:
                 assert L.mgReadsetFileRead(rs, fa.encode()) == 0
             finally:
-                del os.environ["MODGPU_FILE_BATCH_MBP"]; del os.environ["MODGPU_FILE_BATCH_BASES"]
+                del os.environ["MODGPU_FILE_BATCH_MBP"]; del os.environ["MODGPU_FILE_BATCH_BASES"]; L.mgReloadKnobs()
         same(want, lib_arrays(rs))
         assert np.array_equal(np.ctypeslib.as_array(ms.contents.depth, (ms.contents.max + 1,)), oms.depths())
         assert rs_lines(stats_text(rs, str(tmp_path / "s.txt"))) == rs_lines(ors.stats_text(str(tmp_path / "o.txt")))

@@ -20,7 +20,7 @@ FILES = {"mixed.fa": "mixed_fa", "mixed.fa.gz": "mixed_fa", "unterminated.fa": "
 def parse_file(path, max_bases, threads):
     """every record of the file through mgSeqOpen/mgSeqNextBatch: (names, [bases arrays])"""
     L = mg.lib()
-    os.environ["MODGPU_PARSE_THREADS"] = str(threads)
+    os.environ["MODGPU_PARSE_THREADS"] = str(threads); L.mgReloadKnobs()
     r = L.mgSeqOpen(path.encode())
     assert r
     names, seqs = [], []
@@ -36,7 +36,7 @@ def parse_file(path, max_bases, threads):
             names.append(b.names[i].decode()); seqs.append(bases[offs[i]:offs[i + 1]].copy())
         L.mgSeqBatchFree(C.byref(b))
     L.mgSeqClose(r)
-    del os.environ["MODGPU_PARSE_THREADS"]
+    del os.environ["MODGPU_PARSE_THREADS"]; L.mgReloadKnobs()
     return names, seqs
 
 
@@ -254,12 +254,12 @@ def test_add_sequence_file_gpu(fname, golden_dir, tmp_path):
     sh = mg.seqhashCreate(15, 4, 17)
     ms = mg.modsetCreate(sh, 20)
     out = str(tmp_path / "o.txt")
-    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"
+    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"; L.mgReloadKnobs()
     try:
         with mg.CFile(out, "w") as f:
             assert L.mgAddSequenceFile(ms, os.path.join(golden_dir, fname).encode(), f) == 0
     finally:
-        del os.environ["MODGPU_FILE_BATCH_MBP"]
+        del os.environ["MODGPU_FILE_BATCH_MBP"]; L.mgReloadKnobs()
     tag = fname.replace(".", "_")
     assert open(out).read().strip() == added_line(util.golden_text("seqio_%s.stdout.txt" % tag))
     dump = str(tmp_path / "d.txt")
@@ -279,13 +279,13 @@ def test_modmap_from_files_gpu(tag, golden_dir, tmp_path):
     ms = mg.modsetCreate(sh, 20)
     ref = L.mgReferenceCreate(ms, 1 << 26)
     out = str(tmp_path / "mm.txt")
-    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"
+    os.environ["MODGPU_FILE_BATCH_MBP"] = "1"; L.mgReloadKnobs()
     try:
         with mg.CFile(out, "w") as f:
             assert L.mgReferenceFastaRead(ref, os.path.join(golden_dir, "ref.fa").encode(), True, f) == 0
             assert L.mgQueryFile(ref, os.path.join(golden_dir, "queries.fa").encode(), f) == 0
     finally:
-        del os.environ["MODGPU_FILE_BATCH_MBP"]
+        del os.environ["MODGPU_FILE_BATCH_MBP"]; L.mgReloadKnobs()
     want = util.golden_text("modmap_%s.stdout.txt" % tag).splitlines()[1:]      # without the "initialised" line
     assert open(out).read().splitlines() == want
     L.mgReferenceDestroy(ref)

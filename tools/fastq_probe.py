@@ -16,16 +16,19 @@ block.tofile(path); size = os.path.getsize(path); del block, seqs, q
 L = mg.lib()
 for threads in (16,):
     os.environ["MODGPU_PARSE_THREADS"] = str(threads)
+    mg.lib().mgReloadKnobs()
     t0 = time.time(); r = L.mgSeqOpen(path.encode()); b = mg.MgSeqBatch(); tot = 0
     while L.mgSeqNextBatch(r, 512_000_000, C.byref(b)):
         tot += b.total; L.mgSeqBatchFree(C.byref(b))
     L.mgSeqClose(r); dt = time.time() - t0
     print("FASTQ parse, %2d threads: %.2f s  %.2f GB/s text  %.2f Gbp/s" % (threads, dt, size / dt / 1e9, tot / dt / 1e9))
 del os.environ["MODGPU_PARSE_THREADS"]
+mg.lib().mgReloadKnobs()
 if L.mgDeviceCount() > 0:
     sh = mg.seqhashCreate(31, 4, 17); ms = mg.modsetCreate(sh, 32)
     for host in ("1", "0", "0", "1", "0"):
         os.environ["MODGPU_TEXT_HOST"] = host                      # 1: the host parser; 0: the text parsed on the device
+        mg.lib().mgReloadKnobs()
         L.mgModsetClear(ms, None); t0 = time.time()
         with mg.CFile("/dev/null", "w") as f:
             rc = L.mgAddSequenceFile(ms, path.encode(), f)

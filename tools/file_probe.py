@@ -31,6 +31,7 @@ size = os.path.getsize(path)
 L = mg.lib()
 for threads in (16,):
     os.environ["MODGPU_PARSE_THREADS"] = str(threads)
+    mg.lib().mgReloadKnobs()
     t0 = time.time()
     r = L.mgSeqOpen(path.encode()); b = mg.MgSeqBatch(); tot = 0
     while L.mgSeqNextBatch(r, 2_000_000_000, C.byref(b)):
@@ -39,10 +40,12 @@ for threads in (16,):
     dt = time.time() - t0
     print("parse only, %2d threads: %.2f s  %.2f GB/s text  %.2f Gbp/s" % (threads, dt, size / dt / 1e9, tot / dt / 1e9))
 del os.environ["MODGPU_PARSE_THREADS"]
+mg.lib().mgReloadKnobs()
 if L.mgDeviceCount() > 0:
     sh = mg.seqhashCreate(21, 64, 17); ms = mg.modsetCreate(sh, 28)
     for host in ("1", "0", "0", "1", "0"):
         os.environ["MODGPU_TEXT_HOST"] = host                      # 1: the host parser; 0: plain FASTA parsed on the device (read per call)
+        mg.lib().mgReloadKnobs()
         L.mgModsetClear(ms, None)
         t0 = time.time()
         with mg.CFile("/dev/null", "w") as f:
