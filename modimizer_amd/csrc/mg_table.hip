@@ -1013,8 +1013,8 @@ __device__ __forceinline__ void mgDedupRun (const MgBucketArgs &a, U32 b, unsign
     }
 }
 
-#define MG_HOT_SPLIT_DEFAULT 32768u  /* occurrences above which a bucket is reduced chunk by chunk first (a bucket of config 2 holds 2400) */
-#define MG_HOT_CHUNK_DEFAULT 8192u   /* occurrences of a chunk, at least */
+#define MG_HOT_SPLIT_DEFAULT 16384u  /* occurrences above which a bucket is reduced chunk by chunk first (a bucket of config 2 holds 2400); measured on the repeat-genome probe: 8192 / 16384 / 32768 / 65536 -> 1.50 / 1.44 / 1.48 / 1.50 ms per Gbp */
+#define MG_HOT_CHUNK_DEFAULT 4096u   /* occurrences of a chunk, at least */
 #define MG_HOT_MAXCHUNKS 1024u       /* chunks of a bucket, at most: a bucket of 1e9 occurrences is 1024 chunks of 1e6 */
 __host__ __device__ __forceinline__ U64 mgHotChunkLen (U64 cnt, U32 minChunk)
 { const U64 L = (cnt + MG_HOT_MAXCHUNKS - 1) / MG_HOT_MAXCHUNKS; return L < minChunk ? minChunk : L; }
