@@ -228,6 +228,9 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
 bool     mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *counted);
 MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st);
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
+size_t   mgTableFindPartScratchBytes (U64 n);
+bool     mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counted);
+MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st);   /* el: n words of scratch */
 MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dIndexOut, hipStream_t st);   /* the n k-mers of a lazy scan, in order */
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);
 MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st);

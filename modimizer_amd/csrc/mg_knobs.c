@@ -15,6 +15,8 @@ static void readAll (void)
   MgKnobs k;
   const char *e = getenv ("MODGPU_TABLE_PATH");
   k.tablePath = e && *e ? (long) e[0] : MG_KNOB_UNSET;
+  e = getenv ("MODGPU_FIND_PATH");
+  k.findPath = e && *e ? (long) e[0] : MG_KNOB_UNSET;
   k.partPacked = num ("MODGPU_PART_PACKED");       k.partBig = num ("MODGPU_PART_BIG");
   k.addChunk = num ("MODGPU_ADD_CHUNK");           k.scanGrid = num ("MODGPU_SCAN_GRID");
   k.scanGeneric = num ("MODGPU_SCAN_GENERIC");     k.scanHist = num ("MODGPU_SCAN_HIST");

@@ -699,7 +699,8 @@ __global__ __launch_bounds__ (MG_PART_THREADS)
 void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ tIn, const MgSegSrc src, const MgSubSeg *__restrict__ subSeg,
                           MgGeom g, MgPartFmt f, int shift, U32 nBins,
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg, U32 chunkElems,
-                          unsigned long long *__restrict__ cursor, U32 cstride, U64 *__restrict__ kOut, U32 *__restrict__ tOut)
+                          unsigned long long *__restrict__ cursor, U32 cstride, U64 *__restrict__ kOut, U32 *__restrict__ tOut,
+                          unsigned long long *__restrict__ runTab)
 {
   MG_BUILD_PRIO ();
   constexpr bool WIDE = !PACKOUT;
@@ -782,6 +783,11 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
           }
       if ((U32) (2 * tid) < nBins) sBase[2 * tid] = base0;
       if ((U32) (2 * tid + 1) < nBins) sBase[2 * tid + 1] = base1;
+      if (runTab)                                          /* (uniform; the partitioned lookup) where this sub-chunk's run of every bin went, and its length */
+        { const U64 row = (sub / SUB) * nBins;
+          if ((U32) (2 * tid) < nBins) runTab[row + 2 * tid] = base0 | ((unsigned long long) sH[2 * tid] << 40);
+          if ((U32) (2 * tid + 1) < nBins) runTab[row + 2 * tid + 1] = base1 | ((unsigned long long) sH[2 * tid + 1] << 40);
+        }
       /* the registers are free: fetch the next sub-chunk */
       if (nhave)
         { const U64 nsubHi = nsub + SUB < nhi ? nsub + SUB : nhi;
@@ -1418,6 +1424,67 @@ void mgRankLookupKernel (const MgBucketArgs a, U32 groupsPerSlice)
 }
 
 /* ======================================================================================== */
+/* Partitioned lookups (the modmap query path on a table far larger than the caches, round 4).  A lookup in ordinal order
+ * is one random 64-byte line out of a 2 GB table: 35 G lookups/s, the chip's rate for that footprint.  Here the batch's
+ * modimizers go through the FIRST partition pass of the build (by the top bits of the mixed k-mer, straight from the scan's
+ * segments, the digit counts made by the scan); a bin's lookups then touch one contiguous piece of the table -- 1 / nBins
+ * of it -- and the workgroups of one XCD take one bin at a time, so the piece is read from that XCD's L2; every element
+ * becomes (ordinal << 32 | index) in place; and because the scatter kernel noted where each sub-chunk's run of every bin
+ * went (runTab), a workgroup per sub-chunk pulls its 16384 ordinals' results back from the nBins runs into an LDS tile and
+ * writes them out in order: no second sort, no random store.  Semantics: modsetIndexFind (ms, kmer, false), modset.c:45-62. */
+__global__ __launch_bounds__ (256)
+void mgBinFindKernel (const MgSlot *__restrict__ slots, MgGeom g, MgPartFmt f, U64 *__restrict__ el, const U64 *__restrict__ binStart,
+                      U32 nBins, U32 wgPerXcd)
+{
+  const U32 xcd = blockIdx.x & 7, j = blockIdx.x >> 3;      /* workgroups b, b + 8, ... share an XCD (observed placement; speed only) */
+  const U64 ordMask = ((U64) 1 << f.ordBits) - 1;
+  for (U32 b = xcd ; b < nBins ; b += 8)
+    { const U64 lo = binStart[b], hi = binStart[b + 1];
+      for (U64 i = lo + (U64) j * 256 + threadIdx.x ; i < hi ; i += (U64) wgPerXcd * 256)
+        { const U64 x = __builtin_nontemporal_load (&el[i]);
+          const U64 m = ((U64) b << f.remBits) | (x >> f.ordBits), key = m + 1;
+          const U64 base = (U64) mgBucketOfM (m, g) * g.R;
+          U32 slot = mgHomeOfM (m, g), res = 0;
+          for (U32 probes = 0 ; probes < g.R ; ++probes)
+            { const uint4 w = *reinterpret_cast<const uint4 *> (&slots[base + slot]);
+              const U64 cur64 = ((U64) w.y << 32) | w.x;
+              if (cur64 == key) { res = mgIsAssigned (w.z) ? (w.z & ~MG_ASSIGNED) : 0; break; }
+              if (cur64 == 0) break;
+              slot = (slot + 1) & g.rMask;
+            }
+          __builtin_nontemporal_store (((x & ordMask) << 32) | res, &el[i]);
+        }
+    }
+}
+
+template <int SUB>
+__global__ __launch_bounds__ (1024)
+void mgUnpartKernel (const U64 *__restrict__ el, const unsigned long long *__restrict__ runTab, U32 nBins, U64 n, U32 *__restrict__ out)
+{
+  __shared__ U32 sTile[SUB];
+  __shared__ unsigned long long sRun[MG_PART_MAXBINS];
+  const U32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const U64 nSub = (n + SUB - 1) / SUB;
+  for (U64 s = blockIdx.x ; s < nSub ; s += gridDim.x)
+    { const U64 o0 = s * SUB;
+      const U32 cnt = (U32) (o0 + SUB < n ? SUB : n - o0);
+      for (U32 b = tid ; b < nBins ; b += 1024) sRun[b] = runTab[s * nBins + b];
+      __syncthreads ();
+      for (U32 b = wave ; b < nBins ; b += 16)
+        { const unsigned long long r = sRun[b];
+          const U64 base = r & (((U64) 1 << 40) - 1); const U32 len = (U32) (r >> 40);
+          for (U32 i = lane ; i < len ; i += 64)
+            { const U64 v = __builtin_nontemporal_load (&el[base + i]);
+              sTile[(U32) ((v >> 32) - o0)] = (U32) v;
+            }
+        }
+      __syncthreads ();
+      for (U32 i = tid ; i < cnt ; i += 1024) __builtin_nontemporal_store (sTile[i], &out[o0 + i]);
+      __syncthreads ();
+    }
+}
+
+/* ======================================================================================== */
 /* host side                                                                                  */
 
 static inline unsigned mgGrid (U64 n, unsigned per = 256, unsigned cap = 16384)
@@ -1492,7 +1559,8 @@ bool mgTableUseBuckets (const MgTable *t, U64 n)
 static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgPartFmt &f, const U64 *kIn, const U32 *tIn, U64 n,
                             const U64 *segStart, U32 nSeg, int shift, U32 nBins,
                             U64 *kOut, U32 *tOut, U64 *binStart, unsigned long long *cursor, U32 *binCount, U32 *chunkBase,
-                            hipStream_t st, const U32 *counted = 0, const MgSegSrc *segSrc = 0, MgSubSeg *subSeg = 0)
+                            hipStream_t st, const U32 *counted = 0, const MgSegSrc *segSrc = 0, MgSubSeg *subSeg = 0,
+                            unsigned long long *runTab = 0, U32 *subElems = 0)
 {
   MgGeom g = mgGeomOf (t);
   MgSegSrc src; src.segKmer = 0; src.segCount = 0; src.segStart = 0; src.segCap = 0; src.nSegs = 0;
@@ -1508,6 +1576,7 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
   const int bigEnv = mgKnobs ()->partBig == MG_KNOB_UNSET ? 1 : (int) mgKnobs ()->partBig;      /* test knob: 0 = sub-chunks of MG_PART_SUB everywhere */
   const bool big = bigEnv && packed && nBins <= MG_PART_BIG_BINS && MG_PART_THREADS == 1024;
   const U32 chunkElems = 2u * (U32) (big ? MG_PART_SUB_BIG : MG_PART_SUB);
+  if (subElems) *subElems = (U32) (big ? MG_PART_SUB_BIG : MG_PART_SUB);
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkElems, chunkBase);
   unsigned maxChunks = (unsigned) (n / chunkElems + nSeg + 1);
   const int sgEnv = mgKnobs ()->scatterGrid == MG_KNOB_UNSET ? 0 : (int) mgKnobs ()->scatterGrid;   /* dev knob */
@@ -1526,7 +1595,7 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
   const U32 cstride = nSeg == 1 ? 16u : 1u;                  /* (the second pass's 65536 cursors: no gain from padding) */
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, cstride, nSeg, n);
 #define MG_SCATTER(IN, PK, SUB) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK, SUB>), sg, dim3 (MG_PART_THREADS), 0, st, \
-                                           kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, cursor, cstride, kOut, tOut)
+                                           kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, cursor, cstride, kOut, tOut, runTab)
 #define MG_SCATTER_P(IN) do { if (big) MG_SCATTER (IN, true, MG_PART_SUB_BIG); else MG_SCATTER (IN, true, MG_PART_SUB); } while (0)
   if (inMode == MG_EL_DENSE) { if (packed) MG_SCATTER_P (MG_EL_DENSE); else MG_SCATTER (MG_EL_DENSE, false, MG_PART_SUB); }
   else if (inMode == MG_EL_SEG) { if (packed) MG_SCATTER_P (MG_EL_SEG); else MG_SCATTER (MG_EL_SEG, false, MG_PART_SUB); }
@@ -1749,6 +1818,61 @@ MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dInde
   const U64 rowsPerWave = (nRows + waves - 1) / waves;
   waves = (nRows + rowsPerWave - 1) / rowsPerWave;
   MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgTableFindSegKernel, dim3 ((unsigned) ((waves + 3) / 4)), dim3 (256), 0, st, t->slots, mgGeomOf (t), src, n, rowsPerWave, dIndexOut);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+/* scratch of the partitioned lookup for a batch of n: the run table and the partition's small arrays (the packed elements,
+   8 bytes each, go where the caller says: the scan's unused dense k-mer array) */
+size_t mgTableFindPartScratchBytes (U64 n)
+{
+  return mgAl ((n / MG_PART_SUB + 2) * (size_t) MG_PART_MAXBINS * 8) + mgAl (((U64) MG_PART_MAXBINS + 2) * 8) * 2
+       + mgAl (((U64) MG_PART_MAXBINS + 2) * 8 * 16) + mgAl ((MG_PART_MAXBINS + 2) * 4)
+       + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4) + mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg)) + 4096;
+}
+
+/* does a lookup batch take the partitioned path?  It needs the scan's digit counts for this table geometry, elements that
+   fit one word, and a table the direct probes would have to fetch from HBM */
+bool mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counted)
+{
+  const long kp = mgKnobs ()->findPath;                      /* test knob: 'p' / 'd' force it */
+  if (kp == 'd') return false;
+  if (!n || !counted || !counted->binCount || counted->log2NB != t->log2NB || counted->kbits != t->kbits) return false;
+  int hiB, loB; mgPartSplit (t->log2NB, &hiB, &loB);
+  const int ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1;
+  if (!(t->kbits >= t->log2NB + 4 && t->kbits - hiB + ordBits <= 64) || hiB < 3) return false;
+  if (t->kbits < 24 || mgKnobs ()->scanHist == 0) return false;          /* (the counts must be the scan's own: mgLaunchScanRange) */
+  if (kp == 'p') return true;
+  return n >= ((U64) 1 << 24) && t->nSlots >= ((U64) 1 << 24);      /* a table of 256 MB and more, a batch that fills the chip */
+}
+
+MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st)
+{
+  if (!n) return MG_OK;
+  { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
+  char *wb = (char *) scratch;
+  unsigned long long *runTab = (unsigned long long *) wb;    wb += mgAl ((n / MG_PART_SUB + 2) * (size_t) MG_PART_MAXBINS * 8);
+  U64 *binStart = (U64 *) wb;                                wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
+  U64 *whole = (U64 *) wb;                                   wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8);
+  unsigned long long *cursor = (unsigned long long *) wb;    wb += mgAl (((U64) MG_PART_MAXBINS + 2) * 8 * 16);
+  U32 *binCount = (U32 *) wb;                                wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
+  U32 *chunkBase = (U32 *) wb;                               wb += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);
+  MgSubSeg *subSeg = (MgSubSeg *) wb;                        wb += mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg));
+  int hiB, loB; mgPartSplit (t->log2NB, &hiB, &loB);
+  MgPartFmt f; f.ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1; f.remBits = t->kbits - hiB; f.loB = loB;
+  const U32 nBins = (U32) 1 << hiB;
+  U64 segInit[2] = { 0, n };
+  MG_HIP (hipMemcpyAsync (whole, segInit, 16, hipMemcpyHostToDevice, st));
+  U32 subElems = 0;
+  MgStatus s = mgPartPass (t, MG_EL_SEG, true, f, (const U64 *) 0, 0, n, whole, 1, loB, nBins, el, (U32 *) 0, binStart, cursor, binCount, chunkBase, st,
+                           counted->binCount, &segSrc, subSeg, runTab, &subElems);
+  if (s) return s;
+  const U32 wgPerXcd = 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
+  MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgBinFindKernel, dim3 (8 * wgPerXcd), dim3 (256), 0, st, t->slots, mgGeomOf (t), f, el, binStart, nBins, wgPerXcd);
+  const U64 nSub = (n + subElems - 1) / subElems;
+  const unsigned ug = (unsigned) (nSub < 2048 ? nSub : 2048);
+  if (subElems == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartKernel<MG_PART_SUB_BIG>, dim3 (ug), dim3 (1024), 0, st, el, runTab, nBins, n, dIndexOut);
+  else                             MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartKernel<MG_PART_SUB>, dim3 (ug), dim3 (1024), 0, st, el, runTab, nBins, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }

@@ -241,10 +241,19 @@ def test_golden_modmap_flow(tag, golden_dir, tmp_path):
     L.mgReferenceDestroy(ref)
 
 
-def test_seed_lists_vs_oracle():
-    """mgQueryReadsDevice: Seed{index,pos} per read incl. misses (modmap.c:197-206)"""
+@pytest.mark.parametrize("k,w,bits,path", [(21, 32, 22, "direct"), (21, 32, 22, "part"), (19, 31, 23, "part"), (15, 8, 24, "part"),
+                                            (27, 4, 22, "part"), (31, 4, 22, "part")])
+def test_seed_lists_vs_oracle(k, w, bits, path):
+    """mgQueryReadsDevice: Seed{index,pos} per read incl. misses (modmap.c:197-206) -- by direct probes in ordinal order and by
+    the partitioned lookup (mgTableFindPartitioned: first partition pass of the build on the query's modimizers, lookups bin by
+    bin against one piece of the table, results pulled back into ordinal order through the scatter's run table); k = 31 has no
+    one-word element and must fall back to the direct probes by itself"""
     L = mg.lib()
-    k, w, bits = 21, 32, 22
+    with mg.knobs(FIND_PATH=path):
+        _seed_lists_vs_oracle(L, k, w, bits)
+
+
+def _seed_lists_vs_oracle(L, k, w, bits):
     sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
     refb = synth_batch(300_000, 300_000, 41, err=0.0, n50=50_000)
     ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
@@ -269,6 +278,19 @@ def test_seed_lists_vs_oracle():
     rid = d_rid.to_numpy(np.uint32, n.value)
     assert np.array_equal(np.searchsorted(rid, np.arange(len(q[1]))), qst)
     assert (want == 0).any() and (want != 0).any()
+    # a second, larger query batch against the same table (other sub-chunk counts, a last partial sub-chunk), twice
+    q = synth_batch(1_500_000, 300_000, 41, err=0.02, n50=3000)
+    qk = util.oracle_scan_batch(oh, *q)[0]
+    order = np.argsort(oms.values()[1:], kind="stable"); vs = oms.values()[1:][order]
+    at = np.minimum(np.searchsorted(vs, qk), len(vs) - 1)
+    want = np.where(vs[at] == qk, order[at] + 1, 0).astype(np.uint32)
+    total = int(q[1][-1])
+    d_p = mg.DeviceBuffer.from_numpy(mg.pack_host(q[0])); d_o = mg.DeviceBuffer.from_numpy(q[1].astype(np.uint64))
+    cap = len(qk) + 5
+    d_ix = mg.DeviceBuffer(cap * 4)
+    for rep in range(2):
+        mg.check(L.mgQueryReadsDevice(ms, d_p.ptr, total, d_o.ptr, len(q[1]) - 1, d_ix.ptr, None, None, cap, C.byref(n), None))
+        assert n.value == len(qk) and np.array_equal(d_ix.to_numpy(np.uint32, n.value), want), rep
 
 
 def test_full_size_build_properties():
@@ -657,8 +679,9 @@ def _mutate(rng, b, rate):
     return b
 
 
+@pytest.mark.parametrize("path", ["direct", "part"])
 @pytest.mark.parametrize("k,w,seed", [(15, 8, 17), (21, 64, 17), (19, 31, 17), (13, 4, 5), (17, 16, 17), (25, 11, 3)])
-def test_modmap_randomized_vs_oracle(k, w, seed, tmp_path):
+def test_modmap_randomized_vs_oracle(k, w, seed, path, tmp_path):
     """queryProcess (modmap.c:188-281) on randomized references and reads against the ORACLE's restatement of it
     (oracle/orc_modset.c orcQueryRead, itself pinned to the reference program's golden Q / M lines), byte for byte: references
     with duplicated and triplicated segments (copy-2 / copy-M classes, the second-copy retry of modmap.c:242-254), forward
@@ -667,6 +690,11 @@ def test_modmap_randomized_vs_oracle(k, w, seed, tmp_path):
     6 parameter sets x 6 references x 7-9 reads = about 290 reads; the reference build's own report lines and arrays
     (index / offset / id / depth / loc / rev, modmap.c:74-134) are compared on the way."""
     L = mg.lib()
+    with mg.knobs(FIND_PATH=path):                      # the seeds' lookups by direct probes / through the partitioned path
+        _modmap_randomized(L, k, w, seed, tmp_path)
+
+
+def _modmap_randomized(L, k, w, seed, tmp_path):
     rng = np.random.default_rng(1000 * k + w)
     n_reads_total = n_m_lines = n_overflow = 0
     for trial in range(6):

@@ -23,3 +23,6 @@ for pk in 1 0; do
   MODGPU_HOT_SPLIT=200,64 MODGPU_TABLE_PATH=bucket MODGPU_PART_PACKED=$pk python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
   MODGPU_HOT_SPLIT=200,64 MODGPU_TABLE_PATH=bucket MODGPU_PART_PACKED=$pk python tests/fuzz_gpu.py $((17 + pk)) 150 2>&1 | tail -2
 done
+echo "== MODGPU_FIND_PATH=part (every lookup batch through the partitioned path)"
+MODGPU_FIND_PATH=part python -m pytest tests/test_gpu_modset.py tests/test_dropin.py tests/test_ref_files.py tests/test_readset.py tests/test_seqio.py -q -x -m gpu 2>&1 | tail -2
+MODGPU_FIND_PATH=part python tests/fuzz_gpu.py 19 150 2>&1 | tail -2
