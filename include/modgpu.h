@@ -291,6 +291,7 @@ int  mgTextParseFileDevice (const char *filename, char **bases, int64_t **offset
 int  mgAddSequenceFile (Modset *ms, const char *filename, FILE *out) ;                        /* modutils.c:33-51 */
 int  mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out) ;   /* modmap.c:93-134 */
 int  mgQueryFile (MgReference *ref, const char *filename, FILE *out) ;                        /* modmap.c:188-281 */
+int  mgFormatF2 (char *buf64, double x) ;	/* test hook: the "%.2f" of the Q / M lines as the library's parallel formatter writes it (glibc's rounding of the double's exact value, in integer arithmetic; snprintf itself for nan / inf / negative); returns the length */
 
 /* Deterministic synthetic reads generated directly in HBM (not from the reference):
  *   mgSynthGenome: nBases iid-uniform bases, base g = splitmix64(seed ^ g*0x9E3779B97F4A7C15) >> 62

@@ -76,7 +76,7 @@ EXPORTS = [
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
-    "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgFormatF2", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
@@ -144,6 +144,7 @@ def lib():
     sig("modRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
     sig("minimizerRCiterator", IT, SH, vp, i32)
     sig("mgIterScanHost", vp, SH, vp, i32); sig("mgIterHostBelow", i32, i32); sig("mgReloadKnobs", None)
+    sig("mgFormatF2", i32, C.c_char_p, C.c_double)
     sig("minimizerRCnext", C.c_bool, IT, U64P, C.POINTER(i32), C.POINTER(C.c_bool))
     sig("seqString", C.c_char_p, u64, i32)
     sig("mgSeqhashDestroy", None, SH); sig("mgSeqhashRCiteratorDestroy", None, IT)

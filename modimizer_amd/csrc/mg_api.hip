@@ -849,8 +849,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
   b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0; b->findScratch = 0;
   U64 cap = mgSurvivorGuess (sh, totalBases);
   /* a lookup batch whose k-mers stay in the segments may take the partitioned path (mgTableFindPartitioned): it needs the first digit's counts */
-  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && mgKnobs ()->findPath != 'd'
-                          && (mgKnobs ()->findPath == 'p' || (cap >= ((U64) 1 << 24) && d->t.nSlots >= ((U64) 1 << 24)));
+  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && mgKnobs ()->findPath == 'p';
   MgHashParams p = mgMakeParams (sh);
   if (extraPerSurvivor)
     { /* size the table now for the expected number of modimizers (N/d): the insert would do it anyway once the
@@ -873,10 +872,11 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       b->rid = !wantPos ? 0 : (direct ? outRid : (U32 *) d->arena.take (cap * 4));
       b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads, cap));
       b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
-      b->counted.log2NB = 0; b->counted.kbits = 64; b->counted.binCount = 0;
+      b->counted.log2NB = 0; b->counted.kbits = 64; b->counted.binCount = 0; b->counted.hiB = 0;
       if (extraPerSurvivor || lookupHist)              /* the survivors go into the modset, or through the partitioned lookup: have the scan count the first partition digit */
         { b->counted.binCount = (U32 *) d->arena.take (512 * MG_HIST_STRIDE * sizeof (U32));
           b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
+          if (lookupHist) b->counted.hiB = mgTableFindDigitBits (&d->t);
         }
       b->findScratch = lookupHist ? d->arena.take (mgTableFindPartScratchBytes (cap)) : 0;
       const bool lz = lazy && (wantPos ? extraPerSurvivor == 0 : b->counted.binCount != 0);   /* a build needs the digit counts; a pure lookup just the segments */

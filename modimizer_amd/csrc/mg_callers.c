@@ -9,6 +9,8 @@
 #define _GNU_SOURCE             /* fopencookie */
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
+#include <unistd.h>
 #include <zlib.h>
 #include "modgpu.h"
 #include "mg_internal.h"
@@ -98,48 +100,52 @@ static void referencePack (MgReference *ref)
     }
 }
 
-int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,
-                     const char **names, bool isAdd, FILE *out)
+/* the names and lengths of nSeq more sequences; the reference die()s on a duplicate name (modmap.c:102) */
+static void refRegister (MgReference *ref, const char **names, const int64_t *offsets, int nSeq)
 {
-  Modset *ms = ref->ms;
-  /* names: the reference die()s on a duplicate name (modmap.c:102) */
   ref->names = (char **) realloc (ref->names, (size_t) (ref->nSeq + nSeq) * sizeof (char *));
   ref->len = (U32 *) realloc (ref->len, (size_t) (ref->nSeq + nSeq) * sizeof (U32));
-  { /* an open-addressed set of the names seen so far (the reference keeps them in a DICT): a fragmented assembly
-       has 1e5 - 1e6 contigs, so no pairwise comparison */
-    const size_t all = (size_t) ref->nSeq + (size_t) nSeq;
-    size_t cap = 16; while (cap < 4 * all) cap *= 2;
-    int *slot = (int *) calloc (cap, sizeof (int));                       /* 1 + position in ref->names; 0 = empty */
-    for (size_t i = 0 ; i < all ; ++i)
-      { const char *nm = i < (size_t) ref->nSeq ? ref->names[i] : names[i - ref->nSeq];
-        U64 h = 0xcbf29ce484222325ull;
-        for (const unsigned char *c = (const unsigned char *) nm ; *c ; ++c) h = (h ^ *c) * 0x100000001b3ull;
-        size_t at = (size_t) (h ^ (h >> 29)) & (cap - 1);
-        while (slot[at])
-          { if (!strcmp (ref->names[slot[at] - 1], nm))
-              { fprintf (stderr, "FATAL ERROR: duplicate ref sequence name %s\n", nm); exit (-1); }
-            at = (at + 1) & (cap - 1);
-          }
-        slot[at] = (int) i + 1;
-        if (i >= (size_t) ref->nSeq)
-          { ref->names[i] = strdup (nm);
-            ref->len[i] = (U32) (offsets[i - ref->nSeq + 1] - offsets[i - ref->nSeq]);
-          }
-      }
-    free (slot);
-  }
-  U64 totLen = nSeq ? (U64) offsets[nSeq] : 0;
+  /* an open-addressed set of the names seen so far (the reference keeps them in a DICT): a fragmented assembly
+     has 1e5 - 1e6 contigs, so no pairwise comparison */
+  const size_t all = (size_t) ref->nSeq + (size_t) nSeq;
+  size_t cap = 16; while (cap < 4 * all) cap *= 2;
+  int *slot = (int *) calloc (cap, sizeof (int));                       /* 1 + position in ref->names; 0 = empty */
+  for (size_t i = 0 ; i < all ; ++i)
+    { const char *nm = i < (size_t) ref->nSeq ? ref->names[i] : names[i - ref->nSeq];
+      U64 h = 0xcbf29ce484222325ull;
+      for (const unsigned char *c = (const unsigned char *) nm ; *c ; ++c) h = (h ^ *c) * 0x100000001b3ull;
+      size_t at = (size_t) (h ^ (h >> 29)) & (cap - 1);
+      while (slot[at])
+        { if (!strcmp (ref->names[slot[at] - 1], nm))
+            { fprintf (stderr, "FATAL ERROR: duplicate ref sequence name %s\n", nm); exit (-1); }
+          at = (at + 1) & (cap - 1);
+        }
+      slot[at] = (int) i + 1;
+      if (i >= (size_t) ref->nSeq)
+        { ref->names[i] = strdup (nm);
+          ref->len[i] = (U32) (offsets[i - ref->nSeq + 1] - offsets[i - ref->nSeq]);
+        }
+    }
+  free (slot);
+}
 
-  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nSeq);
-  U64 cap = b.total ? b.total : 1, n = 0;
-  if (cap > ((U64) ref->size)) cap = ref->size;       /* more seeds than this cannot be stored anyway */
+/* modmap.c:106-118 for a batch of sequences that is on the device already (2-bit packed, offsets in bases): scan + insert
+ * (or lookup) there, the (index, offset, id) of every occurrence appended here */
+int mgReferenceAddDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nSeq, const char **names, bool isAdd)
+{
+  Modset *ms = ref->ms;
+  int64_t *offsets = (int64_t *) malloc ((size_t) (nSeq + 1) * 8);
+  if (mgMemcpyD2H (offsets, dReadOffsets, (size_t) (nSeq + 1) * 8, 0)) fatal ("D2H");
+  refRegister (ref, names, offsets, nSeq);
+  free (offsets);
+  U64 n = 0;
   void *dIx = 0, *dPos = 0, *dRid = 0;
-  U64 guess = b.total / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > b.total) guess = b.total;
+  U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases) guess = totalBases;
   if (guess < 1) guess = 1;
   for (int attempt = 0 ; attempt < 2 ; ++attempt)
     { if (mgDeviceAlloc (&dIx, guess * 4) || mgDeviceAlloc (&dPos, guess * 4) || mgDeviceAlloc (&dRid, guess * 4)) fatal ("device alloc");
-      MgStatus s = isAdd ? mgInsertReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0)
-                         : mgQueryReadsDevice (ms, (U32 *) b.dPacked, b.total, (U64 *) b.dOff, b.nReads, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
+      MgStatus s = isAdd ? mgInsertReadsDevice (ms, dPacked, totalBases, dReadOffsets, (U32) nSeq, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0)
+                         : mgQueryReadsDevice (ms, dPacked, totalBases, dReadOffsets, (U32) nSeq, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0);
       if (s == MG_OK) break;
       if (s == MG_ERR_CAPACITY && n > guess && attempt == 0)
         { mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); guess = n; continue; }
@@ -148,7 +154,7 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
     }
   U32 *hIx = (U32 *) malloc ((size_t) (n + 1) * 4), *hPos = (U32 *) malloc ((size_t) (n + 1) * 4), *hRid = (U32 *) malloc ((size_t) (n + 1) * 4);
   if (n && (mgMemcpyD2H (hIx, dIx, n * 4, 0) || mgMemcpyD2H (hPos, dPos, n * 4, 0) || mgMemcpyD2H (hRid, dRid, n * 4, 0))) fatal ("D2H");
-  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid); mgBatchFree (&b);
+  mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid);
 
   U32 idBase = (U32) ref->nSeq;
   for (U64 i = 0 ; i < n ; ++i)
@@ -163,7 +169,13 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
     }
   free (hIx); free (hPos); free (hRid);
   ref->nSeq += nSeq;
+  return 0;
+}
 
+/* modmap.c:120-133: the report of a file, the copy classes, the packed arrays */
+void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out)
+{
+  Modset *ms = ref->ms;
   fprintf (out, "  %d hashes from %d reference sequences, total length %lld\n", ref->max, ref->nSeq, (long long) totLen);
   if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");       /* info[] is classified on the host arrays */
   U32 n1 = 0, n2 = 0, nM = 0;
@@ -176,6 +188,15 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
   fprintf (out, "  %d copy 1, %d copy 2, %d multiple\n", n1, n2, nM);
   if (isAdd) modsetPack (ms);
   referencePack (ref);
+}
+
+int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,
+                     const char **names, bool isAdd, FILE *out)
+{
+  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nSeq);
+  mgReferenceAddDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, nSeq, names, isAdd);
+  mgBatchFree (&b);
+  mgReferenceFinish (ref, nSeq ? (U64) offsets[nSeq] : 0, isAdd, out);
   return 0;
 }
 
@@ -452,36 +473,131 @@ static int queryProcessHostChain (MgReference *ref, MgDevBatch *b, const int64_t
   return 0;
 }
 
-/* modmap.c:188-281.  Scan, lookup, the tallies of the "Q" line and the chaining into "M" blocks all run on the
- * device (mg_chain.hip: one lane per read); the host formats the lines from a few integers per read and block. */
 #define MG_QUERY_MAXM 16
+/* ---- the "Q" / "M" lines, formatted by a team of threads ----
+ * A short-read query file is tens of millions of lines a second at the rate the kernels deliver the tallies, and fprintf does
+ * three to five million: the lines of a batch are formatted into per-thread buffers by hand-written conversions and written out
+ * in order.  "%d", "%llu", "%s" are what they are; "%.2f" is glibc's: the double's EXACT binary value rounded to two decimals,
+ * ties to even -- done here in integer arithmetic on the mantissa (x = m * 2^e, so 100 x = 100 m * 2^e exactly; the quotient
+ * and remainder of the shift decide), with snprintf itself for what never occurs at speed (nan from 0 / 0, inf, negative). */
+#include <math.h>
+#include <pthread.h>
+static char *fmtU (char *p, unsigned long long v)
+{ char t[24]; int n = 0; do { t[n++] = (char) ('0' + v % 10); v /= 10; } while (v); while (n) *p++ = t[--n]; return p; }
+static char *fmtI (char *p, long long v) { if (v < 0) { *p++ = '-'; return fmtU (p, (unsigned long long) (-(v + 1)) + 1); } return fmtU (p, (unsigned long long) v); }
+static char *fmtS (char *p, const char *s) { size_t n = strlen (s); memcpy (p, s, n); return p + n; }
+static char *fmtF2 (char *p, double x)
+{
+  if (!(x >= 0) || x >= 1e15 || signbit (x)) return p + snprintf (p, 48, "%.2f", x);
+  int e; const double fr = frexp (x, &e);                              /* x = fr * 2^e, 0.5 <= fr < 1 (or x == 0) */
+  const unsigned long long mant = (unsigned long long) ldexp (fr, 53);   /* exact: 53 bits */
+  const int e2 = e - 53;                                               /* x = mant * 2^e2 */
+  unsigned __int128 v = (unsigned __int128) mant * 100, q;
+  if (e2 >= 0) q = v << e2;
+  else
+    { const int s = -e2;
+      if (s >= 120) q = 0;
+      else
+        { q = v >> s;
+          const unsigned __int128 rem = v & (((unsigned __int128) 1 << s) - 1), half = (unsigned __int128) 1 << (s - 1);
+          if (rem > half || (rem == half && (q & 1))) ++q;
+        }
+    }
+  const unsigned long long whole = (unsigned long long) (q / 100); const unsigned frac = (unsigned) (q % 100);
+  p = fmtU (p, whole); *p++ = '.'; *p++ = (char) ('0' + frac / 10); *p++ = (char) ('0' + frac % 10);
+  return p;
+}
+
+int mgFormatF2 (char *buf, double x) { char *e = fmtF2 (buf, x); *e = 0; return (int) (e - buf); }      /* test hook: buf of 64 bytes */
+
+typedef struct { char *buf; size_t len, cap; } FmtBuf;
+static char *fmtRoom (FmtBuf *b, size_t need)
+{ if (b->len + need > b->cap) { b->cap = 2 * (b->len + need) + 4096; b->buf = (char *) realloc (b->buf, b->cap); if (!b->buf) fatal ("out of memory"); } return b->buf + b->len; }
+
+typedef struct { const MgReference *ref; const MgChainQ *q; const MgChainM *m; const int64_t *offsets; const char **names; int r0, r1; FmtBuf out; } FmtJob;
+static void *fmtQM (void *v)
+{
+  FmtJob *j = (FmtJob *) v;
+  for (int r = j->r0 ; r < j->r1 ; ++r)
+    { const MgChainQ *qq = &j->q[r];
+      const char *nm = j->names[r]; const size_t nl = strlen (nm);
+      char *p0 = fmtRoom (&j->out, 256 + nl), *p = p0;
+      *p++ = 'Q'; *p++ = '\t'; memcpy (p, nm, nl); p += nl; *p++ = '\t';
+      p = fmtU (p, (unsigned long long) (j->offsets[r + 1] - j->offsets[r])); *p++ = '\t';
+      p = fmtI (p, (int) qq->missed); p = fmtS (p, " miss, "); p = fmtI (p, (int) qq->copy1); p = fmtS (p, " copy1, ");
+      p = fmtI (p, (int) qq->copy2); p = fmtS (p, " copy2, "); p = fmtI (p, (int) qq->copyM); p = fmtS (p, " multi, ");
+      p = fmtF2 (p, ((int) qq->nSeeds - (int) qq->missed) / (double) ((int) qq->nSeeds)); p = fmtS (p, " hit\n");
+      j->out.len += (size_t) (p - p0);
+      for (U32 k = 0 ; k < qq->nM ; ++k)
+        { const MgChainM *e = &j->m[(size_t) r * MG_QUERY_MAXM + k];
+          const char *rn = j->ref->names[e->id0];
+          p0 = fmtRoom (&j->out, 320 + nl + strlen (rn)); p = p0;
+          *p++ = 'M'; *p++ = '\t'; memcpy (p, nm, nl); p += nl; *p++ = '\t';
+          p = fmtI (p, (int) e->pos0); *p++ = '\t'; p = fmtI (p, (int) e->posN); *p++ = '\t'; p = fmtI (p, (int) (e->posN - e->pos0)); *p++ = '\t';
+          p = fmtS (p, rn); *p++ = '\t'; p = fmtI (p, (int) e->off0); *p++ = '\t'; p = fmtI (p, (int) e->offN); *p++ = '\t';
+          p = fmtI (p, e->n1); *p++ = ' '; p = fmtI (p, e->n2); *p++ = '\t';
+          p = fmtF2 (p, (e->n1 + e->n2) / (double) e->span); *p++ = '\t';
+          p = fmtF2 (p, e->n1 / (double) (int) qq->copy1); *p++ = '\n';
+          j->out.len += (size_t) (p - p0);
+        }
+    }
+  return 0;
+}
+
+static int fmtThreads (int nReads)
+{
+  if (nReads < 20000) return 1;
+  long v = sysconf (_SC_NPROCESSORS_ONLN);
+  cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
+  const long pk = mgKnobs ()->parseThreads; if (pk != MG_KNOB_UNSET && pk > 0) v = pk;
+  if (v > 16) v = 16;
+  if (v < 1) v = 1;
+  return (int) v;
+}
+
+/* modmap.c:188-281.  Scan, lookup, the tallies of the "Q" line and the chaining into "M" blocks all run on the
+ * device (mg_chain.hip: one lane per read); the host formats the lines from a few integers per read and block.
+ * The batch is on the device already (2-bit packed, offsets in bases): mgQueryProcess uploads one, the file entry point
+ * (mgQueryFile) gets its batches from the device text parser. */
+int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char **names, FILE *out)
+{
+  if (nReads <= 0) return 0;
+  if (modsetSyncToHost (ref->ms, 0)) fatal ("modsetSyncToHost");
+  int64_t *offsets = (int64_t *) malloc ((size_t) (nReads + 1) * 8);
+  if (mgMemcpyD2H (offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
+  MgDevBatch b; b.dPacked = (void *) dPacked; b.dOff = (void *) dReadOffsets; b.total = totalBases; b.nReads = (U32) nReads;
+  MgChainQ *q = (MgChainQ *) malloc ((size_t) nReads * sizeof (MgChainQ));
+  MgChainM *m = (MgChainM *) malloc ((size_t) nReads * MG_QUERY_MAXM * sizeof (MgChainM));
+  const int hostChain = mgKnobs ()->queryHostChain == 1;   /* test knob */
+  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, dPacked, totalBases, dReadOffsets, (U32) nReads, q, m, MG_QUERY_MAXM);
+  if (rc < 0) fatal ("query");
+  if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
+  else
+    { const int T = fmtThreads (nReads);
+      FmtJob job[16]; pthread_t th[16]; int started[16];
+      for (int t = 0 ; t < T ; ++t)
+        { memset (&job[t], 0, sizeof (FmtJob));
+          job[t].ref = ref; job[t].q = q; job[t].m = m; job[t].offsets = offsets; job[t].names = names;
+          job[t].r0 = (int) ((int64_t) nReads * t / T); job[t].r1 = (int) ((int64_t) nReads * (t + 1) / T);
+          started[t] = t && pthread_create (&th[t], 0, fmtQM, &job[t]) == 0;
+        }
+      for (int t = 0 ; t < T ; ++t) if (!started[t]) fmtQM (&job[t]);
+      for (int t = 0 ; t < T ; ++t)
+        { if (started[t]) pthread_join (th[t], 0);
+          if (job[t].out.len && fwrite (job[t].out.buf, 1, job[t].out.len, out) != job[t].out.len) fatal ("write");
+          free (job[t].out.buf);
+        }
+    }
+  free (q); free (m); free (offsets);
+  return rc;
+}
+
 int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
                     const char **names, FILE *out)
 {
   if (nReads <= 0) return 0;
-  if (modsetSyncToHost (ref->ms, 0)) fatal ("modsetSyncToHost");
   MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
-  MgChainQ *q = (MgChainQ *) malloc ((size_t) nReads * sizeof (MgChainQ));
-  MgChainM *m = (MgChainM *) malloc ((size_t) nReads * MG_QUERY_MAXM * sizeof (MgChainM));
-  const int hostChain = mgKnobs ()->queryHostChain == 1;   /* test knob */
-  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, q, m, MG_QUERY_MAXM);
-  if (rc < 0) fatal ("query");
-  if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
-  else
-    for (int r = 0 ; r < nReads ; ++r)
-      { const MgChainQ *qq = &q[r];
-        fprintf (out, "Q\t%s\t%llu\t%d miss, %d copy1, %d copy2, %d multi, %.2f hit\n",
-                 names[r], (unsigned long long) (offsets[r + 1] - offsets[r]), (int) qq->missed, (int) qq->copy1, (int) qq->copy2,
-                 (int) qq->copyM, ((int) qq->nSeeds - (int) qq->missed) / (double) ((int) qq->nSeeds));
-        for (U32 j = 0 ; j < qq->nM ; ++j)
-          { const MgChainM *e = &m[(size_t) r * MG_QUERY_MAXM + j];
-            fprintf (out, "M\t%s\t%d\t%d\t%d\t%s\t%d\t%d\t%d %d\t%.2f\t%.2f\n",
-                     names[r], (int) e->pos0, (int) e->posN, (int) (e->posN - e->pos0),
-                     ref->names[e->id0], (int) e->off0, (int) e->offN, e->n1, e->n2,
-                     (e->n1 + e->n2) / (double) e->span, e->n1 / (double) (int) qq->copy1);
-          }
-      }
-  free (q); free (m);
+  int rc = mgQueryProcessDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, nReads, names, out);
   mgBatchFree (&b);
   return rc;
 }

@@ -152,7 +152,7 @@ static inline void mgPartSplit (int log2NB, int *hiB, int *loB)
  * reads every k-mer anyway, so it can count them on the way (its ALUs are idle: it is a copy): a caller that
  * knows the table geometry asks for that with a request; log2NB says which geometry the counts are for. */
 #define MG_HIST_STRIDE 16      /* words between the counts of consecutive digits: one count per 64 bytes, thousands of workgroups add to each */
-struct MgHistReq { int log2NB; int kbits; U32 *binCount; };   /* binCount: device, 512 x MG_HIST_STRIDE words, zeroed by the launcher; kbits = 2k (the table hash is over 2k bits) */
+struct MgHistReq { int log2NB; int kbits; U32 *binCount; int hiB; };   /* hiB: bits of the digit counted, 0 = the build's own split (mgPartSplit); */   /* binCount: device, 512 x MG_HIST_STRIDE words, zeroed by the launcher; kbits = 2k (the table hash is over 2k bits) */
 
 /* The scan's output BEFORE compaction: worker w's modimizers are segKmer[w * segCap + i], i < segCount[w], and
  * segStart[w] (nSegs + 1 entries, the last one the total) is the ordinal of its first one.  The modset build of a large
@@ -229,6 +229,7 @@ bool     mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *coun
 MgStatus mgTableMarkOccupied (MgTable *t, const U64 *dKmer, U64 n, hipStream_t st);
 MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipStream_t st);
 size_t   mgTableFindPartScratchBytes (U64 n);
+int      mgTableFindDigitBits (const MgTable *t);       /* bits of the partitioned lookup's digit: pieces of the table that fit an XCD's L2 */
 bool     mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counted);
 MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st);   /* el: n words of scratch */
 MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dIndexOut, hipStream_t st);   /* the n k-mers of a lazy scan, in order */

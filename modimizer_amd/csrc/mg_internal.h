@@ -26,6 +26,14 @@ int  mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *nOut);
    record start, line *resumeLine of the file; the counts are those of the records added so far) */
 int  mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash, U64 *resumeOff, U64 *resumeLine);
 int  mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **offsetsOut, int64_t *nSeqOut);   /* test hook: the parser's records as host arrays (malloc) */
+/* the same parser for the callers that print record ids: every batch of complete records (device resident: packed bases, read
+   offsets) with its ids (id r = idBytes + idOff[r], 0-terminated: seqio.c:303-304) to fn; a non-zero return of fn ends the file */
+typedef int (*MgTextBatchFn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, const char *idBytes, const U64 *idOff, void *stream);
+int  mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine);
+/* the device halves of the modmap callers (mg_callers.c): a batch that is already on the device */
+int  mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char **names, FILE *out);
+int  mgReferenceAddDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nSeq, const char **names, bool isAdd);
+void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out);
 void mgTextReleaseBuffers (void);
 /* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */
 #define MG_HIDDEN __attribute__ ((visibility ("hidden")))

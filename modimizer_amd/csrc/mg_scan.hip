@@ -819,7 +819,10 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
   a.fS = 0; a.thresh = 0;
   /* the first partition digit, counted by the scan itself when the table hash allows it (2k >= 24); otherwise by the compaction kernel */
   int hHiB = 0, hLoB = 0;
-  if (hist && hist->binCount) mgPartSplit (hist->log2NB, &hHiB, &hLoB);
+  if (hist && hist->binCount)
+    { mgPartSplit (hist->log2NB, &hHiB, &hLoB);
+      if (hist->hiB > 0 && hist->hiB <= hist->log2NB && hist->hiB <= 9) { hHiB = hist->hiB; hLoB = hist->log2NB - hHiB; }     /* (the partitioned lookup's finer first digit; sHist holds 512) */
+    }
   const int histEnv = mgKnobs ()->scanHist == 0 ? 0 : 1;   /* test knob: 0 = the compaction kernel counts */
   const bool scanCounts = histEnv && hist && hist->binCount && hist->kbits >= 24 && hHiB >= 1 && hHiB <= MG_MIX_TOP && hLoB + hHiB == hist->log2NB;
   a.histCount = scanCounts ? hist->binCount : 0; a.histKbits = hist ? hist->kbits : 64; a.histHiB = hHiB;

@@ -1050,10 +1050,39 @@ int mgAddSequenceFile (Modset *ms, const char *filename, FILE *out)            /
   return 0;
 }
 
+/* the ids of a device batch as the pointer array the callers take */
+static const char **idPointers (const char *idBytes, const U64 *idOff, U32 n)
+{
+  const char **p = (const char **) malloc (((size_t) n + 1) * sizeof (char *));
+  for (U32 i = 0 ; i < n ; ++i) p[i] = idBytes + idOff[i];
+  return p;
+}
+
+typedef struct { MgReference *ref; bool isAdd; } RefDevCtx;
+static int refDeviceBatch (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, void *stream)
+{
+  RefDevCtx *c = (RefDevCtx *) v; (void) stream;
+  const char **names = idPointers (idBytes, idOff, nReads);
+  int rc = mgReferenceAddDevice (c->ref, dPacked, total, dOff, (int) nReads, names, c->isAdd);
+  free (names);
+  return rc;
+}
+
 /* modmap reads the whole reference before it classifies and packs (modmap.c:93-134), and its report
- * lines are per file: one batch holding every record */
+ * lines are per file.  Plain FASTA text is parsed on the device (mg_textgpu.hip), batch by batch -- first-occurrence
+ * indices do not depend on where a stream is cut -- everything else by the host parser as one batch holding every record */
 int mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FILE *out)
 {
+  { RefDevCtx c; c.ref = ref; c.isAdd = isAdd;
+    U64 nSeq = 0, totLen = 0, resumeOff = 0, resumeLine = 1;
+    int first = -1;
+    { FILE *f = fopen (filename, "rb"); if (f) { first = fgetc (f); fclose (f); } }
+    if (first == '>')                                     /* (a FASTQ reference goes the host way: the hand-over in the middle of a file is not worth having here) */
+      { const int rc = mgTextForEachBatchDevice (filename, refDeviceBatch, &c, &nSeq, &totLen, &resumeOff, &resumeLine);
+        if (rc == -1) return -1;
+        if (rc == 0) { mgReferenceFinish (ref, totLen, isAdd, out); return 0; }
+      }
+  }
   MgSeqReader *r = mgSeqOpen (filename);
   if (!r) { fprintf (stderr, "FATAL ERROR: failed to read reference sequence file %s\n", filename); exit (-1); }   /* modmap.c:99 */
   MgSeqBatch b;
@@ -1068,10 +1097,25 @@ typedef struct { MgReference *ref; FILE *out; } QueryCtx;
 static int queryBatch (MgSeqBatch *b, void *v)
 { QueryCtx *c = (QueryCtx *) v; return mgQueryProcess (c->ref, b->bases, b->offsets, b->nSeq, (const char **) b->names, c->out); }
 
+static int queryDeviceBatch (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, void *stream)
+{
+  QueryCtx *c = (QueryCtx *) v; (void) stream;
+  const char **names = idPointers (idBytes, idOff, nReads);
+  int rc = mgQueryProcessDevice (c->ref, dPacked, total, dOff, (int) nReads, names, c->out);
+  free (names);
+  return rc;
+}
+
 int mgQueryFile (MgReference *ref, const char *filename, FILE *out)            /* modmap.c:188-196 */
 {
   QueryCtx c; c.ref = ref; c.out = out;
-  int rc = forEachBatch (filename, queryBatch, &c);
+  /* plain FASTA / FASTQ text: parsed on the device, the batches stay there (no 1-byte-per-base upload); gzip, a last line without
+     its newline, FASTQ that breaks a rule: the host parser (from the first record the device parser has not handed on) */
+  U64 nSeq = 0, totLen = 0, resumeOff = 0, resumeLine = 1;
+  int rc = mgTextForEachBatchDevice (filename, queryDeviceBatch, &c, &nSeq, &totLen, &resumeOff, &resumeLine);
+  if (rc == 0 || rc == -1) return rc;
+  if (rc == -3) return forEachBatchFrom (filename, (size_t) resumeOff, resumeLine, nSeq, queryBatch, &c);
+  rc = forEachBatch (filename, queryBatch, &c);
   if (rc == -1 && access (filename, R_OK)) { fprintf (stderr, "FATAL ERROR: failed to read query sequence file %s\n", filename); exit (-1); }   /* modmap.c:196 */
   return rc;
 }

@@ -1440,7 +1440,7 @@ void mgBinFindKernel (const MgSlot *__restrict__ slots, MgGeom g, MgPartFmt f, U
   const U64 ordMask = ((U64) 1 << f.ordBits) - 1;
   for (U32 b = xcd ; b < nBins ; b += 8)
     { const U64 lo = binStart[b], hi = binStart[b + 1];
-      for (U64 i = lo + (U64) j * 256 + threadIdx.x ; i < hi ; i += (U64) wgPerXcd * 256)
+      for (U64 i = lo + (U64) j * 256 + threadIdx.x ; i < hi ; i += (U64) wgPerXcd * 256)      /* (four lookups in flight per thread: 3.4 against 2.8 ms) */
         { const U64 x = __builtin_nontemporal_load (&el[i]);
           const U64 m = ((U64) b << f.remBits) | (x >> f.ordBits), key = m + 1;
           const U64 base = (U64) mgBucketOfM (m, g) * g.R;
@@ -1543,7 +1543,7 @@ bool mgTableUseBuckets (const MgTable *t, U64 n);
 bool mgTableAddTakesSegments (const MgTable *t, U64 n, const MgHistReq *counted)
 {
   const int off = mgKnobs ()->noSegmentInput == 1;   /* test knob: always compact first */
-  return !off && n && mgTableUseBuckets (t, n) && counted && counted->binCount && counted->log2NB == t->log2NB && counted->kbits == t->kbits;
+  return !off && n && mgTableUseBuckets (t, n) && counted && counted->binCount && counted->log2NB == t->log2NB && counted->kbits == t->kbits && !counted->hiB;
 }
 
 bool mgTableUseBuckets (const MgTable *t, U64 n)
@@ -1667,7 +1667,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   const int j = t->log2NB;
   int hiB, loB;
   mgPartSplit (j, &hiB, &loB);
-  const U32 *pre = (counted && counted->binCount && counted->log2NB == j && counted->kbits == t->kbits) ? counted->binCount : 0;
+  const U32 *pre = (counted && counted->binCount && counted->log2NB == j && counted->kbits == t->kbits && !counted->hiB) ? counted->binCount : 0;
   U64 segInit[2] = { 0, n };
   MG_HIP (hipMemcpyAsync (whole, segInit, 16, hipMemcpyHostToDevice, st));
   /* element format: one packed 8-byte word when the mixed k-mer without its coarse digit and the ordinal fit in 64 bits */
@@ -1833,17 +1833,28 @@ size_t mgTableFindPartScratchBytes (U64 n)
 
 /* does a lookup batch take the partitioned path?  It needs the scan's digit counts for this table geometry, elements that
    fit one word, and a table the direct probes would have to fetch from HBM */
+/* The digit of the partitioned lookup: the top bits of the bucket id one pass sorts by; a bin's piece of the table is
+   nSlots * 16 bytes >> bits (MODGPU_FIND_BITS: dev, 3..9) */
+int mgTableFindDigitBits (const MgTable *t)
+{
+  const long kb = mgKnobs ()->findBits;
+  int hiB, loB; mgPartSplit (t->log2NB, &hiB, &loB);          /* the build's own first digit: 256 bins of 8 MB at config 3 (512 bins of 4 MB: scatter and pull-back cost 0.7 ms more, the lookups gain nothing) */
+  int bits = kb != MG_KNOB_UNSET && kb >= 3 && kb <= 9 ? (int) kb : hiB;
+  if (bits > t->log2NB) bits = t->log2NB;
+  return bits;
+}
+
 bool mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counted)
 {
   const long kp = mgKnobs ()->findPath;                      /* test knob: 'p' / 'd' force it */
   if (kp == 'd') return false;
   if (!n || !counted || !counted->binCount || counted->log2NB != t->log2NB || counted->kbits != t->kbits) return false;
-  int hiB, loB; mgPartSplit (t->log2NB, &hiB, &loB);
+  const int hiB = counted->hiB;
+  if (hiB != mgTableFindDigitBits (t)) return false;
   const int ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1;
   if (!(t->kbits >= t->log2NB + 4 && t->kbits - hiB + ordBits <= 64) || hiB < 3) return false;
   if (t->kbits < 24 || mgKnobs ()->scanHist == 0) return false;          /* (the counts must be the scan's own: mgLaunchScanRange) */
-  if (kp == 'p') return true;
-  return n >= ((U64) 1 << 24) && t->nSlots >= ((U64) 1 << 24);      /* a table of 256 MB and more, a batch that fills the chip */
+  return kp == 'p';      /* opt-in: measured at config 3 it ties with the direct probes (DESIGN_EXPERIMENTS.md, round 4) */
 }
 
 MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st)
@@ -1858,7 +1869,7 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
   U32 *binCount = (U32 *) wb;                                wb += mgAl ((MG_PART_MAXBINS + 2) * 4);
   U32 *chunkBase = (U32 *) wb;                               wb += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);
   MgSubSeg *subSeg = (MgSubSeg *) wb;                        wb += mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg));
-  int hiB, loB; mgPartSplit (t->log2NB, &hiB, &loB);
+  const int hiB = counted->hiB, loB = t->log2NB - hiB;
   MgPartFmt f; f.ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1; f.remBits = t->kbits - hiB; f.loB = loB;
   const U32 nBins = (U32) 1 << hiB;
   U64 segInit[2] = { 0, n };
@@ -1867,7 +1878,8 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
   MgStatus s = mgPartPass (t, MG_EL_SEG, true, f, (const U64 *) 0, 0, n, whole, 1, loB, nBins, el, (U32 *) 0, binStart, cursor, binCount, chunkBase, st,
                            counted->binCount, &segSrc, subSeg, runTab, &subElems);
   if (s) return s;
-  const U32 wgPerXcd = 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
+  const long wk = mgKnobs ()->findSubpass;                    /* (dev: MODGPU_FIND_WGS, workgroups per XCD) */
+  const U32 wgPerXcd = wk != MG_KNOB_UNSET && wk > 0 ? (U32) wk : 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
   MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgBinFindKernel, dim3 (8 * wgPerXcd), dim3 (256), 0, st, t->slots, mgGeomOf (t), f, el, binStart, nBins, wgPerXcd);
   const U64 nSub = (n + subElems - 1) / subElems;
   const unsigned ug = (unsigned) (nSub < 2048 ? nSub : 2048);

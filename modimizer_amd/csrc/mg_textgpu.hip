@@ -233,7 +233,8 @@ void mgTextOffsetScanKernel (const U32 *__restrict__ tileBases, const U32 *__res
 __global__ __launch_bounds__ (TX_THREADS)
 void mgTextEmitKernel (const unsigned char *__restrict__ text, U64 n, U64 textBase, U32 prevByte,
                        const U64 *__restrict__ tileIn, const U64 *__restrict__ tileBaseOff, const U64 *__restrict__ tileStartOff,
-                       unsigned char *__restrict__ bases, U64 basesCap, U64 *__restrict__ recOff, U64 recCap, U32 *__restrict__ overflow)
+                       unsigned char *__restrict__ bases, U64 basesCap, U64 *__restrict__ recOff, U64 recCap, U32 *__restrict__ overflow,
+                       U64 *__restrict__ recPos)      /* != 0: the file position of every record's '>' (the callers that print record ids) */
 {
   __shared__ U64 sScan[TX_THREADS / 64];
   __shared__ U32 sB[TX_THREADS / 64], sS[TX_THREADS / 64];
@@ -284,7 +285,7 @@ void mgTextEmitKernel (const unsigned char *__restrict__ text, U64 n, U64 textBa
   for (int j = 0 ; j < 16 ; ++j)
     { if (at + j < n)
         { const U32 c = b[j];
-          if (c == '>' && prev == '\n') { header = true; recOff[myS++] = myB; }      /* a record's offset: the bases before its '>' */
+          if (c == '>' && prev == '\n') { header = true; if (recPos) recPos[myS] = textBase + at + (U64) j; recOff[myS++] = myB; }      /* a record's offset: the bases before its '>' */
           else if (c == '\n') header = false;
           else if (!header) { const U32 code = txCode (c); if (code < 4) bases[myB++] = (unsigned char) code; }
         }
@@ -493,6 +494,7 @@ struct TxBufs {
   U64 *dTileEvent = 0, *dTileBaseOff = 0, *dTileStartOff = 0; U32 *dTileBases = 0, *dTileStarts = 0; size_t tilesCap = 0;
   U64 *dTileOffQ = 0; U32 *dTileQual = 0; TqState *dTq = 0;      /* FASTQ: the third counted quantity */
   U64 *dEndQ = 0, *dEndP = 0;                                    /* FASTQ: per completed record (dRecOff is the first of the three) */
+  U64 *dRecPos = 0;                                              /* FASTA: file position of every record's '>' (for the record ids) */
   unsigned char *dBases = 0; size_t basesCap = 0;
   U64 *dRecOff = 0; size_t recCap = 0;
   U32 *dPacked = 0; size_t packedWords = 0;
@@ -503,8 +505,8 @@ struct TxBufs {
     if (hCounts) (void) hipHostFree (hCounts);
     (void) hipFree (dState); (void) hipFree (dOverflow); (void) hipFree (dTileEvent); (void) hipFree (dTileBaseOff); (void) hipFree (dTileStartOff);
     (void) hipFree (dTileBases); (void) hipFree (dTileStarts); (void) hipFree (dBases); (void) hipFree (dRecOff); (void) hipFree (dPacked);
-    (void) hipFree (dTileOffQ); (void) hipFree (dTileQual); (void) hipFree (dTq); (void) hipFree (dEndQ); (void) hipFree (dEndP);
-    dTileOffQ = 0; dTileQual = 0; dTq = 0; dEndQ = 0; dEndP = 0;
+    (void) hipFree (dTileOffQ); (void) hipFree (dTileQual); (void) hipFree (dTq); (void) hipFree (dEndQ); (void) hipFree (dEndP); (void) hipFree (dRecPos);
+    dTileOffQ = 0; dTileQual = 0; dTq = 0; dEndQ = 0; dEndP = 0; dRecPos = 0;
     if (copy) (void) hipStreamDestroy (copy);
     hCounts = 0; dState = 0; dOverflow = 0; dTileEvent = dTileBaseOff = dTileStartOff = 0; dTileBases = dTileStarts = 0; dBases = 0; dRecOff = 0; dPacked = 0;
     tilesCap = basesCap = recCap = packedWords = window = 0; copy = 0; dev = -1;
@@ -563,8 +565,8 @@ static int txReserve (TxBufs &t, size_t window, U64 basesNeed, U64 recsNeed)
     }
   if (recsNeed > t.recCap)
     { size_t cap = (size_t) (recsNeed + recsNeed / 4 + 4096); if (cap < 2 * t.recCap) cap = 2 * t.recCap;
-      U64 **arr[3] = { &t.dRecOff, &t.dEndQ, &t.dEndP };
-      for (int i = 0 ; i < 3 ; ++i)
+      U64 **arr[4] = { &t.dRecOff, &t.dEndQ, &t.dEndP, &t.dRecPos };
+      for (int i = 0 ; i < 4 ; ++i)
         { U64 *nr = 0;
           if (hipMalloc ((void **) &nr, cap * 8) != hipSuccess) return -1;
           if (*arr[i]) { (void) hipMemcpy (nr, *arr[i], t.recCap * 8, hipMemcpyDeviceToDevice); (void) hipFree (*arr[i]); }
@@ -615,14 +617,48 @@ static int txHostThreads (void)
 }
 
 struct TxSink {                                            /* what is done with a batch of complete records */
-  int (*fn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, hipStream_t st);
+  int (*fn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st);
   void *ctx;
+  bool wantIds;                                            /* the records' ids (seqio.c:303-304: the header line after its '>' / '@' up to the first white space): id r = idBytes + idOff[r], 0-terminated */
+};
+
+/* The ids of the accumulator's records, in record order, copied out of the pinned text windows while they are there: the
+ * kernels say where every header starts (FASTA: mgTextEmitKernel's recPos; FASTQ: the byte after a record's last newline,
+ * endP + 1), the host copies the few bytes up to the first white space.  An id that runs on into the next window (or starts
+ * at its first byte) is finished when that window is in. */
+#include <ctype.h>
+struct TxIds {
+  std::vector<char> bytes; std::vector<U64> off;
+  bool open = false; bool skipOne = false;                 /* the last id is not finished; its '@' is the next window's first byte */
+  void clear () { bytes.clear (); off.clear (); open = false; skipOne = false; }
+  void feed (const unsigned char *p, size_t n)
+  { if (skipOne) { if (!n) return; ++p; --n; skipOne = false; }
+    size_t i = 0;
+    while (i < n && !isspace (p[i])) ++i;
+    bytes.insert (bytes.end (), (const char *) p, (const char *) p + i);
+    if (i < n) { bytes.push_back (0); open = false; }
+  }
+  /* a header whose first byte ('>' / '@') is byte `at` of the window (at == n: the next window's first byte) */
+  void header (const unsigned char *win, size_t n, size_t at)
+  { off.push_back ((U64) bytes.size ()); open = true;
+    if (at >= n) { skipOne = true; return; }
+    feed (win + at + 1, n - at - 1);
+  }
+  void dropFront (size_t nRec)                              /* the first nRec records were flushed */
+  { if (!nRec) return;
+    const U64 cut = nRec < off.size () ? off[nRec] : (U64) bytes.size ();
+    bytes.erase (bytes.begin (), bytes.begin () + (ptrdiff_t) cut);
+    off.erase (off.begin (), off.begin () + (ptrdiff_t) (nRec < off.size () ? nRec : off.size ()));
+    for (auto &o : off) o -= cut;
+  }
 };
 
 /* one batch: records [0, nRec) of the accumulator, bases [0, total); dRecOff[nRec] == total.  Returns 0 or an error */
-static int txFlush (TxBufs &t, const TxSink &sink, U64 total, U64 nRec, hipStream_t st)
+static int txFlush (TxBufs &t, const TxSink &sink, U64 total, U64 nRec, hipStream_t st, TxIds *ids = 0)
 {
   if (!nRec) return 0;
+  if (sink.wantIds && (!ids || ids->off.size () < nRec || (ids->off.size () == nRec && ids->open)))
+    { mgSetError ("device text parser: %llu records but %llu ids", (unsigned long long) nRec, (unsigned long long) (ids ? ids->off.size () : 0)); return -1; }
   const size_t nw = mgPackedWords (total);
   if (nw > t.packedWords)
     { (void) hipFree (t.dPacked); t.dPacked = 0; t.packedWords = 0;
@@ -630,7 +666,7 @@ static int txFlush (TxBufs &t, const TxSink &sink, U64 total, U64 nRec, hipStrea
       t.packedWords = nw + nw / 4;
     }
   if (mgLaunchPack (t.dBases, total, t.dPacked, st)) return -1;
-  return sink.fn (sink.ctx, t.dPacked, total, t.dRecOff, (U32) nRec, st);
+  return sink.fn (sink.ctx, t.dPacked, total, t.dRecOff, (U32) nRec, sink.wantIds ? ids->bytes.data () : (const char *) 0, sink.wantIds ? ids->off.data () : (const U64 *) 0, st);
 }
 
 static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff, U64 *resumeLine);
@@ -668,6 +704,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
     TxState init; init.lastEvent = 0; init.accBases = 0; init.accRecs = 0;
     if (hipMemcpy (t.dState, &init, sizeof (init), hipMemcpyHostToDevice) != hipSuccess || hipMemset (t.dOverflow, 0, 4) != hipSuccess) break;
     const int nThreads = txHostThreads ();
+    TxIds ids; std::vector<U64> hdr;
     U64 accBases = 0, accRecs = 0;                          /* the accumulator as of the last synchronised window */
     size_t off = 0; int w = 0;
     U32 prevByte = '\n';
@@ -704,13 +741,22 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
           }
         /* the counts are in: room for exactly what this window adds, then the bases and the offsets are written */
         if (hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        const U64 recsBefore = accRecs;
         accBases = t.hCounts[0]; accRecs = t.hCounts[1];
         ck.lap (ck.wait);
         if (accBases + 64 > t.basesCap || accRecs + 2 > t.recCap)
           if (txReserve (t, window, accBases + 64, accRecs + 2)) { mgSetError ("device text parser: allocation failed"); failed = true; break; }
         hipLaunchKernelGGL (mgTextEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevOfWindow,
-                            t.dTileEvent, t.dTileBaseOff, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, (U64) t.recCap, t.dOverflow);
+                            t.dTileEvent, t.dTileBaseOff, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, (U64) t.recCap, t.dOverflow,
+                            sink.wantIds ? t.dRecPos : (U64 *) 0);
         if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        if (sink.wantIds)                                  /* the ids of the records that start in this window, while its text is in the pinned buffer */
+          { if (ids.open) ids.feed (t.hPin[cur], nCur);
+            const U64 nNew = accRecs - recsBefore;
+            hdr.resize ((size_t) nNew);
+            if (nNew && hipMemcpy (hdr.data (), t.dRecPos + recsBefore, (size_t) nNew * 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+            for (U64 r = 0 ; r < nNew ; ++r) ids.header (t.hPin[cur], nCur, (size_t) (hdr[(size_t) r] - (U64) off));
+          }
         const bool eof = !nNext;
         if (eof || accBases >= batch)
           { /* complete records: all of them at the end of the file, otherwise all but the one still open */
@@ -719,8 +765,9 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
             if (eof && hipMemcpy (t.dRecOff + nRec, &total, 8, hipMemcpyHostToDevice) != hipSuccess) { failed = true; break; }
             U32 ov = 0; if (hipMemcpy (&ov, t.dOverflow, 4, hipMemcpyDeviceToHost) != hipSuccess || ov) { mgSetError ("device text parser: accumulator overflow"); failed = true; break; }
             if (nRec)
-              { if (txFlush (t, sink, total, nRec, st)) { failed = true; break; }
+              { if (txFlush (t, sink, total, nRec, st, &ids)) { failed = true; break; }
                 nSeq += nRec; totLen += total;
+                if (sink.wantIds) ids.dropFront ((size_t) nRec);
                 /* the open record's bases move to the front; it becomes record 0 of the next batch */
                 const U64 carry = accBases - total;
                 if (!eof)
@@ -767,6 +814,7 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
     if (hipMemcpy (t.dTq, &init, sizeof (init), hipMemcpyHostToDevice) != hipSuccess || hipMemset (t.dOverflow, 0, 4) != hipSuccess
         || hipMemcpy (t.dRecOff, &zero, 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy (t.dEndQ, &zero, 8, hipMemcpyHostToDevice) != hipSuccess) break;
     const int nThreads = txHostThreads ();
+    TxIds ids; std::vector<U64> hdr;
     U64 accBases = 0, accRecs = 0, accQual = 0;
     size_t off = 0; int w = 0;
     U32 prevByte = '\n';
@@ -811,6 +859,15 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
         if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
         const U64 nlCount = t.hCounts[3];
         bool bad = t.hCounts[4] != 0;
+        if (sink.wantIds && !bad)                         /* a header starts at the file's first byte and after every record's last newline */
+          { if (ids.open) ids.feed (t.hPin[cur], nCur);
+            if (!off) ids.header (t.hPin[cur], nCur, 0);
+            const U64 nNew = accRecs - recsBefore;
+            hdr.resize ((size_t) nNew);
+            if (nNew && hipMemcpy (hdr.data (), t.dEndP + recsBefore + 1, (size_t) nNew * 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+            for (U64 r = 0 ; r < nNew ; ++r)
+              if (hdr[(size_t) r] + 1 < (U64) fileSize) ids.header (t.hPin[cur], nCur, (size_t) (hdr[(size_t) r] + 1 - (U64) off));
+          }
         if (!bad && accRecs > recsBefore)                  /* the records this window completed: sequence and quality lines of one length? */
           { const U64 nNew = accRecs - recsBefore;
             hipLaunchKernelGGL (mgTextFastqCheckKernel, dim3 ((unsigned) ((nNew + 255) / 256)), dim3 (256), 0, st, t.dRecOff, t.dEndQ, recsBefore + 1, accRecs, t.dTq);
@@ -827,8 +884,9 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
         if (bad || (eof && ((nlCount & 3) || accBases != (accRecs ? tail[0] : 0) || accQual != (accRecs ? tail[1] : 0))))
           { handOver = true; break; }                      /* nothing of the accumulator has been added: the host parser starts at its first record */
         if ((eof || accBases >= batch) && accRecs)
-          { if (txFlush (t, sink, tail[0], accRecs, st)) { failed = true; break; }
+          { if (txFlush (t, sink, tail[0], accRecs, st, &ids)) { failed = true; break; }
             nSeq += accRecs; totLen += tail[0];
+            if (sink.wantIds) ids.dropFront ((size_t) accRecs);
             resume = tail[2] + 1;
             if (!eof)
               { const U64 carry = accBases - tail[0];
@@ -856,7 +914,7 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
 /* ---- sinks ---- */
 
 struct TxAddCtx { Modset *ms; U64 totHash; };
-static int txAddSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, hipStream_t st)
+static int txAddSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *, const U64 *, hipStream_t st)
 {
   TxAddCtx *c = (TxAddCtx *) v;
   U64 nHash = 0;
@@ -869,15 +927,27 @@ static int txAddSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U
 extern "C" int mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *nSeq, U64 *totLen, U64 *totHash, U64 *resumeOff, U64 *resumeLine)
 {
   TxAddCtx c; c.ms = ms; c.totHash = 0;
-  TxSink sink; sink.fn = txAddSink; sink.ctx = &c;
+  TxSink sink; sink.fn = txAddSink; sink.ctx = &c; sink.wantIds = false;
   const int rc = txParseFile (filename, sink, nSeq, totLen, resumeOff, resumeLine);
   if (totHash) *totHash = c.totHash;
   return rc;
 }
 
+/* modmap's file entry points (mgReferenceFastaRead, mgQueryFile: modmap.c:93-134,188-281): every batch of complete records,
+   device resident, with the records' ids, to a C callback.  0 / -1 / -2 / -3 as txParseFile */
+struct TxCbCtx { MgTextBatchFn fn; void *ctx; };
+static int txCbSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st)
+{ TxCbCtx *c = (TxCbCtx *) v; return c->fn (c->ctx, dPacked, total, dOff, nReads, idBytes, idOff, (void *) st); }
+extern "C" int mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine)
+{
+  TxCbCtx c; c.fn = fn; c.ctx = ctx;
+  TxSink sink; sink.fn = txCbSink; sink.ctx = &c; sink.wantIds = true;
+  return txParseFile (filename, sink, nSeq, totLen, resumeOff, resumeLine);
+}
+
 /* test hook: the device parser's records as host arrays (bases 0..3 one per byte, offsets[nSeq + 1]), malloc()ed */
 struct TxHostCtx { std::vector<unsigned char> bases; std::vector<int64_t> offs; };
-static int txHostSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, hipStream_t st)
+static int txHostSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st)
 {
   TxHostCtx *c = (TxHostCtx *) v;
   std::vector<U64> o ((size_t) nReads + 1);
@@ -900,7 +970,7 @@ static int txHostSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, 
 extern "C" int mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **offsetsOut, int64_t *nSeqOut)
 {
   TxHostCtx c;
-  TxSink sink; sink.fn = txHostSink; sink.ctx = &c;
+  TxSink sink; sink.fn = txHostSink; sink.ctx = &c; sink.wantIds = false;
   U64 nSeq = 0, totLen = 0;
   const int rc = txParseFile (filename, sink, &nSeq, &totLen);
   if (rc) return rc;

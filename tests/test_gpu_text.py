@@ -198,3 +198,72 @@ np.save(sys.argv[3], np.concatenate([v[1:], d[1:].astype(np.uint64)]))
     tag = "seqio_%s.stdout.txt" % fname.replace(".", "_")
     if os.path.exists(os.path.join(golden_dir, tag)):
         assert outs[0][0].strip() == added_line(util.golden_text(tag))
+
+
+def _awkward_ids(rng, n):
+    """record ids that try the id extraction (seqio.c:303-304: the header after its first byte up to the first white space): long, with
+    punctuation and '>' / '@' inside, followed by a space / tab and a description, or by nothing; empty ids"""
+    out = []
+    alphabet = np.frombuffer(b"abcXYZ0189_:/|.#>@+-", np.uint8)
+    for i in range(n):
+        ln = int(rng.choice([0, 1, 5, 12, 40, 120]))
+        core = alphabet[rng.integers(0, len(alphabet), ln)].tobytes() + (b"r%d" % i if rng.random() < 0.8 else b"")
+        tail = [b"", b" description with spaces", b"\tafter a tab", b" > not a record", b" "][int(rng.integers(0, 5))]
+        out.append((core, tail))
+    return out
+
+
+@pytest.mark.parametrize("fmt,crlf", [("fa", False), ("fq", False), ("fa", True), ("fq", True)])
+@pytest.mark.parametrize("window_kb,batch_bases", [(0, 0), (4, 2500), (8, 40000)])
+def test_query_file_device_parser_equals_host_parser(fmt, crlf, window_kb, batch_bases, golden_dir, tmp_path):
+    """mgReferenceFastaRead + mgQueryFile (modmap.c:93-134,188-281) with the text parsed on the device against the same through the
+    host parser (itself pinned to the reference's seqio.c): the same report, Q and M lines -- i.e. the same record ids, lengths,
+    seeds -- for FASTA (wrapped lines) and FASTQ queries with awkward ids, windows of 4 KiB (ids cut by window edges) and batches
+    of 2500 bases (ids carried from batch to batch)"""
+    L = mg.lib()
+    rng = np.random.default_rng(17 + window_kb)
+    names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, "ref.fa"))
+    refseqs = [bases[offs[i]:offs[i + 1]] for i in range(len(names))]
+    n = 700
+    ids = _awkward_ids(rng, n)
+    eol = b"\r\n" if crlf else b"\n"
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    recs = []
+    for i, (core, tail) in enumerate(ids):
+        u = rng.random()
+        if u < 0.6:
+            s = refseqs[int(rng.integers(0, len(refseqs)))]
+            ln = int(rng.integers(30, 2500)); a = int(rng.integers(0, max(1, len(s) - ln)))
+            b = s[a:a + ln].copy()
+            if rng.random() < 0.5:
+                b = (3 - b[::-1]).astype(np.uint8)
+        elif u < 0.9:
+            b = rng.integers(0, 4, int(rng.integers(0, 600))).astype(np.uint8)
+        else:
+            b = np.zeros(int(rng.integers(0, 20)), np.uint8)
+        txt = letters[b].tobytes()
+        if fmt == "fa":
+            body = b"".join(txt[j:j + 61] + eol for j in range(0, len(txt), 61))
+            recs.append(b">" + core + tail + eol + body)
+        else:
+            recs.append(b"@" + core + tail + eol + txt + eol + b"+" + eol + b"I" * len(txt) + eol)
+    qpath = str(tmp_path / ("q." + fmt))
+    open(qpath, "wb").write(b"".join(recs))
+    outs = []
+    for host in (1, 0):
+        kn = dict(TEXT_HOST=host)
+        if window_kb and not host:
+            kn.update(TEXT_WINDOW_KB=window_kb, FILE_BATCH_BASES=batch_bases)
+        elif batch_bases:
+            kn.update(FILE_BATCH_BASES=batch_bases)
+        with mg.knobs(**kn):
+            sh = mg.seqhashCreate(15, 8, 17); ms = mg.modsetCreate(sh, 20)
+            ref = L.mgReferenceCreate(ms, 1 << 26)
+            out = str(tmp_path / ("o%d.txt" % host))
+            with mg.CFile(out, "w") as f:
+                assert L.mgReferenceFastaRead(ref, os.path.join(golden_dir, "ref.fa").encode(), True, f) == 0
+                assert L.mgQueryFile(ref, qpath.encode(), f) == 0
+            outs.append(open(out, "rb").read())
+            L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+    assert outs[0] == outs[1], [x for x in zip(outs[0].splitlines(), outs[1].splitlines()) if x[0] != x[1]][:3]
+    assert outs[0].count(b"\nQ\t") >= n - 1 and outs[0].count(b"\nM\t") > 5

@@ -182,3 +182,33 @@ def test_pack_host_matches_the_word_layout():
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                            env=dict(os.environ, MODGPU_NO_TORCH="1", MODGPU_NO_AVX2=no))
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
+
+
+def test_format_f2_equals_printf():
+    """the parallel formatter of the Q / M lines (mg_callers.c fmtF2) against printf ("%.2f") itself: every ratio a / b the lines
+    can hold for small a, b (ties like 1/8 = 0.125 -> 0.12, 3/8 -> 0.38, and 0.005-neighbours such as 1/200), random ratios,
+    values beyond 1, and the non-finite cases (0/0 -> -nan or nan as glibc prints it, x/0 -> inf)"""
+    import ctypes as C
+    L = mg.lib()
+    buf = C.create_string_buffer(64)
+
+    def f2(x):
+        n = L.mgFormatF2(buf, x)
+        return buf.raw[:n].decode()
+    bad = []
+    for b in range(1, 401):
+        for a in range(0, b + 1):
+            x = a / b
+            if f2(x) != "%.2f" % x:
+                bad.append((a, b))
+    assert not bad, bad[:10]
+    rng = np.random.default_rng(3)
+    for a, b in zip(rng.integers(0, 10**6, 200000), rng.integers(1, 10**6, 200000)):
+        x = int(a) / int(b)
+        assert f2(x) == "%.2f" % x, (a, b)
+    for x in (0.0, 0.125, 0.375, 0.625, 0.875, 2.675, 1e-9, 0.004999999999999999, 0.005, 0.015, 0.025, 123456.785, 1e14 + 0.125, 2.5e15,
+              float("inf"), 1e20):
+        assert f2(x) == "%.2f" % x, x
+    # what glibc's printf makes of the rest (the library calls snprintf itself there): the sign of a nan is printed
+    for x, want in ((float("nan"), "nan"), (-float("nan"), "-nan"), (-0.0, "-0.00"), (-1.5, "-1.50"), (-float("inf"), "-inf")):
+        assert f2(x) == want, x

@@ -270,10 +270,19 @@ def test_add_sequence_file_gpu(fname, golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("parser", ["device", "host", "device_small_windows"])
 @pytest.mark.parametrize("tag", list(util.MODMAP_TAGS))
-def test_modmap_from_files_gpu(tag, golden_dir, tmp_path):
-    """modmap -f ref.fa -q queries.fa from the files themselves (queries in several batches)"""
+def test_modmap_from_files_gpu(tag, parser, golden_dir, tmp_path):
+    """modmap -f ref.fa -q queries.fa from the files themselves (queries in several batches): the text parsed on the device
+    (mg_textgpu.hip: the batches stay there, the record ids come out of the pinned text windows), by the host parser, and on
+    the device with 4 KiB windows and 3000-base batches (ids, records and batches cut everywhere)"""
     L = mg.lib()
+    kn = {"device": dict(TEXT_HOST=0), "host": dict(TEXT_HOST=1), "device_small_windows": dict(TEXT_HOST=0, TEXT_WINDOW_KB=4, FILE_BATCH_BASES=3000)}[parser]
+    with mg.knobs(**kn):
+        _modmap_from_files(L, tag, golden_dir, tmp_path)
+
+
+def _modmap_from_files(L, tag, golden_dir, tmp_path):
     k, w = util.MODMAP_TAGS[tag]
     sh = mg.seqhashCreate(k, w, 17)
     ms = mg.modsetCreate(sh, 20)
