@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import modimizer_amd as mg
+from modimizer_amd import fasta
 from tests import util
 from tests.test_seqio import parse_file, added_line
 
