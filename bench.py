@@ -922,6 +922,53 @@ def end_to_end(cx, reads, offsets, k, d, seed):
                              "bases": nq * 150, "reads": nq, "file_bytes": os.path.getsize(path),
                              "what": "150-base reads, four-line FASTQ in the page cache, parsed on the device (line = newlines before a byte, line mod 4 = what the byte is; "
                                      "'@', '+' and equal lengths checked, any breach goes back to the host parser)"}
+        # modmap from files (modmap.c:93-134,188-281): a 20 Mbp reference FASTA, then the 150-base FASTQ file queried against it --
+        # parse, scan, lookup, tallies and chaining on the device, one "Q" line per read (and "M" lines) formatted by the host's threads
+        rpath = os.path.join(shm, "modgpu_e2e_%d_ref.fa" % os.getpid())
+        try:
+            rb = min(20_000_000, nb) // 80 * 80
+            t_ = np.concatenate([letters[h[:rb]].reshape(-1, 80), np.full((rb // 80, 1), 10, np.uint8)], axis=1)
+            with open(rpath, "wb") as f:
+                f.write(b">ref1\n"); f.write(t_.tobytes())
+            del t_
+
+            def time_query(host_parser):
+                os.environ["MODGPU_TEXT_HOST"] = "1" if host_parser else "0"
+                L.mgReloadKnobs()
+                try:
+                    sh2 = mg.seqhashCreate(k, d, seed); ms2 = mg.modsetCreate(sh2, 24)
+                    ref = L.mgReferenceCreate(ms2, 1 << 26)
+                    best_, lines = None, 0
+                    with mg.CFile(os.devnull, "w") as fo:
+                        if L.mgReferenceFastaRead(ref, rpath.encode(), True, fo):
+                            raise RuntimeError("mgReferenceFastaRead failed")
+                    for it in range(3):
+                        outp = os.path.join(shm, "modgpu_e2e_%d_q.txt" % os.getpid())
+                        t0 = time.perf_counter()
+                        with mg.CFile(outp, "w") as fo:
+                            rc = L.mgQueryFile(ref, path.encode(), fo)
+                        dt = time.perf_counter() - t0
+                        if rc:
+                            raise RuntimeError("mgQueryFile failed")
+                        lines = os.path.getsize(outp); os.remove(outp)
+                        if it:
+                            best_ = dt if best_ is None else min(best_, dt)
+                    L.mgReferenceDestroy(ref); L.modsetDestroy(ms2)
+                    return best_, lines
+                finally:
+                    del os.environ["MODGPU_TEXT_HOST"]
+                    L.mgReloadKnobs()
+            (t_dev, out_bytes), (t_host, out_bytes_h) = time_query(False), time_query(True)
+            res["modmap_query_file"] = {"entry": "mgReferenceFastaRead + mgQueryFile", "Gbp_per_s": round(nq * 150 / t_dev / 1e9, 2),
+                                        "Gbp_per_s_host_parser": round(nq * 150 / t_host / 1e9, 2), "reads": nq, "bases": nq * 150,
+                                        "reference_bases": rb, "output_bytes": out_bytes, "same_output_size": out_bytes == out_bytes_h,
+                                        "lines_per_s": round(nq / t_dev / 1e6, 1),
+                                        "what": "150-base reads, four-line FASTQ in the page cache -> parsed on the device (record ids copied out of the pinned windows) -> scan + "
+                                                "lookup + tallies + chaining on the device -> one Q line per read (M lines where blocks chain) formatted by the host's threads "
+                                                "into a file in /dev/shm; host_parser: the same through mg_seqio.c and the 1-byte-per-base upload; unit of lines_per_s: million"}
+        finally:
+            if os.path.exists(rpath):
+                os.remove(rpath)
     finally:
         if os.path.exists(path):
             os.remove(path)
