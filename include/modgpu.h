@@ -281,11 +281,12 @@ void mgSeqBatchFree (MgSeqBatch *b) ;
 void mgSeqClose (MgSeqReader *r) ;
 void mgSeqReleaseBuffers (void) ;	/* the readers keep their two largest buffers for the next file (unmapping and touching gigabytes again costs as much as parsing them); this gives them back -- a no-op while a reader is open; also run when the library is unloaded */
 void mgReleaseBuffers (void) ;	/* everything the library caches between calls: the readers' buffers (mgSeqReleaseBuffers), the device buffers and pinned staging of the host-buffer entry points (mgAddSequenceBatch, mgUploadPack: they live on the device the last call ran on and are re-made by themselves when the caller moves to another one), the calling thread's iterator scratch (modRCiterator) */
-/* A plain FASTA file parsed ON THE DEVICE (the host only moves the bytes: parallel pread into pinned memory, the text as it is
- * across PCIe, record starts / headers / bases found by three small kernels per window): mgAddSequenceFile takes this path by
- * itself for plain FASTA text and falls back to the reader above for gzip, FASTQ, a file that does not end in a newline.
+/* Plain FASTA / FASTQ text parsed ON THE DEVICE (the host only moves the bytes: parallel pread into pinned memory, the text as it
+ * is across PCIe, record starts / headers / bases found by small kernels per window): mgAddSequenceFile, mgReferenceFastaRead and
+ * mgQueryFile take this path by themselves for plain text and use the reader above for gzip, a file that does not end in a
+ * newline, a FASTA file whose last line is a header, FASTQ that breaks a rule (from the first record not handed on).
  * This entry returns the parser's records as host arrays (bases 0..3 one per byte, offsets[nSeq + 1]; free () both): 0 = done,
- * -1 = error, -2 = not a file for the device parser. */
+ * -1 = error (mgLastError), -2 = not a file the device parser takes as a whole (nothing is returned). */
 int  mgTextParseFileDevice (const char *filename, char **bases, int64_t **offsets, int64_t *nSeq) ;
 /* the callers' per-file loops: parsing of the next batch overlaps the GPU work on the current one */
 int  mgAddSequenceFile (Modset *ms, const char *filename, FILE *out) ;                        /* modutils.c:33-51 */

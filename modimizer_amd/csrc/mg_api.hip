@@ -975,12 +975,12 @@ extern "C" MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 tot
 /* grow-only device buffers for the host-buffer entry points (a hipMalloc + hipFree of a gigabyte per call costs
  * milliseconds): the packed reads and their offsets of the batch in flight */
 static struct MgHostBatchBufs { U32 *dP = 0; size_t words = 0; U64 *dOff = 0; size_t offs = 0; int dev = -1; std::mutex lock; } gHb;   /* on device `dev` */
-extern "C" void mgHostBatchRelease (void)
-{ std::lock_guard<std::mutex> g (gHb.lock);
-  if (gHb.dP) (void) hipFree (gHb.dP);
+static void mgHostBatchReleaseLocked (void)              /* gHb.lock is held */
+{ if (gHb.dP) (void) hipFree (gHb.dP);
   if (gHb.dOff) (void) hipFree (gHb.dOff);
   gHb.dP = 0; gHb.words = 0; gHb.dOff = 0; gHb.offs = 0; gHb.dev = -1;
 }
+extern "C" void mgHostBatchRelease (void) { std::lock_guard<std::mutex> g (gHb.lock); mgHostBatchReleaseLocked (); }
 static double mgNowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads)
@@ -988,12 +988,10 @@ extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int6
   if (mgEnsureDevice ()) return -1;
   if (nReads <= 0) return 0;
   const int timing = mgKnobs ()->uploadTiming == 1;   /* dev */
-  { int curDev = 0; if (hipGetDevice (&curDev) != hipSuccess) { mgSetError ("mgAddSequenceBatch: no current device"); return -1; }
-    bool moved; { std::lock_guard<std::mutex> g0 (gHb.lock); moved = gHb.dev >= 0 && gHb.dev != curDev; }
-    if (moved) mgHostBatchRelease ();                  /* the cached buffers live on the device the previous call ran on */
-    std::lock_guard<std::mutex> g0 (gHb.lock); gHb.dev = curDev;
-  }
-  std::lock_guard<std::mutex> g (gHb.lock);
+  int curDev = 0; if (hipGetDevice (&curDev) != hipSuccess) { mgSetError ("mgAddSequenceBatch: no current device"); return -1; }
+  std::lock_guard<std::mutex> g (gHb.lock);            /* ONE lock over the check, the release and the re-key: two host threads on two GPUs cannot interleave them */
+  if (gHb.dev >= 0 && gHb.dev != curDev) mgHostBatchReleaseLocked ();      /* the cached buffers live on the device the previous call ran on */
+  gHb.dev = curDev;
   U64 total = (U64) readOffsets[nReads];
   size_t nw = mgPackedWords (total);
   if (nw > gHb.words)
@@ -1052,6 +1050,9 @@ extern "C" void mgDepthHistogram (Modset *ms, FILE *f)
  * no stream wait on the way.  Reads longer than mgIterMaxBases () take the batch scan with the block copied back.
  * The scratch is per host thread and per device. */
 #include <immintrin.h>
+static bool gRuntimeAlive = true;                          /* false once the library is being unloaded: thread-local destructors that run after that leave HIP alone */
+__attribute__ ((destructor)) static void mgRuntimeDown (void) { gRuntimeAlive = false; }
+static bool mgRuntimeAlive (void) { return gRuntimeAlive; }
 struct MgIterScratch {
   int dev = -1; hipStream_t st = 0;
   char *hIn = 0; char *dIn = 0; size_t inBytes = 0;          /* pinned: {0, len} (2 x U64), then the packed words */
@@ -1062,8 +1063,10 @@ struct MgIterScratch {
   U32 *dPacked = 0; U64 *dOff = 0; U64 *dKmer = 0; U32 *dPosF = 0; void *dWork = 0; U64 *dCount = 0;
   size_t wordsCap = 0, survCap = 0, workCap = 0;
   U32 *hPacked = 0; size_t hWordsCap = 0;
+  ~MgIterScratch () { if (dev >= 0 && mgRuntimeAlive ()) release (); }      /* a host thread that ends gives its pinned buffers and its stream back */
   void release ()
-  { if (hIn) (void) hipHostFree (hIn);
+  { if (st) (void) hipStreamSynchronize (st);              /* no kernel of this scratch is still writing into what is freed */
+    if (hIn) (void) hipHostFree (hIn);
     if (hOut) (void) hipHostFree (hOut);
     if (hFlag) (void) hipHostFree (hFlag);
     (void) hipFree (dSegK); (void) hipFree (dSegP); (void) hipFree (dPacked); (void) hipFree (dOff); (void) hipFree (dKmer);
@@ -1178,13 +1181,14 @@ extern "C" int mgIterScan (Seqhash *sh, const char *s, int len, U64 **blkOut)
     { if (mgIterOutReserve (g, want)) { mgSetError ("iterator scratch: pinned allocation failed"); return -1; }
       const U64 seq = ++g.seq;
       if (mgLaunchIterScan (p, (const U32 *) (g.dIn + 16), total, (const U64 *) g.dIn, g.dSegK, g.dSegP, g.dOut, g.outEntries, g.dFlag, seq, g.st)) return -1;
-      volatile U64 *flag = g.hFlag;
+      U64 *flag = g.hFlag;
       bool done = false;
-      for (int spin = 0 ; spin < (1 << 22) ; ++spin) { if (*flag == seq) { done = true; break; } _mm_pause (); }
+      /* acquire loads: the block the kernel wrote before its release store of the flag is read after the flag is seen */
+      for (int spin = 0 ; spin < (1 << 22) ; ++spin) { if (__atomic_load_n (flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; } _mm_pause (); }
       if (!done)                                           /* a kernel that takes this long, or one that failed: ask the runtime */
         { hipError_t e = hipStreamSynchronize (g.st);
-          if (e != hipSuccess) { mgHipFail (e, "iterator scan"); return -1; }
-          if (*flag != seq) { mgSetError ("iterator scan: no completion flag"); return -1; }
+          if (e != hipSuccess) { mgHipFail (e, "iterator scan"); g.release (); return -1; }      /* (nothing of this scratch is reused after a failure) */
+          if (__atomic_load_n (flag, __ATOMIC_ACQUIRE) != seq) { mgSetError ("iterator scan: no completion flag"); g.release (); return -1; }
         }
       const U64 n = g.hOut[0];
       if (n > g.outEntries) { want = n; continue; }

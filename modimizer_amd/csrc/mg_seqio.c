@@ -469,6 +469,8 @@ static int cutFasta (MgSeqReader *r, size_t at, size_t next, RawRec *rec, U64 li
   if (next) { rec->seqEnd = rec->end = next; return 1; }
   if (!r->eof) return 0;
   if (end[-1] != '\n') return 0;             /* unterminated last line: the caller reports it */
+  if (nl + 1 == end) return 0;               /* the file ends with this header line: the reference reads on for the sequence, finds the end and
+                                                reports "incomplete sequence record" without returning the record (seqio.c:213-217,314) */
   rec->seqEnd = rec->end = r->len;
   return 1;
 }

@@ -21,9 +21,16 @@
  *   The bases of complete records are packed to 2 bits (mgLaunchPack) and handed to mgAddReadsDevice a batch at a time; the
  *   record the batch ends in the middle of is carried to the front of the next batch on the device.
  *
- * Not handled here, and left to the host parser by returning -2 ("not applicable"): gzip / blocked gzip, FASTQ, a file whose
- * last byte is not a newline (the reference reports the unfinished record, seqio.c:213-217), anything that is not a regular
- * file.  Record ids are not extracted (addSequenceFile ignores them, modutils.c:35).
+ * FASTQ goes the same way with other kernels (see "FASTQ" below): the line a byte belongs to is the number of newlines before
+ * it, line mod 4 says what the byte is; the format's rules are checked on the device and never judged there.
+ *
+ * Return codes of the parser (txParseFile, mgAddSequenceFileDevice, mgTextForEachBatchDevice): 0 = the whole file; -1 = error
+ * (mgLastError); -2 = not a file for this path -- gzip / blocked gzip, a file whose last byte is not a newline (the reference reports
+ * the unfinished record, seqio.c:213-217), a FASTA file whose last line is a header, anything that is not a regular file, no
+ * device: the caller uses the host parser from the start; -3 = FASTQ text that breaks a rule, or ends inside a record, somewhere
+ * after byte *resumeOff: the records before it have been handed on, the host parser continues from there (and says what the
+ * reference says).  mgTextParseFileDevice (the test hook) maps -3 to -2 and hands nothing on.  Record ids (seqio.c:303-304) are
+ * extracted for the callers that print them (mgReferenceFastaRead, mgQueryFile), not for mgAddSequenceFile (modutils.c:35 ignores them).
  */
 #include <fcntl.h>
 #include <pthread.h>
@@ -535,7 +542,14 @@ static U64 txBatchBases (void)
   return b;
 }
 
+static int txReserveInner (TxBufs &t, size_t window, U64 basesNeed, U64 recsNeed);
 static int txReserve (TxBufs &t, size_t window, U64 basesNeed, U64 recsNeed)
+{
+  const int rc = txReserveInner (t, window, basesNeed, recsNeed);
+  if (rc) t.release ();      /* an allocation failed half way: give back what was made (release () tolerates null pointers) */
+  return rc;
+}
+static int txReserveInner (TxBufs &t, size_t window, U64 basesNeed, U64 recsNeed)
 {
   int dev = 0; if (hipGetDevice (&dev) != hipSuccess) return -1;
   if (t.dev >= 0 && (t.dev != dev || t.window < window)) t.release ();      /* (buffers made for a larger window serve a smaller one) */
@@ -684,6 +698,14 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
   const size_t fileSize = (size_t) sb.st_size;
   unsigned char first = 0, lastc = 0;
   if (pread (fd, &first, 1, 0) != 1 || pread (fd, &lastc, 1, (off_t) fileSize - 1) != 1 || (first != '>' && first != '@') || lastc != '\n') { close (fd); return -2; }
+  if (first == '>')                                       /* a FASTA file whose LAST line is a header: the reference reports the record as incomplete and does not
+                                                             return it (seqio.c:213-217,314) -- left to the host parser, which says so with the line number */
+    { unsigned char tail[4096]; const size_t tn = fileSize < sizeof (tail) ? fileSize : sizeof (tail);
+      if (pread (fd, tail, tn, (off_t) (fileSize - tn)) != (ssize_t) tn) { close (fd); return -2; }
+      size_t i = tn - 1;                                   /* the final newline */
+      while (i > 0 && tail[i - 1] != '\n') --i;            /* start of the last line (or of the tail: a header longer than that is no record id line we want to judge here) */
+      if (tail[i] == '>' && (i > 0 || tn == fileSize)) { close (fd); return -2; }
+    }
 
   TxBufs &t = gTx;
   std::lock_guard<std::mutex> g (t.lock);
@@ -973,7 +995,7 @@ extern "C" int mgTextParseFileDevice (const char *filename, char **basesOut, int
   TxSink sink; sink.fn = txHostSink; sink.ctx = &c; sink.wantIds = false;
   U64 nSeq = 0, totLen = 0;
   const int rc = txParseFile (filename, sink, &nSeq, &totLen);
-  if (rc) return rc;
+  if (rc) return rc == -3 ? -2 : rc;                       /* (FASTQ handed back to the host parser in the middle: nothing of it is returned here) */
   if (c.offs.empty ()) c.offs.push_back (0);
   char *b = (char *) malloc (c.bases.size () + 1); int64_t *o = (int64_t *) malloc (c.offs.size () * sizeof (int64_t));
   if (!b || !o) { free (b); free (o); return -1; }

@@ -230,6 +230,8 @@ def make_seqio_inputs():
         recs.append(">r%d len=%d\n" % (i, L) + wrap(text(g[a:a + L], lower_rate=0.1, n_rate=0.005), int(rng.integers(20, 120))))
     open(os.path.join(HERE, "mixed.fa"), "w", newline="").write("".join(recs))
     open(os.path.join(HERE, "unterminated.fa"), "w", newline="").write("".join(recs[:3]) + ">last\n" + text(g[100:400]))
+    # a file whose LAST line is a header: the reference reports the record as incomplete and does not return it (seqio.c:213-217,314)
+    open(os.path.join(HERE, "header_last.fa"), "w", newline="").write(">a\nACGTACGTACGTACGTACGTAAACCCGGGTTT\n>b\nACGTTTGACCGATAGACCAGATAGGGAC\n>lonely\n")
     import gzip as _gz
     with _gz.GzipFile(os.path.join(HERE, "mixed.fa.gz"), "wb", mtime=0) as f:
         f.write("".join(recs).encode())
@@ -244,7 +246,7 @@ def make_seqio_inputs():
 
 def gen_seqio():
     mu = os.path.join(REFDIR, "modutils_ref")
-    for name in ("mixed.fa", "mixed.fa.gz", "unterminated.fa", "mixed.fq"):
+    for name in ("mixed.fa", "mixed.fa.gz", "unterminated.fa", "mixed.fq", "header_last.fa"):
         tag = name.replace(".", "_")
         r = subprocess.run([mu, "-c", "20", "15", "4", "17", "-a", name, "-wt", "seqio_%s.dump.txt" % tag],
                            capture_output=True, text=True, cwd=HERE)

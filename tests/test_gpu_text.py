@@ -161,14 +161,14 @@ print("rc", rc, "max", ms.contents.max, "sum", int(v[1:].sum() % (1 << 61)), int
 
 def test_device_parser_declines_what_it_does_not_take(golden_dir, tmp_path):
     """gzip, an unterminated last line, a missing file: -2, so that mgAddSequenceFile goes to the host parser"""
-    for name in ("mixed.fa.gz", "unterminated.fa"):
+    for name in ("mixed.fa.gz", "unterminated.fa", "header_last.fa"):      # (the last: a file that ends with a header line)
         rc, _ = device_records(os.path.join(golden_dir, name))
         assert rc == -2, name
     rc, _ = device_records(str(tmp_path / "nope.fa"))
     assert rc == -2
 
 
-@pytest.mark.parametrize("fname", ["mixed.fa", "many.fa", "reads.fa", "mixed.fa.gz", "unterminated.fa", "mixed.fq"])
+@pytest.mark.parametrize("fname", ["mixed.fa", "many.fa", "reads.fa", "mixed.fa.gz", "unterminated.fa", "mixed.fq", "header_last.fa"])
 @pytest.mark.parametrize("window_kb", [0, 4])
 def test_add_sequence_file_device_path_vs_host_path(fname, window_kb, golden_dir):
     """mgAddSequenceFile through the device parser (plain FASTA) or its fallback (the others) gives the modset and the "added"

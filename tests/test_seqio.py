@@ -14,7 +14,7 @@ import pytest
 import modimizer_amd as mg
 from tests import util
 
-FILES = {"mixed.fa": "mixed_fa", "mixed.fa.gz": "mixed_fa", "unterminated.fa": "unterminated_fa", "mixed.fq": "mixed_fq"}
+FILES = {"mixed.fa": "mixed_fa", "mixed.fa.gz": "mixed_fa", "unterminated.fa": "unterminated_fa", "mixed.fq": "mixed_fq", "header_last.fa": "header_last_fa"}
 
 
 def parse_file(path, max_bases, threads):
@@ -75,6 +75,14 @@ def test_unterminated_last_record_is_reported(golden_dir, capfd):
     names, seqs = parse_file(os.path.join(golden_dir, "unterminated.fa"), 1 << 40, 2)
     assert names == ["plain60", "lower", "withN"]
     assert capfd.readouterr().err == util.golden_text("seqio_unterminated_fa.stderr.txt")
+
+
+def test_header_line_as_last_line_is_an_incomplete_record(golden_dir, capfd):
+    """a FASTA file that ends with a header line: the reference reads on for the sequence, meets the end of the file, reports
+    "incomplete sequence record line N" and does NOT return the record (seqio.c:213-217,314) -- golden from the reference program"""
+    names, seqs = parse_file(os.path.join(golden_dir, "header_last.fa"), 1 << 40, 2)
+    assert names == ["a", "b"] and [len(s) for s in seqs] == [32, 28]
+    assert capfd.readouterr().err == util.golden_text("seqio_header_last_fa.stderr.txt")
 
 
 def test_unreadable_and_empty(tmp_path, capfd):
