@@ -661,7 +661,8 @@ def bench_ref_default(cx, args):
         if pm and scan_ms:
             alu = dict(alu, valu_per_start=pm["valu_per_start"], valu_per_start_from=pm["from"],
                        wave_valu_per_s=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3), 1),
-                       issue_frac=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3) / VALU_ISSUE_PEAK, 4))
+                       issue_frac=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3) / alu["issue_peak_wave_insts_per_s"], 4),
+                       filter_floor_valu_per_start=None, floor_ms=None)
     except Exception:
         pass
     res = {"timed_regions_ms_per_step": regions,

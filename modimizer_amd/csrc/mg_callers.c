@@ -514,7 +514,7 @@ typedef struct { char *buf; size_t len, cap; } FmtBuf;
 static char *fmtRoom (FmtBuf *b, size_t need)
 { if (b->len + need > b->cap) { b->cap = 2 * (b->len + need) + 4096; b->buf = (char *) realloc (b->buf, b->cap); if (!b->buf) fatal ("out of memory"); } return b->buf + b->len; }
 
-typedef struct { const MgReference *ref; const MgChainQ *q; const MgChainM *m; const int64_t *offsets; const char **names; int r0, r1; FmtBuf out; } FmtJob;
+typedef struct { const MgReference *ref; const MgChainQ *q; const MgChainM *m; const U64 *mStart; const int64_t *offsets; const char **names; int r0, r1; FmtBuf out; } FmtJob;
 static void *fmtQM (void *v)
 {
   FmtJob *j = (FmtJob *) v;
@@ -529,7 +529,7 @@ static void *fmtQM (void *v)
       p = fmtF2 (p, ((int) qq->nSeeds - (int) qq->missed) / (double) ((int) qq->nSeeds)); p = fmtS (p, " hit\n");
       j->out.len += (size_t) (p - p0);
       for (U32 k = 0 ; k < qq->nM ; ++k)
-        { const MgChainM *e = &j->m[(size_t) r * MG_QUERY_MAXM + k];
+        { const MgChainM *e = &j->m[j->mStart[r] + k];
           const char *rn = j->ref->names[e->id0];
           p0 = fmtRoom (&j->out, 320 + nl + strlen (rn)); p = p0;
           *p++ = 'M'; *p++ = '\t'; memcpy (p, nm, nl); p += nl; *p++ = '\t';
@@ -567,17 +567,19 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
   if (mgMemcpyD2H (offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
   MgDevBatch b; b.dPacked = (void *) dPacked; b.dOff = (void *) dReadOffsets; b.total = totalBases; b.nReads = (U32) nReads;
   MgChainQ *q = (MgChainQ *) malloc ((size_t) nReads * sizeof (MgChainQ));
-  MgChainM *m = (MgChainM *) malloc ((size_t) nReads * MG_QUERY_MAXM * sizeof (MgChainM));
+  MgChainM *m = 0;                                         /* all reads' blocks, densely, in read order */
   const int hostChain = mgKnobs ()->queryHostChain == 1;   /* test knob */
-  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, dPacked, totalBases, dReadOffsets, (U32) nReads, q, m, MG_QUERY_MAXM);
+  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, dPacked, totalBases, dReadOffsets, (U32) nReads, q, &m, MG_QUERY_MAXM);
   if (rc < 0) fatal ("query");
   if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
   else
-    { const int T = fmtThreads (nReads);
+    { U64 *mStart = (U64 *) malloc (((size_t) nReads + 1) * 8);
+      { U64 tot = 0; for (int r = 0 ; r < nReads ; ++r) { mStart[r] = tot; tot += q[r].nM; } mStart[nReads] = tot; }
+      const int T = fmtThreads (nReads);
       FmtJob job[16]; pthread_t th[16]; int started[16];
       for (int t = 0 ; t < T ; ++t)
         { memset (&job[t], 0, sizeof (FmtJob));
-          job[t].ref = ref; job[t].q = q; job[t].m = m; job[t].offsets = offsets; job[t].names = names;
+          job[t].ref = ref; job[t].q = q; job[t].m = m; job[t].mStart = mStart; job[t].offsets = offsets; job[t].names = names;
           job[t].r0 = (int) ((int64_t) nReads * t / T); job[t].r1 = (int) ((int64_t) nReads * (t + 1) / T);
           started[t] = t && pthread_create (&th[t], 0, fmtQM, &job[t]) == 0;
         }
@@ -587,6 +589,7 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
           if (job[t].out.len && fwrite (job[t].out.buf, 1, job[t].out.len, out) != job[t].out.len) fatal ("write");
           free (job[t].out.buf);
         }
+      free (mStart);
     }
   free (q); free (m); free (offsets);
   return rc;

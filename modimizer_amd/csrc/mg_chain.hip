@@ -132,17 +132,31 @@ void mgChainKernel (const U32 *__restrict__ seedIx, const U32 *__restrict__ seed
   q[r] = qq;
 }
 
-/* Q tallies and M blocks of every read of a device-resident batch.  hQ[nReads], hM[nReads*maxM] are host
- * arrays filled here; returns 1 if some read had more than maxM blocks (the caller then does that batch the
- * long way), 0 on success, -1 on error. */
-extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
-                                   MgChainQ *hQ, MgChainM *hM, U32 maxM)
+/* the blocks of all reads, densely: read r's min (nM, maxM) blocks go to mStart[r] .. (the kernel above leaves them in slots of maxM per read:
+   a short-read batch of 4e6 reads would copy 2 GB of mostly empty slots to the host) */
+__global__ __launch_bounds__ (256)
+void mgChainCompactKernel (const MgChainQ *__restrict__ q, const MgChainM *__restrict__ mRec, U32 maxM, const U64 *__restrict__ mStart, U32 nReads,
+                           MgChainM *__restrict__ out)
 {
+  const U32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nReads) return;
+  const U32 n = q[r].nM < maxM ? q[r].nM : maxM;
+  const U64 at = mStart[r];
+  for (U32 j = 0 ; j < n ; ++j) out[at + j] = mRec[(U64) r * maxM + j];
+}
+
+/* Q tallies and M blocks of every read of a device-resident batch.  hQ[nReads] is filled here; *hMOut is a malloc ()ed array
+ * of all reads' blocks in read order (read r's are the next min (hQ[r].nM, maxM) entries), 0 when there is none; returns 1 if
+ * some read had more than maxM blocks (the caller then does that batch the long way), 0 on success, -1 on error. */
+extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                   MgChainQ *hQ, MgChainM **hMOut, U32 maxM)
+{
+  *hMOut = 0;
   Modset *ms = ref->ms;
   MgRefDev d;
   if (mgRefDevGet (ref, &d)) return -1;
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
-  U32 *dIx = 0, *dPos = 0, *dRid = 0; U64 *dStart = 0; MgChainQ *dQ = 0; MgChainM *dM = 0; U32 *dOv = 0;
+  U32 *dIx = 0, *dPos = 0, *dRid = 0; U64 *dStart = 0; MgChainQ *dQ = 0; MgChainM *dM = 0, *dMc = 0; U32 *dOv = 0;
   U64 n = 0;
   int rc = -1;
   do {
@@ -163,11 +177,31 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
     hipLaunchKernelGGL (mgChainKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, d, dQ, dM, maxM, dOv);
     if (hipGetLastError () != hipSuccess) break;
     U32 ov = 0;
-    if (hipMemcpy (&ov, dOv, 4, hipMemcpyDeviceToHost) || hipMemcpy (hQ, dQ, (size_t) nReads * sizeof (MgChainQ), hipMemcpyDeviceToHost)
-        || hipMemcpy (hM, dM, (size_t) nReads * maxM * sizeof (MgChainM), hipMemcpyDeviceToHost)) break;
+    if (hipMemcpy (&ov, dOv, 4, hipMemcpyDeviceToHost) || hipMemcpy (hQ, dQ, (size_t) nReads * sizeof (MgChainQ), hipMemcpyDeviceToHost)) break;
+    if (!ov)
+      { /* where every read's blocks go in the dense array (dStart is free: the chain kernel is done with it) */
+        U64 *hStart = (U64 *) malloc (((size_t) nReads + 1) * 8);
+        if (!hStart) break;
+        U64 tot = 0;
+        for (U32 r = 0 ; r < nReads ; ++r) { hStart[r] = tot; tot += hQ[r].nM < maxM ? hQ[r].nM : maxM; }
+        hStart[nReads] = tot;
+        bool ok = true;
+        if (tot)
+          { MgChainM *hM = (MgChainM *) malloc ((size_t) tot * sizeof (MgChainM));
+            ok = hM && hipMalloc ((void **) &dMc, (size_t) tot * sizeof (MgChainM)) == hipSuccess
+                 && hipMemcpy (dStart, hStart, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+            if (ok)
+              { hipLaunchKernelGGL (mgChainCompactKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dQ, dM, maxM, dStart, nReads, dMc);
+                ok = hipGetLastError () == hipSuccess && hipMemcpy (hM, dMc, (size_t) tot * sizeof (MgChainM), hipMemcpyDeviceToHost) == hipSuccess;
+              }
+            if (ok) *hMOut = hM; else free (hM);
+          }
+        free (hStart);
+        if (!ok) break;
+      }
     rc = ov ? 1 : 0;
   } while (0);
-  (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dQ); (void) hipFree (dM); (void) hipFree (dOv);
+  (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dQ); (void) hipFree (dM); (void) hipFree (dOv); (void) hipFree (dMc);
   if (rc < 0 && !mgLastError ()[0]) mgSetError ("query chaining on the device failed");
   return rc;
 }

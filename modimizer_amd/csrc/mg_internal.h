@@ -45,7 +45,7 @@ MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);
 typedef struct { U32 nSeeds, missed, copy1, copy2, copyM, nM; } MgChainQ;
 typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChainM;
 MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
-                                   MgChainQ *hQ, MgChainM *hM, U32 maxM);
+                                   MgChainQ *hQ, MgChainM **hMOut, U32 maxM);
 MG_HIDDEN void mgChainForget (const MgReference *ref);
 /* readsetFileRead's per-read loop on the device (mg_chain.hip): hit lists, distances, counts, hits per mod */
 MG_HIDDEN int  mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,

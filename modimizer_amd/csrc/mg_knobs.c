@@ -32,6 +32,7 @@ static void readAll (void)
   k.fileBatchMbp = num ("MODGPU_FILE_BATCH_MBP");  k.fileBatchBases = num ("MODGPU_FILE_BATCH_BASES");
   k.queryHostChain = num ("MODGPU_QUERY_HOST_CHAIN");
   k.iterHostBelow = num ("MODGPU_ITER_HOST_BELOW");
+  k.segSlack = num ("MODGPU_SEG_SLACK");
   k.findBits = num ("MODGPU_FIND_BITS"); k.findSubpass = num ("MODGPU_FIND_WGS");
   k.scatterGrid = num ("MODGPU_SCATTER_GRID");     k.tableLoad = num ("MODGPU_TABLE_LOAD");
   k.packThreads = num ("MODGPU_PACK_THREADS");     k.parseThreads = num ("MODGPU_PARSE_THREADS");

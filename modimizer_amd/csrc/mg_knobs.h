@@ -37,6 +37,7 @@ typedef struct {
   long iterHostBelow;      /* MODGPU_ITER_HOST_BELOW: modRCiterator's crossover in bases */
   /* development knobs */
   long scatterGrid;        /* MODGPU_SCATTER_GRID */
+  long segSlack;           /* MODGPU_SEG_SLACK: the scan's segment room as a multiple of the fair share (1..8, default 3) */
   long findSubpass;        /* MODGPU_FIND_WGS: dev, workgroups per XCD of the partitioned lookup */
   long findBits;           /* MODGPU_FIND_BITS: bits of the partitioned lookup's digit (3..9) */
   long tableLoad;          /* MODGPU_TABLE_LOAD: per cent */

@@ -737,8 +737,16 @@ static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
      is rich in modimizers, or with a long homopolymer, hold two or three times the average -- with an eighth of slack every real
      batch had a worker that overflowed, and an overflow means the whole scan again with more room (tools/realistic_probe.py:
      the scan 0.72 instead of 0.36 ms per Gbp) */
+  /* Footprint (what mgScanWorkBytes asks for): 16 bytes per segment entry (k-mer 8, pos 4, read 4), segments three times the
+     fair share of the caller's capacity, capacity itself 1.25 N / d + 65536: 60 N / d bytes -- 9.4 GB for a 10 Gbp batch at d = 64;
+     at small d the cap below binds (a segment never holds more than its range's k-mer starts) and the scratch approaches 16 bytes
+     per base of the batch (config 5, d = 4, 1 Gbp: 16 GB).  Memory only: a segment is read up to its count.  Callers that scan
+     several large batches at once on one device should size for that (MODGPU_SEG_SLACK, 1..8: the factor, default 3; 1 = an
+     eighth of slack as in round 2, at the price of a second scan when a worker overflows). */
   U64 share = capacity / g.nBlocks;
-  U64 seg = 3 * share + 64;
+  const long slackKnob = mgKnobs ()->segSlack;
+  const U64 slack = slackKnob != MG_KNOB_UNSET && slackKnob >= 1 && slackKnob <= 8 ? (U64) slackKnob : 3;
+  U64 seg = slack > 1 ? slack * share + 64 : share + share / 8 + 64;
   U64 most = g.tilesPerBlock * (U64) MG_TILE_BASES;
   g.segCap = seg < most ? seg : most;
   return g;
