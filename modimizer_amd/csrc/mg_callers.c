@@ -562,6 +562,8 @@ static int fmtThreads (int nReads)
 int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char **names, FILE *out)
 {
   if (nReads <= 0) return 0;
+  const int timing = mgKnobs ()->seedTiming == 1;          /* dev */
+  struct timespec c0, c1, c2, c3; if (timing) clock_gettime (CLOCK_MONOTONIC, &c0);
   if (modsetSyncToHost (ref->ms, 0)) fatal ("modsetSyncToHost");
   int64_t *offsets = (int64_t *) malloc ((size_t) (nReads + 1) * 8);
   if (mgMemcpyD2H (offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
@@ -571,6 +573,7 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
   const int hostChain = mgKnobs ()->queryHostChain == 1;   /* test knob */
   int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, dPacked, totalBases, dReadOffsets, (U32) nReads, q, &m, MG_QUERY_MAXM);
   if (rc < 0) fatal ("query");
+  if (timing) clock_gettime (CLOCK_MONOTONIC, &c1);
   if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
   else
     { U64 *mStart = (U64 *) malloc (((size_t) nReads + 1) * 8);
@@ -584,12 +587,20 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
           started[t] = t && pthread_create (&th[t], 0, fmtQM, &job[t]) == 0;
         }
       for (int t = 0 ; t < T ; ++t) if (!started[t]) fmtQM (&job[t]);
+      for (int t = 0 ; t < T ; ++t) if (started[t]) pthread_join (th[t], 0);
+      if (timing) clock_gettime (CLOCK_MONOTONIC, &c2);
       for (int t = 0 ; t < T ; ++t)
-        { if (started[t]) pthread_join (th[t], 0);
-          if (job[t].out.len && fwrite (job[t].out.buf, 1, job[t].out.len, out) != job[t].out.len) fatal ("write");
+        { if (job[t].out.len && fwrite (job[t].out.buf, 1, job[t].out.len, out) != job[t].out.len) fatal ("write");
           free (job[t].out.buf);
         }
       free (mStart);
+      if (timing)
+        { clock_gettime (CLOCK_MONOTONIC, &c3);
+#define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+          fprintf (stderr, "mgQueryProcessDevice: %d reads: device (scan, lookups, chain, copies) %.1f ms, format %.1f ms (%d threads), write %.1f ms\n",
+                   nReads, MS_ (c0, c1), MS_ (c1, c2), T, MS_ (c2, c3));
+#undef MS_
+        }
     }
   free (q); free (m); free (offsets);
   return rc;

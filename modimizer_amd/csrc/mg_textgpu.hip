@@ -658,6 +658,44 @@ struct TxIds {
     if (at >= n) { skipOne = true; return; }
     feed (win + at + 1, n - at - 1);
   }
+  static inline bool space (unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }      /* isspace in the C locale */
+  /* cnt headers at window bytes at[0 .. cnt), every one of them with its id's end inside the window: lengths by a team of
+     threads, places by a prefix over the threads' sums, copies by the team again (a window of short reads starts 4e5 records) */
+  void headersTeam (const unsigned char *win, size_t n, const U64 *at, size_t cnt, int nThreads)
+  { if (!cnt) return;
+    if (nThreads > 16) nThreads = 16;
+    if (cnt < 20000 || nThreads < 2) { for (size_t i = 0 ; i < cnt ; ++i) header (win, n, (size_t) at[i]); return; }
+    std::vector<U32> len (cnt);
+    std::vector<U64> sum ((size_t) nThreads + 1, 0);
+    auto lens = [&] (int t)
+      { const size_t a = cnt * (size_t) t / nThreads, b = cnt * ((size_t) t + 1) / nThreads; U64 s = 0;
+        for (size_t i = a ; i < b ; ++i)
+          { const unsigned char *p = win + at[i] + 1, *e = win + n; const unsigned char *q = p;
+            while (q < e && !space (*q)) ++q;
+            len[i] = (U32) (q - p); s += (U64) (q - p) + 1;
+          }
+        sum[(size_t) t + 1] = s;
+      };
+    { std::vector<std::thread> th; for (int t = 1 ; t < nThreads ; ++t) th.emplace_back (lens, t); lens (0); for (auto &x : th) x.join (); }
+    for (int t = 0 ; t < nThreads ; ++t) sum[(size_t) t + 1] += sum[(size_t) t];
+    const size_t base = bytes.size (), first = off.size ();
+    bytes.resize (base + (size_t) sum[(size_t) nThreads]); off.resize (first + cnt);
+    auto copy = [&] (int t)
+      { const size_t a = cnt * (size_t) t / nThreads, b = cnt * ((size_t) t + 1) / nThreads; size_t o = base + (size_t) sum[(size_t) t];
+        for (size_t i = a ; i < b ; ++i)
+          { off[first + i] = (U64) o; memcpy (bytes.data () + o, win + at[i] + 1, len[i]); o += len[i]; bytes[o++] = 0; }
+      };
+    { std::vector<std::thread> th; for (int t = 1 ; t < nThreads ; ++t) th.emplace_back (copy, t); copy (0); for (auto &x : th) x.join (); }
+    open = false;
+  }
+  /* the headers of a window: all but the last through the team (an id ends before the next header starts), the last one -- which may
+     run on into the next window -- by header () */
+  void headers (const unsigned char *win, size_t n, std::vector<U64> &at, int nThreads)
+  { if (at.empty ()) return;
+    const size_t cnt = at.size ();
+    if (cnt > 1) headersTeam (win, n, at.data (), cnt - 1, nThreads);
+    header (win, n, (size_t) at[cnt - 1]);
+  }
   void dropFront (size_t nRec)                              /* the first nRec records were flushed */
   { if (!nRec) return;
     const U64 cut = nRec < off.size () ? off[nRec] : (U64) bytes.size ();
@@ -777,7 +815,8 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
             const U64 nNew = accRecs - recsBefore;
             hdr.resize ((size_t) nNew);
             if (nNew && hipMemcpy (hdr.data (), t.dRecPos + recsBefore, (size_t) nNew * 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
-            for (U64 r = 0 ; r < nNew ; ++r) ids.header (t.hPin[cur], nCur, (size_t) (hdr[(size_t) r] - (U64) off));
+            for (auto &h : hdr) h -= (U64) off;
+            ids.headers (t.hPin[cur], nCur, hdr, nThreads);
           }
         const bool eof = !nNext;
         if (eof || accBases >= batch)
@@ -883,12 +922,13 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
         bool bad = t.hCounts[4] != 0;
         if (sink.wantIds && !bad)                         /* a header starts at the file's first byte and after every record's last newline */
           { if (ids.open) ids.feed (t.hPin[cur], nCur);
-            if (!off) ids.header (t.hPin[cur], nCur, 0);
             const U64 nNew = accRecs - recsBefore;
             hdr.resize ((size_t) nNew);
             if (nNew && hipMemcpy (hdr.data (), t.dEndP + recsBefore + 1, (size_t) nNew * 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
-            for (U64 r = 0 ; r < nNew ; ++r)
-              if (hdr[(size_t) r] + 1 < (U64) fileSize) ids.header (t.hPin[cur], nCur, (size_t) (hdr[(size_t) r] + 1 - (U64) off));
+            for (auto &h : hdr) h = h + 1 - (U64) off;     /* the byte after a record's last newline, in this window (or its end: the next window's first byte) */
+            if (!hdr.empty () && hdr.back () + (U64) off >= (U64) fileSize) hdr.pop_back ();      /* the file's last record: no header follows */
+            if (!off) hdr.insert (hdr.begin (), (U64) 0);
+            ids.headers (t.hPin[cur], nCur, hdr, nThreads);
           }
         if (!bad && accRecs > recsBefore)                  /* the records this window completed: sequence and quality lines of one length? */
           { const U64 nNew = accRecs - recsBefore;

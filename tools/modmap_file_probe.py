@@ -27,7 +27,7 @@ with open(qpath, "wb") as f:
         part = b"".join(ids[j].encode() + seqs[j].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for j in range(i, min(nq, i + 200000)))
         f.write(part)
 for host in ("0", "1"):
-    with mg.knobs(TEXT_HOST=host, TEXT_TIMING=1, SEED_TIMING=0):
+    with mg.knobs(TEXT_HOST=host, TEXT_TIMING=1, SEED_TIMING=1):
         sh = mg.seqhashCreate(21, 64, 17); ms = mg.modsetCreate(sh, 24)
         ref = L.mgReferenceCreate(ms, 1 << 26)
         with mg.CFile(os.devnull, "w") as fo:
