@@ -40,7 +40,10 @@ for cfg, key in tags.items():
         si["measured_int_valu_peak_lane_ops_per_s"] = old.get("measured_int_valu_peak_lane_ops_per_s", 37.6e12)
         si["measured_int_valu_peak_wave_insts_per_s"] = old.get("measured_int_valu_peak_wave_insts_per_s", 587.5e9)
         si["avg_ms_under_trace"] = s.get("avg_ms")
-        si["history"] = {"round 1": 13.2, "round 2": 11.87, "round 3": si["valu_per_start"]}
+        hist = dict(old.get("history", {"round 1": 13.2, "round 2": 11.87, "round 3": 10.9}))
+        hist["round %d" % int(tag.lstrip("r"))] = si["valu_per_start"]
+        si["history"] = hist
+        if "ref_default" in old: si["ref_default"] = old["ref_default"]      # the exact-mode scan's own pass (tools/prof_pmc.sh --only ref_default)
         json.dump(si, open(os.path.join(R, "profiles", "scan_issue.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(R, "profiles", "traffic.json"), "w"), indent=1)
 print("wrote profiles/traffic.json, profiles/scan_issue.json;", {k: v for k, v in out.items() if k in ("mgScanKernel", "mgTableFindSegKernel", "mgPartScatterKernel")})
