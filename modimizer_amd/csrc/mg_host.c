@@ -152,11 +152,14 @@ U64 *mgIterScanHost (const Seqhash *sh, const char *s, int len)
   U64 inv = wOdd;                                        /* Newton: five steps double 3 correct bits to 64 and more */
   for (int i = 0 ; i < 5 ; ++i) inv *= 2 - wOdd * inv;
   const U64 lim = ~(U64) 0 / wOdd, lowMask = ((U64) 1 << wShift) - 1;
-  const size_t cap = (size_t) (len - k + 1);
-  U64 *blk = (U64 *) xalloc ((cap + 1) * 8 + cap * 4 + 8, 0);
-  U64 *km = blk + 1;
-  U32 stackPf[1024];
-  U32 *pf = cap <= 1024 ? stackPf : (U32 *) xalloc (cap * 4, 0);
+  /* room for the expected number of modimizers and a quarter more (on the stack for short reads); a read that holds more -- a
+     homopolymer that is a modimizer, d = 1 -- gets room for every start */
+  const size_t most = (size_t) (len - k + 1);
+  size_t cap = (size_t) len / (size_t) w + (size_t) len / (4 * (size_t) w) + 64;
+  if (cap > most) cap = most;
+  U64 stackKm[512]; U32 stackPf[512];
+  U64 *km = cap <= 512 ? stackKm : (U64 *) xalloc (cap * 8, 0);
+  U32 *pf = cap <= 512 ? stackPf : (U32 *) xalloc (cap * 4, 0);
   const unsigned char *b = (const unsigned char *) s;
   U64 h = 0, r = 0;
   for (int i = 0 ; i < k - 1 ; ++i)
@@ -173,14 +176,22 @@ U64 *mgIterScanHost (const Seqhash *sh, const char *s, int len)
       const int isF = hF < hR;
       const U64 hash = isF ? hF : hR;
       if (!(hash & lowMask) && ((hash >> wShift) * inv) <= lim)
-        { km[n] = isF ? h : r;
+        { if (n == cap)
+            { U64 *nk = (U64 *) xalloc (most * 8, 0); U32 *np = (U32 *) xalloc (most * 4, 0);
+              memcpy (nk, km, n * 8); memcpy (np, pf, n * 4);
+              if (km != stackKm) { free (km); free (pf); }
+              km = nk; pf = np; cap = most;
+            }
+          km[n] = isF ? h : r;
           pf[n] = (U32) (i - k + 1) | (isF ? MG_FWD_BIT : 0);
           ++n;
         }
     }
+  U64 *blk = (U64 *) xalloc ((n + 1) * 8 + n * 4 + 8, 0);
   blk[0] = n;
-  memcpy (km + n, pf, n * 4);
-  if (pf != stackPf) free (pf);
+  memcpy (blk + 1, km, n * 8);
+  memcpy (blk + 1 + n, pf, n * 4);
+  if (km != stackKm) { free (km); free (pf); }
   return blk;
 }
 
