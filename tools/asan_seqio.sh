@@ -12,6 +12,12 @@ cat > $B/main.c <<'EOC'
 int64_t mgAddSequenceBatch (Modset *ms, const char *b, const int64_t *o, int n) { (void) ms; (void) b; (void) o; (void) n; return 0; }
 int mgReferenceRead (MgReference *r, const char *b, const int64_t *o, int n, const char **nm, bool a, FILE *f) { (void) r; (void) b; (void) o; (void) n; (void) nm; (void) a; (void) f; return 0; }
 int mgQueryProcess (MgReference *r, const char *b, const int64_t *o, int n, const char **nm, FILE *f) { (void) r; (void) b; (void) o; (void) n; (void) nm; (void) f; return 0; }
+#include "mg_internal.h"
+int mgTextForEachBatchDevice (const char *fn, MgTextBatchFn f, void *c, U64 *a, U64 *b, U64 *d, U64 *e) { (void) fn; (void) f; (void) c; (void) a; (void) b; (void) d; (void) e; return -2; }
+int mgQueryProcessDevice (MgReference *r, const U32 *p, U64 t, const U64 *o, int n, const char **nm, FILE *f) { (void) r; (void) p; (void) t; (void) o; (void) n; (void) nm; (void) f; return 0; }
+int mgReferenceAddDevice (MgReference *r, const U32 *p, U64 t, const U64 *o, int n, const char **nm, bool a) { (void) r; (void) p; (void) t; (void) o; (void) n; (void) nm; (void) a; return 0; }
+void mgReferenceFinish (MgReference *r, U64 t, bool a, FILE *f) { (void) r; (void) t; (void) a; (void) f; }
+int mgAddSequenceFileDevice (Modset *ms, const char *fn, U64 *a, U64 *b, U64 *c, U64 *d, U64 *e) { (void) ms; (void) fn; (void) a; (void) b; (void) c; (void) d; (void) e; return -2; }
 int main (int argc, char **argv)
 {
   for (int a = 2 ; a < argc ; ++a)
@@ -29,7 +35,7 @@ int main (int argc, char **argv)
 }
 EOC
 gcc -g -O1 -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Imodimizer_amd/csrc \
-    $B/main.c modimizer_amd/csrc/mg_seqio.c -o $B/seqio_asan -lz -lpthread
+    $B/main.c modimizer_amd/csrc/mg_seqio.c modimizer_amd/csrc/mg_knobs.c -o $B/seqio_asan -lz -lpthread
 python3 - <<'EOP'
 import numpy as np
 rng = np.random.default_rng(2)
