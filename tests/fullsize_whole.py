@@ -20,6 +20,9 @@ configs:  c2  BASELINE config 2 (10 Gbp ONT-like, k=21 d=64, table bits 30)
           c3ref  BASELINE config 3's reference: 24 x 125 Mbp built by mgReferenceRead (modmap.c:93-134, referencePack :74-91):
                  value[], info copy classes, ref->index / offset / id of every occurrence, ref->depth, loc[] and rev[] -- all
                  rebuilt on the host from the oracle-pinned stream and compared entirely
+          c3q    BASELINE config 3's queries: a 10 Gbp batch of ONT-like reads against the 3 Gbp reference modset (mgQueryReadsDevice,
+                 modmap.c:197-206): EVERY seed's index, position, strand and read -- the k-mer stream of the batch pinned entirely to
+                 the oracle, the index of every k-mer from a sorted copy of value[] (itself pinned by c3ref), on both lookup paths
           refdef the reference's default parameters (modmap.c:314-317, modutils.c:140: k=19, w=31, seed 17 -- the MG_MODE_ANY
                  scan) on config 2's reads
 MODGPU_FULLSIZE_SCALE=<f> shrinks the workload (development on small boxes).
@@ -176,10 +179,90 @@ def main_c3ref():
     print("FULLSIZE_WHOLE_OK")
 
 
+def main_c3q():
+    """config 3's query batch at full size, every seed (the remaining sampled comparison of round 3)"""
+    import modimizer_amd as mg
+    from modimizer_amd import synth
+    from oracle import pyoracle as po
+    L = mg.lib()
+    mg.check(L.mgSetDevice(0))
+    scale = float(os.environ.get("MODGPU_FULLSIZE_SCALE", "1"))
+    k, w, bits = 21, 64, 28
+    n_seq, seq_len = 24, int(125_000_000 * scale)
+    G = n_seq * seq_len
+    total = int(10_000_000_000 * scale)
+    t0 = time.time()
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    d_g = mg.DeviceBuffer(L.mgPackedWords(G) * 4)
+    mg.check(L.mgSynthGenome(d_g.ptr, G, 333, None))
+    ref_off = np.arange(n_seq + 1, dtype=np.uint64) * np.uint64(seq_len)
+    d_ro = mg.DeviceBuffer.from_numpy(ref_off)
+    # the reference modset straight from the device-resident genome (scan + insert; the reference arrays are c3ref's business)
+    cap0 = int(G / w * 1.3) + (1 << 16)
+    d_a = mg.DeviceBuffer(cap0 * 4); d_b = mg.DeviceBuffer(cap0 * 4); d_c = mg.DeviceBuffer(cap0 * 4)
+    ns = C.c_uint64()
+    mg.check(L.mgInsertReadsDevice(ms, d_g.ptr, G, d_ro.ptr, n_seq, d_a.ptr, d_b.ptr, d_c.ptr, cap0, C.byref(ns), None))
+    for d in (d_a, d_b, d_c, d_ro):
+        d.free()
+    mg.check(L.modsetSyncToHost(ms, 0))
+    U = ms.contents.max
+    value = np.ctypeslib.as_array(ms.contents.value, (U + 1,))[1:].copy()
+    plan = synth.ont_read_plan(total, G, 4000)
+    starts, offs, strands = plan
+    n_reads = len(starts)
+    d_s = mg.DeviceBuffer.from_numpy(starts); d_of = mg.DeviceBuffer.from_numpy(offs); d_st = mg.DeviceBuffer.from_numpy(strands)
+    d_r = mg.DeviceBuffer(L.mgPackedWords(total) * 4)
+    mg.check(L.mgSynthReads(d_g.ptr, G, d_s.ptr, d_of.ptr, d_st.ptr, n_reads, total, 0.05, 5000, d_r.ptr, None))
+    mg.check(L.mgStreamSynchronize(None))
+    d_g.free(); d_s.free(); d_st.free()
+    # ---- the batch's ordered k-mer stream, pinned ENTIRELY to the oracle ------------------------------------------------
+    cap = int(total / w * 1.3) + (1 << 16)
+    d_k = mg.DeviceBuffer(cap * 8); d_p = mg.DeviceBuffer(cap * 4); d_i = mg.DeviceBuffer(cap * 4)
+    d_cn = mg.DeviceBuffer(64); d_w = mg.DeviceBuffer(L.mgScanWorkBytes(total, n_reads, cap))
+    mg.check(L.seqhashScanBatchDevice(sh, d_r.ptr, total, d_of.ptr, n_reads, d_k.ptr, d_p.ptr, d_i.ptr, cap, d_cn.ptr, d_w.ptr, None))
+    cnt = d_cn.to_numpy(np.uint64, 4)
+    S = int(cnt[0]); assert int(cnt[1]) == 0 and S <= cap
+    d_w.free()
+    km = d_k.to_numpy(np.uint64, S); d_k.free()
+    pf = d_p.to_numpy(np.uint32, S); d_p.free()
+    rd = d_i.to_numpy(np.uint32, S); d_i.free()
+    first = np.searchsorted(rd, np.arange(n_reads + 1, dtype=np.uint32))
+    checked, n_pieces = check_whole_stream(L, mg, po, oh, d_r, offs.astype(np.int64), n_reads, km, pf, first)
+    assert checked == S
+    t_scan = time.time() - t0
+    # ---- what modsetIndexFind (ms, kmer, false) returns for every one of them (modset.c:45-62: index of the k-mer or 0) ----
+    order = np.argsort(value, kind="stable"); vs = value[order]
+    at = np.minimum(np.searchsorted(vs, km), len(vs) - 1)
+    want = np.where(vs[at] == km, order[at] + 1, 0).astype(np.uint32)
+    del at, vs, order
+    hit = float((want != 0).mean())
+    assert 0.30 < hit < 0.40 or scale != 1
+    d_ix = mg.DeviceBuffer(cap * 4); d_ps = mg.DeviceBuffer(cap * 4); d_rd = mg.DeviceBuffer(cap * 4)
+    for path in ("direct", "part"):
+        with mg.knobs(FIND_PATH=path):
+            for d in (d_ix, d_ps, d_rd):
+                mg.check(L.mgMemsetD(d.ptr, 0xEE, d.nbytes, None))
+            mg.check(L.mgQueryReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, d_ix.ptr, d_ps.ptr, d_rd.ptr, cap, C.byref(ns), None))
+            assert ns.value == S, (path, ns.value, S)
+            got = d_ix.to_numpy(np.uint32, S)
+            bad = np.flatnonzero(got != want)
+            assert bad.size == 0, (path, "seed index differs at", bad[:5], got[bad[:5]], want[bad[:5]])
+            assert np.array_equal(d_ps.to_numpy(np.uint32, S), pf), (path, "seed pos | strand")
+            assert np.array_equal(d_rd.to_numpy(np.uint32, S), rd), (path, "seed read")
+    L.modsetDestroy(ms)
+    print("fullsize_whole c3q: %d reference entries, %d query bases in %d reads, %d seeds (%.3f hit): the whole k-mer stream == oracle (%d pieces); index, "
+          "pos | strand and read of EVERY seed pinned on both lookup paths; scan + oracle check %.1f s, all %.1f s"
+          % (U, total, n_reads, S, hit, n_pieces, t_scan, time.time() - t0))
+    print("FULLSIZE_WHOLE_OK")
+
+
 def main():
     name = sys.argv[1]
     if name == "c3ref":
         return main_c3ref()
+    if name == "c3q":
+        return main_c3q()
     variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
     k, w, bits, total, G, err, kind, (sg, sp, se) = CONFIGS[name]
     scale = float(os.environ.get("MODGPU_FULLSIZE_SCALE", "1"))

@@ -290,3 +290,14 @@ def test_reference_default_parameters_whole_at_full_size():
     r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), "refdef", "auto"],
                        capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
     assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_config3_query_seeds_whole_at_full_size():
+    """config 3's query batch: every one of the 1.56e8 seeds of a 10 Gbp batch against the 3 Gbp reference -- index (from a sorted
+    copy of value[]), position, strand and read -- with the batch's k-mer stream pinned entirely to the oracle, on the direct and
+    the partitioned lookup path (tests/fullsize_whole.py c3q)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), "c3q"],
+                       capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
+    assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
