@@ -141,6 +141,7 @@ int64_t orcFirstOccurrences (const uint64_t *km, uint64_t n, int nThreads, uint8
 int64_t orcScanCheckMany (const OrcHasher *h, const uint8_t *bases, const int64_t *offsets, int64_t nReads,
                           const int64_t *first, const uint64_t *km, const uint32_t *posF, int nThreads,
                           int64_t *firstBad, int64_t *nChecked);
+void orcSortedLookupMany (const uint64_t *sorted, const uint32_t *idxOfSorted, uint64_t n, const uint64_t *keys, uint64_t m, int nThreads, uint32_t *out);   /* orc_modset.c */
 int64_t orcScanMany (const OrcHasher *h, const uint8_t *bases, const int64_t *offsets, int64_t nReads,
                      OrcModset *msOrNull);
 

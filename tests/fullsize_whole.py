@@ -232,10 +232,16 @@ def main_c3q():
     assert checked == S
     t_scan = time.time() - t0
     # ---- what modsetIndexFind (ms, kmer, false) returns for every one of them (modset.c:45-62: index of the k-mer or 0) ----
-    order = np.argsort(value, kind="stable"); vs = value[order]
-    at = np.minimum(np.searchsorted(vs, km), len(vs) - 1)
-    want = np.where(vs[at] == km, order[at] + 1, 0).astype(np.uint32)
-    del at, vs, order
+    order = np.argsort(value, kind="stable"); vs = np.ascontiguousarray(value[order]); ix = (order + 1).astype(np.uint32)
+    want = np.zeros(S, np.uint32)
+    OL = po.lib()
+    OL.orcSortedLookupMany.restype = None
+    OL.orcSortedLookupMany.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    OL.orcSortedLookupMany(vs.ctypes.data, ix.ctypes.data, len(vs), km.ctypes.data, S, max(1, min(32, len(os.sched_getaffinity(0)))), want.ctypes.data)
+    probe = np.random.default_rng(3).integers(0, S, 200000)               # (the helper itself against numpy on a sample)
+    at = np.minimum(np.searchsorted(vs, km[probe]), len(vs) - 1)
+    assert np.array_equal(want[probe], np.where(vs[at] == km[probe], ix[at], 0))
+    del at, vs, order, ix
     hit = float((want != 0).mean())
     assert 0.30 < hit < 0.40 or scale != 1
     d_ix = mg.DeviceBuffer(cap * 4); d_ps = mg.DeviceBuffer(cap * 4); d_rd = mg.DeviceBuffer(cap * 4)
