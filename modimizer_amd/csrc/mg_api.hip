@@ -835,7 +835,7 @@ extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *st
 /* composite: scan a device-resident batch straight into the modset                           */
 
 struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 cap; MgHistReq counted;
-                    MgSegSrc seg; bool lazy; void *findScratch; };      /* lazy: kmer[] has not been written, the modimizers are in seg */
+                    MgSegSrc seg; bool lazy; void *findScratch, *findScratch2; };      /* lazy: kmer[] has not been written, the modimizers are in seg */
 
 /* scan into arena buffers, growing once if the survivor guess was too small */
 /* outPosF / outRid (with room for outCap entries): the caller's own arrays; when they are large enough for the scan's
@@ -846,10 +846,11 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
                                  MgScanBufs *b, U64 *nOut, hipStream_t st,
                                  U32 *outPosF = 0, U32 *outRid = 0, U64 outCap = 0, bool lazy = false)
 {
-  b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0; b->findScratch = 0;
+  b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0; b->findScratch = 0; b->findScratch2 = 0;
   U64 cap = mgSurvivorGuess (sh, totalBases);
   /* a lookup batch whose k-mers stay in the segments may take the partitioned path (mgTableFindPartitioned): it needs the first digit's counts */
-  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && mgKnobs ()->findPath == 'p';
+  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && (mgKnobs ()->findPath == 'p' || mgKnobs ()->findPath == '2');
+  const bool lookup2 = lookupHist && mgKnobs ()->findPath == '2';
   MgHashParams p = mgMakeParams (sh);
   if (extraPerSurvivor)
     { /* size the table now for the expected number of modimizers (N/d): the insert would do it anyway once the
@@ -862,7 +863,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
     { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
       size_t need = al256 (cap * perS) + 4 * 4096 + 512 * MG_HIST_STRIDE * 4 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
                     + (extraPerSurvivor ? mgTableAddScratchBytes (&d->t, cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK) + 8192 : 0) + 8 * 256
-                    + (lookupHist ? mgTableFindPartScratchBytes (cap) + 8192 : 0);
+                    + (lookupHist ? mgTableFindPartScratchBytes (cap) + 8192 : 0) + (lookup2 ? mgTableFindPart2ScratchBytes (cap) + 8192 : 0);
       MgStatus s = d->arena.reserve (need); if (s) return s;
       d->arena.reset ();
       b->cap = cap;
@@ -879,6 +880,7 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
           if (lookupHist) b->counted.hiB = mgTableFindDigitBits (&d->t);
         }
       b->findScratch = lookupHist ? d->arena.take (mgTableFindPartScratchBytes (cap)) : 0;
+      b->findScratch2 = lookup2 ? d->arena.take (mgTableFindPart2ScratchBytes (cap)) : 0;
       const bool lz = lazy && (wantPos ? extraPerSurvivor == 0 : b->counted.binCount != 0);   /* a build needs the digit counts; a pure lookup just the segments */
       if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
                              b->counted.binCount ? &b->counted : 0, lz ? &b->seg : 0))) return s;
@@ -941,7 +943,7 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
     { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) capacity); return MG_ERR_CAPACITY; }
   if (mode == 0)
     { if (b.lazy && b.findScratch && mgTableFindTakesPartition (&d->t, n, &b.counted))
-        s = mgTableFindPartitioned (&d->t, b.seg, n, &b.counted, dSeedIndex, b.kmer, b.findScratch, st);     /* (b.kmer: the dense array a lazy scan leaves unused) */
+        s = mgTableFindPartitioned (&d->t, b.seg, n, &b.counted, dSeedIndex, b.kmer, b.findScratch, st, b.findScratch2);     /* (b.kmer: the dense array a lazy scan leaves unused) */
       else s = b.lazy ? mgTableFindSegments (&d->t, b.seg, n, dSeedIndex, st) : mgTableFind (&d->t, b.kmer, n, dSeedIndex, st);
     }
   else s = mgAddBatch (ms, d, b.kmer, n, dSeedIndex, 0, true, st, &b.counted);

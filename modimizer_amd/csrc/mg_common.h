@@ -231,7 +231,9 @@ MgStatus mgTableFind (MgTable *t, const U64 *dKmer, U64 n, U32 *dIndexOut, hipSt
 size_t   mgTableFindPartScratchBytes (U64 n);
 int      mgTableFindDigitBits (const MgTable *t);       /* bits of the partitioned lookup's digit: pieces of the table that fit an XCD's L2 */
 bool     mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counted);
-MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st);   /* el: n words of scratch */
+size_t   mgTableFindPart2ScratchBytes (U64 n);
+MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st,
+                                 void *scratch2 = 0);   /* el: n words of scratch; scratch2 (mgTableFindPart2ScratchBytes): the two-level path */
 MgStatus mgTableFindSegments (MgTable *t, const MgSegSrc &src, U64 n, U32 *dIndexOut, hipStream_t st);   /* the n k-mers of a lazy scan, in order */
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st);
 MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st);

@@ -14,7 +14,7 @@ extern "C" {
 #define MG_KNOB_UNSET LONG_MIN
 typedef struct {
   /* test knobs */
-  long findPath;           /* MODGPU_FIND_PATH: 'p' partitioned lookups, 'd' direct probes (the first letter), else automatic */
+  long findPath;           /* MODGPU_FIND_PATH: 'p' partitioned lookups (one level), '2' two levels, 'd' direct probes (the first letter), else automatic */
   long tablePath;          /* MODGPU_TABLE_PATH: 'd' direct atomics, 'b' bucketed (the first letter), else automatic */
   long partPacked;         /* MODGPU_PART_PACKED: 0 = wide partition elements */
   long partBig;            /* MODGPU_PART_BIG: 0 = sub-chunks of MG_PART_SUB everywhere */

@@ -700,8 +700,11 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
                           MgGeom g, MgPartFmt f, int shift, U32 nBins,
                           const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg, U32 chunkElems,
                           unsigned long long *__restrict__ cursor, U32 cstride, U64 *__restrict__ kOut, U32 *__restrict__ tOut,
-                          unsigned long long *__restrict__ runTab)
+                          unsigned long long *__restrict__ runTab, int runMode)
 {
+  /* runMode (with runTab, the partitioned lookup): 0 = the run table's rows are the sub-chunks of ONE segment (row = sub / SUB);
+     1 = the second level: rows are (chunk, half) = 2 c + (sub - lo) / SUB, and every element's ordinal field is replaced by its
+     position in kIn -- where its result has to go back to */
   MG_BUILD_PRIO ();
   constexpr bool WIDE = !PACKOUT;
   constexpr bool BIG = SUB > MG_PART_SUB;
@@ -750,6 +753,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
               U32 d = mgDigitOf<(FIRST ? MG_EL_WIDE : INMODE)> (km[j], g, f, shift, nBins - 1);
               dr[j] = (d << 16) | atomicAdd (&sH[d], 1u);        /* rank within (sub-chunk, bin) */
               if (FIRST && PACKOUT) km[j] = ((km[j] & remMask) << f.ordBits) | (U64) tk[j];
+              if (INMODE == MG_EL_PACKED && runMode == 1) km[j] = ((km[j] >> f.ordBits) << f.ordBits) | i;
             }
         }
       __syncthreads ();
@@ -784,7 +788,7 @@ void mgPartScatterKernel (const U64 *__restrict__ kIn, const U32 *__restrict__ t
       if ((U32) (2 * tid) < nBins) sBase[2 * tid] = base0;
       if ((U32) (2 * tid + 1) < nBins) sBase[2 * tid + 1] = base1;
       if (runTab)                                          /* (uniform; the partitioned lookup) where this sub-chunk's run of every bin went, and its length */
-        { const U64 row = (sub / SUB) * nBins;
+        { const U64 row = (runMode == 1 ? 2 * (U64) c + (sub - lo) / SUB : sub / SUB) * nBins;
           if ((U32) (2 * tid) < nBins) runTab[row + 2 * tid] = base0 | ((unsigned long long) sH[2 * tid] << 40);
           if ((U32) (2 * tid + 1) < nBins) runTab[row + 2 * tid + 1] = base1 | ((unsigned long long) sH[2 * tid + 1] << 40);
         }
@@ -1484,6 +1488,110 @@ void mgUnpartKernel (const U64 *__restrict__ el, const unsigned long long *__res
     }
 }
 
+/* ---- two levels (MODGPU_FIND_PATH=2): the second partition pass of the build as well, so that a bucket's lookups are contiguous
+ * and the bucket (64 KiB) sits in LDS while they run.  The second pass replaces every element's ordinal by its position in the
+ * first pass's output, where the element itself (with its ordinal) stays; results come back in two pulls: (chunk, half) tiles of
+ * the first pass's output from the second pass's runs, then sub-chunks of ordinals from the first pass's runs. ---- */
+__global__ __launch_bounds__ (1024)
+void mgBucketFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, MgGeom g, MgPartFmt f, U32 nBuckets,
+                         const U64 *__restrict__ bucketStart, U64 *__restrict__ el, U32 bucketsPerBlock)
+{
+  const U32 R = g.R, T = blockDim.x, tid = threadIdx.x;
+  unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
+  U32 *sIdx = reinterpret_cast<U32 *> (mgDynLds + (size_t) R * 8);
+  const U64 posMask = ((U64) 1 << f.ordBits) - 1;
+  U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
+  if (bEnd > nBuckets) bEnd = nBuckets;
+  for ( ; b < bEnd ; ++b)
+    { const U64 lo = bucketStart[b], hi = bucketStart[b + 1];
+      if (hi == lo) continue;                                /* (uniform) */
+      const bool any = occ[b] != 0;
+      if (any)
+        { for (U32 i = tid ; i < R ; i += T)
+            { const uint4 v = *reinterpret_cast<const uint4 *> (&slots[(U64) b * R + i]);
+              sKey[i] = ((unsigned long long) v.y << 32) | v.x; sIdx[i] = mgIsAssigned (v.z) ? (v.z & ~MG_ASSIGNED) : 0;
+            }
+          __syncthreads ();
+        }
+      for (U64 i = lo + tid ; i < hi ; i += T)
+        { const U64 x = __builtin_nontemporal_load (&el[i]);
+          U32 res = 0;
+          if (any)
+            { const U64 m = ((U64) (b >> f.loB) << f.remBits) | (x >> f.ordBits), key = m + 1;
+              U32 slot = mgHomeOfM (m, g);
+              for (U32 probes = 0 ; probes < R ; ++probes)
+                { const unsigned long long cur = sKey[slot];
+                  if (cur == key) { res = sIdx[slot]; break; }
+                  if (cur == 0) break;
+                  slot = (slot + 1) & g.rMask;
+                }
+            }
+          __builtin_nontemporal_store (((x & posMask) << 32) | res, &el[i]);
+        }
+      __syncthreads ();                                      /* the image is loaded again for the next bucket */
+    }
+}
+
+/* the second level's results back into the order of the first pass's output: a workgroup per (chunk, half) of that output */
+template <int SUB>
+__global__ __launch_bounds__ (1024)
+void mgUnpartPosKernel (const U64 *__restrict__ el, const unsigned long long *__restrict__ runTab, U32 nBins,
+                        const U64 *__restrict__ segStart, const U32 *__restrict__ chunkBase, U32 nSeg, U32 chunkElems, U32 *__restrict__ idxOut)
+{
+  __shared__ U32 sTile[SUB];
+  __shared__ unsigned long long sRun[MG_PART_MAXBINS];
+  const U32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const U32 nChunks = chunkBase[nSeg];
+  for (U32 w = blockIdx.x ; w < 2 * nChunks ; w += gridDim.x)
+    { const U32 c = w >> 1, h = w & 1;
+      U32 seg; U64 lo, hi;
+      if (!mgChunkRange (segStart, chunkBase, nSeg, chunkElems, c, &seg, &lo, &hi)) continue;
+      const U64 sub = lo + (U64) h * SUB;
+      if (sub >= hi) continue;                               /* (uniform) */
+      const U32 cnt = (U32) (sub + SUB < hi ? SUB : hi - sub);
+      for (U32 b = tid ; b < nBins ; b += 1024) sRun[b] = runTab[(U64) w * nBins + b];
+      __syncthreads ();
+      for (U32 b = wave ; b < nBins ; b += 16)
+        { const unsigned long long r = sRun[b];
+          const U64 base = r & (((U64) 1 << 40) - 1); const U32 len = (U32) (r >> 40);
+          for (U32 i = lane ; i < len ; i += 64)
+            { const U64 v = __builtin_nontemporal_load (&el[base + i]);
+              sTile[(U32) ((v >> 32) - sub)] = (U32) v;
+            }
+        }
+      __syncthreads ();
+      for (U32 i = tid ; i < cnt ; i += 1024) idxOut[sub + i] = sTile[i];
+      __syncthreads ();
+    }
+}
+
+/* the first level's pull when the results sit beside the elements (idx[]) and the elements still hold their ordinals */
+template <int SUB>
+__global__ __launch_bounds__ (1024)
+void mgUnpartOrdKernel (const U64 *__restrict__ el, const U32 *__restrict__ idx, int ordBits, const unsigned long long *__restrict__ runTab, U32 nBins, U64 n,
+                        U32 *__restrict__ out)
+{
+  __shared__ U32 sTile[SUB];
+  __shared__ unsigned long long sRun[MG_PART_MAXBINS];
+  const U32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const U64 nSub = (n + SUB - 1) / SUB, ordMask = ((U64) 1 << ordBits) - 1;
+  for (U64 s = blockIdx.x ; s < nSub ; s += gridDim.x)
+    { const U64 o0 = s * SUB;
+      const U32 cnt = (U32) (o0 + SUB < n ? SUB : n - o0);
+      for (U32 b = tid ; b < nBins ; b += 1024) sRun[b] = runTab[s * nBins + b];
+      __syncthreads ();
+      for (U32 b = wave ; b < nBins ; b += 16)
+        { const unsigned long long r = sRun[b];
+          const U64 base = r & (((U64) 1 << 40) - 1); const U32 len = (U32) (r >> 40);
+          for (U32 i = lane ; i < len ; i += 64)
+            sTile[(U32) ((__builtin_nontemporal_load (&el[base + i]) & ordMask) - o0)] = __builtin_nontemporal_load (&idx[base + i]);
+        }
+      __syncthreads ();
+      for (U32 i = tid ; i < cnt ; i += 1024) __builtin_nontemporal_store (sTile[i], &out[o0 + i]);
+      __syncthreads ();
+    }
+}
+
 /* ======================================================================================== */
 /* host side                                                                                  */
 
@@ -1560,7 +1668,7 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
                             const U64 *segStart, U32 nSeg, int shift, U32 nBins,
                             U64 *kOut, U32 *tOut, U64 *binStart, unsigned long long *cursor, U32 *binCount, U32 *chunkBase,
                             hipStream_t st, const U32 *counted = 0, const MgSegSrc *segSrc = 0, MgSubSeg *subSeg = 0,
-                            unsigned long long *runTab = 0, U32 *subElems = 0)
+                            unsigned long long *runTab = 0, U32 *subElems = 0, int runMode = 0, U32 *maxChunksOut = 0)
 {
   MgGeom g = mgGeomOf (t);
   MgSegSrc src; src.segKmer = 0; src.segCount = 0; src.segStart = 0; src.segCap = 0; src.nSegs = 0;
@@ -1579,6 +1687,7 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
   if (subElems) *subElems = (U32) (big ? MG_PART_SUB_BIG : MG_PART_SUB);
   MG_LAUNCH (MG_K_PART, st, mgPartChunksKernel, dim3 (1), dim3 (MG_PART_MAXBINS), 0, st, segStart, nSeg, chunkElems, chunkBase);
   unsigned maxChunks = (unsigned) (n / chunkElems + nSeg + 1);
+  if (maxChunksOut) *maxChunksOut = maxChunks;
   const int sgEnv = mgKnobs ()->scatterGrid == MG_KNOB_UNSET ? 0 : (int) mgKnobs ()->scatterGrid;   /* dev knob */
   unsigned scatterGrid = maxChunks < (unsigned) (sgEnv > 0 ? sgEnv : 1024) ? maxChunks : (unsigned) (sgEnv > 0 ? sgEnv : 1024);
   const dim3 hg (maxChunks < 4096 ? maxChunks : 4096), sg (scatterGrid);
@@ -1595,7 +1704,7 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
   const U32 cstride = nSeg == 1 ? 16u : 1u;                  /* (the second pass's 65536 cursors: no gain from padding) */
   MG_LAUNCH (MG_K_PART, st, mgPartScanKernel, dim3 (nSeg), dim3 (MG_PART_MAXBINS), 0, st, binCount, nBins, segStart, binStart, cursor, cstride, nSeg, n);
 #define MG_SCATTER(IN, PK, SUB) MG_LAUNCH (MG_K_PART_SCATTER, st, (mgPartScatterKernel<IN, PK, SUB>), sg, dim3 (MG_PART_THREADS), 0, st, \
-                                           kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, cursor, cstride, kOut, tOut, runTab)
+                                           kIn, tIn, src, subSeg, g, f, shift, nBins, segStart, chunkBase, nSeg, chunkElems, cursor, cstride, kOut, tOut, runTab, runMode)
 #define MG_SCATTER_P(IN) do { if (big) MG_SCATTER (IN, true, MG_PART_SUB_BIG); else MG_SCATTER (IN, true, MG_PART_SUB); } while (0)
   if (inMode == MG_EL_DENSE) { if (packed) MG_SCATTER_P (MG_EL_DENSE); else MG_SCATTER (MG_EL_DENSE, false, MG_PART_SUB); }
   else if (inMode == MG_EL_SEG) { if (packed) MG_SCATTER_P (MG_EL_SEG); else MG_SCATTER (MG_EL_SEG, false, MG_PART_SUB); }
@@ -1831,6 +1940,16 @@ size_t mgTableFindPartScratchBytes (U64 n)
        + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4) + mgAl ((n / MG_PART_SUB + 2) * sizeof (MgSubSeg)) + 4096;
 }
 
+/* the two-level path's extra scratch: the second pass's output (8 bytes an element), the results beside the first pass's output
+   (4), the second run table, the fine starts / cursors / counts and its chunk table */
+size_t mgTableFindPart2ScratchBytes (U64 n)
+{
+  const U64 NB = (U64) 1 << 18;
+  return mgAl (n * 8) + mgAl (n * 4) + mgAl ((2 * (n / (2 * (U64) MG_PART_SUB) + MG_PART_MAXBINS + 2)) * (size_t) MG_PART_MAXBINS * 8)
+       + mgAl ((NB + 2) * 8) + mgAl ((NB + 2 + (U64) MG_PART_MAXBINS * 16) * 8) + mgAl ((NB + 2) * 4)
+       + mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4) + 4096;
+}
+
 /* does a lookup batch take the partitioned path?  It needs the scan's digit counts for this table geometry, elements that
    fit one word, and a table the direct probes would have to fetch from HBM */
 /* The digit of the partitioned lookup: the top bits of the bucket id one pass sorts by; a bin's piece of the table is
@@ -1854,10 +1973,11 @@ bool mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counte
   const int ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1;
   if (!(t->kbits >= t->log2NB + 4 && t->kbits - hiB + ordBits <= 64) || hiB < 3) return false;
   if (t->kbits < 24 || mgKnobs ()->scanHist == 0) return false;          /* (the counts must be the scan's own: mgLaunchScanRange) */
-  return kp == 'p';      /* opt-in: measured at config 3 it ties with the direct probes (DESIGN_EXPERIMENTS.md, round 4) */
+  return kp == 'p' || kp == '2';      /* opt-in: measured at config 3 it ties with the direct probes (DESIGN_EXPERIMENTS.md, round 4) */
 }
 
-MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st)
+MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st,
+                                 void *scratch2)
 {
   if (!n) return MG_OK;
   { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
@@ -1879,6 +1999,38 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
                            counted->binCount, &segSrc, subSeg, runTab, &subElems);
   if (s) return s;
   const long wk = mgKnobs ()->findSubpass;                    /* (dev: MODGPU_FIND_WGS, workgroups per XCD) */
+  if (scratch2)                                             /* ---- two levels: the lookups bucket by bucket out of LDS ---- */
+    { char *w2 = (char *) scratch2;
+      const U64 NB = (U64) 1 << t->log2NB;
+      U64 *el2 = (U64 *) w2;                                   w2 += mgAl (n * 8);
+      U32 *idxA = (U32 *) w2;                                  w2 += mgAl (n * 4);
+      unsigned long long *runTab2 = (unsigned long long *) w2; w2 += mgAl ((2 * (n / (2 * (U64) MG_PART_SUB) + MG_PART_MAXBINS + 2)) * (size_t) MG_PART_MAXBINS * 8);
+      U64 *fineStart = (U64 *) w2;                             w2 += mgAl ((NB + 2) * 8);
+      unsigned long long *fineCursor = (unsigned long long *) w2; w2 += mgAl ((NB + 2 + (U64) MG_PART_MAXBINS * 16) * 8);
+      U32 *fineCount = (U32 *) w2;                             w2 += mgAl ((NB + 2) * 4);
+      U32 *chunkBase2 = (U32 *) w2;                            w2 += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);
+      U32 sub2 = 0, maxChunks2 = 0;
+      const U32 nBins2 = (U32) 1 << loB;
+      if (!loB || nBins2 > MG_PART_MAXBINS) { mgSetError ("internal: two-level lookup needs a fine digit"); return MG_ERR_ARG; }
+      s = mgPartPass (t, MG_EL_PACKED, true, f, el, (const U32 *) 0, n, binStart, nBins, 0, nBins2, el2, (U32 *) 0, fineStart, fineCursor, fineCount, chunkBase2, st,
+                      (const U32 *) 0, (const MgSegSrc *) 0, (MgSubSeg *) 0, runTab2, &sub2, 1, &maxChunks2);
+      if (s) return s;
+      const size_t lds = (size_t) t->R * 12 + 16;
+      if (lds > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgBucketFindKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
+      const U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
+      bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
+      MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgBucketFindKernel, dim3 (bGrid), dim3 (1024), lds, st, t->slots, t->occ, mgGeomOf (t), f, (U32) NB, fineStart, el2, perBlock);
+      const unsigned g2 = 2 * maxChunks2 < 2048 ? 2 * maxChunks2 : 2048;
+      if (sub2 == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartPosKernel<MG_PART_SUB_BIG>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
+      else                         MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartPosKernel<MG_PART_SUB>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
+      const U64 nSub1 = (n + subElems - 1) / subElems;
+      const unsigned g1 = (unsigned) (nSub1 < 2048 ? nSub1 : 2048);
+      if (subElems == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartOrdKernel<MG_PART_SUB_BIG>, dim3 (g1), dim3 (1024), 0, st, el, idxA, f.ordBits, runTab, nBins, n, dIndexOut);
+      else                             MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartOrdKernel<MG_PART_SUB>, dim3 (g1), dim3 (1024), 0, st, el, idxA, f.ordBits, runTab, nBins, n, dIndexOut);
+      MG_HIP (hipGetLastError ());
+      return MG_OK;
+    }
   const U32 wgPerXcd = wk != MG_KNOB_UNSET && wk > 0 ? (U32) wk : 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
   MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgBinFindKernel, dim3 (8 * wgPerXcd), dim3 (256), 0, st, t->slots, mgGeomOf (t), f, el, binStart, nBins, wgPerXcd);
   const U64 nSub = (n + subElems - 1) / subElems;

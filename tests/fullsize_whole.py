@@ -245,7 +245,7 @@ def main_c3q():
     hit = float((want != 0).mean())
     assert 0.30 < hit < 0.40 or scale != 1
     d_ix = mg.DeviceBuffer(cap * 4); d_ps = mg.DeviceBuffer(cap * 4); d_rd = mg.DeviceBuffer(cap * 4)
-    for path in ("direct", "part"):
+    for path in ("direct", "part", "2 levels"):
         with mg.knobs(FIND_PATH=path):
             for d in (d_ix, d_ps, d_rd):
                 mg.check(L.mgMemsetD(d.ptr, 0xEE, d.nbytes, None))

@@ -242,7 +242,8 @@ def test_golden_modmap_flow(tag, golden_dir, tmp_path):
 
 
 @pytest.mark.parametrize("k,w,bits,path", [(21, 32, 22, "direct"), (21, 32, 22, "part"), (19, 31, 23, "part"), (15, 8, 24, "part"),
-                                            (27, 4, 22, "part"), (31, 4, 22, "part")])
+                                            (27, 4, 22, "part"), (31, 4, 22, "part"),
+                                            (21, 32, 22, "2 levels"), (19, 31, 23, "2 levels"), (15, 8, 24, "2 levels"), (27, 4, 22, "2 levels"), (21, 64, 28, "2 levels")])
 def test_seed_lists_vs_oracle(k, w, bits, path):
     """mgQueryReadsDevice: Seed{index,pos} per read incl. misses (modmap.c:197-206) -- by direct probes in ordinal order and by
     the partitioned lookup (mgTableFindPartitioned: first partition pass of the build on the query's modimizers, lookups bin by
@@ -679,7 +680,7 @@ def _mutate(rng, b, rate):
     return b
 
 
-@pytest.mark.parametrize("path", ["direct", "part"])
+@pytest.mark.parametrize("path", ["direct", "part", "2 levels"])
 @pytest.mark.parametrize("k,w,seed", [(15, 8, 17), (21, 64, 17), (19, 31, 17), (13, 4, 5), (17, 16, 17), (25, 11, 3)])
 def test_modmap_randomized_vs_oracle(k, w, seed, path, tmp_path):
     """queryProcess (modmap.c:188-281) on randomized references and reads against the ORACLE's restatement of it
