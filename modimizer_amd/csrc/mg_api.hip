@@ -849,8 +849,10 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
   b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0; b->findScratch = 0; b->findScratch2 = 0;
   U64 cap = mgSurvivorGuess (sh, totalBases);
   /* a lookup batch whose k-mers stay in the segments may take the partitioned path (mgTableFindPartitioned): it needs the first digit's counts */
-  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && (mgKnobs ()->findPath == 'p' || mgKnobs ()->findPath == '2');
-  const bool lookup2 = lookupHist && mgKnobs ()->findPath == '2';
+  const long fp = mgKnobs ()->findPath;
+  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && fp != 'd'
+                          && (fp == 'p' || fp == '2' || (cap >= ((U64) 1 << 24) && d->t.nSlots >= ((U64) 1 << 24) && d->t.log2NB > 9));
+  const bool lookup2 = lookupHist && fp != 'p';
   MgHashParams p = mgMakeParams (sh);
   if (extraPerSurvivor)
     { /* size the table now for the expected number of modimizers (N/d): the insert would do it anyway once the

@@ -1973,7 +1973,10 @@ bool mgTableFindTakesPartition (const MgTable *t, U64 n, const MgHistReq *counte
   const int ordBits = mgLog2 (n) > 1 ? mgLog2 (n) : 1;
   if (!(t->kbits >= t->log2NB + 4 && t->kbits - hiB + ordBits <= 64) || hiB < 3) return false;
   if (t->kbits < 24 || mgKnobs ()->scanHist == 0) return false;          /* (the counts must be the scan's own: mgLaunchScanRange) */
-  return kp == 'p' || kp == '2';      /* opt-in: measured at config 3 it ties with the direct probes (DESIGN_EXPERIMENTS.md, round 4) */
+  if (kp == 'p' || kp == '2') return true;
+  /* by itself: the two-level path where the direct probes would fetch a line from HBM per lookup -- a table of 256 MB and more,
+     a batch that fills the chip (config 3: 3.5 against 4.2-4.6 ms per 1.56e8 lookups; one level ties with the direct probes) */
+  return n >= ((U64) 1 << 24) && t->nSlots >= ((U64) 1 << 24) && t->log2NB > 9;
 }
 
 MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, const MgHistReq *counted, U32 *dIndexOut, U64 *el, void *scratch, hipStream_t st,
@@ -1999,7 +2002,7 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
                            counted->binCount, &segSrc, subSeg, runTab, &subElems);
   if (s) return s;
   const long wk = mgKnobs ()->findSubpass;                    /* (dev: MODGPU_FIND_WGS, workgroups per XCD) */
-  if (scratch2)                                             /* ---- two levels: the lookups bucket by bucket out of LDS ---- */
+  if (scratch2 && loB > 0 && ((U32) 1 << loB) <= MG_PART_MAXBINS)      /* ---- two levels: the lookups bucket by bucket out of LDS (a table of few buckets has no fine digit: one level) ---- */
     { char *w2 = (char *) scratch2;
       const U64 NB = (U64) 1 << t->log2NB;
       U64 *el2 = (U64 *) w2;                                   w2 += mgAl (n * 8);
@@ -2011,7 +2014,6 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
       U32 *chunkBase2 = (U32 *) w2;                            w2 += mgAl ((MG_PART_MAXBINS + 2 + n / MG_PART_CHUNK + MG_PART_MAXBINS + 2) * 4);
       U32 sub2 = 0, maxChunks2 = 0;
       const U32 nBins2 = (U32) 1 << loB;
-      if (!loB || nBins2 > MG_PART_MAXBINS) { mgSetError ("internal: two-level lookup needs a fine digit"); return MG_ERR_ARG; }
       s = mgPartPass (t, MG_EL_PACKED, true, f, el, (const U32 *) 0, n, binStart, nBins, 0, nBins2, el2, (U32 *) 0, fineStart, fineCursor, fineCount, chunkBase2, st,
                       (const U32 *) 0, (const MgSegSrc *) 0, (MgSubSeg *) 0, runTab2, &sub2, 1, &maxChunks2);
       if (s) return s;
