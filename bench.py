@@ -177,6 +177,8 @@ def alg_bytes_table(total, S, entries, d, slots, k=21):
         "mgTableInsertKernel": 16.0 * S,
         "mgTableFindKernel": 24.0 * S,               # kmer 8 read + one 16-byte slot probed + (index) 4 written ~ SURVEY's 24*S
         "mgTableFindSegKernel": 24.0 * S,            # the same lookups, k-mers read from the scan's segments
+        "mgBucketFindKernel": 16.0 * S + 16.0 * slots,   # partitioned lookups: an element read and rewritten, the table's buckets once
+        "mgUnpartKernel": 28.0 * S,                  # both pulls: (position, index) 8 in + 4 out, then element 8 + index 4 in, index 4 out
     }
 
 
@@ -835,6 +837,8 @@ def bench_c3(cx, args, shard=None):
            "whole_batch": {"bytes_per_base": 0.25 + 36.0 / d, "GBps": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9, 1),
                            "frac": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9 / HBM_PEAK_GBS, 4),
                            "note": "0.25 B/base read + per seed: 12 B written by the scan + 24 B lookup (kmer 8, one 16-byte slot, wait index 4 out)"},
+           "lookup_path": "partitioned (two levels): counts + 2 scatter passes + mgBucketFindKernel + 2 pulls" if "mgBucketFindKernel" in per_batch else "direct probes in ordinal order (mgTableFindSegKernel)",
+           "lookups_ms_per_batch": round(sum(v[0] for kn, v in per_batch.items() if kn in ("mgBucketFindKernel", "mgUnpartKernel", "mgPartScatterKernel", "mgPartHistKernel", "mgPartChunks+ScanKernel", "mgTableFindSegKernel", "mgTableFindKernel")), 3),
            "roofline": roofline_of(kern, per_batch, alg, "c3", units={"mgTableFindSegKernel": S, "mgTableFindKernel": S})}
     L.modsetDestroy(ms)
     del genome, q_pos, q_rd

@@ -64,7 +64,7 @@ static const char *gKernelNames[MG_K_COUNT] = {
   "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
   "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel",
   "mgPartChunks+ScanKernel", "mgPartHistKernel", "mgPartScatterKernel", "mgRankCountKernel", "mgRankScanKernel", "mgBucketDedupKernel",
-  "mgBucketMergeKernel", "mgRankLookupKernel", "mgTableFindSegKernel", "mgHotPlan+ReduceKernel" };
+  "mgBucketMergeKernel", "mgRankLookupKernel", "mgTableFindSegKernel", "mgHotPlan+ReduceKernel", "mgBucketFindKernel", "mgUnpartKernel" };
 #define MG_PROF_POOL 8192
 struct MgProfRec { int id; hipEvent_t a, b; };
 static struct {

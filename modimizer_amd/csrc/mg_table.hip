@@ -2022,23 +2022,23 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
       unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
       const U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
       bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
-      MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgBucketFindKernel, dim3 (bGrid), dim3 (1024), lds, st, t->slots, t->occ, mgGeomOf (t), f, (U32) NB, fineStart, el2, perBlock);
+      MG_LAUNCH (MG_K_BUCKET_FIND, st, mgBucketFindKernel, dim3 (bGrid), dim3 (1024), lds, st, t->slots, t->occ, mgGeomOf (t), f, (U32) NB, fineStart, el2, perBlock);
       const unsigned g2 = 2 * maxChunks2 < 2048 ? 2 * maxChunks2 : 2048;
-      if (sub2 == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartPosKernel<MG_PART_SUB_BIG>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
-      else                         MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartPosKernel<MG_PART_SUB>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
+      if (sub2 == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_UNPART, st, mgUnpartPosKernel<MG_PART_SUB_BIG>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
+      else                         MG_LAUNCH (MG_K_UNPART, st, mgUnpartPosKernel<MG_PART_SUB>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
       const U64 nSub1 = (n + subElems - 1) / subElems;
       const unsigned g1 = (unsigned) (nSub1 < 2048 ? nSub1 : 2048);
-      if (subElems == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartOrdKernel<MG_PART_SUB_BIG>, dim3 (g1), dim3 (1024), 0, st, el, idxA, f.ordBits, runTab, nBins, n, dIndexOut);
-      else                             MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartOrdKernel<MG_PART_SUB>, dim3 (g1), dim3 (1024), 0, st, el, idxA, f.ordBits, runTab, nBins, n, dIndexOut);
+      if (subElems == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_UNPART, st, mgUnpartOrdKernel<MG_PART_SUB_BIG>, dim3 (g1), dim3 (1024), 0, st, el, idxA, f.ordBits, runTab, nBins, n, dIndexOut);
+      else                             MG_LAUNCH (MG_K_UNPART, st, mgUnpartOrdKernel<MG_PART_SUB>, dim3 (g1), dim3 (1024), 0, st, el, idxA, f.ordBits, runTab, nBins, n, dIndexOut);
       MG_HIP (hipGetLastError ());
       return MG_OK;
     }
   const U32 wgPerXcd = wk != MG_KNOB_UNSET && wk > 0 ? (U32) wk : 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
-  MG_LAUNCH (MG_K_TABLE_FIND_SEG, st, mgBinFindKernel, dim3 (8 * wgPerXcd), dim3 (256), 0, st, t->slots, mgGeomOf (t), f, el, binStart, nBins, wgPerXcd);
+  MG_LAUNCH (MG_K_BUCKET_FIND, st, mgBinFindKernel, dim3 (8 * wgPerXcd), dim3 (256), 0, st, t->slots, mgGeomOf (t), f, el, binStart, nBins, wgPerXcd);
   const U64 nSub = (n + subElems - 1) / subElems;
   const unsigned ug = (unsigned) (nSub < 2048 ? nSub : 2048);
-  if (subElems == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartKernel<MG_PART_SUB_BIG>, dim3 (ug), dim3 (1024), 0, st, el, runTab, nBins, n, dIndexOut);
-  else                             MG_LAUNCH (MG_K_SEG_COMPACT, st, mgUnpartKernel<MG_PART_SUB>, dim3 (ug), dim3 (1024), 0, st, el, runTab, nBins, n, dIndexOut);
+  if (subElems == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_UNPART, st, mgUnpartKernel<MG_PART_SUB_BIG>, dim3 (ug), dim3 (1024), 0, st, el, runTab, nBins, n, dIndexOut);
+  else                             MG_LAUNCH (MG_K_UNPART, st, mgUnpartKernel<MG_PART_SUB>, dim3 (ug), dim3 (1024), 0, st, el, runTab, nBins, n, dIndexOut);
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
