@@ -9,7 +9,7 @@ profiles/traffic.json."""
 import csv, glob, os, sys, json, collections
 root = sys.argv[1]
 STREAMING = {"mgScanKernel", "mgSegCompactKernel", "mgPartHistKernel", "mgPartScatterKernel", "mgRankCountKernel",
-             "mgSynthReadsKernel", "mgSynthGenomeKernel", "mgTableHistKernel", "mgTileInfoKernel", "mgPackKernel", "mgUnpackKernel"}
+             "mgSynthReadsKernel", "mgSynthGenomeKernel", "mgBucketFindKernel", "mgTableHistKernel", "mgTileInfoKernel", "mgPackKernel", "mgUnpackKernel"}
 def find(sub, pat):
     fs = glob.glob(os.path.join(root, sub, "**", pat), recursive=True)
     return fs[0] if fs else None

@@ -24,7 +24,9 @@ prof () {   # name, bench args...
   rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq $OUT/sq2 $OUT/grbm       # the raw per-dispatch CSVs are large
   head -c 3000 $OUT/summary.txt
 }
-prof c2 --steps 5 --warmup 1 --no-cpu --no-other
-prof c3 --only c3 --steps 3
-prof c5 --only c5 --steps 5
-prof c4 --only c4_block --steps 3
+ONLY=${2:-all}                                  # second argument: one of c2 c3 c5 c4 (default: all four)
+[ $ONLY = all -o $ONLY = c2 ] && prof c2 --steps 5 --warmup 1 --no-cpu --no-other
+[ $ONLY = all -o $ONLY = c3 ] && prof c3 --only c3 --steps 3
+[ $ONLY = all -o $ONLY = c5 ] && prof c5 --only c5 --steps 5
+[ $ONLY = all -o $ONLY = c4 ] && prof c4 --only c4_block --steps 3
+true
