@@ -28,11 +28,12 @@ with tempfile.TemporaryDirectory() as d:
         w = int(rng.choice([0, 4, 8, 12, 64, 1024])); b = int(rng.choice([0, 1, 500, 3000, 100000]))
         if w: env["MODGPU_TEXT_WINDOW_KB"] = str(w)
         if b: env["MODGPU_FILE_BATCH_BASES"] = str(b)
-        os.environ.update(env)
+        os.environ.update(env); mg.lib().mgReloadKnobs()           # (the library reads its knobs once)
         try:
             rc, got = device_records(path)
         finally:
             for k in env: del os.environ[k]
+            mg.lib().mgReloadKnobs()
         ok = rc == 0 and len(got) == len(want) and all(np.array_equal(a & 3, c & 3) if fq else np.array_equal(a, c) for a, c in zip(got, want))
         if not ok:
             bad += 1
