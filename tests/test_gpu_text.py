@@ -58,9 +58,19 @@ def crafted_fasta(rng, n_rec, kind):
 
 @pytest.mark.parametrize("kind,n_rec,seed", [("mixed", 300, 1), ("tiny", 5000, 2), ("long", 40, 3), ("mixed", 3, 4)])
 @pytest.mark.parametrize("window_kb,batch_bases", [(0, 0), (4, 0), (8, 3000), (64, 100000)])
+def last_line_is_header(text):
+    """a FASTA text whose last line starts with '>': the reference reports that record as incomplete and does not return it
+    (seqio.c:213-217,314), and the device parser leaves such a file to the host parser (-2)"""
+    body = text[:-1] if text.endswith(b"\n") else text
+    return body[body.rfind(b"\n") + 1:].startswith(b">")
+
+
 def test_device_parser_equals_host_parser(kind, n_rec, seed, window_kb, batch_bases, tmp_path):
     path = str(tmp_path / "t.fa")
-    open(path, "wb").write(crafted_fasta(np.random.default_rng(seed), n_rec, kind))
+    text = crafted_fasta(np.random.default_rng(seed), n_rec, kind)
+    if last_line_is_header(text):
+        text += b"ACGT\n"                                   # (that case has its own test: test_device_parser_declines_what_it_does_not_take)
+    open(path, "wb").write(text)
     _, want = parse_file(path, 1 << 40, 4)
     env = {}
     if window_kb:
