@@ -280,7 +280,7 @@ int  mgSeqNextBatch (MgSeqReader *r, int64_t maxBases, MgSeqBatch *out) ; /* who
 void mgSeqBatchFree (MgSeqBatch *b) ;
 void mgSeqClose (MgSeqReader *r) ;
 void mgSeqReleaseBuffers (void) ;	/* the readers keep their two largest buffers for the next file (unmapping and touching gigabytes again costs as much as parsing them); this gives them back -- a no-op while a reader is open; also run when the library is unloaded */
-void mgReleaseBuffers (void) ;	/* everything the library caches between calls: the readers' buffers (mgSeqReleaseBuffers), the device buffers and pinned staging of the host-buffer entry points (mgAddSequenceBatch, mgUploadPack: they live on the device the last call ran on and are re-made by themselves when the caller moves to another one), the calling thread's iterator scratch (modRCiterator) */
+void mgReleaseBuffers (void) ;	/* everything the library caches between calls: the readers' buffers (mgSeqReleaseBuffers), the device buffers and pinned staging of the host-buffer entry points (mgAddSequenceBatch, mgUploadPack: they live on the device the last call ran on and are re-made by themselves when the caller moves to another one), the calling thread's iterator scratch (modRCiterator), the page-locked blocks and device arrays mgQueryFile leaves */
 /* Plain FASTA / FASTQ text parsed ON THE DEVICE (the host only moves the bytes: parallel pread into pinned memory, the text as it
  * is across PCIe, record starts / headers / bases found by small kernels per window): mgAddSequenceFile, mgReferenceFastaRead and
  * mgQueryFile take this path by themselves for plain text and use the reader above for gzip, a file that does not end in a

@@ -50,6 +50,11 @@ extern "C" MgStatus mgMemcpyH2D (void *dst, const void *src, size_t bytes, void 
 extern "C" MgStatus mgMemcpyD2H (void *dst, const void *src, size_t bytes, void *stream)
 { if (bytes) MG_HIP (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream));
   MG_HIP (hipStreamSynchronize ((hipStream_t) stream)); return MG_OK; }
+/* page-locked host memory for the C callers' device-to-host copies (a copy into pageable memory goes through the runtime's staging
+   buffers at a few GB/s) */
+extern "C" void *mgPinnedAlloc (size_t bytes)
+{ void *p = 0; if (mgEnsureDevice () || hipHostMalloc (&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError (); return 0; } return p; }
+extern "C" void mgPinnedFree (void *p) { if (p) (void) hipHostFree (p); }
 extern "C" MgStatus mgMemsetD (void *dst, int byte, size_t bytes, void *stream)
 { if (bytes) MG_HIP (hipMemsetAsync (dst, byte, bytes, (hipStream_t) stream)); return MG_OK; }
 extern "C" MgStatus mgStreamSynchronize (void *stream)
@@ -1216,6 +1221,7 @@ extern "C" void mgReleaseBuffers (void)
 {
   mgSeqReleaseBuffers ();
   mgTextReleaseBuffers ();
+  mgQueryReleaseBuffers ();
   mgHostBatchRelease ();
   mgIterReleaseBuffers ();
   std::lock_guard<std::mutex> g (gUp.lock);

@@ -491,17 +491,13 @@ static char *fmtF2 (char *p, double x)
   if (!(x >= 0) || x >= 1e15 || signbit (x)) return p + snprintf (p, 48, "%.2f", x);
   int e; const double fr = frexp (x, &e);                              /* x = fr * 2^e, 0.5 <= fr < 1 (or x == 0) */
   const unsigned long long mant = (unsigned long long) ldexp (fr, 53);   /* exact: 53 bits */
-  const int e2 = e - 53;                                               /* x = mant * 2^e2 */
-  unsigned __int128 v = (unsigned __int128) mant * 100, q;
-  if (e2 >= 0) q = v << e2;
-  else
-    { const int s = -e2;
-      if (s >= 120) q = 0;
-      else
-        { q = v >> s;
-          const unsigned __int128 rem = v & (((unsigned __int128) 1 << s) - 1), half = (unsigned __int128) 1 << (s - 1);
-          if (rem > half || (rem == half && (q & 1))) ++q;
-        }
+  const int s = 53 - e;                                                /* x = mant * 2^-s; x < 1e15 < 2^50, so s >= 3 */
+  const unsigned long long v = mant * 100;                             /* < 2^60 */
+  unsigned long long q = 0;
+  if (s < 64)
+    { q = v >> s;
+      const unsigned long long rem = v & ((1ull << s) - 1), half = 1ull << (s - 1);
+      if (rem > half || (rem == half && (q & 1))) ++q;
     }
   const unsigned long long whole = (unsigned long long) (q / 100); const unsigned frac = (unsigned) (q % 100);
   p = fmtU (p, whole); *p++ = '.'; *p++ = (char) ('0' + frac / 10); *p++ = (char) ('0' + frac % 10);
@@ -518,6 +514,8 @@ typedef struct { const MgReference *ref; const MgChainQ *q; const MgChainM *m; c
 static void *fmtQM (void *v)
 {
   FmtJob *j = (FmtJob *) v;
+  j->out.cap = (size_t) (j->r1 - j->r0) * 80 + 4096; j->out.buf = (char *) malloc (j->out.cap);       /* a Q line of a short read is 60 bytes */
+  if (!j->out.buf) fatal ("out of memory");
   for (int r = j->r0 ; r < j->r1 ; ++r)
     { const MgChainQ *qq = &j->q[r];
       const char *nm = j->names[r]; const size_t nl = strlen (nm);
@@ -555,6 +553,44 @@ static int fmtThreads (int nReads)
   return (int) v;
 }
 
+#define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+/* the lines of a batch whose tallies and blocks are on the host: formatted by a team of threads, each its range of the reads
+   into its own buffer (piece[0 .. *nPieces)), and written in order.  (Positioned writes of the pieces by the team itself were tried:
+   writes to one file take turns on its inode lock, 234 MB take the 40 ms one fwrite takes.) */
+static void queryFormatLines (const MgReference *ref, const MgChainQ *q, const MgChainM *m, const int64_t *offsets, int nReads, const char **names,
+                              FmtBuf piece[16], int *nPieces, double *ms)
+{
+  struct timespec c1, c2; clock_gettime (CLOCK_MONOTONIC, &c1);
+  U64 *mStart = (U64 *) malloc (((size_t) nReads + 1) * 8);
+  if (!mStart) fatal ("out of memory");
+  { U64 tot = 0; for (int r = 0 ; r < nReads ; ++r) { mStart[r] = tot; tot += q[r].nM; } mStart[nReads] = tot; }
+  const int T = fmtThreads (nReads);
+  FmtJob job[16]; pthread_t th[16]; int started[16];
+  for (int t = 0 ; t < T ; ++t)
+    { memset (&job[t], 0, sizeof (FmtJob));
+      job[t].ref = ref; job[t].q = q; job[t].m = m; job[t].mStart = mStart; job[t].offsets = offsets; job[t].names = names;
+      job[t].r0 = (int) ((int64_t) nReads * t / T); job[t].r1 = (int) ((int64_t) nReads * (t + 1) / T);
+      started[t] = t && pthread_create (&th[t], 0, fmtQM, &job[t]) == 0;
+    }
+  for (int t = 0 ; t < T ; ++t) if (!started[t]) fmtQM (&job[t]);
+  for (int t = 0 ; t < T ; ++t) if (started[t]) pthread_join (th[t], 0);
+  for (int t = 0 ; t < T ; ++t) piece[t] = job[t].out;
+  *nPieces = T;
+  free (mStart);
+  clock_gettime (CLOCK_MONOTONIC, &c2);
+  if (ms) *ms += MS_ (c1, c2);
+}
+static void queryWritePieces (FmtBuf piece[16], int nPieces, FILE *out, double *ms)
+{
+  struct timespec c1, c2; clock_gettime (CLOCK_MONOTONIC, &c1);
+  for (int t = 0 ; t < nPieces ; ++t)
+    { if (piece[t].len && fwrite (piece[t].buf, 1, piece[t].len, out) != piece[t].len) fatal ("write");
+      free (piece[t].buf); piece[t].buf = 0;
+    }
+  clock_gettime (CLOCK_MONOTONIC, &c2);
+  if (ms) *ms += MS_ (c1, c2);
+}
+
 /* modmap.c:188-281.  Scan, lookup, the tallies of the "Q" line and the chaining into "M" blocks all run on the
  * device (mg_chain.hip: one lane per read); the host formats the lines from a few integers per read and block.
  * The batch is on the device already (2-bit packed, offsets in bases): mgQueryProcess uploads one, the file entry point
@@ -563,7 +599,7 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
 {
   if (nReads <= 0) return 0;
   const int timing = mgKnobs ()->seedTiming == 1;          /* dev */
-  struct timespec c0, c1, c2, c3; if (timing) clock_gettime (CLOCK_MONOTONIC, &c0);
+  struct timespec c0, c1; if (timing) clock_gettime (CLOCK_MONOTONIC, &c0);
   if (modsetSyncToHost (ref->ms, 0)) fatal ("modsetSyncToHost");
   int64_t *offsets = (int64_t *) malloc ((size_t) (nReads + 1) * 8);
   if (mgMemcpyD2H (offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
@@ -576,35 +612,216 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
   if (timing) clock_gettime (CLOCK_MONOTONIC, &c1);
   if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
   else
-    { U64 *mStart = (U64 *) malloc (((size_t) nReads + 1) * 8);
-      { U64 tot = 0; for (int r = 0 ; r < nReads ; ++r) { mStart[r] = tot; tot += q[r].nM; } mStart[nReads] = tot; }
-      const int T = fmtThreads (nReads);
-      FmtJob job[16]; pthread_t th[16]; int started[16];
-      for (int t = 0 ; t < T ; ++t)
-        { memset (&job[t], 0, sizeof (FmtJob));
-          job[t].ref = ref; job[t].q = q; job[t].m = m; job[t].mStart = mStart; job[t].offsets = offsets; job[t].names = names;
-          job[t].r0 = (int) ((int64_t) nReads * t / T); job[t].r1 = (int) ((int64_t) nReads * (t + 1) / T);
-          started[t] = t && pthread_create (&th[t], 0, fmtQM, &job[t]) == 0;
-        }
-      for (int t = 0 ; t < T ; ++t) if (!started[t]) fmtQM (&job[t]);
-      for (int t = 0 ; t < T ; ++t) if (started[t]) pthread_join (th[t], 0);
-      if (timing) clock_gettime (CLOCK_MONOTONIC, &c2);
-      for (int t = 0 ; t < T ; ++t)
-        { if (job[t].out.len && fwrite (job[t].out.buf, 1, job[t].out.len, out) != job[t].out.len) fatal ("write");
-          free (job[t].out.buf);
-        }
-      free (mStart);
+    { double msF = 0, msW = 0;
+      FmtBuf piece[16]; int nPieces = 0;
+      queryFormatLines (ref, q, m, offsets, nReads, names, piece, &nPieces, &msF);
+      queryWritePieces (piece, nPieces, out, &msW);
       if (timing)
-        { clock_gettime (CLOCK_MONOTONIC, &c3);
-#define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
-          fprintf (stderr, "mgQueryProcessDevice: %d reads: device (scan, lookups, chain, copies) %.1f ms, format %.1f ms (%d threads), write %.1f ms\n",
-                   nReads, MS_ (c0, c1), MS_ (c1, c2), T, MS_ (c2, c3));
-#undef MS_
-        }
+        fprintf (stderr, "mgQueryProcessDevice: %d reads: device (scan, lookups, chain, copies) %.1f ms, format %.1f ms (%d threads), write %.1f ms\n",
+                 nReads, MS_ (c0, c1), msF, nPieces, msW);
     }
   free (q); free (m); free (offsets);
   return rc;
 }
+
+/* ---- the file entry point's batches: three stages, three threads ----
+ * mgQueryFile hands over a batch per window of the file.  Push runs the device half (scan, lookups, tallies, chaining, the copies
+ * to the host) on the caller's thread -- which goes on to read, parse and query the next window -- and queues the rest: a
+ * FORMATTER thread (with its team) turns a batch's tallies and blocks into lines, a WRITER thread puts them out; batches pass
+ * through both in order, at most two waiting in front of each.  A batch that needs the long way (-v, a read with more blocks than
+ * the chain kernel keeps) waits for both to be idle and is done on the spot, so the order of the lines is the file's. */
+typedef struct MgQJob
+{ struct MgQJob *next; MgChainQ *q; MgChainM *m; int64_t *offsets; char *idBytes; U64 *idOff; int nReads;
+  int pinQ, pinOff;                                        /* q / offsets are blocks of the pipe's page-locked pool (slot + 1), not malloc ()ed */
+  FmtBuf piece[16]; int nPieces;
+} MgQJob;
+#define MG_QPIPE_PINS 10
+typedef struct { MgQJob *head, *tail; int n; } MgQQueue;
+struct MgQueryPipe
+{ MgReference *ref; FILE *out; pthread_t thFormat, thWrite; int started;
+  pthread_mutex_t mu; pthread_cond_t cv;
+  MgQQueue toFormat, toWrite; int pending;                 /* batches anywhere between Push and the last fwrite */
+  int closing;
+  double msDevice, msFormat, msWrite, msWait; int nBatches;
+};
+
+/* page-locked blocks the device halves copy into: kept between calls like the parser's windows (page-locking 10 MB takes 2 ms),
+   given back by mgReleaseBuffers ().  A block of at least `bytes` for a job (*slot = its number + 1), or malloc () memory
+   (*slot = 0) when the pool has none */
+static struct { pthread_mutex_t mu; void *pin[MG_QPIPE_PINS]; size_t cap[MG_QPIPE_PINS]; int busy[MG_QPIPE_PINS]; } gPin = { PTHREAD_MUTEX_INITIALIZER, { 0 }, { 0 }, { 0 } };
+static void *pipePinGet (size_t bytes, int *slot)
+{
+  void *r = 0; *slot = 0;
+  pthread_mutex_lock (&gPin.mu);
+  int pick = -1;
+  for (int i = 0 ; i < MG_QPIPE_PINS ; ++i) if (!gPin.busy[i] && gPin.cap[i] >= bytes && (pick < 0 || gPin.cap[i] < gPin.cap[pick])) pick = i;
+  if (pick < 0) for (int i = 0 ; i < MG_QPIPE_PINS ; ++i) if (!gPin.busy[i] && (pick < 0 || gPin.cap[i] < gPin.cap[pick])) pick = i;      /* the smallest free one grows */
+  if (pick >= 0) gPin.busy[pick] = 1;
+  pthread_mutex_unlock (&gPin.mu);
+  if (pick >= 0 && gPin.cap[pick] < bytes)                 /* (busy: nobody else looks at it) */
+    { mgPinnedFree (gPin.pin[pick]); gPin.cap[pick] = 0;
+      gPin.pin[pick] = mgPinnedAlloc (bytes + bytes / 4);
+      if (gPin.pin[pick]) gPin.cap[pick] = bytes + bytes / 4;
+      else { pthread_mutex_lock (&gPin.mu); gPin.busy[pick] = 0; pthread_mutex_unlock (&gPin.mu); pick = -1; }
+    }
+  if (pick >= 0) { r = gPin.pin[pick]; *slot = pick + 1; }
+  else { r = malloc (bytes); if (!r) fatal ("out of memory"); }
+  return r;
+}
+static void pipePinPut (void *ptr, int slot)
+{
+  if (!slot) { free (ptr); return; }
+  pthread_mutex_lock (&gPin.mu); gPin.busy[slot - 1] = 0; pthread_mutex_unlock (&gPin.mu);
+}
+void mgQueryReleaseBuffers (void)
+{
+  pthread_mutex_lock (&gPin.mu);
+  for (int i = 0 ; i < MG_QPIPE_PINS ; ++i) if (!gPin.busy[i] && gPin.pin[i]) { mgPinnedFree (gPin.pin[i]); gPin.pin[i] = 0; gPin.cap[i] = 0; }
+  pthread_mutex_unlock (&gPin.mu);
+  mgChainReleaseBuffers ();
+}
+
+static void queryJobFree (MgQueryPipe *p, MgQJob *j)
+{ pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); free (j->idBytes); free (j->idOff);
+  for (int t = 0 ; t < j->nPieces ; ++t) free (j->piece[t].buf);
+  free (j);
+}
+
+/* (all three with p->mu held) */
+static void qPut (MgQQueue *q, MgQJob *j) { j->next = 0; if (q->tail) q->tail->next = j; else q->head = j; q->tail = j; ++q->n; }
+static MgQJob *qTake (MgQQueue *q) { MgQJob *j = q->head; if (j) { q->head = j->next; if (!q->head) q->tail = 0; --q->n; } return j; }
+
+static void *queryFormatter (void *v)
+{
+  MgQueryPipe *p = (MgQueryPipe *) v;
+  for (;;)
+    { pthread_mutex_lock (&p->mu);
+      while (!p->toFormat.head && !p->closing) pthread_cond_wait (&p->cv, &p->mu);
+      MgQJob *j = qTake (&p->toFormat);
+      pthread_mutex_unlock (&p->mu);
+      if (!j) break;                                       /* closing, nothing left */
+      const char **names = (const char **) malloc (((size_t) j->nReads + 1) * sizeof (char *));
+      if (!names) fatal ("out of memory");
+      for (int r = 0 ; r < j->nReads ; ++r) names[r] = j->idBytes + j->idOff[r];
+      queryFormatLines (p->ref, j->q, j->m, j->offsets, j->nReads, names, j->piece, &j->nPieces, &p->msFormat);
+      free (names);
+      pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); free (j->idBytes); free (j->idOff);
+      j->q = 0; j->m = 0; j->offsets = 0; j->idBytes = 0; j->idOff = 0; j->pinQ = j->pinOff = 0;
+      pthread_mutex_lock (&p->mu);
+      while (p->toWrite.n >= 2) pthread_cond_wait (&p->cv, &p->mu);
+      qPut (&p->toWrite, j);
+      pthread_cond_broadcast (&p->cv);
+      pthread_mutex_unlock (&p->mu);
+    }
+  pthread_mutex_lock (&p->mu); p->closing = 2; pthread_cond_broadcast (&p->cv); pthread_mutex_unlock (&p->mu);      /* the writer's turn to finish */
+  return 0;
+}
+
+static void *queryWriter (void *v)
+{
+  MgQueryPipe *p = (MgQueryPipe *) v;
+  for (;;)
+    { pthread_mutex_lock (&p->mu);
+      while (!p->toWrite.head && p->closing != 2) pthread_cond_wait (&p->cv, &p->mu);
+      MgQJob *j = qTake (&p->toWrite);
+      if (j) pthread_cond_broadcast (&p->cv);             /* room in front of the writer */
+      pthread_mutex_unlock (&p->mu);
+      if (!j) return 0;
+      queryWritePieces (j->piece, j->nPieces, p->out, &p->msWrite);
+      queryJobFree (p, j);
+      pthread_mutex_lock (&p->mu);
+      --p->pending;
+      pthread_cond_broadcast (&p->cv);
+      pthread_mutex_unlock (&p->mu);
+    }
+}
+
+MgQueryPipe *mgQueryPipeOpen (MgReference *ref, FILE *out)
+{
+  MgQueryPipe *p = (MgQueryPipe *) calloc (1, sizeof (MgQueryPipe));
+  if (!p) fatal ("out of memory");
+  p->ref = ref; p->out = out;
+  pthread_mutex_init (&p->mu, 0); pthread_cond_init (&p->cv, 0);
+  if (pthread_create (&p->thFormat, 0, queryFormatter, p) == 0)
+    { if (pthread_create (&p->thWrite, 0, queryWriter, p) == 0) p->started = 1;
+      else
+        { pthread_mutex_lock (&p->mu); p->closing = 1; pthread_cond_broadcast (&p->cv); pthread_mutex_unlock (&p->mu);
+          pthread_join (p->thFormat, 0); p->closing = 0;
+        }
+    }                                                      /* (no threads: Push does everything on the spot) */
+  mgChainScratchKeep (1);
+  return p;
+}
+
+static void queryPipeDrain (MgQueryPipe *p)
+{
+  pthread_mutex_lock (&p->mu);
+  while (p->pending) pthread_cond_wait (&p->cv, &p->mu);
+  pthread_mutex_unlock (&p->mu);
+}
+
+int mgQueryPipePush (MgQueryPipe *p, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char *idBytes, const U64 *idOff)
+{
+  if (nReads <= 0) return 0;
+  struct timespec c0, c1, c2; clock_gettime (CLOCK_MONOTONIC, &c0);
+  const int hostChain = mgKnobs ()->queryHostChain == 1;
+  int rc = 1;
+  MgQJob *j = 0;
+  if (!hostChain && !gVerbose && p->started)
+    { if (modsetSyncToHost (p->ref->ms, 0)) fatal ("modsetSyncToHost");
+      j = (MgQJob *) calloc (1, sizeof (MgQJob));
+      if (!j) fatal ("out of memory");
+      j->nReads = nReads;
+      j->offsets = (int64_t *) pipePinGet ((size_t) (nReads + 1) * 8, &j->pinOff);
+      j->q = (MgChainQ *) pipePinGet ((size_t) nReads * sizeof (MgChainQ), &j->pinQ);
+      if (mgMemcpyD2H (j->offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
+      rc = mgChainQueryDevice (p->ref, dPacked, totalBases, dReadOffsets, (U32) nReads, j->q, &j->m, MG_QUERY_MAXM);
+      if (rc < 0) fatal ("query");
+    }
+  clock_gettime (CLOCK_MONOTONIC, &c1);
+  p->msDevice += MS_ (c0, c1); ++p->nBatches;
+  if (rc == 1)                                             /* the long way, on the spot, once the lines before it are out */
+    { if (j) queryJobFree (p, j);
+      queryPipeDrain (p);
+      const char **names = (const char **) malloc (((size_t) nReads + 1) * sizeof (char *));
+      if (!names) fatal ("out of memory");
+      for (int r = 0 ; r < nReads ; ++r) names[r] = idBytes + idOff[r];
+      rc = mgQueryProcessDevice (p->ref, dPacked, totalBases, dReadOffsets, nReads, names, p->out);
+      free (names);
+      return rc;
+    }
+  /* the ids belong to the parser, which moves on: a copy goes with the job */
+  const size_t idLen = (size_t) idOff[nReads - 1] + strlen (idBytes + idOff[nReads - 1]) + 1;
+  j->idBytes = (char *) malloc (idLen); j->idOff = (U64 *) malloc ((size_t) nReads * 8);
+  if (!j->idBytes || !j->idOff) fatal ("out of memory");
+  memcpy (j->idBytes, idBytes, idLen); memcpy (j->idOff, idOff, (size_t) nReads * 8);
+  pthread_mutex_lock (&p->mu);
+  while (p->toFormat.n >= 2) pthread_cond_wait (&p->cv, &p->mu);
+  qPut (&p->toFormat, j); ++p->pending;
+  pthread_cond_broadcast (&p->cv);
+  pthread_mutex_unlock (&p->mu);
+  clock_gettime (CLOCK_MONOTONIC, &c2);
+  p->msWait += MS_ (c1, c2);
+  return 0;
+}
+
+void mgQueryPipeClose (MgQueryPipe *p)
+{
+  if (!p) return;
+  struct timespec c0, c1; clock_gettime (CLOCK_MONOTONIC, &c0);
+  if (p->started)
+    { pthread_mutex_lock (&p->mu); p->closing = 1; pthread_cond_broadcast (&p->cv); pthread_mutex_unlock (&p->mu);
+      pthread_join (p->thFormat, 0); pthread_join (p->thWrite, 0);
+    }
+  clock_gettime (CLOCK_MONOTONIC, &c1);
+  mgChainScratchKeep (0);
+  if (mgKnobs ()->seedTiming == 1)
+    fprintf (stderr, "mgQueryFile: %d batches: device halves %.1f ms, waiting for room in the queue %.1f + %.1f ms at the end; formatter %.1f ms, writer %.1f ms\n",
+             p->nBatches, p->msDevice, p->msWait, MS_ (c0, c1), p->msFormat, p->msWrite);
+  pthread_mutex_destroy (&p->mu); pthread_cond_destroy (&p->cv);
+  free (p);
+}
+#undef MS_
 
 int mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,
                     const char **names, FILE *out)

@@ -145,6 +145,35 @@ void mgChainCompactKernel (const MgChainQ *__restrict__ q, const MgChainM *__res
   for (U32 j = 0 ; j < n ; ++j) out[at + j] = mRec[(U64) r * maxM + j];
 }
 
+/* the device arrays of a query batch.  A call allocates and frees them; a caller with many batches in a row (mgQueryFile: one per
+   window of the file) keeps them between its calls (mgChainScratchKeep): ten allocations and frees a batch are milliseconds.  What
+   such a caller leaves stays allocated, like the text parser's windows, until mgReleaseBuffers () or a call that does not keep. */
+enum { CS_IX, CS_POS, CS_RID, CS_START, CS_Q, CS_M, CS_OV, CS_MC, CS_N };
+static struct { void *p[CS_N]; size_t cap[CS_N]; int keep; } gCs;
+static std::mutex gCsLock;
+static void *csGet (int i, size_t bytes)
+{
+  if (gCs.cap[i] < bytes)
+    { (void) hipFree (gCs.p[i]); gCs.p[i] = 0; gCs.cap[i] = 0;
+      const size_t want = gCs.keep ? bytes + bytes / 4 : bytes;
+      if (hipMalloc (&gCs.p[i], want) != hipSuccess) return 0;
+      gCs.cap[i] = want;
+    }
+  return gCs.p[i];
+}
+static void csDrop (int i) { (void) hipFree (gCs.p[i]); gCs.p[i] = 0; gCs.cap[i] = 0; }
+static void csDropAll (void) { for (int i = 0 ; i < CS_N ; ++i) csDrop (i); }
+extern "C" void mgChainScratchKeep (int on)               /* (what a keeper leaves stays for the next one: mgReleaseBuffers () frees it) */
+{
+  std::lock_guard<std::mutex> g (gCsLock);
+  if (on) ++gCs.keep; else if (gCs.keep) --gCs.keep;
+}
+extern "C" void mgChainReleaseBuffers (void)
+{
+  std::lock_guard<std::mutex> g (gCsLock);
+  if (!gCs.keep) csDropAll ();
+}
+
 /* Q tallies and M blocks of every read of a device-resident batch.  hQ[nReads] is filled here; *hMOut is a malloc ()ed array
  * of all reads' blocks in read order (read r's are the next min (hQ[r].nM, maxM) entries), 0 when there is none; returns 1 if
  * some read had more than maxM blocks (the caller then does that batch the long way), 0 on success, -1 on error. */
@@ -156,21 +185,24 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
   MgRefDev d;
   if (mgRefDevGet (ref, &d)) return -1;
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
+  std::lock_guard<std::mutex> g (gCsLock);
   U32 *dIx = 0, *dPos = 0, *dRid = 0; U64 *dStart = 0; MgChainQ *dQ = 0; MgChainM *dM = 0, *dMc = 0; U32 *dOv = 0;
   U64 n = 0;
   int rc = -1;
   do {
     for (int attempt = 0 ; attempt < 2 ; ++attempt)
-      { if (hipMalloc ((void **) &dIx, guess * 4) || hipMalloc ((void **) &dPos, guess * 4) || hipMalloc ((void **) &dRid, guess * 4)) { attempt = 9; break; }
+      { dIx = (U32 *) csGet (CS_IX, guess * 4); dPos = (U32 *) csGet (CS_POS, guess * 4); dRid = (U32 *) csGet (CS_RID, guess * 4);
+        if (!dIx || !dPos || !dRid) { dIx = 0; break; }
         MgStatus s = mgQueryReadsDevice (ms, dPacked, totalBases, dReadOffsets, nReads, dIx, dPos, dRid, guess, &n, 0);
         if (s == MG_OK) break;
-        (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); dIx = dPos = dRid = 0;
+        dIx = 0;
         if (s == MG_ERR_CAPACITY && attempt == 0) { guess = n; continue; }
         break;
       }
     if (!dIx) break;
-    if (hipMalloc ((void **) &dStart, ((size_t) nReads + 2) * 8) || hipMalloc ((void **) &dQ, (size_t) nReads * sizeof (MgChainQ))
-        || hipMalloc ((void **) &dM, (size_t) nReads * maxM * sizeof (MgChainM)) || hipMalloc ((void **) &dOv, 4)) break;
+    dStart = (U64 *) csGet (CS_START, ((size_t) nReads + 2) * 8); dQ = (MgChainQ *) csGet (CS_Q, (size_t) nReads * sizeof (MgChainQ));
+    dM = (MgChainM *) csGet (CS_M, (size_t) nReads * maxM * sizeof (MgChainM)); dOv = (U32 *) csGet (CS_OV, 4);
+    if (!dStart || !dQ || !dM || !dOv) break;
     if (hipMemset (dOv, 0, 4)) break;
     unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL (mgSeedStartKernel, dim3 (grid), dim3 (256), 0, 0, dRid, n, nReads, dStart);
@@ -188,8 +220,8 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
         bool ok = true;
         if (tot)
           { MgChainM *hM = (MgChainM *) malloc ((size_t) tot * sizeof (MgChainM));
-            ok = hM && hipMalloc ((void **) &dMc, (size_t) tot * sizeof (MgChainM)) == hipSuccess
-                 && hipMemcpy (dStart, hStart, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+            dMc = (MgChainM *) csGet (CS_MC, (size_t) tot * sizeof (MgChainM));
+            ok = hM && dMc && hipMemcpy (dStart, hStart, ((size_t) nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
             if (ok)
               { hipLaunchKernelGGL (mgChainCompactKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dQ, dM, maxM, dStart, nReads, dMc);
                 ok = hipGetLastError () == hipSuccess && hipMemcpy (hM, dMc, (size_t) tot * sizeof (MgChainM), hipMemcpyDeviceToHost) == hipSuccess;
@@ -201,7 +233,7 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
       }
     rc = ov ? 1 : 0;
   } while (0);
-  (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dQ); (void) hipFree (dM); (void) hipFree (dOv); (void) hipFree (dMc);
+  if (!gCs.keep) csDropAll ();
   if (rc < 0 && !mgLastError ()[0]) mgSetError ("query chaining on the device failed");
   return rc;
 }

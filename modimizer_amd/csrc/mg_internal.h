@@ -29,9 +29,14 @@ int  mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **off
 /* the same parser for the callers that print record ids: every batch of complete records (device resident: packed bases, read
    offsets) with its ids (id r = idBytes + idOff[r], 0-terminated: seqio.c:303-304) to fn; a non-zero return of fn ends the file */
 typedef int (*MgTextBatchFn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, const char *idBytes, const U64 *idOff, void *stream);
-int  mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine);
+int  mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 batchBases, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine);   /* batchBases: a batch is handed on once it holds this many bases (0: the default, 1 Gbp) */
 /* the device halves of the modmap callers (mg_callers.c): a batch that is already on the device */
 int  mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char **names, FILE *out);
+/* mgQueryFile's batches: Push runs the device half now, one writer thread formats and writes the lines, in order, behind it */
+typedef struct MgQueryPipe MgQueryPipe;
+MgQueryPipe *mgQueryPipeOpen (MgReference *ref, FILE *out);
+int  mgQueryPipePush (MgQueryPipe *p, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char *idBytes, const U64 *idOff);
+void mgQueryPipeClose (MgQueryPipe *p);                    /* returns when every line is written */
 int  mgReferenceAddDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nSeq, const char **names, bool isAdd);
 void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out);
 void mgTextReleaseBuffers (void);
@@ -47,6 +52,11 @@ typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChai
 MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
                                    MgChainQ *hQ, MgChainM **hMOut, U32 maxM);
 MG_HIDDEN void mgChainForget (const MgReference *ref);
+MG_HIDDEN void *mgPinnedAlloc (size_t bytes);          /* page-locked host memory (0: none to be had) */
+MG_HIDDEN void mgPinnedFree (void *p);
+MG_HIDDEN void mgChainReleaseBuffers (void);
+MG_HIDDEN void mgQueryReleaseBuffers (void);           /* the query path's cached buffers: page-locked blocks (mg_callers.c), device arrays (mg_chain.hip) */
+MG_HIDDEN void mgChainScratchKeep (int on);      /* 1: the query's device arrays stay allocated between batches; 0: ends that (and frees them) */
 /* readsetFileRead's per-read loop on the device (mg_chain.hip): hit lists, distances, counts, hits per mod */
 MG_HIDDEN int  mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
                                      U64 *hHitStart, U32 *hNMiss, U32 **hHit, unsigned short **hDx, U32 *hDepthCount);      /* drop the device copies of the reference's arrays */

@@ -1080,7 +1080,7 @@ int mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FI
     int first = -1;
     { FILE *f = fopen (filename, "rb"); if (f) { first = fgetc (f); fclose (f); } }
     if (first == '>')                                     /* (a FASTQ reference goes the host way: the hand-over in the middle of a file is not worth having here) */
-      { const int rc = mgTextForEachBatchDevice (filename, refDeviceBatch, &c, &nSeq, &totLen, &resumeOff, &resumeLine);
+      { const int rc = mgTextForEachBatchDevice (filename, refDeviceBatch, &c, 0, &nSeq, &totLen, &resumeOff, &resumeLine);
         if (rc == -1) return -1;
         if (rc == 0) { mgReferenceFinish (ref, totLen, isAdd, out); return 0; }
       }
@@ -1100,13 +1100,11 @@ static int queryBatch (MgSeqBatch *b, void *v)
 { QueryCtx *c = (QueryCtx *) v; return mgQueryProcess (c->ref, b->bases, b->offsets, b->nSeq, (const char **) b->names, c->out); }
 
 static int queryDeviceBatch (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, void *stream)
-{
-  QueryCtx *c = (QueryCtx *) v; (void) stream;
-  const char **names = idPointers (idBytes, idOff, nReads);
-  int rc = mgQueryProcessDevice (c->ref, dPacked, total, dOff, (int) nReads, names, c->out);
-  free (names);
-  return rc;
-}
+{ (void) stream; return mgQueryPipePush ((MgQueryPipe *) v, dPacked, total, dOff, (int) nReads, idBytes, idOff); }
+
+/* a query batch per window of the file (128 MiB of text; a batch is handed on at the first window's end at which it holds this
+   many bases): the lines of one batch are formatted and written while the next one is read, parsed and queried */
+#define MG_QUERY_FILE_BATCH 32000000ull
 
 int mgQueryFile (MgReference *ref, const char *filename, FILE *out)            /* modmap.c:188-196 */
 {
@@ -1114,7 +1112,9 @@ int mgQueryFile (MgReference *ref, const char *filename, FILE *out)            /
   /* plain FASTA / FASTQ text: parsed on the device, the batches stay there (no 1-byte-per-base upload); gzip, a last line without
      its newline, FASTQ that breaks a rule: the host parser (from the first record the device parser has not handed on) */
   U64 nSeq = 0, totLen = 0, resumeOff = 0, resumeLine = 1;
-  int rc = mgTextForEachBatchDevice (filename, queryDeviceBatch, &c, &nSeq, &totLen, &resumeOff, &resumeLine);
+  MgQueryPipe *pipe = mgQueryPipeOpen (ref, out);
+  int rc = mgTextForEachBatchDevice (filename, queryDeviceBatch, pipe, MG_QUERY_FILE_BATCH, &nSeq, &totLen, &resumeOff, &resumeLine);
+  mgQueryPipeClose (pipe);                                 /* every line of the device parser's batches is out */
   if (rc == 0 || rc == -1) return rc;
   if (rc == -3) return forEachBatchFrom (filename, (size_t) resumeOff, resumeLine, nSeq, queryBatch, &c);
   rc = forEachBatch (filename, queryBatch, &c);

@@ -489,7 +489,7 @@ static inline size_t txAl (size_t n) { return (n + 255) & ~(size_t) 255; }
 #include <time.h>
 static double txNow (void) { struct timespec ts; clock_gettime (CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static bool txTiming (void) { return mgKnobs ()->textTiming == 1; }   /* dev knob */
-struct TxClock { double reserve = 0, read = 0, wait = 0, flush = 0, t0 = 0; void lap (double &slot) { const double n = txNow (); slot += n - t0; t0 = n; } };
+struct TxClock { double reserve = 0, read = 0, wait = 0, flush = 0, ids = 0, sink = 0, t0 = 0; void lap (double &slot) { const double n = txNow (); slot += n - t0; t0 = n; } };
 
 struct TxBufs {
   int dev = -1;
@@ -497,6 +497,7 @@ struct TxBufs {
   unsigned char *hPin[2] = { 0, 0 }; hipEvent_t h2dDone[2];
   unsigned char *dText[2] = { 0, 0 };
   U64 *hCounts = 0;                    /* pinned: {accBases, accRecs} after the last window's K4 */
+  U64 *hHdr = 0, *dHdr = 0; size_t hdrCap = 0;    /* pinned: where a window's record headers start (4e5 of them in a window of short reads: into pageable memory the copy took as long as extracting the ids) */
   TxState *dState = 0; U32 *dOverflow = 0;
   U64 *dTileEvent = 0, *dTileBaseOff = 0, *dTileStartOff = 0; U32 *dTileBases = 0, *dTileStarts = 0; size_t tilesCap = 0;
   U64 *dTileOffQ = 0; U32 *dTileQual = 0; TqState *dTq = 0;      /* FASTQ: the third counted quantity */
@@ -510,6 +511,8 @@ struct TxBufs {
   void release ()
   { for (int i = 0 ; i < 2 ; ++i) { if (hPin[i]) { (void) hipHostFree (hPin[i]); (void) hipEventDestroy (h2dDone[i]); } (void) hipFree (dText[i]); hPin[i] = 0; dText[i] = 0; }
     if (hCounts) (void) hipHostFree (hCounts);
+    if (hHdr) (void) hipHostFree (hHdr);
+    hHdr = 0; dHdr = 0; hdrCap = 0;
     (void) hipFree (dState); (void) hipFree (dOverflow); (void) hipFree (dTileEvent); (void) hipFree (dTileBaseOff); (void) hipFree (dTileStartOff);
     (void) hipFree (dTileBases); (void) hipFree (dTileStarts); (void) hipFree (dBases); (void) hipFree (dRecOff); (void) hipFree (dPacked);
     (void) hipFree (dTileOffQ); (void) hipFree (dTileQual); (void) hipFree (dTq); (void) hipFree (dEndQ); (void) hipFree (dEndP); (void) hipFree (dRecPos);
@@ -532,12 +535,13 @@ static size_t txWindowBytes (size_t fileSize)
   if (kb <= 0) while (w > ((size_t) 1 << 20) && w / 2 >= fileSize) w /= 2;
   return (w + TX_TILE - 1) / TX_TILE * TX_TILE;
 }
-static U64 txBatchBases (void)
+static U64 txBatchBases (U64 asked)
 {
   const MgKnobs *kn = mgKnobs ();
   long mbp = kn->fileBatchMbp != MG_KNOB_UNSET ? kn->fileBatchMbp : 1024;
   if (mbp < 1) mbp = 1;
   U64 b = (U64) mbp * 1000000;
+  if (asked && kn->fileBatchMbp == MG_KNOB_UNSET) b = asked;
   if (kn->fileBatchBases != MG_KNOB_UNSET && kn->fileBatchBases > 0) b = (U64) kn->fileBatchBases;        /* test knob (as in mg_seqio.c) */
   return b;
 }
@@ -633,6 +637,7 @@ static int txHostThreads (void)
 struct TxSink {                                            /* what is done with a batch of complete records */
   int (*fn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st);
   void *ctx;
+  U64 batchBases = 0;                                      /* != 0: a batch is handed on once it holds this many bases (the knobs, which tests set, come first) */
   bool wantIds;                                            /* the records' ids (seqio.c:303-304: the header line after its '>' / '@' up to the first white space): id r = idBytes + idOff[r], 0-terminated */
 };
 
@@ -644,6 +649,7 @@ struct TxSink {                                            /* what is done with 
 struct TxIds {
   std::vector<char> bytes; std::vector<U64> off;
   bool open = false; bool skipOne = false;                 /* the last id is not finished; its '@' is the next window's first byte */
+  double tLens = 0;                 /* (dev timing) */
   void clear () { bytes.clear (); off.clear (); open = false; skipOne = false; }
   void feed (const unsigned char *p, size_t n)
   { if (skipOne) { if (!n) return; ++p; --n; skipOne = false; }
@@ -667,25 +673,33 @@ struct TxIds {
     if (cnt < 20000 || nThreads < 2) { for (size_t i = 0 ; i < cnt ; ++i) header (win, n, (size_t) at[i]); return; }
     std::vector<U32> len (cnt);
     std::vector<U64> sum ((size_t) nThreads + 1, 0);
-    auto lens = [&] (int t)
+    size_t base = 0, first = 0;
+    pthread_barrier_t bar; pthread_barrier_init (&bar, 0, (unsigned) nThreads);
+    /* one team for both passes (starting and joining fifteen threads costs as much as a pass): lengths; then member 0 makes the room; then copies */
+    auto work = [&] (int t)
       { const size_t a = cnt * (size_t) t / nThreads, b = cnt * ((size_t) t + 1) / nThreads; U64 s = 0;
         for (size_t i = a ; i < b ; ++i)
-          { const unsigned char *p = win + at[i] + 1, *e = win + n; const unsigned char *q = p;
+          { if (i + 24 < b) __builtin_prefetch (win + at[i + 24] + 1);      /* a header per 300 bytes of a short-read file: every one is a cache miss */
+            const unsigned char *p = win + at[i] + 1, *e = win + n; const unsigned char *q = p;
             while (q < e && !space (*q)) ++q;
             len[i] = (U32) (q - p); s += (U64) (q - p) + 1;
           }
         sum[(size_t) t + 1] = s;
-      };
-    { std::vector<std::thread> th; for (int t = 1 ; t < nThreads ; ++t) th.emplace_back (lens, t); lens (0); for (auto &x : th) x.join (); }
-    for (int t = 0 ; t < nThreads ; ++t) sum[(size_t) t + 1] += sum[(size_t) t];
-    const size_t base = bytes.size (), first = off.size ();
-    bytes.resize (base + (size_t) sum[(size_t) nThreads]); off.resize (first + cnt);
-    auto copy = [&] (int t)
-      { const size_t a = cnt * (size_t) t / nThreads, b = cnt * ((size_t) t + 1) / nThreads; size_t o = base + (size_t) sum[(size_t) t];
+        pthread_barrier_wait (&bar);
+        if (t == 0)
+          { for (int u = 0 ; u < nThreads ; ++u) sum[(size_t) u + 1] += sum[(size_t) u];
+            base = bytes.size (); first = off.size ();
+            bytes.resize (base + (size_t) sum[(size_t) nThreads]); off.resize (first + cnt);
+          }
+        pthread_barrier_wait (&bar);
+        size_t o = base + (size_t) sum[(size_t) t];
         for (size_t i = a ; i < b ; ++i)
           { off[first + i] = (U64) o; memcpy (bytes.data () + o, win + at[i] + 1, len[i]); o += len[i]; bytes[o++] = 0; }
       };
-    { std::vector<std::thread> th; for (int t = 1 ; t < nThreads ; ++t) th.emplace_back (copy, t); copy (0); for (auto &x : th) x.join (); }
+    const double tA = txNow ();
+    { std::vector<std::thread> th; for (int t = 1 ; t < nThreads ; ++t) th.emplace_back (work, t); work (0); for (auto &x : th) x.join (); }
+    pthread_barrier_destroy (&bar);
+    tLens += txNow () - tA;
     open = false;
   }
   /* the headers of a window: all but the last through the team (an id ends before the next header starts), the last one -- which may
@@ -721,6 +735,27 @@ static int txFlush (TxBufs &t, const TxSink &sink, U64 total, U64 nRec, hipStrea
   return sink.fn (sink.ctx, t.dPacked, total, t.dRecOff, (U32) nRec, sink.wantIds ? ids->bytes.data () : (const char *) 0, sink.wantIds ? ids->off.data () : (const U64 *) 0, st);
 }
 
+
+/* where a window's record headers start, from the device to the host: a kernel writes them straight into page-locked host memory
+   behind the emit kernel (hipMemcpy from the device took its turn behind the NEXT window's 128 MiB on its way to the device: 2 ms a
+   window, as long as extracting the ids) */
+__global__ void mgTextCopyOutKernel (const U64 *__restrict__ src, U64 *__restrict__ dstHost, U64 n)
+{ for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i < n ; i += (U64) gridDim.x * blockDim.x) dstHost[i] = src[i]; }
+static bool txHeadersLaunch (TxBufs &t, const U64 *dSrc, size_t n, hipStream_t st)
+{
+  if (!n) return true;
+  if (n > t.hdrCap)
+    { if (t.hHdr) (void) hipHostFree (t.hHdr);
+      t.hHdr = 0; t.hdrCap = 0; t.dHdr = 0;
+      if (hipHostMalloc ((void **) &t.hHdr, (n + n / 4) * 8, hipHostMallocMapped) != hipSuccess
+          || hipHostGetDevicePointer ((void **) &t.dHdr, t.hHdr, 0) != hipSuccess) return false;
+      t.hdrCap = n + n / 4;
+    }
+  unsigned grid = (unsigned) ((n + 255) / 256); if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL (mgTextCopyOutKernel, dim3 (grid), dim3 (256), 0, st, dSrc, t.dHdr, (U64) n);
+  return hipGetLastError () == hipSuccess;
+}
+
 static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff, U64 *resumeLine);
 
 /* the file through the device parser; every batch of complete records goes to sink.  Returns 0, -1 (error: mgLastError), or -2
@@ -753,7 +788,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
       return rq;
     }
   const size_t window = txWindowBytes (fileSize);
-  const U64 batch = txBatchBases ();
+  const U64 batch = txBatchBases (sink.batchBases);
   hipStream_t st = 0;
   int rc = -1;
   U64 nSeq = 0, totLen = 0;
@@ -809,12 +844,13 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
         hipLaunchKernelGGL (mgTextEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevOfWindow,
                             t.dTileEvent, t.dTileBaseOff, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, (U64) t.recCap, t.dOverflow,
                             sink.wantIds ? t.dRecPos : (U64 *) 0);
-        if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        if (hipGetLastError () != hipSuccess) { failed = true; break; }
+        if (sink.wantIds && !txHeadersLaunch (t, t.dRecPos + recsBefore, (size_t) (accRecs - recsBefore), st)) { failed = true; break; }
+        if (hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
         if (sink.wantIds)                                  /* the ids of the records that start in this window, while its text is in the pinned buffer */
           { if (ids.open) ids.feed (t.hPin[cur], nCur);
             const U64 nNew = accRecs - recsBefore;
-            hdr.resize ((size_t) nNew);
-            if (nNew && hipMemcpy (hdr.data (), t.dRecPos + recsBefore, (size_t) nNew * 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+            hdr.assign (t.hHdr, t.hHdr + nNew);
             for (auto &h : hdr) h -= (U64) off;
             ids.headers (t.hPin[cur], nCur, hdr, nThreads);
           }
@@ -862,7 +898,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
 static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff, U64 *resumeLine)
 {
   const size_t window = txWindowBytes (fileSize);
-  const U64 batch = txBatchBases ();
+  const U64 batch = txBatchBases (sink.batchBases);
   hipStream_t st = 0;
   int rc = -1;
   U64 nSeq = 0, totLen = 0, resume = 0;
@@ -917,18 +953,21 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
           if (txReserve (t, window, accBases + 64, accRecs + 3)) { mgSetError ("device text parser: allocation failed"); failed = true; break; }
         hipLaunchKernelGGL (mgTextFastqEmitKernel, dim3 ((unsigned) nTiles), dim3 (TX_THREADS), 0, st, t.dText[cur], (U64) nCur, (U64) off, prevOfWindow, t.dTileEvent,
                             t.dTileBaseOff, t.dTileOffQ, t.dTileStartOff, t.dBases, (U64) t.basesCap, t.dRecOff, t.dEndQ, t.dEndP, (U64) t.recCap, t.dOverflow);
-        if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
+        if (hipGetLastError () != hipSuccess) { failed = true; break; }
+        if (sink.wantIds && !txHeadersLaunch (t, t.dEndP + recsBefore + 1, (size_t) (accRecs - recsBefore), st)) { failed = true; break; }
+        if (hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
         const U64 nlCount = t.hCounts[3];
         bool bad = t.hCounts[4] != 0;
         if (sink.wantIds && !bad)                         /* a header starts at the file's first byte and after every record's last newline */
-          { if (ids.open) ids.feed (t.hPin[cur], nCur);
+          { ck.lap (ck.flush);
+            if (ids.open) ids.feed (t.hPin[cur], nCur);
             const U64 nNew = accRecs - recsBefore;
-            hdr.resize ((size_t) nNew);
-            if (nNew && hipMemcpy (hdr.data (), t.dEndP + recsBefore + 1, (size_t) nNew * 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+            hdr.assign (t.hHdr, t.hHdr + nNew);
             for (auto &h : hdr) h = h + 1 - (U64) off;     /* the byte after a record's last newline, in this window (or its end: the next window's first byte) */
             if (!hdr.empty () && hdr.back () + (U64) off >= (U64) fileSize) hdr.pop_back ();      /* the file's last record: no header follows */
             if (!off) hdr.insert (hdr.begin (), (U64) 0);
             ids.headers (t.hPin[cur], nCur, hdr, nThreads);
+            ck.lap (ck.ids);
           }
         if (!bad && accRecs > recsBefore)                  /* the records this window completed: sequence and quality lines of one length? */
           { const U64 nNew = accRecs - recsBefore;
@@ -946,7 +985,9 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
         if (bad || (eof && ((nlCount & 3) || accBases != (accRecs ? tail[0] : 0) || accQual != (accRecs ? tail[1] : 0))))
           { handOver = true; break; }                      /* nothing of the accumulator has been added: the host parser starts at its first record */
         if ((eof || accBases >= batch) && accRecs)
-          { if (txFlush (t, sink, tail[0], accRecs, st, &ids)) { failed = true; break; }
+          { ck.lap (ck.flush);
+            if (txFlush (t, sink, tail[0], accRecs, st, &ids)) { failed = true; break; }
+            ck.lap (ck.sink);
             nSeq += accRecs; totLen += tail[0];
             if (sink.wantIds) ids.dropFront ((size_t) accRecs);
             resume = tail[2] + 1;
@@ -962,7 +1003,8 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
         off = offNext; nCur = nNext; ++w;
       }
     ck.lap (ck.flush);
-    if (txTiming ()) fprintf (stderr, "  [device text] FASTQ: reserve %.3f s, read %.3f, wait for the device %.3f, emit + flush + rest %.3f\n", ck.reserve, ck.read, ck.wait, ck.flush);
+    if (txTiming ()) fprintf (stderr, "  [device text] FASTQ: reserve %.3f s, read %.3f, wait for the device %.3f, record ids %.3f, pack + sink %.3f, emit + rest %.3f\n", ck.reserve, ck.read, ck.wait, ck.ids, ck.sink, ck.flush);
+    if (txTiming ()) fprintf (stderr, "  [device text] ids: the team's two passes %.3f (%d threads)\n", ids.tLens, nThreads);
     if (failed) { if (!mgLastError ()[0]) mgSetError ("device text parser: HIP failure (%s)", hipGetErrorString (hipGetLastError ())); break; }
     rc = handOver ? -3 : 0;
   } while (0);
@@ -1000,10 +1042,10 @@ extern "C" int mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *n
 struct TxCbCtx { MgTextBatchFn fn; void *ctx; };
 static int txCbSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st)
 { TxCbCtx *c = (TxCbCtx *) v; return c->fn (c->ctx, dPacked, total, dOff, nReads, idBytes, idOff, (void *) st); }
-extern "C" int mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine)
+extern "C" int mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 batchBases, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine)
 {
   TxCbCtx c; c.fn = fn; c.ctx = ctx;
-  TxSink sink; sink.fn = txCbSink; sink.ctx = &c; sink.wantIds = true;
+  TxSink sink; sink.fn = txCbSink; sink.ctx = &c; sink.wantIds = true; sink.batchBases = batchBases;
   return txParseFile (filename, sink, nSeq, totLen, resumeOff, resumeLine);
 }
 

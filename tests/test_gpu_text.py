@@ -278,3 +278,53 @@ def test_query_file_device_parser_equals_host_parser(fmt, crlf, window_kb, batch
             L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
     assert outs[0] == outs[1], [x for x in zip(outs[0].splitlines(), outs[1].splitlines()) if x[0] != x[1]][:3]
     assert outs[0].count(b"\nQ\t") >= n - 1 and outs[0].count(b"\nM\t") > 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["w", "a"])
+def test_query_lines_written_by_the_team_at_their_places(mode, golden_dir, tmp_path):
+    """A batch of many reads is formatted by a team of threads, piece by piece, and the pieces are written in order (mg_callers.c
+    queryFormatLines / queryWritePieces) around whatever the caller puts into the same FILE before and after -- a file opened for
+    writing or for appending.  Against the single-thread output (MODGPU_PARSE_THREADS=1), through the device parser (a batch per
+    window, formatter and writer threads behind it) and the host parser."""
+    L = mg.lib()
+    libc = mg._libc
+    libc.fputs.argtypes = [C.c_char_p, C.c_void_p]
+    rng = np.random.default_rng(99)
+    names, bases, offs = fasta.read_fasta(os.path.join(golden_dir, "ref.fa"))
+    refseqs = [bases[offs[i]:offs[i + 1]] for i in range(len(names))]
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    n = 60000
+    recs = []
+    for i in range(n):
+        s = refseqs[i % len(refseqs)]
+        ln = int(rng.integers(40, 400)) if i % 50 else int(rng.integers(1500, 4000))
+        a = int(rng.integers(0, max(1, len(s) - ln)))
+        txt = letters[s[a:a + ln]].tobytes()
+        recs.append(b"@q%d some text\n" % i + txt + b"\n+\n" + b"I" * len(txt) + b"\n")
+    qpath = str(tmp_path / "q.fq")
+    open(qpath, "wb").write(b"".join(recs))
+    outs = {}
+    for tag, kn in (("one", dict(PARSE_THREADS=1, TEXT_HOST=1)), ("team_host", dict(TEXT_HOST=1)), ("team_device", dict(TEXT_WINDOW_KB=2048)),
+                    ("team_device_1", dict())):
+        with mg.knobs(**kn):
+            sh = mg.seqhashCreate(15, 8, 17); ms = mg.modsetCreate(sh, 20)
+            ref = L.mgReferenceCreate(ms, 1 << 26)
+            out = str(tmp_path / (tag + ".txt"))
+            open(out, "wb").write(b"already there\n")
+            with mg.CFile(out, "a" if mode == "a" else "r+") as f:
+                if mode != "a":
+                    libc.fseek.argtypes = [C.c_void_p, C.c_long, C.c_int]
+                    libc.fseek(f, 0, 2)
+                libc.fputs(b"before the reference\n", f)
+                assert L.mgReferenceFastaRead(ref, os.path.join(golden_dir, "ref.fa").encode(), True, f) == 0
+                libc.fputs(b"before the queries\n", f)
+                assert L.mgQueryFile(ref, qpath.encode(), f) == 0
+                libc.fputs(b"after the queries\n", f)
+            outs[tag] = open(out, "rb").read()
+            L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+    one = outs["one"]
+    assert one.startswith(b"already there\nbefore the reference\n") and one.endswith(b"after the queries\n")
+    assert one.count(b"\nQ\t") == n and one.count(b"\nM\t") > 100
+    for tag, o in outs.items():
+        assert o == one, (tag, len(o), len(one))
