@@ -55,6 +55,24 @@ extern "C" MgStatus mgMemcpyD2H (void *dst, const void *src, size_t bytes, void 
 extern "C" void *mgPinnedAlloc (size_t bytes)
 { void *p = 0; if (mgEnsureDevice () || hipHostMalloc (&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError (); return 0; } return p; }
 extern "C" void mgPinnedFree (void *p) { if (p) (void) hipHostFree (p); }
+/* device memory to a page-locked block by a kernel that writes host memory, then a wait for the stream: megabytes copied by the
+   copy engine take their turn behind a text window (128 MiB) that is on its way to the device at the same time, stores from a kernel
+   do not (tools/ubench_copyq.hip) */
+__global__ void mgCopyOutKernel (const U64 *__restrict__ src, U64 *__restrict__ dstHost, U64 nWords)
+{ for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i < nWords ; i += (U64) gridDim.x * blockDim.x) dstHost[i] = src[i]; }
+extern "C" MgStatus mgCopyOutPinned (void *dstPinned, const void *srcDev, size_t bytes, void *stream)
+{
+  if (!bytes) return MG_OK;
+  void *dDst = 0;
+  if ((bytes & 7) || ((uintptr_t) dstPinned & 7) || ((uintptr_t) srcDev & 7) || hipHostGetDevicePointer (&dDst, dstPinned, 0) != hipSuccess)
+    { (void) hipGetLastError (); return mgMemcpyD2H (dstPinned, srcDev, bytes, stream); }
+  const U64 nWords = bytes >> 3;
+  unsigned grid = (unsigned) ((nWords + 255) / 256); if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL (mgCopyOutKernel, dim3 (grid), dim3 (256), 0, (hipStream_t) stream, (const U64 *) srcDev, (U64 *) dDst, nWords);
+  MG_HIP (hipGetLastError ());
+  MG_HIP (hipStreamSynchronize ((hipStream_t) stream));
+  return MG_OK;
+}
 extern "C" MgStatus mgMemsetD (void *dst, int byte, size_t bytes, void *stream)
 { if (bytes) MG_HIP (hipMemsetAsync (dst, byte, bytes, (hipStream_t) stream)); return MG_OK; }
 extern "C" MgStatus mgStreamSynchronize (void *stream)

@@ -506,16 +506,63 @@ static char *fmtF2 (char *p, double x)
 
 int mgFormatF2 (char *buf, double x) { char *e = fmtF2 (buf, x); *e = 0; return (int) (e - buf); }      /* test hook: buf of 64 bytes */
 
-typedef struct { char *buf; size_t len, cap; } FmtBuf;
-static char *fmtRoom (FmtBuf *b, size_t need)
-{ if (b->len + need > b->cap) { b->cap = 2 * (b->len + need) + 4096; b->buf = (char *) realloc (b->buf, b->cap); if (!b->buf) fatal ("out of memory"); } return b->buf + b->len; }
+/* the buffers of the output stages -- the teams' pieces, the ids that travel with a batch -- come from a small pool and go back to
+   it: a fresh 2 MB block from malloc () is 500 page faults when it is written, by sixteen threads at once, and as many pages given
+   back when it is freed; 4e6 lines a batch-sequence are 57 000 of each.  The pool keeps up to MG_POOL_SLOTS blocks between calls
+   (mgReleaseBuffers () frees them); a block remembers its capacity in the 16 bytes in front of it. */
+#define MG_POOL_SLOTS 128
+static struct { pthread_mutex_t mu; void *blk[MG_POOL_SLOTS]; int n; } gPool = { PTHREAD_MUTEX_INITIALIZER, { 0 }, 0 };
+static size_t poolCap (const void *p) { return *(const size_t *) ((const char *) p - 16); }
+static void *poolGet (size_t bytes)
+{
+  void *hit = 0;
+  pthread_mutex_lock (&gPool.mu);
+  int pick = -1;
+  for (int i = 0 ; i < gPool.n ; ++i)
+    { const size_t c = poolCap (gPool.blk[i]);
+      if (c >= bytes && (pick < 0 || c < poolCap (gPool.blk[pick]))) pick = i;      /* the tightest fit */
+    }
+  if (pick >= 0) { hit = gPool.blk[pick]; gPool.blk[pick] = gPool.blk[--gPool.n]; }
+  pthread_mutex_unlock (&gPool.mu);
+  if (hit) return hit;
+  const size_t cap = bytes + bytes / 8 + 64;
+  char *raw = (char *) malloc (cap + 16);
+  if (!raw) fatal ("out of memory");
+  *(size_t *) raw = cap;
+  return raw + 16;
+}
+static void poolPut (void *p)
+{
+  if (!p) return;
+  pthread_mutex_lock (&gPool.mu);
+  if (gPool.n < MG_POOL_SLOTS) { gPool.blk[gPool.n++] = p; p = 0; }
+  pthread_mutex_unlock (&gPool.mu);
+  if (p) free ((char *) p - 16);
+}
+static void *poolGrow (void *p, size_t keep, size_t bytes)  /* a block of at least `bytes` holding the first `keep` bytes of p */
+{
+  void *q = poolGet (bytes);
+  if (keep) memcpy (q, p, keep);
+  poolPut (p);
+  return q;
+}
+static void poolFreeAll (void)
+{
+  pthread_mutex_lock (&gPool.mu);
+  for (int i = 0 ; i < gPool.n ; ++i) free ((char *) gPool.blk[i] - 16);
+  gPool.n = 0;
+  pthread_mutex_unlock (&gPool.mu);
+}
 
-typedef struct { const MgReference *ref; const MgChainQ *q; const MgChainM *m; const U64 *mStart; const int64_t *offsets; const char **names; int r0, r1; FmtBuf out; } FmtJob;
+typedef struct { char *buf; size_t len, cap; } FmtBuf;      /* buf: a pool block */
+static char *fmtRoom (FmtBuf *b, size_t need)
+{ if (b->len + need > b->cap) { b->buf = (char *) poolGrow (b->buf, b->len, 2 * (b->len + need) + 4096); b->cap = poolCap (b->buf); } return b->buf + b->len; }
+typedef struct { const MgReference *ref; const MgChainQ *q; const MgChainM *m; const U64 *mStart; const int64_t *offsets; const char **names; int r0, r1; FmtBuf out; double cpuMs; } FmtJob;
 static void *fmtQM (void *v)
 {
   FmtJob *j = (FmtJob *) v;
-  j->out.cap = (size_t) (j->r1 - j->r0) * 80 + 4096; j->out.buf = (char *) malloc (j->out.cap);       /* a Q line of a short read is 60 bytes */
-  if (!j->out.buf) fatal ("out of memory");
+  struct timespec u0, u1; clock_gettime (CLOCK_THREAD_CPUTIME_ID, &u0);
+  j->out.buf = (char *) poolGet ((size_t) (j->r1 - j->r0) * 80 + 4096); j->out.cap = poolCap (j->out.buf);      /* a Q line of a short read is 60 bytes */
   for (int r = j->r0 ; r < j->r1 ; ++r)
     { const MgChainQ *qq = &j->q[r];
       const char *nm = j->names[r]; const size_t nl = strlen (nm);
@@ -539,6 +586,8 @@ static void *fmtQM (void *v)
           j->out.len += (size_t) (p - p0);
         }
     }
+  clock_gettime (CLOCK_THREAD_CPUTIME_ID, &u1);
+  j->cpuMs = (u1.tv_sec - u0.tv_sec) * 1e3 + (u1.tv_nsec - u0.tv_nsec) * 1e-6;
   return 0;
 }
 
@@ -554,6 +603,7 @@ static int fmtThreads (int nReads)
 }
 
 #define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+static double gFmtCpuMs;                                   /* (dev timing: CPU time of the formatting threads, one formatter at a time) */
 /* the lines of a batch whose tallies and blocks are on the host: formatted by a team of threads, each its range of the reads
    into its own buffer (piece[0 .. *nPieces)), and written in order.  (Positioned writes of the pieces by the team itself were tried:
    writes to one file take turns on its inode lock, 234 MB take the 40 ms one fwrite takes.) */
@@ -561,8 +611,7 @@ static void queryFormatLines (const MgReference *ref, const MgChainQ *q, const M
                               FmtBuf piece[16], int *nPieces, double *ms)
 {
   struct timespec c1, c2; clock_gettime (CLOCK_MONOTONIC, &c1);
-  U64 *mStart = (U64 *) malloc (((size_t) nReads + 1) * 8);
-  if (!mStart) fatal ("out of memory");
+  U64 *mStart = (U64 *) poolGet (((size_t) nReads + 1) * 8);
   { U64 tot = 0; for (int r = 0 ; r < nReads ; ++r) { mStart[r] = tot; tot += q[r].nM; } mStart[nReads] = tot; }
   const int T = fmtThreads (nReads);
   FmtJob job[16]; pthread_t th[16]; int started[16];
@@ -574,9 +623,9 @@ static void queryFormatLines (const MgReference *ref, const MgChainQ *q, const M
     }
   for (int t = 0 ; t < T ; ++t) if (!started[t]) fmtQM (&job[t]);
   for (int t = 0 ; t < T ; ++t) if (started[t]) pthread_join (th[t], 0);
-  for (int t = 0 ; t < T ; ++t) piece[t] = job[t].out;
+  for (int t = 0 ; t < T ; ++t) { piece[t] = job[t].out; gFmtCpuMs += job[t].cpuMs; }
   *nPieces = T;
-  free (mStart);
+  poolPut (mStart);
   clock_gettime (CLOCK_MONOTONIC, &c2);
   if (ms) *ms += MS_ (c1, c2);
 }
@@ -585,7 +634,7 @@ static void queryWritePieces (FmtBuf piece[16], int nPieces, FILE *out, double *
   struct timespec c1, c2; clock_gettime (CLOCK_MONOTONIC, &c1);
   for (int t = 0 ; t < nPieces ; ++t)
     { if (piece[t].len && fwrite (piece[t].buf, 1, piece[t].len, out) != piece[t].len) fatal ("write");
-      free (piece[t].buf); piece[t].buf = 0;
+      poolPut (piece[t].buf); piece[t].buf = 0;
     }
   clock_gettime (CLOCK_MONOTONIC, &c2);
   if (ms) *ms += MS_ (c1, c2);
@@ -607,7 +656,7 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
   MgChainQ *q = (MgChainQ *) malloc ((size_t) nReads * sizeof (MgChainQ));
   MgChainM *m = 0;                                         /* all reads' blocks, densely, in read order */
   const int hostChain = mgKnobs ()->queryHostChain == 1;   /* test knob */
-  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, dPacked, totalBases, dReadOffsets, (U32) nReads, q, &m, MG_QUERY_MAXM);
+  int rc = (hostChain || gVerbose) ? 1 : mgChainQueryDevice (ref, dPacked, totalBases, dReadOffsets, (U32) nReads, q, &m, MG_QUERY_MAXM, 0);
   if (rc < 0) fatal ("query");
   if (timing) clock_gettime (CLOCK_MONOTONIC, &c1);
   if (rc == 1) rc = queryProcessHostChain (ref, &b, offsets, nReads, names, out);
@@ -678,12 +727,13 @@ void mgQueryReleaseBuffers (void)
   pthread_mutex_lock (&gPin.mu);
   for (int i = 0 ; i < MG_QPIPE_PINS ; ++i) if (!gPin.busy[i] && gPin.pin[i]) { mgPinnedFree (gPin.pin[i]); gPin.pin[i] = 0; gPin.cap[i] = 0; }
   pthread_mutex_unlock (&gPin.mu);
+  poolFreeAll ();
   mgChainReleaseBuffers ();
 }
 
 static void queryJobFree (MgQueryPipe *p, MgQJob *j)
-{ pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); free (j->idBytes); free (j->idOff);
-  for (int t = 0 ; t < j->nPieces ; ++t) free (j->piece[t].buf);
+{ pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); poolPut (j->idBytes); poolPut (j->idOff);
+  for (int t = 0 ; t < j->nPieces ; ++t) poolPut (j->piece[t].buf);
   free (j);
 }
 
@@ -700,12 +750,11 @@ static void *queryFormatter (void *v)
       MgQJob *j = qTake (&p->toFormat);
       pthread_mutex_unlock (&p->mu);
       if (!j) break;                                       /* closing, nothing left */
-      const char **names = (const char **) malloc (((size_t) j->nReads + 1) * sizeof (char *));
-      if (!names) fatal ("out of memory");
+      const char **names = (const char **) poolGet (((size_t) j->nReads + 1) * sizeof (char *));
       for (int r = 0 ; r < j->nReads ; ++r) names[r] = j->idBytes + j->idOff[r];
       queryFormatLines (p->ref, j->q, j->m, j->offsets, j->nReads, names, j->piece, &j->nPieces, &p->msFormat);
-      free (names);
-      pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); free (j->idBytes); free (j->idOff);
+      poolPut (names);
+      pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); poolPut (j->idBytes); poolPut (j->idOff);
       j->q = 0; j->m = 0; j->offsets = 0; j->idBytes = 0; j->idOff = 0; j->pinQ = j->pinOff = 0;
       pthread_mutex_lock (&p->mu);
       while (p->toWrite.n >= 2) pthread_cond_wait (&p->cv, &p->mu);
@@ -774,8 +823,8 @@ int mgQueryPipePush (MgQueryPipe *p, const U32 *dPacked, U64 totalBases, const U
       j->nReads = nReads;
       j->offsets = (int64_t *) pipePinGet ((size_t) (nReads + 1) * 8, &j->pinOff);
       j->q = (MgChainQ *) pipePinGet ((size_t) nReads * sizeof (MgChainQ), &j->pinQ);
-      if (mgMemcpyD2H (j->offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
-      rc = mgChainQueryDevice (p->ref, dPacked, totalBases, dReadOffsets, (U32) nReads, j->q, &j->m, MG_QUERY_MAXM);
+      if (j->pinOff ? mgCopyOutPinned (j->offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0) : mgMemcpyD2H (j->offsets, dReadOffsets, (size_t) (nReads + 1) * 8, 0)) fatal ("D2H");
+      rc = mgChainQueryDevice (p->ref, dPacked, totalBases, dReadOffsets, (U32) nReads, j->q, &j->m, MG_QUERY_MAXM, j->pinQ != 0);
       if (rc < 0) fatal ("query");
     }
   clock_gettime (CLOCK_MONOTONIC, &c1);
@@ -792,8 +841,7 @@ int mgQueryPipePush (MgQueryPipe *p, const U32 *dPacked, U64 totalBases, const U
     }
   /* the ids belong to the parser, which moves on: a copy goes with the job */
   const size_t idLen = (size_t) idOff[nReads - 1] + strlen (idBytes + idOff[nReads - 1]) + 1;
-  j->idBytes = (char *) malloc (idLen); j->idOff = (U64 *) malloc ((size_t) nReads * 8);
-  if (!j->idBytes || !j->idOff) fatal ("out of memory");
+  j->idBytes = (char *) poolGet (idLen); j->idOff = (U64 *) poolGet ((size_t) nReads * 8);
   memcpy (j->idBytes, idBytes, idLen); memcpy (j->idOff, idOff, (size_t) nReads * 8);
   pthread_mutex_lock (&p->mu);
   while (p->toFormat.n >= 2) pthread_cond_wait (&p->cv, &p->mu);
@@ -816,8 +864,9 @@ void mgQueryPipeClose (MgQueryPipe *p)
   clock_gettime (CLOCK_MONOTONIC, &c1);
   mgChainScratchKeep (0);
   if (mgKnobs ()->seedTiming == 1)
-    fprintf (stderr, "mgQueryFile: %d batches: device halves %.1f ms, waiting for room in the queue %.1f + %.1f ms at the end; formatter %.1f ms, writer %.1f ms\n",
-             p->nBatches, p->msDevice, p->msWait, MS_ (c0, c1), p->msFormat, p->msWrite);
+    fprintf (stderr, "mgQueryFile: %d batches: device halves %.1f ms, waiting for room in the queue %.1f + %.1f ms at the end; formatter %.1f ms (its threads' CPU time %.1f ms), writer %.1f ms\n",
+             p->nBatches, p->msDevice, p->msWait, MS_ (c0, c1), p->msFormat, gFmtCpuMs, p->msWrite);
+  gFmtCpuMs = 0;
   pthread_mutex_destroy (&p->mu); pthread_cond_destroy (&p->cv);
   free (p);
 }

@@ -178,7 +178,7 @@ extern "C" void mgChainReleaseBuffers (void)
  * of all reads' blocks in read order (read r's are the next min (hQ[r].nM, maxM) entries), 0 when there is none; returns 1 if
  * some read had more than maxM blocks (the caller then does that batch the long way), 0 on success, -1 on error. */
 extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
-                                   MgChainQ *hQ, MgChainM **hMOut, U32 maxM)
+                                   MgChainQ *hQ, MgChainM **hMOut, U32 maxM, int hQPinned)
 {
   *hMOut = 0;
   Modset *ms = ref->ms;
@@ -209,7 +209,8 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
     hipLaunchKernelGGL (mgChainKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, d, dQ, dM, maxM, dOv);
     if (hipGetLastError () != hipSuccess) break;
     U32 ov = 0;
-    if (hipMemcpy (&ov, dOv, 4, hipMemcpyDeviceToHost) || hipMemcpy (hQ, dQ, (size_t) nReads * sizeof (MgChainQ), hipMemcpyDeviceToHost)) break;
+    if (hipMemcpy (&ov, dOv, 4, hipMemcpyDeviceToHost)) break;
+    if (hQPinned ? mgCopyOutPinned (hQ, dQ, (size_t) nReads * sizeof (MgChainQ), 0) != MG_OK : hipMemcpy (hQ, dQ, (size_t) nReads * sizeof (MgChainQ), hipMemcpyDeviceToHost) != hipSuccess) break;
     if (!ov)
       { /* where every read's blocks go in the dense array (dStart is free: the chain kernel is done with it) */
         U64 *hStart = (U64 *) malloc (((size_t) nReads + 1) * 8);

@@ -50,10 +50,11 @@ MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);
 typedef struct { U32 nSeeds, missed, copy1, copy2, copyM, nM; } MgChainQ;
 typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChainM;
 MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
-                                   MgChainQ *hQ, MgChainM **hMOut, U32 maxM);
+                                   MgChainQ *hQ, MgChainM **hMOut, U32 maxM, int hQPinned);
 MG_HIDDEN void mgChainForget (const MgReference *ref);
 MG_HIDDEN void *mgPinnedAlloc (size_t bytes);          /* page-locked host memory (0: none to be had) */
 MG_HIDDEN void mgPinnedFree (void *p);
+MG_HIDDEN MgStatus mgCopyOutPinned (void *dstPinned, const void *srcDev, size_t bytes, void *stream);   /* device -> page-locked block by a kernel (not the copy engine), waited for */
 MG_HIDDEN void mgChainReleaseBuffers (void);
 MG_HIDDEN void mgQueryReleaseBuffers (void);           /* the query path's cached buffers: page-locked blocks (mg_callers.c), device arrays (mg_chain.hip) */
 MG_HIDDEN void mgChainScratchKeep (int on);      /* 1: the query's device arrays stay allocated between batches; 0: ends that (and frees them) */

@@ -14,6 +14,7 @@ cat > $D/stubs.c <<'EOS'
 /* "device" memory is host memory here */
 MgStatus mgMemcpyD2H (void *d, const void *s, size_t n, void *st) { (void) st; memcpy (d, s, n); return MG_OK; }
 MgStatus mgMemcpyH2D (void *d, const void *s, size_t n, void *st) { (void) st; memcpy (d, s, n); return MG_OK; }
+MgStatus mgCopyOutPinned (void *d, const void *s, size_t n, void *st) { (void) st; memcpy (d, s, n); return MG_OK; }
 void *mgPinnedAlloc (size_t n) { return malloc (n ? n : 16); } void mgPinnedFree (void *p) { free (p); }
 void mgChainScratchKeep (int on) { (void) on; } void mgChainReleaseBuffers (void) {} void mgChainForget (const MgReference *r) { (void) r; }
 MgStatus modsetSyncToHost (Modset *ms, int w) { (void) ms; (void) w; return MG_OK; }
@@ -27,8 +28,8 @@ void stubQ (U64 len, MgChainQ *q, MgChainM *m)
       m[k].n1 = (int) (len % 9 + k); m[k].n2 = (int) (len % 6); m[k].span = (U32) (len % 17 + 1);
     }
 }
-int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, MgChainQ *hQ, MgChainM **hMOut, U32 maxM)
-{ (void) ref; (void) dPacked; (void) total; (void) maxM;
+int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, MgChainQ *hQ, MgChainM **hMOut, U32 maxM, int pinned)
+{ (void) ref; (void) dPacked; (void) total; (void) maxM; (void) pinned;
   MgChainM *m = (MgChainM *) malloc (((size_t) nReads * 4 + 1) * sizeof (MgChainM)); size_t nm = 0;
   for (U32 r = 0 ; r < nReads ; ++r) { stubQ (dOff[r + 1] - dOff[r], &hQ[r], m + nm); nm += hQ[r].nM; }
   if (nm) *hMOut = m; else { free (m); *hMOut = 0; }
