@@ -971,8 +971,9 @@ def end_to_end(cx, reads, offsets, k, d, seed):
                                         "reference_bases": rb, "output_bytes": out_bytes, "same_output_size": out_bytes == out_bytes_h,
                                         "lines_per_s": round(nq / t_dev / 1e6, 1),
                                         "what": "150-base reads, four-line FASTQ in the page cache -> parsed on the device (record ids copied out of the pinned windows) -> scan + "
-                                                "lookup + tallies + chaining on the device -> one Q line per read (M lines where blocks chain) formatted by the host's threads "
-                                                "into a file in /dev/shm; host_parser: the same through mg_seqio.c and the 1-byte-per-base upload; unit of lines_per_s: million"}
+                                                "lookup + tallies + chaining on the device, a batch per 128 MiB window -> one Q line per read (M lines where blocks chain) formatted by a "
+                                                "team of threads and written into a file in /dev/shm by two more threads while the next window is parsed and queried (mgQueryPipe*); "
+                                                "host_parser: the same through mg_seqio.c and the 1-byte-per-base upload; unit of lines_per_s: million"}
         finally:
             if os.path.exists(rpath):
                 os.remove(rpath)
