@@ -1,3 +1,4 @@
+"""dev probe: a batch of identical k-mers through the direct (atomic) table path: time per call"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

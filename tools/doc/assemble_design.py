@@ -1,3 +1,5 @@
+"""DESIGN.md and DESIGN_EXPERIMENTS.md from tools/doc/parts/*.md, the numbers of section 5 filled in from a bench.py JSON line.
+usage: python tools/doc/assemble_design.py profiles/<round>_bench.json"""
 import json, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from reflow import reflow

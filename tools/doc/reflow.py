@@ -1,3 +1,4 @@
+"""paragraph reflow to 118 columns for the design documents (tables, code blocks and list structure kept)"""
 import textwrap, re, sys
 def reflow(lines, width=118):
     out=[]; code=False; cur=None  # cur = (lead, text)

@@ -1,3 +1,4 @@
+"""dev probe: the scan alone on poly-A reads (every start a modimizer): kernel time and the segment re-scan it triggers"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
