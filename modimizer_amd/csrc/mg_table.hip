@@ -1813,8 +1813,12 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
   /* slices of the ordinal range for the rank lookups: 2^sliceShift ordinals each (2^22: 1 MiB of rank records, and a
      bucket's share of a slice is usually shorter than a wave), at most MG_RANK_GROUPS - 1 of them */
-  { const int shEnv = mgKnobs ()->rankSliceShift == MG_KNOB_UNSET ? 22 : (int) mgKnobs ()->rankSliceShift;   /* dev knob */
-    a.sliceShift = shEnv;
+  { a.sliceShift = 22;
+    /* a batch much smaller than the headline's would be three or four slices -- and the lookup kernel gives a slice to an XCD, so half
+       the chip would idle (1 Gbp batches, as the file entry points make them: the rank lookups 0.31 ms of 1.39, with 2^18-ordinal slices
+       0.11 of 1.11): smaller slices until there are 32 of them */
+    while (a.sliceShift > 16 && ((n - 1) >> a.sliceShift) + 1 < 32) --a.sliceShift;
+    if (mgKnobs ()->rankSliceShift != MG_KNOB_UNSET) a.sliceShift = (int) mgKnobs ()->rankSliceShift;   /* dev knob */
     while (((n - 1) >> a.sliceShift) + 1 > (U64) (MG_RANK_GROUPS - 1)) ++a.sliceShift;
     a.nSlices = (U32) (((n - 1) >> a.sliceShift) + 1);
     a.sliceOff = sliceOff;
