@@ -729,6 +729,14 @@ static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
   const long gridKnob = mgKnobs ()->scanGrid;                 /* test knob: several tiles in a worker's range */
   const long maxBlocks = gridKnob != MG_KNOB_UNSET && gridKnob > 0 ? gridKnob : MG_SCAN_MAX_BLOCKS;
   U64 want = g.nTiles < (U64) maxBlocks ? g.nTiles : (U64) maxBlocks;
+  /* a batch below the headline's size: eight tiles a worker rather than a worker per tile or two, down to 8192 workers (the chip's wave
+     slots).  Every workgroup ends by adding its digit counts to the same few hundred words, and every segment is one more piece for
+     the kernels that walk them: 0.2 Gbp at a tile per worker -- scan 0.24 ms, step 0.70 -- against six tiles per worker -- 0.08, 0.46
+     (tools/size_sweep_probe.py) */
+  if (gridKnob == MG_KNOB_UNSET || gridKnob <= 0)
+    { U64 fewer = g.nTiles / 8; if (fewer < 8192) fewer = 8192;
+      if (want > fewer) want = fewer;
+    }
   if (!want) want = 1;
   g.tilesPerBlock = (g.nTiles + want - 1) / want; if (!g.tilesPerBlock) g.tilesPerBlock = 1;
   g.nBlocks = (U32) ((g.nTiles + g.tilesPerBlock - 1) / g.tilesPerBlock); if (!g.nBlocks) g.nBlocks = 1;
