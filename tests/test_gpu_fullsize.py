@@ -301,3 +301,16 @@ def test_config3_query_seeds_whole_at_full_size():
     r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), "c3q"],
                        capture_output=True, text=True, timeout=3000, env=dict(os.environ, PYTHONPATH=util.ROOT))
     assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("config,scale", [("c2", 0.004), ("c2", 0.03), ("c2", 0.1), ("c5", 0.2), ("refdef", 0.05)])
+def test_whole_arrays_at_sizes_between_the_small_tests_and_baseline(config, scale):
+    """The same whole-stream / whole-array comparison at batch sizes where the launch shapes change with the size (round 4): 40 Mbp
+    (0.6 M modimizers: the atomic path whatever the table), 0.3 Gbp (8192 scan workers of several tiles, rank-lookup slices of 2^17
+    ordinals), 1 Gbp (what the file entry points hand on: 30 000 workers, slices of 2^18), a fifth of config 5, a twentieth of the
+    reference-default run."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "fullsize_whole.py"), config, "auto"],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, PYTHONPATH=util.ROOT, MODGPU_FULLSIZE_SCALE=str(scale)))
+    assert r.returncode == 0 and "FULLSIZE_WHOLE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
