@@ -244,12 +244,7 @@ static int mgHostThreads (void)
   if (n) return n;
   const long kv = mgKnobs ()->packThreads;
   long v = kv != MG_KNOB_UNSET ? kv : 0;
-  if (v <= 0)
-    { v = sysconf (_SC_NPROCESSORS_ONLN);
-      cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
-      FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");                 /* a cgroup CPU quota caps what threads can get */
-      if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < v) v = c; } fclose (q); }
-    }
+  if (v <= 0) v = mgCpuBudget ();                                      /* (a cgroup CPU quota caps what threads can get) */
   if (kv == MG_KNOB_UNSET) v = v / 2;                                   /* measured (16-CPU quota): 8 packers keep the link busy, 16 starve the thread that issues the copies */
   if (v < 1) v = 1;
   if (v > 16) v = 16;

@@ -594,8 +594,7 @@ static void *fmtQM (void *v)
 static int fmtThreads (int nReads)
 {
   if (nReads < 20000) return 1;
-  long v = sysconf (_SC_NPROCESSORS_ONLN);
-  cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
+  long v = mgCpuBudget ();
   const long pk = mgKnobs ()->parseThreads; if (pk != MG_KNOB_UNSET && pk > 0) v = pk;
   if (v > 16) v = 16;
   if (v < 1) v = 1;

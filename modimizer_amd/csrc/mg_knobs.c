@@ -1,7 +1,11 @@
 /* mg_knobs.c — the library's environment knobs, read once (see mg_knobs.h) */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include "mg_knobs.h"
 
 static MgKnobs gKnobs;
@@ -44,3 +48,20 @@ static void readAll (void)
 
 const MgKnobs *mgKnobs (void) { pthread_once (&gOnce, readAll); return &gKnobs; }
 void mgReloadKnobs (void) { pthread_once (&gOnce, readAll); readAll (); }
+
+static int gCpuBudget;
+static pthread_once_t gCpuOnce = PTHREAD_ONCE_INIT;
+static void cpuBudgetOnce (void)
+{
+  long v = sysconf (_SC_NPROCESSORS_ONLN);
+  cpu_set_t set;
+  if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
+  FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");           /* "max 100000" or "<quota> <period>" */
+  if (q)
+    { char a[64]; long per = 0;
+      if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { const long c = (atol (a) + per - 1) / per; if (c < v) v = c; }
+      fclose (q);
+    }
+  gCpuBudget = v < 1 ? 1 : (int) v;
+}
+int mgCpuBudget (void) { pthread_once (&gCpuOnce, cpuBudgetOnce); return gCpuBudget; }

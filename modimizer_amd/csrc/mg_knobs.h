@@ -48,6 +48,9 @@ typedef struct {
 } MgKnobs;
 const MgKnobs *mgKnobs (void);
 void mgReloadKnobs (void);
+/* the CPUs this process may really use: what is online, cut down by the affinity mask and by a cgroup CPU quota (cpu.max) -- the
+   number the host-side thread teams size themselves by (worked out once) */
+int mgCpuBudget (void);
 #ifdef __cplusplus
 }
 #endif

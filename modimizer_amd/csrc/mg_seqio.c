@@ -127,14 +127,7 @@ static int threadCount (void)
 {
   const long pk = mgKnobs ()->parseThreads;
   const int e = pk != MG_KNOB_UNSET;
-  static long budget = 0;
-  if (!e && !budget)                                  /* the CPUs this process may really use: affinity mask and cgroup quota, not what is online */
-    { budget = sysconf (_SC_NPROCESSORS_ONLN);
-      cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < budget) budget = CPU_COUNT (&set);
-      FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");
-      if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < budget) budget = c; } fclose (q); }
-      if (budget < 1) budget = 1;
-    }
+  const long budget = mgCpuBudget ();                 /* the CPUs this process may really use: affinity mask and cgroup quota, not what is online */
   long n = e ? pk : budget;
   if (n < 1) n = 1;
   if (n > 32) n = 32;

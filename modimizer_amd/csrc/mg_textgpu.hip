@@ -623,12 +623,7 @@ static int txHostThreads (void)
 {
   const long pk = mgKnobs ()->parseThreads;
   long v = pk != MG_KNOB_UNSET ? pk : 0;
-  if (v <= 0)
-    { v = sysconf (_SC_NPROCESSORS_ONLN);
-      cpu_set_t set; if (sched_getaffinity (0, sizeof (set), &set) == 0 && CPU_COUNT (&set) < v) v = CPU_COUNT (&set);
-      FILE *q = fopen ("/sys/fs/cgroup/cpu.max", "r");
-      if (q) { char a[64]; long per = 0; if (fscanf (q, "%63s %ld", a, &per) == 2 && strcmp (a, "max") && per > 0) { long c = (atol (a) + per - 1) / per; if (c < v) v = c; } fclose (q); }
-    }
+  if (v <= 0) v = mgCpuBudget ();
   if (v < 1) v = 1;
   if (v > 32) v = 32;
   return (int) v;
