@@ -602,12 +602,11 @@ static int fmtThreads (int nReads)
 }
 
 #define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
-static double gFmtCpuMs;                                   /* (dev timing: CPU time of the formatting threads, one formatter at a time) */
 /* the lines of a batch whose tallies and blocks are on the host: formatted by a team of threads, each its range of the reads
    into its own buffer (piece[0 .. *nPieces)), and written in order.  (Positioned writes of the pieces by the team itself were tried:
    writes to one file take turns on its inode lock, 234 MB take the 40 ms one fwrite takes.) */
 static void queryFormatLines (const MgReference *ref, const MgChainQ *q, const MgChainM *m, const int64_t *offsets, int nReads, const char **names,
-                              FmtBuf piece[16], int *nPieces, double *ms)
+                              FmtBuf piece[16], int *nPieces, double *ms, double *cpuMs)
 {
   struct timespec c1, c2; clock_gettime (CLOCK_MONOTONIC, &c1);
   U64 *mStart = (U64 *) poolGet (((size_t) nReads + 1) * 8);
@@ -622,7 +621,7 @@ static void queryFormatLines (const MgReference *ref, const MgChainQ *q, const M
     }
   for (int t = 0 ; t < T ; ++t) if (!started[t]) fmtQM (&job[t]);
   for (int t = 0 ; t < T ; ++t) if (started[t]) pthread_join (th[t], 0);
-  for (int t = 0 ; t < T ; ++t) { piece[t] = job[t].out; gFmtCpuMs += job[t].cpuMs; }
+  for (int t = 0 ; t < T ; ++t) { piece[t] = job[t].out; if (cpuMs) *cpuMs += job[t].cpuMs; }
   *nPieces = T;
   poolPut (mStart);
   clock_gettime (CLOCK_MONOTONIC, &c2);
@@ -662,7 +661,7 @@ int mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
   else
     { double msF = 0, msW = 0;
       FmtBuf piece[16]; int nPieces = 0;
-      queryFormatLines (ref, q, m, offsets, nReads, names, piece, &nPieces, &msF);
+      queryFormatLines (ref, q, m, offsets, nReads, names, piece, &nPieces, &msF, 0);
       queryWritePieces (piece, nPieces, out, &msW);
       if (timing)
         fprintf (stderr, "mgQueryProcessDevice: %d reads: device (scan, lookups, chain, copies) %.1f ms, format %.1f ms (%d threads), write %.1f ms\n",
@@ -690,7 +689,7 @@ struct MgQueryPipe
   pthread_mutex_t mu; pthread_cond_t cv;
   MgQQueue toFormat, toWrite; int pending;                 /* batches anywhere between Push and the last fwrite */
   int closing;
-  double msDevice, msFormat, msWrite, msWait; int nBatches;
+  double msDevice, msFormat, msFormatCpu, msWrite, msWait; int nBatches;      /* (dev timing) */
 };
 
 /* page-locked blocks the device halves copy into: kept between calls like the parser's windows (page-locking 10 MB takes 2 ms),
@@ -751,7 +750,7 @@ static void *queryFormatter (void *v)
       if (!j) break;                                       /* closing, nothing left */
       const char **names = (const char **) poolGet (((size_t) j->nReads + 1) * sizeof (char *));
       for (int r = 0 ; r < j->nReads ; ++r) names[r] = j->idBytes + j->idOff[r];
-      queryFormatLines (p->ref, j->q, j->m, j->offsets, j->nReads, names, j->piece, &j->nPieces, &p->msFormat);
+      queryFormatLines (p->ref, j->q, j->m, j->offsets, j->nReads, names, j->piece, &j->nPieces, &p->msFormat, &p->msFormatCpu);
       poolPut (names);
       pipePinPut (j->q, j->pinQ); pipePinPut (j->offsets, j->pinOff); free (j->m); poolPut (j->idBytes); poolPut (j->idOff);
       j->q = 0; j->m = 0; j->offsets = 0; j->idBytes = 0; j->idOff = 0; j->pinQ = j->pinOff = 0;
@@ -864,8 +863,7 @@ void mgQueryPipeClose (MgQueryPipe *p)
   mgChainScratchKeep (0);
   if (mgKnobs ()->seedTiming == 1)
     fprintf (stderr, "mgQueryFile: %d batches: device halves %.1f ms, waiting for room in the queue %.1f + %.1f ms at the end; formatter %.1f ms (its threads' CPU time %.1f ms), writer %.1f ms\n",
-             p->nBatches, p->msDevice, p->msWait, MS_ (c0, c1), p->msFormat, gFmtCpuMs, p->msWrite);
-  gFmtCpuMs = 0;
+             p->nBatches, p->msDevice, p->msWait, MS_ (c0, c1), p->msFormat, p->msFormatCpu, p->msWrite);
   pthread_mutex_destroy (&p->mu); pthread_cond_destroy (&p->cv);
   free (p);
 }
