@@ -51,9 +51,9 @@ extern "C" MgStatus mgMemcpyD2H (void *dst, const void *src, size_t bytes, void 
 { if (bytes) MG_HIP (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream));
   MG_HIP (hipStreamSynchronize ((hipStream_t) stream)); return MG_OK; }
 /* page-locked host memory for the C callers' device-to-host copies (a copy into pageable memory goes through the runtime's staging
-   buffers at a few GB/s) */
+   buffers at a few GB/s); portable and mapped: the blocks are kept between calls, and the caller may have moved to another device */
 extern "C" void *mgPinnedAlloc (size_t bytes)
-{ void *p = 0; if (mgEnsureDevice () || hipHostMalloc (&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError (); return 0; } return p; }
+{ void *p = 0; if (mgEnsureDevice () || hipHostMalloc (&p, bytes ? bytes : 16, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void) hipGetLastError (); return 0; } return p; }
 extern "C" void mgPinnedFree (void *p) { if (p) (void) hipHostFree (p); }
 /* device memory to a page-locked block by a kernel that writes host memory, then a wait for the stream: megabytes copied by the
    copy engine take their turn behind a text window (128 MiB) that is on its way to the device at the same time, stores from a kernel

@@ -742,7 +742,7 @@ static bool txHeadersLaunch (TxBufs &t, const U64 *dSrc, size_t n, hipStream_t s
   if (n > t.hdrCap)
     { if (t.hHdr) (void) hipHostFree (t.hHdr);
       t.hHdr = 0; t.hdrCap = 0; t.dHdr = 0;
-      if (hipHostMalloc ((void **) &t.hHdr, (n + n / 4) * 8, hipHostMallocMapped) != hipSuccess
+      if (hipHostMalloc ((void **) &t.hHdr, (n + n / 4) * 8, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess
           || hipHostGetDevicePointer ((void **) &t.dHdr, t.hHdr, 0) != hipSuccess) return false;
       t.hdrCap = n + n / 4;
     }
