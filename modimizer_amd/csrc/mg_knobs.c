@@ -37,6 +37,7 @@ static void readAll (void)
   k.queryHostChain = num ("MODGPU_QUERY_HOST_CHAIN");
   k.iterHostBelow = num ("MODGPU_ITER_HOST_BELOW");
   k.segSlack = num ("MODGPU_SEG_SLACK");
+  k.partDigits = num ("MODGPU_PART_DIGITS");
   k.findBits = num ("MODGPU_FIND_BITS"); k.findSubpass = num ("MODGPU_FIND_WGS");
   k.scatterGrid = num ("MODGPU_SCATTER_GRID");     k.tableLoad = num ("MODGPU_TABLE_LOAD");
   k.packThreads = num ("MODGPU_PACK_THREADS");     k.parseThreads = num ("MODGPU_PARSE_THREADS");

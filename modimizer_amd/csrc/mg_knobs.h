@@ -39,6 +39,7 @@ typedef struct {
   long scatterGrid;        /* MODGPU_SCATTER_GRID */
   long segSlack;           /* MODGPU_SEG_SLACK: the scan's segment room as a multiple of the fair share (1..8, default 3) */
   long findSubpass;        /* MODGPU_FIND_WGS: dev, workgroups per XCD of the partitioned lookup */
+  long partDigits;         /* MODGPU_PART_DIGITS: 0 = the second partition pass counts its digits from the elements (8 bytes each) instead of from the digit bytes the first pass leaves beside them */
   long findBits;           /* MODGPU_FIND_BITS: bits of the partitioned lookup's digit (3..9) */
   long tableLoad;          /* MODGPU_TABLE_LOAD: per cent */
   long packThreads;        /* MODGPU_PACK_THREADS */

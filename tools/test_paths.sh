@@ -32,3 +32,7 @@ MODGPU_FIND_PATH=2 python tests/fuzz_gpu.py 20 150 2>&1 | tail -2
 echo "== MODGPU_RANK_SLICE_SHIFT=16 (the smallest rank-lookup slices, as many as the list groups allow)"
 MODGPU_RANK_SLICE_SHIFT=16 MODGPU_TABLE_PATH=bucket python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
 MODGPU_RANK_SLICE_SHIFT=16 MODGPU_TABLE_PATH=bucket python tests/fuzz_gpu.py 23 150 2>&1 | tail -2
+echo "== MODGPU_PART_DIGITS=0 (the second partition pass counts its digits from the elements, not from the first pass's digit bytes)"
+MODGPU_PART_DIGITS=0 MODGPU_TABLE_PATH=bucket python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
+MODGPU_PART_DIGITS=0 MODGPU_FIND_PATH=2 python -m pytest tests/test_gpu_modset.py tests/test_dropin.py -q -x -m gpu 2>&1 | tail -2
+MODGPU_PART_DIGITS=0 MODGPU_TABLE_PATH=bucket python tests/fuzz_gpu.py 29 150 2>&1 | tail -2
