@@ -168,8 +168,8 @@ def alg_bytes_table(total, S, entries, d, slots, k=21):
     return {
         "mgScanKernel": (0.25 + 8.0 / d) * total,    # 2-bit read + the 8-byte k-mer per modimizer (this path needs no pos)
         "mgSegCompactKernel": 16.0 * S,              # kmer read + written
-        "mgPartHistKernel": 8.0 * S,
-        "mgPartScatterKernel": (16.0 if packed else 24.0) * S,      # one 8-byte word (or k-mer 8 + ordinal 4) read and written, per pass
+        "mgPartHistKernel": 1.0 * S,               # (round 4) the second pass counts its digits from the bytes the first pass leaves: 1 byte per modimizer (8 before)
+        "mgPartScatterKernel": (16.5 if packed else 24.5) * S,      # one 8-byte word (or k-mer 8 + ordinal 4) read and written, per pass; the first of the two also writes a digit byte
         "mgBucketDedupKernel": (8.0 if packed else 12.0) * S + 16.0 * entries,
         "mgRankAssignKernel": 9.0 * S + 8.0 * entries,
         "mgRankLookupKernel": 8.0 * entries,         # a unique's ordinal read, its index written

@@ -8,7 +8,7 @@ random bucket probes) the raw figure is the one to use.  Both are printed; STREA
 profiles/traffic.json."""
 import csv, glob, os, sys, json, collections
 root = sys.argv[1]
-STREAMING = {"mgScanKernel", "mgSegCompactKernel", "mgPartHistKernel", "mgPartScatterKernel", "mgRankCountKernel",
+STREAMING = {"mgScanKernel", "mgSegCompactKernel", "mgPartHistKernel", "mgPartHistBytesKernel", "mgPartScatterKernel", "mgRankCountKernel",
              "mgSynthReadsKernel", "mgSynthGenomeKernel", "mgBucketFindKernel", "mgTableHistKernel", "mgTileInfoKernel", "mgPackKernel", "mgUnpackKernel"}
 def find(sub, pat):
     fs = glob.glob(os.path.join(root, sub, "**", pat), recursive=True)
