@@ -160,6 +160,7 @@ MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, U32 *dIndex
  * depth[] += device counts (modutils.c:26), and (when wantIndex) the open-addressed index[] table
  * rebuilt exactly as the reference's sequence of inserts would have left it (modset.c:51-57). */
 MgStatus modsetSyncToHost (Modset *ms, int wantIndex) ;
+int      mgXferThreadCount (void) ;         /* host threads that move whole arrays between the device and the Modset's own arrays (modsetSyncToHost, device rebuilds): the CPUs the process may use, at most 16; MODGPU_XFER_THREADS overrides */
 /* Drop the device table (host arrays untouched; pending device depth counts are synced first). */
 MgStatus mgModsetDeviceRelease (Modset *ms) ;
 /* Tell the library the caller changed ms->value/max/depth on the host behind its back. */

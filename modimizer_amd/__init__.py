@@ -69,7 +69,7 @@ EXPORTS = [
     "mgMemcpyH2D", "mgMemcpyD2H", "mgMemsetD", "mgStreamSynchronize",
     "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice", "mgUploadPack",
     "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch", "seqhashMinimizerBatchDevice", "seqhashMinimizerBatch",
-    "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgModsetDeviceRelease",
+    "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgXferThreadCount", "mgModsetDeviceRelease",
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
@@ -167,7 +167,7 @@ def lib():
     sig("seqhashMinimizerBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
     sig("modsetAddBatchDevice", i32, MS, vp, u64, vp, i32, vp)
     sig("modsetFindBatchDevice", i32, MS, vp, u64, vp, vp)
-    sig("modsetSyncToHost", i32, MS, i32); sig("mgModsetDeviceRelease", i32, MS)
+    sig("modsetSyncToHost", i32, MS, i32); sig("mgXferThreadCount", i32); sig("mgModsetDeviceRelease", i32, MS)
     sig("mgModsetHostChanged", None, MS)
     sig("modsetDepthHistogramDevice", i32, MS, vp, vp)
     sig("mgAddReadsDevice", i32, MS, vp, u64, vp, u32, U64P, vp)

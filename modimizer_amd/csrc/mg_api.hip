@@ -10,6 +10,7 @@
 #include <unordered_map>
 #include "mg_common.h"
 #include "mg_internal.h"
+#include "mg_xfer.h"
 
 /* ---------------------------------------------------------------------------------------- */
 /* errors / device                                                                            */
@@ -518,9 +519,11 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
   t.max = 0; t.syncedMax = 0;
   t.baseZero = !ms->max;
   if (ms->max)
-    { MG_HIP (hipMemcpyAsync (t.value, ms->value, ((size_t) ms->max + 1) * sizeof (U64), hipMemcpyHostToDevice, st));
-      MG_HIP (hipMemcpyAsync (t.baseDepth, ms->depth, ((size_t) ms->max + 1) * sizeof (U16), hipMemcpyHostToDevice, st));
-      MgStatus s = mgTableLoadHost (&t, t.value, 1, ms->max, st); if (s) return s;
+    { MG_HIP (hipStreamSynchronize (st));               /* (the memsets above: the team copies on streams of its own) */
+      MgStatus s;
+      if ((s = mgXferH2D (t.value, ms->value, ((size_t) ms->max + 1) * sizeof (U64)))) return s;
+      if ((s = mgXferH2D (t.baseDepth, ms->depth, ((size_t) ms->max + 1) * sizeof (U16)))) return s;
+      if ((s = mgTableLoadHost (&t, t.value, 1, ms->max, st))) return s;
       MG_HIP (hipStreamSynchronize (st));
       t.max = t.syncedMax = ms->max;
     }
@@ -611,10 +614,12 @@ static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
 {
   MgTable &t = d->t;
   if (!t.max) return MG_OK;
-  U16 *dDelta; MG_HIP (hipMalloc ((void **) &dDelta, (size_t) t.max * sizeof (U16)));
-  MgStatus s = mgTableExportDepth (&t, dDelta, st);
+  if (!t.pendingDepth) return MG_OK;                   /* nothing has counted since the last fold */
+  MgStatus s = d->arena.reserve (al256 ((size_t) t.max * sizeof (U16)) + 4096); if (s) return s;      /* (no call is using the arena while a whole-set pass runs) */
+  d->arena.reset ();
+  U16 *dDelta = (U16 *) d->arena.take ((size_t) t.max * sizeof (U16));
+  s = mgTableExportDepth (&t, dDelta, st);
   MG_HIP (hipStreamSynchronize (st));
-  (void) hipFree (dDelta);
   return s;
 }
 
@@ -634,9 +639,9 @@ extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
   do {
     if (hipMalloc ((void **) &dV2, (size_t) n2 * 8) || hipMalloc ((void **) &dD2, (size_t) n2 * 2) || hipMalloc ((void **) &dI2, n2)
         || hipMalloc ((void **) &dI1, cap1) || hipMalloc ((void **) &dIdx, (size_t) n2 * 4)) break;
-    if (hipMemcpy (dV2, ms2->value + 1, (size_t) n2 * 8, hipMemcpyHostToDevice) || hipMemcpy (dD2, ms2->depth + 1, (size_t) n2 * 2, hipMemcpyHostToDevice)
-        || hipMemcpy (dI2, ms2->info + 1, n2, hipMemcpyHostToDevice) || hipMemset (dI1, 0, cap1)
-        || hipMemcpy (dI1, ms1->info, (size_t) max1 + 1, hipMemcpyHostToDevice)) break;
+    if (hipMemset (dI1, 0, cap1) || hipDeviceSynchronize ()) break;
+    if (mgXferH2D (dV2, ms2->value + 1, (size_t) n2 * 8) || mgXferH2D (dD2, ms2->depth + 1, (size_t) n2 * 2)
+        || mgXferH2D (dI2, ms2->info + 1, n2) || mgXferH2D (dI1, ms1->info, (size_t) max1 + 1)) break;
     /* ms2's values in ms2 index order: existing ones are found, new ones get max1+1, max1+2, ... (modset.c:120) */
     MgStatus as = mgAddBatch (ms1, d, dV2, n2, dIdx, 0, false, st);
     if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }
@@ -646,11 +651,11 @@ extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
     if (hipStreamSynchronize (st)) break;
     /* bring the host mirror up to date wholesale: values of the new entries, all depths and info */
     if (t.max > t.syncedMax)
-      { if (hipMemcpy (ms1->value + t.syncedMax + 1, t.value + t.syncedMax + 1, (size_t) (t.max - t.syncedMax) * 8, hipMemcpyDeviceToHost)) break;
+      { if (mgXferD2H (ms1->value + t.syncedMax + 1, t.value + t.syncedMax + 1, (size_t) (t.max - t.syncedMax) * 8, MG_XFER_COPY)) break;
         t.syncedMax = t.max;
       }
-    if (hipMemcpy (ms1->depth, t.baseDepth, ((size_t) t.max + 1) * 2, hipMemcpyDeviceToHost)) break;
-    if (hipMemcpy (ms1->info, dI1, (size_t) t.max + 1, hipMemcpyDeviceToHost)) break;
+    if (mgXferD2H (ms1->depth, t.baseDepth, ((size_t) t.max + 1) * 2, MG_XFER_COPY)) break;
+    if (mgXferD2H (ms1->info, dI1, (size_t) t.max + 1, MG_XFER_COPY)) break;
     ms1->depth[0] = 0;
     ms1->max = t.max;
     rc = 0;
@@ -675,7 +680,7 @@ extern "C" int mgHookPruneDevice (Modset *ms, int lo, int hi)
   do {
     if (hipMalloc ((void **) &dInfo, (size_t) n + 1) || hipMalloc ((void **) &dNewInfo, (size_t) n + 2) || hipMalloc ((void **) &dNewValue, ((size_t) n + 2) * 8)
         || hipMalloc ((void **) &dNewDepth, ((size_t) n + 2) * 2) || hipMalloc (&scratch, mgTablePruneScratchBytes (n ? n : 1))) break;
-    if (hipMemcpy (dInfo, ms->info, (size_t) n + 1, hipMemcpyHostToDevice)) break;
+    if (mgXferH2D (dInfo, ms->info, (size_t) n + 1)) break;
     if (mgTablePrune (&t, dInfo, lo, hi, dNewValue, dNewDepth, dNewInfo, scratch, st)) break;
     U64 c[2];
     if (hipMemcpyAsync (c, t.counters, 16, hipMemcpyDeviceToHost, st) || hipStreamSynchronize (st)) break;
@@ -684,8 +689,8 @@ extern "C" int mgHookPruneDevice (Modset *ms, int lo, int hi)
     if (m)
       { t.baseZero = false; t.liveHistValid = false;
         if (hipMemcpy (t.value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToDevice) || hipMemcpy (t.baseDepth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToDevice)
-            || hipMemcpy (ms->value + 1, dNewValue + 1, (size_t) m * 8, hipMemcpyDeviceToHost) || hipMemcpy (ms->depth + 1, dNewDepth + 1, (size_t) m * 2, hipMemcpyDeviceToHost)
-            || hipMemcpy (ms->info + 1, dNewInfo + 1, m, hipMemcpyDeviceToHost)) break;
+            || mgXferD2H (ms->value + 1, dNewValue + 1, (size_t) m * 8, MG_XFER_COPY) || mgXferD2H (ms->depth + 1, dNewDepth + 1, (size_t) m * 2, MG_XFER_COPY)
+            || mgXferD2H (ms->info + 1, dNewInfo + 1, m, MG_XFER_COPY)) break;
       }
     if (n > m && hipMemset (t.baseDepth + m + 1, 0, (size_t) (n - m) * 2)) break;
     mgTableForget (&t, st);
@@ -802,39 +807,43 @@ extern "C" MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, 
   return mgTableFind (&d->t, dKmer, n, dIndexOut, st);
 }
 
+/* What the device holds and the host arrays do not yet: value[] of the entries past syncedMax, the pending depth counts, the
+ * index[] layout.  The callers read those arrays themselves (modset.h:17-28; modutils.c:26,69,186-198; modset.c:79-88), so this IS
+ * the last step of the path for them.  Everything moves through mg_xfer.hip's team (page-locked pieces, several copy streams, the
+ * final memcpy / saturating add spread over the host's threads); the device-side temporaries (the 16-bit counts, the replayed
+ * index[]) come out of the modset's grow-only arena, which no call is using while this one runs: nothing is allocated per call.
+ * The host's depth[] stays the authority (a caller may have bumped it directly, modutils.c:26): pending counts are ADDED to it,
+ * saturating -- the thread that empties a page-locked piece does that instead of a memcpy, at the same memory traffic. */
 extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
 {
   MgDev *d = mgDevLookup (ms);
   if (!d) return MG_OK;
   MgTable &t = d->t;
   hipStream_t st = 0;
+  MgStatus s;
   MG_HIP (hipDeviceSynchronize ());
   if (t.max > t.syncedMax)
-    { U32 first = t.syncedMax + 1;
-      MG_HIP (hipMemcpy (ms->value + first, t.value + first, (size_t) (t.max - first + 1) * sizeof (U64), hipMemcpyDeviceToHost));
+    { const U32 first = t.syncedMax + 1;
+      if ((s = mgXferD2H (ms->value + first, t.value + first, (size_t) (t.max - first + 1) * sizeof (U64), MG_XFER_COPY))) return s;
       t.syncedMax = t.max;
     }
   ms->max = t.max;
-  if (t.max)
+  if (t.max && t.pendingDepth)
     { /* depth[i] = min (65535, depth[i] + pending)   (modutils.c:26 applied `pending` times) */
-      U16 *dDelta; MG_HIP (hipMalloc ((void **) &dDelta, (size_t) t.max * sizeof (U16)));
-      MgStatus s = mgTableExportDepth (&t, dDelta, st);
-      U16 *h = (U16 *) malloc ((size_t) t.max * sizeof (U16));
-      hipError_t e = s ? hipSuccess : hipMemcpy (h, dDelta, (size_t) t.max * sizeof (U16), hipMemcpyDeviceToHost);
-      (void) hipFree (dDelta);
-      if (s) { free (h); return s; }
-      if (e != hipSuccess) { free (h); return mgHipFail (e, "depth D2H"); }
-      for (U32 i = 1 ; i <= t.max ; ++i)
-        { U32 v = (U32) ms->depth[i] + h[i - 1]; ms->depth[i] = (U16) (v > 0xffffu ? 0xffffu : v); }
-      free (h);
+      if ((s = d->arena.reserve (al256 ((size_t) t.max * sizeof (U16)) + 4096))) return s;
+      d->arena.reset ();
+      U16 *dDelta = (U16 *) d->arena.take ((size_t) t.max * sizeof (U16));
+      if ((s = mgTableExportDepth (&t, dDelta, st))) return s;
+      MG_HIP (hipStreamSynchronize (st));
+      if ((s = mgXferD2H (ms->depth + 1, dDelta, (size_t) t.max * sizeof (U16), MG_XFER_SATADD16))) return s;
     }
   if (wantIndex && d->hostIndexMax < t.max)
-    { U32 *dIndex; MG_HIP (hipMalloc ((void **) &dIndex, ms->tableSize * sizeof (U32)));
-      MgStatus s = mgTableReplayIndex (&t, mgMakeParams (ms->hasher), ms->tableBits, dIndex, st);
-      hipError_t e = s ? hipSuccess : hipMemcpy (ms->index, dIndex, ms->tableSize * sizeof (U32), hipMemcpyDeviceToHost);
-      (void) hipFree (dIndex);
-      if (s) return s;
-      if (e != hipSuccess) return mgHipFail (e, "index D2H");
+    { if ((s = d->arena.reserve (al256 (ms->tableSize * sizeof (U32)) + 4096))) return s;
+      d->arena.reset ();
+      U32 *dIndex = (U32 *) d->arena.take (ms->tableSize * sizeof (U32));
+      if ((s = mgTableReplayIndex (&t, mgMakeParams (ms->hasher), ms->tableBits, dIndex, st))) return s;
+      MG_HIP (hipStreamSynchronize (st));
+      if ((s = mgXferD2H (ms->index, dIndex, ms->tableSize * sizeof (U32), MG_XFER_COPY))) return s;
       d->hostIndexMax = t.max;
     }
   return MG_OK;
@@ -1237,6 +1246,7 @@ extern "C" void mgReleaseBuffers (void)
   mgQueryReleaseBuffers ();
   mgHostBatchRelease ();
   mgIterReleaseBuffers ();
+  mgXferReleaseBuffers ();
   std::lock_guard<std::mutex> g (gUp.lock);
   if (gUp.ready)
     { for (int i = 0 ; i < 2 ; ++i) { (void) hipEventDestroy (gUp.done[i]); (void) hipHostFree (gUp.pin[i]); gUp.pin[i] = 0; }

@@ -35,6 +35,24 @@ static void *xalloc (size_t n, int zero)
   return p;
 }
 
+/* the Modset arrays are hundreds of megabytes to gigabytes that the first sync from the device writes end to end: with 4 KiB pages
+   that is a page fault per 4 KiB (a million for a 4 GiB index[]), with transparent huge pages one per 2 MiB.  A hint, not a
+   requirement (the kernel's THP mode decides); the memory stays what malloc () / calloc () returned, free ()-able as the
+   reference's modsetDestroy frees it (modset.c:33-34). */
+#include <sys/mman.h>
+static void *xallocBig (size_t n, int zero)
+{
+  char *p = (char *) xalloc (n, zero);
+#ifdef MADV_HUGEPAGE
+  if (n >= ((size_t) 8 << 20))
+    { const size_t pg = 4096;
+      char *a = (char *) (((size_t) p + pg - 1) & ~(pg - 1)), *e = (char *) (((size_t) p + n) & ~(pg - 1));
+      if (e > a) (void) madvise (a, (size_t) (e - a), MADV_HUGEPAGE);
+    }
+#endif
+  return p;
+}
+
 /* ------------------------------ seqhash ------------------------------ */
 
 Seqhash *seqhashCreate (int k, int w, int seed)
@@ -275,12 +293,12 @@ Modset *modsetCreate (Seqhash *sh, int bits, U32 size)
   ms->tableBits = bits;
   ms->tableSize = (U64) 1 << bits;
   ms->tableMask = ms->tableSize - 1;
-  ms->index = (U32 *) xalloc (ms->tableSize * sizeof (U32), 1);
+  ms->index = (U32 *) xallocBig (ms->tableSize * sizeof (U32), 1);
   if (size >= (ms->tableSize >> 2)) die ("Modset size %u is too big for %d bits", size, bits);
   ms->size = size ? size : (U32) ((ms->tableSize >> 2) - 1);
-  ms->value = (U64 *) xalloc ((size_t) ms->size * sizeof (U64), 0);
-  ms->depth = (U16 *) xalloc ((size_t) ms->size * sizeof (U16), 1);
-  ms->info = (U8 *) xalloc ((size_t) ms->size, 1);
+  ms->value = (U64 *) xallocBig ((size_t) ms->size * sizeof (U64), 0);
+  ms->depth = (U16 *) xallocBig ((size_t) ms->size * sizeof (U16), 1);
+  ms->info = (U8 *) xallocBig ((size_t) ms->size, 1);
   return ms;
 }
 
