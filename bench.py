@@ -773,6 +773,12 @@ def bench_c3(cx, args, shard=None):
     ref_occ, ref_entries = n_seeds.value, ms.contents.max
     del s_idx, s_pos, s_rd
     torch.cuda.empty_cache()
+    ref_read = None
+    if not shard and os.environ.get("MODGPU_BENCH_C3_REFREAD", "1") == "1":
+        try:
+            ref_read = reference_read_whole(cx, genome, genome_bases, n_seq, seq_len, k, d, bits, ref_occ, ref_entries)
+        except Exception as e:
+            ref_read = {"error": str(e)[:300]}
 
     qcap = int(batch / d * 1.3) + (1 << 16)
     q_pos = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
@@ -827,7 +833,7 @@ def bench_c3(cx, args, shard=None):
                            "no data-path collective" % (world, n_seq, seq_len // 1_000_000, bits, ref_entries, n_batches, batch / 1e9),
                "value": round(job_bases / t_job / 1e9, 2), "unit": "Gbp/s", "n_gpus": world, "query_bases": job_bases, "seeds": job_seeds,
                "seed_hit_fraction": round(job_hits / max(job_seeds, 1), 4), "ms_each_batch_rank0": per,
-               "rank0_Gbp_per_s": round(tot_bases / t_query / 1e9, 2), "reference_build_s": round(t_ref, 3)}
+               "rank0_Gbp_per_s": round(tot_bases / t_query / 1e9, 2), "reference_insert_device_s": round(t_ref, 3)}
         L.modsetDestroy(ms)
         del genome, q_pos, q_rd
         torch.cuda.empty_cache()
@@ -837,7 +843,8 @@ def bench_c3(cx, args, shard=None):
                        % (n_seq, seq_len // 1_000_000, genome_bases / 1e9, bits, ref_occ, ref_entries, n_batches, batch / 1e9),
            "value": round(tot_bases / t_query / 1e9, 2), "unit": "Gbp/s", "ms_per_batch": round(t_query / n_batches * 1e3, 3),
            "ms_each_batch": per, "query_bases": tot_bases, "seeds": tot_seeds, "seed_hit_fraction": round(tot_hits / max(tot_seeds, 1), 4),
-           "reference_build_s": round(t_ref, 3), "reference_build_Gbp_per_s": round(genome_bases / t_ref / 1e9, 1),
+           "reference_insert_device_s": round(t_ref, 3), "reference_insert_device_Gbp_per_s": round(genome_bases / t_ref / 1e9, 1),
+           "reference_read": ref_read, "reference_read_s": (ref_read or {}).get("whole_call_s"),
            "whole_batch": {"bytes_per_base": 0.25 + 36.0 / d, "GBps": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9, 1),
                            "frac": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9 / HBM_PEAK_GBS, 4),
                            "note": "0.25 B/base read + per seed: 12 B written by the scan + 24 B lookup (kmer 8, one 16-byte slot, wait index 4 out)"},
@@ -847,6 +854,50 @@ def bench_c3(cx, args, shard=None):
     L.modsetDestroy(ms)
     del genome, q_pos, q_rd
     torch.cuda.empty_cache()
+    return res
+
+
+def reference_read_whole(cx, genome, genome_bases, n_seq, seq_len, k, d, bits, want_occ, want_entries):
+    """What `modmap -f` does with the reference (modmap.c:93-134 + 74-91), as ONE call from host bytes: mgReferenceRead = upload +
+    scan + insert + per-occurrence bookkeeping + copy classes + referencePack + every array back in the caller's Reference /
+    Modset (index, offset, id, depth, rev, loc, info, value).  `reference_insert_device_s` beside it is mgInsertReadsDevice alone."""
+    import numpy as np
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    d_bytes = torch.empty(genome_bases, dtype=torch.uint8, device=cx.dev)
+    mg.check(L.mgUnpackDevice(genome.data_ptr(), genome_bases, d_bytes.data_ptr(), cx.stream))
+    torch.cuda.synchronize()
+    h = d_bytes.cpu().numpy(); del d_bytes
+    torch.cuda.empty_cache()
+    off = (np.arange(n_seq + 1, dtype=np.int64) * seq_len)
+    names = (C.c_char_p * n_seq)(*[b"chr%d" % (i + 1) for i in range(n_seq)])
+    times = []
+    res = {}
+    for it in range(2):
+        sh = mg.seqhashCreate(k, d, 17); ms = mg.modsetCreate(sh, bits)
+        ref = L.mgReferenceCreate(ms, 1 << 26)
+        with mg.CFile(os.devnull, "w") as fo:
+            t0 = time.perf_counter()
+            rc = L.mgReferenceRead(ref, h.ctypes.data, off.ctypes.data, n_seq, names, True, fo)
+            times.append(time.perf_counter() - t0)
+        if rc:
+            raise RuntimeError("mgReferenceRead failed")
+        r = C.cast(ref, C.POINTER(mg.MgReference)).contents
+        n, m = r.max, ms.contents.max + 1
+        if it == 0:
+            rev = np.ctypeslib.as_array(r.rev, (n,)); loc = np.ctypeslib.as_array(r.loc, (m,)); ix = np.ctypeslib.as_array(r.index, (n,))
+            dep = np.ctypeslib.as_array(r.depth, (m,))
+            grouped = ix[rev]                                     # rev lists the occurrences index by index ...
+            ok = (n == want_occ and m - 1 == want_entries and bool(np.all(np.diff(grouped.astype(np.int64)) >= 0))
+                  and int(loc[-1]) + int(dep[-1]) == n and bool(np.array_equal(np.bincount(ix, minlength=m)[:m], dep)))
+            same = grouped[1:] == grouped[:-1]                    # ... and inside an index in occurrence order
+            ok = ok and bool(np.all(rev[1:][same] > rev[:-1][same]))
+            res["checks_ok"] = ok
+            del rev, loc, ix, dep, grouped, same
+        L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+    res.update({"entry": "mgReferenceRead", "whole_call_s": round(min(times), 4), "first_call_s": round(times[0], 4),
+                "Gbp_per_s": round(genome_bases / min(times) / 1e9, 2), "occurrences": want_occ, "modset_entries": want_entries,
+                "what": "host bytes (1 per base) -> pack + H2D -> scan + insert -> occurrences appended, copy classes, loc (exclusive scan), rev "
+                        "(stable radix sort by index) on the device -> index / offset / id / depth / rev / loc / info / value in the caller's arrays"})
     return res
 
 

@@ -79,27 +79,6 @@ void mgReferenceDestroy (MgReference *ref)
   free (ref->names); free (ref->len); free (ref);
 }
 
-/* modmap.c:74-91 */
-static void referencePack (MgReference *ref)
-{
-  Modset *ms = ref->ms;
-  U32 n = ref->max ? ref->max : 1, m = ms->max + 1;
-  ref->depth = (U32 *) realloc (ref->depth, (size_t) (m > ms->size ? m : ms->size) * sizeof (U32));
-  ref->index = (U32 *) realloc (ref->index, (size_t) n * sizeof (U32));
-  ref->offset = (U32 *) realloc (ref->offset, (size_t) n * sizeof (U32));
-  ref->id = (U32 *) realloc (ref->id, (size_t) n * sizeof (U32));
-  ref->size = ref->max;
-  ref->rev = (U32 *) malloc ((size_t) n * sizeof (U32));
-  ref->loc = (U32 *) malloc ((size_t) m * sizeof (U32));
-  ref->loc[0] = 0;
-  for (U32 i = 1 ; i < m ; ++i) ref->loc[i] = ref->loc[i - 1] + ref->depth[i - 1];
-  memset (ref->depth, 0, (size_t) m * sizeof (U32));
-  for (U32 i = 0 ; i < ref->max ; ++i)
-    { U32 ix = ref->index[i];
-      ref->rev[ref->loc[ix] + ref->depth[ix]++] = i;
-    }
-}
-
 /* the names and lengths of nSeq more sequences; the reference die()s on a duplicate name (modmap.c:102) */
 static void refRegister (MgReference *ref, const char **names, const int64_t *offsets, int nSeq)
 {
@@ -152,42 +131,40 @@ int mgReferenceAddDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
       if (s == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }   /* modset.c:58 */
       fatal ("reference scan");
     }
-  U32 *hIx = (U32 *) malloc ((size_t) (n + 1) * 4), *hPos = (U32 *) malloc ((size_t) (n + 1) * 4), *hRid = (U32 *) malloc ((size_t) (n + 1) * 4);
-  if (n && (mgMemcpyD2H (hIx, dIx, n * 4, 0) || mgMemcpyD2H (hPos, dPos, n * 4, 0) || mgMemcpyD2H (hRid, dRid, n * 4, 0))) fatal ("D2H");
+  /* modmap.c:110-117: the occurrences stay on the device (mg_refpack.hip), appended in order behind those of earlier batches */
+  U32 added = 0;
+  MgStatus as = mgRefBuildAppend (ref, (const U32 *) dIx, (const U32 *) dPos, (const U32 *) dRid, n, (U32) ref->nSeq, &added);
+  if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: reference size overflow\n"); exit (-1); }      /* modmap.c:111 */
+  if (as) fatal ("reference append");
+  ref->max += added;
   mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid);
-
-  U32 idBase = (U32) ref->nSeq;
-  for (U64 i = 0 ; i < n ; ++i)
-    { U32 ix = hIx[i];
-      if (!ix) continue;                                            /* modmap.c:110 */
-      if (ref->max + 1 >= ref->size) { fprintf (stderr, "FATAL ERROR: reference size overflow\n"); exit (-1); }
-      ref->index[ref->max] = ix;
-      ++ref->depth[ix];
-      ref->offset[ref->max] = hPos[i] & MG_POS_MASK;
-      ref->id[ref->max] = idBase + hRid[i];
-      ++ref->max;
-    }
-  free (hIx); free (hPos); free (hRid);
   ref->nSeq += nSeq;
   return 0;
 }
 
-/* modmap.c:120-133: the report of a file, the copy classes, the packed arrays */
+/* modmap.c:120-133: the report of a file, the copy classes, the packed arrays.  Classification, loc (exclusive sums) and rev (stable
+   sort of the occurrences by index) are made on the device from the occurrences it holds (mg_refpack.hip); the host's arrays -- sized
+   as referencePack sizes them (modmap.c:76-81) -- receive them in one piece each */
 void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out)
 {
   Modset *ms = ref->ms;
   fprintf (out, "  %d hashes from %d reference sequences, total length %lld\n", ref->max, ref->nSeq, (long long) totLen);
-  if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");       /* info[] is classified on the host arrays */
-  U32 n1 = 0, n2 = 0, nM = 0;
-  for (U32 i = 1 ; i <= ms->max ; ++i)                             /* modmap.c:125-129 */
-    { U32 dp = ref->depth[i];
-      if (dp == 1) { ms->info[i] = (U8) ((ms->info[i] & 0xfc) | 1); ++n1; }
-      else if (dp == 2) { ms->info[i] = (U8) ((ms->info[i] & 0xfc) | 2); ++n2; }
-      else { ms->info[i] |= 3; ++nM; }
-    }
-  fprintf (out, "  %d copy 1, %d copy 2, %d multiple\n", n1, n2, nM);
+  if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");       /* value[] of the new entries */
+  const U32 n = ref->max ? ref->max : 1, m = ms->max + 1;
+  free (ref->index); free (ref->offset); free (ref->id); free (ref->depth); free (ref->rev); free (ref->loc);   /* (nothing was written into them: the occurrences are on the device) */
+  ref->index = (U32 *) mgAllocBig ((size_t) n * sizeof (U32));
+  ref->offset = (U32 *) mgAllocBig ((size_t) n * sizeof (U32));
+  ref->id = (U32 *) mgAllocBig ((size_t) n * sizeof (U32));
+  ref->rev = (U32 *) mgAllocBig ((size_t) n * sizeof (U32));
+  ref->depth = (U32 *) mgAllocBig ((size_t) (m > ms->size ? m : ms->size) * sizeof (U32));
+  ref->loc = (U32 *) mgAllocBig ((size_t) m * sizeof (U32));
+  if (!ref->index || !ref->offset || !ref->id || !ref->rev || !ref->depth || !ref->loc) { fprintf (stderr, "FATAL ERROR: out of memory\n"); exit (-1); }
+  ref->size = ref->max;
+  U32 tal[3];
+  if (mgRefBuildFinish (ref, ref->index, ref->offset, ref->id, ref->depth, ref->rev, ref->loc, ms->info, tal)) fatal ("reference pack");
+  if ((size_t) ms->size > (size_t) m) memset (ref->depth + m, 0, ((size_t) ms->size - m) * sizeof (U32));      /* (the reference's resize keeps ms->size zeroed entries when the set is not packed) */
+  fprintf (out, "  %d copy 1, %d copy 2, %d multiple\n", tal[0], tal[1], tal[2]);
   if (isAdd) modsetPack (ms);
-  referencePack (ref);
 }
 
 int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,

@@ -21,48 +21,8 @@
 #include <unordered_map>
 #include "mg_common.h"
 #include "mg_internal.h"
-
-struct MgRefDev { U8 *info; U32 *loc, *rev, *id, *offset; U32 msMax, refMax; };
-
-static std::mutex gRefLock;
-static std::unordered_map<const MgReference *, MgRefDev> gRefDev;
-
-static void mgRefDevFree (MgRefDev &d)
-{ (void) hipFree (d.info); (void) hipFree (d.loc); (void) hipFree (d.rev); (void) hipFree (d.id); (void) hipFree (d.offset); d = MgRefDev (); }
-
-extern "C" void mgChainForget (const MgReference *ref)
-{
-  std::lock_guard<std::mutex> g (gRefLock);
-  auto it = gRefDev.find (ref);
-  if (it != gRefDev.end ()) { mgRefDevFree (it->second); gRefDev.erase (it); }
-}
-
-/* device copies of what the chaining reads; rebuilt when the reference or its modset has grown */
-static MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
-{
-  std::lock_guard<std::mutex> g (gRefLock);
-  MgRefDev &d = gRefDev[ref];
-  const U32 msMax = ref->ms->max, refMax = ref->max;
-  if (d.info && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
-  mgRefDevFree (d);
-  const size_t m = (size_t) msMax + 1, n = refMax ? refMax : 1;
-  MG_HIP (hipMalloc ((void **) &d.info, m));
-  MG_HIP (hipMalloc ((void **) &d.loc, m * 4));
-  MG_HIP (hipMalloc ((void **) &d.rev, (n + 1) * 4));
-  MG_HIP (hipMalloc ((void **) &d.id, n * 4));
-  MG_HIP (hipMalloc ((void **) &d.offset, n * 4));
-  MG_HIP (hipMemcpy (d.info, ref->ms->info, m, hipMemcpyHostToDevice));
-  MG_HIP (hipMemcpy (d.loc, ref->loc, m * 4, hipMemcpyHostToDevice));
-  MG_HIP (hipMemset (d.rev, 0, (n + 1) * 4));
-  if (refMax)
-    { MG_HIP (hipMemcpy (d.rev, ref->rev, (size_t) refMax * 4, hipMemcpyHostToDevice));
-      MG_HIP (hipMemcpy (d.id, ref->id, (size_t) refMax * 4, hipMemcpyHostToDevice));
-      MG_HIP (hipMemcpy (d.offset, ref->offset, (size_t) refMax * 4, hipMemcpyHostToDevice));
-    }
-  d.msMax = msMax; d.refMax = refMax;
-  *out = d;
-  return MG_OK;
-}
+#include "mg_xfer.h"
+#include "mg_ref.h"
 
 /* seedStart[r] = first seed of read r (seeds are in read order); seedStart[nReads] = nSeeds */
 __global__ void mgSeedStartKernel (const U32 *__restrict__ seedRead, U64 nSeeds, U32 nReads, U64 *__restrict__ seedStart)
@@ -147,32 +107,41 @@ void mgChainCompactKernel (const MgChainQ *__restrict__ q, const MgChainM *__res
 
 /* the device arrays of a query batch.  A call allocates and frees them; a caller with many batches in a row (mgQueryFile: one per
    window of the file) keeps them between its calls (mgChainScratchKeep): ten allocations and frees a batch are milliseconds.  What
-   such a caller leaves stays allocated, like the text parser's windows, until mgReleaseBuffers () or a call that does not keep. */
+   such a caller leaves stays allocated, like the text parser's windows, until mgReleaseBuffers () or a call that does not keep.
+   The scratch belongs to the calling HOST THREAD and to the device it was allocated on (like the iterator's scratch, mg_api.hip): a
+   thread that has moved to another GPU (mgSetDevice) drops it and starts again there, two threads driving two GPUs share nothing
+   and do not wait for each other, and a thread that ends gives its blocks back. */
 enum { CS_IX, CS_POS, CS_RID, CS_START, CS_Q, CS_M, CS_OV, CS_MC, CS_N };
-static struct { void *p[CS_N]; size_t cap[CS_N]; int keep; } gCs;
-static std::mutex gCsLock;
+static bool gChainAlive = true;                            /* false once the library is being unloaded: thread-local destructors that run after that leave HIP alone */
+__attribute__ ((destructor)) static void mgChainDown (void) { gChainAlive = false; }
+struct MgChainScratch
+{ void *p[CS_N] = { 0 }; size_t cap[CS_N] = { 0 }; int keep = 0; int dev = -1;
+  void drop (int i) { if (p[i]) (void) hipFree (p[i]); p[i] = 0; cap[i] = 0; }
+  void dropAll () { for (int i = 0 ; i < CS_N ; ++i) drop (i); dev = -1; }
+  ~MgChainScratch () { if (gChainAlive) dropAll (); }
+};
+static thread_local MgChainScratch gCs;
+static int csPrepare (void)                                /* the scratch on the calling thread's current device */
+{
+  int dev = 0;
+  if (hipGetDevice (&dev) != hipSuccess) return -1;
+  if (gCs.dev >= 0 && gCs.dev != dev) gCs.dropAll ();
+  gCs.dev = dev;
+  return 0;
+}
 static void *csGet (int i, size_t bytes)
 {
   if (gCs.cap[i] < bytes)
-    { (void) hipFree (gCs.p[i]); gCs.p[i] = 0; gCs.cap[i] = 0;
+    { gCs.drop (i);
       const size_t want = gCs.keep ? bytes + bytes / 4 : bytes;
       if (hipMalloc (&gCs.p[i], want) != hipSuccess) return 0;
       gCs.cap[i] = want;
     }
   return gCs.p[i];
 }
-static void csDrop (int i) { (void) hipFree (gCs.p[i]); gCs.p[i] = 0; gCs.cap[i] = 0; }
-static void csDropAll (void) { for (int i = 0 ; i < CS_N ; ++i) csDrop (i); }
-extern "C" void mgChainScratchKeep (int on)               /* (what a keeper leaves stays for the next one: mgReleaseBuffers () frees it) */
-{
-  std::lock_guard<std::mutex> g (gCsLock);
-  if (on) ++gCs.keep; else if (gCs.keep) --gCs.keep;
-}
-extern "C" void mgChainReleaseBuffers (void)
-{
-  std::lock_guard<std::mutex> g (gCsLock);
-  if (!gCs.keep) csDropAll ();
-}
+extern "C" void mgChainScratchKeep (int on)               /* (what a keeper leaves stays for the thread's next one: mgReleaseBuffers () frees it) */
+{ if (on) ++gCs.keep; else if (gCs.keep) --gCs.keep; }
+extern "C" void mgChainReleaseBuffers (void) { if (!gCs.keep) gCs.dropAll (); }
 
 /* Q tallies and M blocks of every read of a device-resident batch.  hQ[nReads] is filled here; *hMOut is a malloc ()ed array
  * of all reads' blocks in read order (read r's are the next min (hQ[r].nM, maxM) entries), 0 when there is none; returns 1 if
@@ -185,7 +154,7 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
   MgRefDev d;
   if (mgRefDevGet (ref, &d)) return -1;
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
-  std::lock_guard<std::mutex> g (gCsLock);
+  if (csPrepare ()) { mgSetError ("query chaining: no current device"); return -1; }
   U32 *dIx = 0, *dPos = 0, *dRid = 0; U64 *dStart = 0; MgChainQ *dQ = 0; MgChainM *dM = 0, *dMc = 0; U32 *dOv = 0;
   U64 n = 0;
   int rc = -1;
@@ -234,7 +203,7 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
       }
     rc = ov ? 1 : 0;
   } while (0);
-  if (!gCs.keep) csDropAll ();
+  if (!gCs.keep) gCs.dropAll ();
   if (rc < 0 && !mgLastError ()[0]) mgSetError ("query chaining on the device failed");
   return rc;
 }

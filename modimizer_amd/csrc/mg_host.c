@@ -35,23 +35,9 @@ static void *xalloc (size_t n, int zero)
   return p;
 }
 
-/* the Modset arrays are hundreds of megabytes to gigabytes that the first sync from the device writes end to end: with 4 KiB pages
-   that is a page fault per 4 KiB (a million for a 4 GiB index[]), with transparent huge pages one per 2 MiB.  A hint, not a
-   requirement (the kernel's THP mode decides); the memory stays what malloc () / calloc () returned, free ()-able as the
-   reference's modsetDestroy frees it (modset.c:33-34). */
-#include <sys/mman.h>
-static void *xallocBig (size_t n, int zero)
-{
-  char *p = (char *) xalloc (n, zero);
-#ifdef MADV_HUGEPAGE
-  if (n >= ((size_t) 8 << 20))
-    { const size_t pg = 4096;
-      char *a = (char *) (((size_t) p + pg - 1) & ~(pg - 1)), *e = (char *) (((size_t) p + n) & ~(pg - 1));
-      if (e > a) (void) madvise (a, (size_t) (e - a), MADV_HUGEPAGE);
-    }
-#endif
-  return p;
-}
+/* the Modset arrays are what the first sync from the device writes end to end: ask for huge pages (mg_knobs.c mgHugeHint); the memory
+   stays what malloc () / calloc () returned, free ()-able as the reference's modsetDestroy frees it (modset.c:33-34) */
+static void *xallocBig (size_t n, int zero) { void *p = xalloc (n, zero); mgHugeHint (p, n); return p; }
 
 /* ------------------------------ seqhash ------------------------------ */
 
@@ -308,16 +294,19 @@ void modsetDestroy (Modset *ms)
   free (ms->index); free (ms->value); free (ms->depth); free (ms->info); free (ms);
 }
 
+/* the reference's resize (utils.h): new arrays of newSize entries holding the first min (size, newSize) old ones, the rest of depth / info
+   zero.  realloc () does it without touching what is kept (a block of this size shrinks or grows by remapping pages). */
 static void regrow (Modset *ms, U32 newSize)
 {
-  U32 keep = ms->size < newSize ? ms->size : newSize;
-  U64 *v = (U64 *) xalloc ((size_t) newSize * sizeof (U64), 0);
-  U16 *d = (U16 *) xalloc ((size_t) newSize * sizeof (U16), 1);
-  U8 *f = (U8 *) xalloc ((size_t) newSize, 1);
-  memcpy (v, ms->value, (size_t) keep * sizeof (U64));
-  memcpy (d, ms->depth, (size_t) keep * sizeof (U16));
-  memcpy (f, ms->info, (size_t) keep);
-  free (ms->value); free (ms->depth); free (ms->info);
+  const U32 keep = ms->size < newSize ? ms->size : newSize;
+  U64 *v = (U64 *) realloc (ms->value, (size_t) (newSize ? newSize : 1) * sizeof (U64));
+  U16 *d = (U16 *) realloc (ms->depth, (size_t) (newSize ? newSize : 1) * sizeof (U16));
+  U8 *f = (U8 *) realloc (ms->info, (size_t) (newSize ? newSize : 1));
+  if (!v || !d || !f) die ("memory allocation failure requesting %llu bytes", (unsigned long long) newSize * 11);
+  if (newSize > keep)
+    { memset (d + keep, 0, (size_t) (newSize - keep) * sizeof (U16));
+      memset (f + keep, 0, (size_t) (newSize - keep));
+    }
   ms->value = v; ms->depth = d; ms->info = f; ms->size = newSize;
 }
 

@@ -52,6 +52,9 @@ typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChai
 MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
                                    MgChainQ *hQ, MgChainM **hMOut, U32 maxM, int hQPinned);
 MG_HIDDEN void mgChainForget (const MgReference *ref);
+/* the Reference built on the device (mg_refpack.hip): a batch's seeds appended (modmap.c:110-117), then copy classes + referencePack (modmap.c:125-129,74-91) into the caller's arrays */
+MG_HIDDEN MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U32 *dPosF, const U32 *dRid, U64 n, U32 idBase, U32 *appended);
+MG_HIDDEN MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffset, U32 *hId, U32 *hDepth, U32 *hRev, U32 *hLoc, U8 *hInfo, U32 tallies[3]);
 MG_HIDDEN void *mgPinnedAlloc (size_t bytes);          /* page-locked host memory (0: none to be had) */
 MG_HIDDEN void mgPinnedFree (void *p);
 MG_HIDDEN MgStatus mgCopyOutPinned (void *dstPinned, const void *srcDev, size_t bytes, void *stream);   /* device -> page-locked block by a kernel (not the copy engine), waited for */

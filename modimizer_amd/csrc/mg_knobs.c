@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include "mg_knobs.h"
 
 static MgKnobs gKnobs;
@@ -67,3 +68,20 @@ static void cpuBudgetOnce (void)
   gCpuBudget = v < 1 ? 1 : (int) v;
 }
 int mgCpuBudget (void) { pthread_once (&gCpuOnce, cpuBudgetOnce); return gCpuBudget; }
+
+/* arrays of hundreds of megabytes that a transfer from the device writes end to end: with 4 KiB pages that is a page fault per
+   4 KiB (a million for a 4 GiB index[]), with transparent huge pages one per 2 MiB.  A hint, not a requirement (the kernel's THP
+   mode decides); the memory stays what malloc () returned, free ()-able as the reference's callers free it. */
+void mgHugeHint (void *p, size_t n)
+{
+#ifdef MADV_HUGEPAGE
+  if (p && n >= ((size_t) 8 << 20))
+    { const size_t pg = 4096;
+      char *a = (char *) (((size_t) p + pg - 1) & ~(pg - 1)), *e = (char *) (((size_t) p + n) & ~(pg - 1));
+      if (e > a) (void) madvise (a, (size_t) (e - a), MADV_HUGEPAGE);
+    }
+#else
+  (void) p; (void) n;
+#endif
+}
+void *mgAllocBig (size_t n) { void *p = malloc (n ? n : 1); mgHugeHint (p, n); return p; }

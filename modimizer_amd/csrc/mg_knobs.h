@@ -53,6 +53,9 @@ void mgReloadKnobs (void);
 /* the CPUs this process may really use: what is online, cut down by the affinity mask and by a cgroup CPU quota (cpu.max) -- the
    number the host-side thread teams size themselves by (worked out once) */
 int mgCpuBudget (void);
+#include <stddef.h>
+void mgHugeHint (void *p, size_t n);      /* madvise (MADV_HUGEPAGE) on the whole pages of a large malloc ()ed block */
+void *mgAllocBig (size_t n);              /* malloc () + that hint */
 #ifdef __cplusplus
 }
 #endif

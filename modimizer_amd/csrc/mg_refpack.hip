@@ -1,0 +1,402 @@
+/* mg_refpack.hip — modmap's Reference built on the device: the bookkeeping of referenceFastaRead
+ * (modmap.c:106-118: per occurrence index / offset / id, ++depth[index]), the copy classes (modmap.c:125-129) and
+ * referencePack (modmap.c:74-91: loc = exclusive sums of depth, rev = the occurrences grouped by modset index, in
+ * occurrence order inside an index).
+ *
+ * The seeds of a batch -- (index, pos, sequence) per modimizer, in (sequence, pos) order -- are dense on the device when
+ * mgInsertReadsDevice / mgQueryReadsDevice return.  They stay there:
+ *   append    ordered compaction of the seeds with index != 0 (modmap.c:110) behind what the reference holds already,
+ *             pos masked, id = first id of the batch + sequence ordinal, depth counted with atomics (a count: order free);
+ *   finish    info[] classified from depth (one pass, the three tallies reduced per workgroup); loc[] by a device-wide
+ *             exclusive scan; rev[] by a STABLE least-significant-digit radix sort of (index, occurrence ordinal), 8 bits a pass:
+ *             stability is what keeps the occurrences of one index in occurrence order, which modmap.c:86-90 produces by
+ *             walking the occurrences in order and queryProcess relies on (rev[loc[x]] is the FIRST occurrence, rev[loc[x] + 1]
+ *             the second: modmap.c:219-221,242-254).  Ranks inside a tile come from wave-level matching (8 ballots give every
+ *             lane the set of lanes that hold its digit), so a reference that is one k-mer a million times over sorts at the
+ *             speed of any other;
+ *   mirror    the six arrays go back to the host's Reference in one piece each (mg_xfer.hip), and the device copies of info / loc /
+ *             rev / id / offset stay resident: they are what mg_chain.hip's chaining kernel reads -- no re-upload.
+ * A Reference whose arrays came from a file (mgReferenceLoad) or were written by the host is uploaded as before.
+ */
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <unordered_map>
+#include "mg_common.h"
+#include "mg_internal.h"
+#include "mg_xfer.h"
+#include "mg_ref.h"
+
+static std::mutex gRefLock;
+static std::unordered_map<const MgReference *, MgRefDev> gRefDev;
+
+static void mgRefDevFree (MgRefDev &d)
+{ (void) hipFree (d.info); (void) hipFree (d.loc); (void) hipFree (d.rev); (void) hipFree (d.id); (void) hipFree (d.offset);
+  (void) hipFree (d.index); (void) hipFree (d.depth); d = MgRefDev ();
+}
+
+extern "C" void mgChainForget (const MgReference *ref)
+{
+  std::lock_guard<std::mutex> g (gRefLock);
+  auto it = gRefDev.find (ref);
+  if (it != gRefDev.end ()) { mgRefDevFree (it->second); gRefDev.erase (it); }
+}
+
+/* device copies of what the chaining reads: the ones the builder left, or uploaded from the host arrays (a Reference read from a
+   file, or one whose modset has grown since) */
+MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
+{
+  std::lock_guard<std::mutex> g (gRefLock);
+  MgRefDev &d = gRefDev[ref];
+  const U32 msMax = ref->ms->max, refMax = ref->max;
+  if (d.info && d.packed && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
+  mgRefDevFree (d);
+  const size_t m = (size_t) msMax + 1, n = refMax ? refMax : 1;
+  MG_HIP (hipMalloc ((void **) &d.info, m));
+  MG_HIP (hipMalloc ((void **) &d.loc, m * 4));
+  MG_HIP (hipMalloc ((void **) &d.rev, (n + 1) * 4));
+  MG_HIP (hipMalloc ((void **) &d.id, n * 4));
+  MG_HIP (hipMalloc ((void **) &d.offset, n * 4));
+  MG_HIP (hipMemset (d.rev, 0, (n + 1) * 4));
+  MG_HIP (hipDeviceSynchronize ());
+  MgStatus s;
+  if ((s = mgXferH2D (d.info, ref->ms->info, m)) || (s = mgXferH2D (d.loc, ref->loc, m * 4))) return s;
+  if (refMax && ((s = mgXferH2D (d.rev, ref->rev, (size_t) refMax * 4)) || (s = mgXferH2D (d.id, ref->id, (size_t) refMax * 4))
+                 || (s = mgXferH2D (d.offset, ref->offset, (size_t) refMax * 4)))) return s;
+  d.msMax = msMax; d.refMax = refMax; d.packed = true;
+  *out = d;
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* device-wide exclusive scan of U32 (sums stay below 2^32: they count occurrences)           */
+
+#define MG_SCAN_TILE 4096          /* 256 threads x 16 */
+__global__ __launch_bounds__ (256)
+void mgRefTileSumKernel (const U32 *__restrict__ in, U64 n, U32 *__restrict__ tileSum)
+{
+  __shared__ U32 sW[4];
+  const U64 base = (U64) blockIdx.x * MG_SCAN_TILE;
+  U32 s = 0;
+  for (int j = 0 ; j < 16 ; ++j) { const U64 i = base + (U64) j * 256 + threadIdx.x; if (i < n) s += in[i]; }
+  for (int o = 32 ; o ; o >>= 1) s += __shfl_down (s, o);
+  if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = s;
+  __syncthreads ();
+  if (!threadIdx.x) tileSum[blockIdx.x] = sW[0] + sW[1] + sW[2] + sW[3];
+}
+/* one workgroup: a[0 .. n) exclusive in place, a[n] = the total */
+__global__ __launch_bounds__ (1024)
+void mgRefScanSmallKernel (U32 *__restrict__ a, U32 n)
+{
+  __shared__ U32 sPart[1024];
+  const int tid = threadIdx.x;
+  const U32 per = (n + 1023) / 1024;
+  U32 sum = 0;
+  for (U32 i = 0 ; i < per ; ++i) { const U32 j = tid * per + i; if (j < n) sum += a[j]; }
+  sPart[tid] = sum;
+  __syncthreads ();
+  for (int off = 1 ; off < 1024 ; off <<= 1)
+    { const U32 v = tid >= off ? sPart[tid - off] : 0;
+      __syncthreads ();
+      sPart[tid] += v;
+      __syncthreads ();
+    }
+  U32 run = sPart[tid] - sum;
+  for (U32 i = 0 ; i < per ; ++i) { const U32 j = tid * per + i; if (j < n) { const U32 c = a[j]; a[j] = run; run += c; } }
+  if (tid == 1023) a[n] = sPart[1023];
+}
+__global__ __launch_bounds__ (256)
+void mgRefTileScanKernel (const U32 *__restrict__ in, U64 n, const U32 *__restrict__ tileBase, U32 *__restrict__ out)
+{
+  __shared__ U32 sT[256];
+  const U64 base = (U64) blockIdx.x * MG_SCAN_TILE + (U64) threadIdx.x * 16;      /* a thread's 16 items are consecutive */
+  U32 v[16]; U32 s = 0;
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j) { v[j] = base + j < n ? in[base + j] : 0u; s += v[j]; }
+  sT[threadIdx.x] = s;
+  __syncthreads ();
+  for (int off = 1 ; off < 256 ; off <<= 1)
+    { const U32 x = (int) threadIdx.x >= off ? sT[threadIdx.x - off] : 0;
+      __syncthreads ();
+      sT[threadIdx.x] += x;
+      __syncthreads ();
+    }
+  U32 run = tileBase[blockIdx.x] + sT[threadIdx.x] - s;
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j) { if (base + j < n) out[base + j] = run; run += v[j]; }
+}
+/* out[i] = sum of in[0 .. i) for i < n (in == out allowed); tiles: (n / 4096 + 2) words of scratch; the total is left in tiles[nTiles] */
+static MgStatus mgRefExclusiveScan (const U32 *in, U32 *out, U64 n, U32 *tiles, hipStream_t st)
+{
+  if (!n) return MG_OK;
+  const U32 nTiles = (U32) ((n + MG_SCAN_TILE - 1) / MG_SCAN_TILE);
+  hipLaunchKernelGGL (mgRefTileSumKernel, dim3 (nTiles), dim3 (256), 0, st, in, n, tiles);
+  hipLaunchKernelGGL (mgRefScanSmallKernel, dim3 (1), dim3 (1024), 0, st, tiles, nTiles);
+  hipLaunchKernelGGL (mgRefTileScanKernel, dim3 (nTiles), dim3 (256), 0, st, in, n, tiles, out);
+  MG_HIP (hipGetLastError ());
+  return MG_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* append: modmap.c:110-117 for a batch of seeds                                              */
+
+__global__ __launch_bounds__ (256)
+void mgRefCountHitsKernel (const U32 *__restrict__ ix, U64 n, U32 *__restrict__ tileCount)
+{
+  __shared__ U32 sW[4];
+  const U64 base = (U64) blockIdx.x * MG_SCAN_TILE;
+  U32 s = 0;
+  for (int j = 0 ; j < 16 ; ++j) { const U64 i = base + (U64) j * 256 + threadIdx.x; if (i < n && ix[i]) ++s; }
+  for (int o = 32 ; o ; o >>= 1) s += __shfl_down (s, o);
+  if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = s;
+  __syncthreads ();
+  if (!threadIdx.x) tileCount[blockIdx.x] = sW[0] + sW[1] + sW[2] + sW[3];
+}
+/* tile b's hits go to at0 + tileBase[b] .. in order: inside the tile a wave takes 64 consecutive seeds at a time (ballot + popcount),
+   the four waves one after the other over the tile's 16 rows of 256 */
+__global__ __launch_bounds__ (256)
+void mgRefAppendKernel (const U32 *__restrict__ ix, const U32 *__restrict__ posF, const U32 *__restrict__ rid, U64 n, const U32 *__restrict__ tileBase,
+                        U32 at0, U32 idBase, U32 *__restrict__ index, U32 *__restrict__ offset, U32 *__restrict__ id, U32 *__restrict__ depth)
+{
+  __shared__ U32 sRow[64];                                         /* hits per (row of 256, wave): 16 x 4 */
+  const U64 base = (U64) blockIdx.x * MG_SCAN_TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  U32 x[16];
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j)
+    { const U64 i = base + (U64) j * 256 + threadIdx.x;
+      x[j] = i < n ? ix[i] : 0u;
+      const U64 b = __ballot (x[j] != 0);
+      if (!lane) sRow[j * 4 + w] = (U32) __popcll (b);
+    }
+  __syncthreads ();
+  if (threadIdx.x == 0) { U32 run = 0; for (int q = 0 ; q < 64 ; ++q) { const U32 c = sRow[q]; sRow[q] = run; run += c; } }
+  __syncthreads ();
+  const U32 tb = at0 + tileBase[blockIdx.x];
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j)
+    { const U64 i = base + (U64) j * 256 + threadIdx.x;
+      const U64 b = __ballot (x[j] != 0);
+      if (x[j])
+        { const U32 at = tb + sRow[j * 4 + w] + (U32) __popcll (b & (((U64) 1 << lane) - 1));
+          index[at] = x[j]; offset[at] = posF[i] & MG_POS_MASK; id[at] = idBase + rid[i];
+          atomicAdd (&depth[x[j]], 1u);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* finish: copy classes, loc, rev                                                             */
+
+/* modmap.c:125-129: depth 1 -> copy 1, 2 -> copy 2, anything else (0 included) -> copy M; entries 1 .. max; tallies[3] */
+__global__ __launch_bounds__ (256)
+void mgRefClassifyKernel (const U32 *__restrict__ depth, U32 max, U8 *__restrict__ info, U32 *__restrict__ tallies)
+{
+  __shared__ U32 sT[3];
+  if (threadIdx.x < 3) sT[threadIdx.x] = 0;
+  __syncthreads ();
+  U32 c1 = 0, c2 = 0, cM = 0;
+  for (U64 i = 1 + (U64) blockIdx.x * blockDim.x + threadIdx.x ; i <= max ; i += (U64) gridDim.x * blockDim.x)
+    { const U32 dp = depth[i]; const U8 f = info[i];
+      if (dp == 1) { info[i] = (U8) ((f & 0xfc) | 1); ++c1; }
+      else if (dp == 2) { info[i] = (U8) ((f & 0xfc) | 2); ++c2; }
+      else { info[i] = (U8) (f | 3); ++cM; }
+    }
+  for (int o = 32 ; o ; o >>= 1) { c1 += __shfl_down (c1, o); c2 += __shfl_down (c2, o); cM += __shfl_down (cM, o); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd (&sT[0], c1); atomicAdd (&sT[1], c2); atomicAdd (&sT[2], cM); }
+  __syncthreads ();
+  if (threadIdx.x < 3 && sT[threadIdx.x]) atomicAdd (&tallies[threadIdx.x], sT[threadIdx.x]);
+}
+
+/* one pass of the stable radix sort: a workgroup's tile is 8192 consecutive elements, wave w's part of it elements
+   [2048 w, 2048 (w + 1)), taken 64 at a time in order.  hist[digit * nTiles + tile]: digit-major, so that ONE exclusive scan over
+   the whole array gives every (digit, tile) its place in the output. */
+#define MG_RSORT_TILE 8192
+#define MG_RSORT_WAVE (MG_RSORT_TILE / 4)
+__global__ __launch_bounds__ (256)
+void mgRefSortHistKernel (const U32 *__restrict__ keys, U64 n, int shift, U32 *__restrict__ hist, U32 nTiles)
+{
+  __shared__ U32 sC[256];
+  sC[threadIdx.x] = 0;
+  __syncthreads ();
+  const U64 base = (U64) blockIdx.x * MG_RSORT_TILE;
+  for (int j = 0 ; j < MG_RSORT_TILE / 256 ; ++j)
+    { const U64 i = base + (U64) j * 256 + threadIdx.x;
+      if (i < n) atomicAdd (&sC[(keys[i] >> shift) & 255u], 1u);
+    }
+  __syncthreads ();
+  hist[(U64) threadIdx.x * nTiles + blockIdx.x] = sC[threadIdx.x];
+}
+template <bool FIRST>        /* FIRST: the values are the elements' own positions (the occurrence ordinals) */
+__global__ __launch_bounds__ (256)
+void mgRefSortScatterKernel (const U32 *__restrict__ keys, const U32 *__restrict__ vals, U64 n, int shift, const U32 *__restrict__ place, U32 nTiles,
+                             U32 *__restrict__ keysOut, U32 *__restrict__ valsOut)
+{
+  __shared__ U32 sC[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int q = 0 ; q < 4 ; ++q) sC[q][threadIdx.x] = 0;
+  __syncthreads ();
+  const U64 wbase = (U64) blockIdx.x * MG_RSORT_TILE + (U64) w * MG_RSORT_WAVE;
+  for (int r = 0 ; r < MG_RSORT_WAVE / 64 ; ++r)
+    { const U64 i = wbase + (U64) r * 64 + lane;
+      if (i < n) atomicAdd (&sC[w][(keys[i] >> shift) & 255u], 1u);
+    }
+  __syncthreads ();
+  { U32 run = place[(U64) threadIdx.x * nTiles + blockIdx.x];        /* digit threadIdx.x: where the tile's first such element goes; then wave by wave */
+    for (int q = 0 ; q < 4 ; ++q) { const U32 c = sC[q][threadIdx.x]; sC[q][threadIdx.x] = run; run += c; }
+  }
+  __syncthreads ();
+  for (int r = 0 ; r < MG_RSORT_WAVE / 64 ; ++r)
+    { const U64 i = wbase + (U64) r * 64 + lane;
+      const bool live = i < n;
+      const U32 key = live ? keys[i] : 0u;
+      const U32 dg = (key >> shift) & 255u;
+      U64 peers = __ballot (live);                                   /* the lanes that hold my digit */
+#pragma unroll
+      for (int b = 0 ; b < 8 ; ++b)
+        { const U64 m = __ballot ((dg >> b) & 1u);
+          peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+      const U32 before = (U32) __popcll (peers & (((U64) 1 << lane) - 1));
+      const U32 old = sC[w][dg];                                      /* every peer reads the same counter ... */
+      __builtin_amdgcn_wave_barrier ();
+      if (live && before == 0) sC[w][dg] = old + (U32) __popcll (peers);      /* ... and the first of them moves it on (one wave, LDS in order) */
+      __builtin_amdgcn_wave_barrier ();
+      if (live)
+        { const U32 at = old + before;
+          if (keysOut) keysOut[at] = key;
+          valsOut[at] = FIRST ? (U32) i : vals[i];
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+static MgStatus mgRefGrow (U32 **p, size_t have, size_t keep, size_t want)      /* device array of `want` words holding the first `keep` of the old one */
+{
+  (void) have;
+  U32 *q = 0;
+  MG_HIP (hipMalloc ((void **) &q, (want ? want : 1) * 4));
+  if (*p && keep) MG_HIP (hipMemcpy (q, *p, keep * 4, hipMemcpyDeviceToDevice));
+  if (*p) MG_HIP (hipFree (*p));
+  *p = q;
+  return MG_OK;
+}
+
+/* the seeds of a batch (device arrays, n of them, in order) behind the ref->max occurrences held so far; *appended = how many had an index */
+extern "C" MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U32 *dPosF, const U32 *dRid, U64 n, U32 idBase, U32 *appended)
+{
+  *appended = 0;
+  std::lock_guard<std::mutex> g (gRefLock);
+  MgRefDev &d = gRefDev[ref];
+  if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
+  hipStream_t st = 0;
+  const size_t msCap = ref->ms->size;
+  if (!d.depth)
+    { MG_HIP (hipMalloc ((void **) &d.depth, (msCap + 1) * 4));
+      MG_HIP (hipMemsetAsync (d.depth, 0, (msCap + 1) * 4, st));
+      d.capMs = msCap;
+      if (ref->max)                                                  /* occurrences the host holds already (a caller that filled the arrays itself) */
+        { mgSetError ("mgRefBuildAppend: a reference with host-built occurrences cannot be extended on the device"); return MG_ERR_ARG; }
+    }
+  if (!n) return MG_OK;
+  if (n >= ((U64) 1 << 32)) { mgSetError ("too many seeds in one batch"); return MG_ERR_ARG; }
+  const U32 nTiles = (U32) ((n + MG_SCAN_TILE - 1) / MG_SCAN_TILE);
+  U32 *tiles = 0;
+  MG_HIP (hipMalloc ((void **) &tiles, ((size_t) nTiles + 2) * 4));
+  MgStatus s = MG_OK;
+  do {
+    hipLaunchKernelGGL (mgRefCountHitsKernel, dim3 (nTiles), dim3 (256), 0, st, dIx, n, tiles);
+    hipLaunchKernelGGL (mgRefScanSmallKernel, dim3 (1), dim3 (1024), 0, st, tiles, nTiles);
+    U32 cnt = 0;
+    if (hipMemcpyAsync (&cnt, tiles + nTiles, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { s = mgHipFail (hipGetLastError (), "reference append"); break; }
+    /* modmap.c:111: an append is refused once max + 1 >= size */
+    if (cnt && (U64) ref->max + cnt > (U64) ref->size - 1) { mgSetError ("reference size overflow"); s = MG_ERR_CAPACITY; break; }
+    const size_t want = (size_t) ref->max + cnt;
+    if (want > d.capOcc)
+      { size_t cap = want + want / 2 + 65536; if (cap > ref->size) cap = ref->size; if (cap < want) cap = want;
+        if ((s = mgRefGrow (&d.index, d.capOcc, ref->max, cap)) || (s = mgRefGrow (&d.offset, d.capOcc, ref->max, cap)) || (s = mgRefGrow (&d.id, d.capOcc, ref->max, cap))) break;
+        d.capOcc = cap;
+      }
+    if (cnt)
+      { hipLaunchKernelGGL (mgRefAppendKernel, dim3 (nTiles), dim3 (256), 0, st, dIx, dPosF, dRid, n, tiles, ref->max, idBase, d.index, d.offset, d.id, d.depth);
+        if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) { s = mgHipFail (hipGetLastError (), "reference append"); break; }
+      }
+    *appended = cnt;
+  } while (0);
+  (void) hipFree (tiles);
+  return s;
+}
+
+/* modmap.c:125-129 + 74-91.  The host arrays are the caller's, sized as referencePack sizes them: index / offset / id / rev
+   [ref->max], depth / loc [ms->max + 1], info = ms->info; tallies[3] = copy 1, copy 2, multiple. */
+extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffset, U32 *hId, U32 *hDepth, U32 *hRev, U32 *hLoc, U8 *hInfo, U32 tallies[3])
+{
+  std::lock_guard<std::mutex> g (gRefLock);
+  MgRefDev &d = gRefDev[ref];
+  hipStream_t st = 0;
+  const U32 msMax = ref->ms->max, n = ref->max;
+  const size_t m = (size_t) msMax + 1;
+  tallies[0] = tallies[1] = tallies[2] = 0;
+  if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
+  if (!d.depth)                                                      /* no batch ever came: an empty reference */
+    { MG_HIP (hipMalloc ((void **) &d.depth, (m + 1) * 4)); MG_HIP (hipMemsetAsync (d.depth, 0, (m + 1) * 4, st)); d.capMs = m; }
+  if (m > d.capMs + 1) { mgSetError ("modset grew beyond its size"); return MG_ERR_CAPACITY; }
+  MgStatus s;
+  U32 *tiles = 0, *dTal = 0, *k1 = 0, *k2 = 0, *v1 = 0, *v2 = 0, *hist = 0;
+  do {
+    s = MG_ERR_HIP;
+    const U32 nSortTiles = (U32) (((U64) n + MG_RSORT_TILE - 1) / MG_RSORT_TILE);
+    const size_t histWords = (size_t) 256 * (nSortTiles ? nSortTiles : 1);
+    const size_t scanTiles = (m > histWords ? m : histWords) / MG_SCAN_TILE + 4;
+    if (hipMalloc ((void **) &tiles, scanTiles * 4) || hipMalloc ((void **) &dTal, 16) || hipMemsetAsync (dTal, 0, 16, st)) break;
+    /* info: the host's flag bytes up, the copy classes set, back down (and kept for the chaining) */
+    (void) hipFree (d.info); d.info = 0; (void) hipFree (d.loc); d.loc = 0;
+    if (hipMalloc ((void **) &d.info, m) || hipMalloc ((void **) &d.loc, (m + 1) * 4) || hipStreamSynchronize (st)) break;
+    if ((s = mgXferH2D (d.info, hInfo, m))) break;
+    s = MG_ERR_HIP;
+    if (msMax) hipLaunchKernelGGL (mgRefClassifyKernel, dim3 (2048), dim3 (256), 0, st, d.depth, msMax, d.info, dTal);
+    if ((s = mgRefExclusiveScan (d.depth, d.loc, m, tiles, st))) break;
+    s = MG_ERR_HIP;
+    if (hipMemcpyAsync (tallies, dTal, 12, hipMemcpyDeviceToHost, st)) break;
+    /* rev: the occurrence ordinals sorted by index, stably */
+    (void) hipFree (d.rev); d.rev = 0;
+    if (n)
+      { int keyBits = 1; while (keyBits < 32 && ((U64) 1 << keyBits) <= msMax) ++keyBits;
+        const int passes = (keyBits + 7) / 8;
+        if (hipMalloc ((void **) &hist, (histWords + 2) * 4) || hipMalloc ((void **) &v1, ((size_t) n + 1) * 4) || hipMalloc ((void **) &v2, ((size_t) n + 1) * 4)) break;
+        if (passes > 1 && (hipMalloc ((void **) &k1, (size_t) n * 4) || (passes > 2 && hipMalloc ((void **) &k2, (size_t) n * 4)))) break;
+        const U32 *kin = d.index; const U32 *vin = 0;
+        U32 *kout = k1, *vout = v1;
+        bool bad = false;
+        for (int p = 0 ; p < passes ; ++p)
+          { const bool last = p + 1 == passes;
+            hipLaunchKernelGGL (mgRefSortHistKernel, dim3 (nSortTiles), dim3 (256), 0, st, kin, (U64) n, 8 * p, hist, nSortTiles);
+            if (mgRefExclusiveScan (hist, hist, histWords, tiles, st)) { bad = true; break; }
+            if (p == 0) hipLaunchKernelGGL (mgRefSortScatterKernel<true>, dim3 (nSortTiles), dim3 (256), 0, st, kin, vin, (U64) n, 8 * p, hist, nSortTiles, last ? (U32 *) 0 : kout, vout);
+            else hipLaunchKernelGGL (mgRefSortScatterKernel<false>, dim3 (nSortTiles), dim3 (256), 0, st, kin, vin, (U64) n, 8 * p, hist, nSortTiles, last ? (U32 *) 0 : kout, vout);
+            kin = kout; vin = vout;
+            kout = kout == k1 ? k2 : k1; vout = vout == v1 ? v2 : v1;
+          }
+        if (bad || hipGetLastError () != hipSuccess) break;
+        d.rev = (U32 *) vin;                                         /* the last pass's output */
+        if (d.rev == v1) v1 = 0; else v2 = 0;
+        if (hipMemsetAsync (d.rev + n, 0, 4, st)) break;            /* (the chaining reads rev[loc[x] + 1] of a copy-2 seed: inside the array, but keep the slack defined) */
+      }
+    else { if (hipMalloc ((void **) &d.rev, 8) || hipMemsetAsync (d.rev, 0, 8, st)) break; }
+    if (hipStreamSynchronize (st)) break;
+    /* mirror */
+    if ((s = mgXferD2H (hInfo, d.info, m, MG_XFER_COPY)) || (s = mgXferD2H (hDepth, d.depth, m * 4, MG_XFER_COPY)) || (s = mgXferD2H (hLoc, d.loc, m * 4, MG_XFER_COPY))) break;
+    if (n && ((s = mgXferD2H (hIndex, d.index, (size_t) n * 4, MG_XFER_COPY)) || (s = mgXferD2H (hOffset, d.offset, (size_t) n * 4, MG_XFER_COPY))
+              || (s = mgXferD2H (hId, d.id, (size_t) n * 4, MG_XFER_COPY)) || (s = mgXferD2H (hRev, d.rev, (size_t) n * 4, MG_XFER_COPY)))) break;
+    /* what the chaining does not read goes; the rest is the resident copy */
+    (void) hipFree (d.index); d.index = 0; (void) hipFree (d.depth); d.depth = 0; d.capOcc = 0; d.capMs = 0;
+    if (!d.id) { if (hipMalloc ((void **) &d.id, 8) || hipMalloc ((void **) &d.offset, 8)) { s = MG_ERR_HIP; break; } }
+    d.msMax = msMax; d.refMax = n; d.packed = true;
+    s = MG_OK;
+  } while (0);
+  (void) hipFree (tiles); (void) hipFree (dTal); (void) hipFree (k1); (void) hipFree (k2); (void) hipFree (v1); (void) hipFree (v2); (void) hipFree (hist);
+  if (s == MG_ERR_HIP && !mgLastError ()[0]) mgHipFail (hipGetLastError (), "reference pack on the device");
+  return s;
+}
