@@ -237,6 +237,12 @@ int  mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offset
  * mgReferenceLoad also creates the Modset (ref->ms, with its own Seqhash) as referenceRead does; as in the
  * reference, mgReferenceDestroy leaves ref->ms alone (modmap.c:66-72): the caller destroys it, and its hasher. */
 void mgReferenceWrite (MgReference *ref, const char *root) ;
+/* What the library's writers (mgReferenceWrite, mgReadsetWrite) put between themselves and the disk, for a caller's own modsetWrite
+ * (modset.c:79-88 takes any FILE *): the bytes written to the returned FILE * become a gzip file of independent members of 16 MiB,
+ * deflated by a team of threads (MODGPU_GZIP_THREADS; default: the CPUs the process may use) and written in order.  gzread -- the
+ * reference's fzopen "r" (utils.c:107-127) -- and gunzip read such a file as the one stream the reference's single gzwrite would have
+ * made; fclose () finishes it.  0 if `name` cannot be created. */
+FILE *mgGzipOpenWrite (const char *name) ;
 MgReference *mgReferenceLoad (const char *root) ;
 /* modmap.c:188-281: "Q" line and "M" lines for every read. */
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,

@@ -73,7 +73,7 @@ EXPORTS = [
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
-    "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgReferenceLoad",
+    "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgGzipOpenWrite", "mgReferenceLoad",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
     "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgFormatF2", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
@@ -189,7 +189,7 @@ def lib():
     sig("mgTextParseFileDevice", i32, C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64))
     sig("mgAddSequenceFile", i32, MS, C.c_char_p, vp); sig("mgReferenceFastaRead", i32, vp, C.c_char_p, C.c_bool, vp)
     sig("mgQueryFile", i32, vp, C.c_char_p, vp)
-    sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
+    sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgGzipOpenWrite", vp, C.c_char_p); sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetClear", i32, MS, vp); sig("mgModsetDeviceSlots", u64, MS); sig("mgSetVerbose", None, i32)
     sig("mgProfileEnable", None, i32); sig("mgProfileOnly", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)

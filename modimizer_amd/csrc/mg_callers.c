@@ -181,20 +181,24 @@ int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets
  * Both go through the reference's fzopen (utils.c:107-127): gzopen wrapped as a FILE*, so files it
  * writes are gzip streams and it reads gzip or plain alike.  Same here, with glibc's fopencookie in
  * the place of BSD funopen. */
-static ssize_t gzCookieRead (void *c, char *buf, size_t n) { int r = gzread ((gzFile) c, buf, (unsigned) n); return r < 0 ? -1 : r; }
-static ssize_t gzCookieWrite (void *c, const char *buf, size_t n) { int r = gzwrite ((gzFile) c, buf, (unsigned) n); return r <= 0 ? 0 : r; }
+static ssize_t gzCookieRead (void *c, char *buf, size_t n)        /* (gzread takes an unsigned count: a 4 GiB fread -- index[] at table bits 30 -- comes in pieces) */
+{ if (n > ((size_t) 1 << 30)) n = (size_t) 1 << 30; int r = gzread ((gzFile) c, buf, (unsigned) n); return r < 0 ? -1 : r; }
 static int gzCookieClose (void *c) { return gzclose ((gzFile) c) == Z_OK ? 0 : -1; }
 
 FILE *mgTagOpen (const char *root, const char *tag, const char *mode)      /* utils.c:129-139 */
 {
   char *name = (char *) malloc (strlen (root) + strlen (tag) + 2);
   sprintf (name, "%s.%s", root, tag);
-  gzFile z = gzopen (name, mode);
   FILE *f = 0;
-  if (z)
-    { cookie_io_functions_t io = { gzCookieRead, gzCookieWrite, 0, gzCookieClose };
-      f = fopencookie (z, mode, io);
-      if (!f) gzclose (z);
+  if (mode[0] == 'w') f = mgGzipOpenWrite (name);                  /* a gzip file of independent members, deflated by a team of threads (mg_pgzip.c) */
+  else
+    { gzFile z = gzopen (name, mode);
+      if (z)
+        { (void) gzbuffer (z, 1 << 20);
+          cookie_io_functions_t io = { gzCookieRead, 0, 0, gzCookieClose };
+          f = fopencookie (z, mode, io);
+          if (!f) gzclose (z);
+        }
     }
   free (name);
   return f;

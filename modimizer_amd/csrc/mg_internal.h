@@ -45,7 +45,7 @@ void mgTextReleaseBuffers (void);
 typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } MgDevBatch;     /* host bytes -> 2-bit words in HBM */
 MG_HIDDEN void mgBatchUpload (MgDevBatch *b, const char *bases, const int64_t *offsets, int nReads);
 MG_HIDDEN void mgBatchFree (MgDevBatch *b);
-MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);   /* <root>.<tag> through gzip, as utils.c:107-139 */
+MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);
 /* queryProcess on the device (mg_chain.hip): per read the tallies of its "Q" line and its "M" blocks */
 typedef struct { U32 nSeeds, missed, copy1, copy2, copyM, nM; } MgChainQ;
 typedef struct { U32 pos0, posN, id0, off0, offN; int n1, n2; U32 span; } MgChainM;

@@ -44,6 +44,7 @@ typedef struct {
   long tableLoad;          /* MODGPU_TABLE_LOAD: per cent */
   long packThreads;        /* MODGPU_PACK_THREADS */
   long parseThreads;       /* MODGPU_PARSE_THREADS */
+  long gzipThreads;        /* MODGPU_GZIP_THREADS: threads that deflate the members of a .mod / .ref / .readset file (mg_pgzip.c) */
   long xferThreads;        /* MODGPU_XFER_THREADS: host threads of the array transfers (mg_xfer.hip) */
   long seedTiming, uploadTiming, textTiming, parseTiming;   /* MODGPU_*_TIMING prints */
   long scanDebug, bucketDebug;                               /* only read by -DMG_ABLATE builds */

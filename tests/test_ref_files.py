@@ -209,3 +209,73 @@ def test_query_against_loaded_reference(tag, golden_dir, tmp_path):
     want = [l for l in util.golden_text("modmap_%s_files.stdout.txt" % tag).splitlines() if l[:2] in ("Q\t", "M\t")]
     assert open(out).read().splitlines() == want
     L.mgReferenceDestroy(ref)
+
+
+MODUTILS_REF = os.path.join(util.ROOT, "oracle", "_ref", "modutils_ref")
+
+
+def _host_modset(bits=24, n=300_000, seed=5):
+    """a host-only Modset (scalar API, no device) large enough for its .mod to be several gzip members (index[] alone is 4 << bits bytes)"""
+    L = mg.lib()
+    sh = mg.seqhashCreate(21, 64, 17)
+    ms = mg.modsetCreate(sh, bits)
+    rng = np.random.default_rng(seed)
+    for kmer in rng.integers(0, 1 << 42, n, dtype=np.uint64):
+        ix = L.modsetIndexFind(ms, int(kmer), 1)
+        ms.contents.depth[ix] += 1
+    return sh, ms
+
+
+def test_multi_member_gzip_is_the_single_stream(tmp_path):
+    """mgGzipOpenWrite: the members of the file, decompressed one after the other, are exactly the bytes modsetWrite (modset.c:79-88)
+    hands over -- written here into a plain file for comparison -- and there are several of them"""
+    import ctypes as C
+    L = mg.lib()
+    sh, ms = _host_modset()
+    plain, gz = str(tmp_path / "plain.mod"), str(tmp_path / "multi.mod")
+    with mg.CFile(plain, "w") as f:
+        L.modsetWrite(ms, f)
+    libc = C.CDLL(None); libc.fclose.argtypes = [C.c_void_p]
+    for threads in ("1", "5"):
+        with mg.knobs(GZIP_THREADS=threads):
+            f = L.mgGzipOpenWrite(gz.encode())
+            assert f
+            L.modsetWrite(ms, C.c_void_p(f))
+            assert libc.fclose(C.c_void_p(f)) == 0
+        raw = open(gz, "rb").read()
+        assert raw.count(b"\x1f\x8b\x08\x00\x00\x00\x00\x00") >= 4          # 64 MiB of index[] in members of 16 MiB
+        assert gzip.decompress(raw) == open(plain, "rb").read()
+    # small writes only: they collect and still come out as one valid stream; an empty file is one empty member
+    f = L.mgGzipOpenWrite(gz.encode())
+    libc.fputs.argtypes = [C.c_char_p, C.c_void_p]
+    for i in range(1000):
+        libc.fputs(b"line %d\n" % i, C.c_void_p(f))
+    assert libc.fclose(C.c_void_p(f)) == 0
+    assert gzip.decompress(open(gz, "rb").read()) == b"".join(b"line %d\n" % i for i in range(1000))
+    f = L.mgGzipOpenWrite(gz.encode()); assert libc.fclose(C.c_void_p(f)) == 0
+    assert gzip.decompress(open(gz, "rb").read()) == b""
+    L.modsetDestroy(ms)
+
+
+@pytest.mark.skipif(not os.path.exists(MODUTILS_REF), reason="oracle/_ref/modutils_ref not built")
+def test_reference_program_reads_a_multi_member_mod(tmp_path):
+    """the reference's own modutils -r (fzopen + gzread, utils.c:107-127; modsetRead modset.c:90-104) on a .mod of several gzip members
+    prints the summary it prints for the same set written by its own single gzwrite stream"""
+    import ctypes as C
+    L = mg.lib()
+    sh, ms = _host_modset(bits=24, n=200_000, seed=9)
+    ours = str(tmp_path / "ours.mod")
+    f = L.mgGzipOpenWrite(ours.encode())
+    L.modsetWrite(ms, C.c_void_p(f))
+    libc = C.CDLL(None); libc.fclose.argtypes = [C.c_void_p]
+    assert libc.fclose(C.c_void_p(f)) == 0
+    theirs = str(tmp_path / "theirs.mod")
+    with gzip.open(theirs, "wb", compresslevel=6) as g:               # one member, as gzopen "w" makes it
+        g.write(gzip.decompress(open(ours, "rb").read()))
+    outs = []
+    for path in (ours, theirs):
+        r = subprocess.run([MODUTILS_REF, "-r", path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        outs.append(strip_timing(r.stdout + r.stderr).replace(path, "FILE"))
+    assert outs[0] == outs[1] and "number of entries %d" % ms.contents.max in outs[0]
+    L.modsetDestroy(ms)
