@@ -496,10 +496,20 @@ def gpu_rank(args):
             out["end_to_end"]["sync_to_host"] = sync_to_host(cx, ms, step, S, entries)
         except Exception as e:
             out["end_to_end"]["sync_to_host"] = {"error": str(e)[:300]}
+        try:
+            out["end_to_end"]["write_mod"] = write_mod(cx, ms)
+        except Exception as e:
+            out["end_to_end"]["write_mod"] = {"error": str(e)[:300]}
 
     L.modsetDestroy(ms)
     del reads, d_offsets
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not multi and not args.no_cpu and os.environ.get("MODGPU_BENCH_LONGFILES", "1") == "1":
+        try:
+            out["end_to_end"]["modmap_query_file_long"] = modmap_query_file_long(cx)
+        except Exception as e:
+            out["end_to_end"]["modmap_query_file_long"] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not multi and not args.no_other:
         other = {}
         for name, fn in (("c4_block", bench_c4_block), ("c5", bench_c5), ("c3", bench_c3), ("ref_default", bench_ref_default), ("realistic", bench_realistic)):
@@ -1087,6 +1097,151 @@ def sync_to_host(cx, ms, step, S, entries):
             "what": "device -> the Modset's own malloc()ed arrays: pending 32-bit counts exported as 16-bit, value[] / counts / replayed index[] in 4 MiB "
                     "pieces through page-locked blocks on one copy stream per host thread, each thread emptying its pieces into the destination "
                     "(memcpy; depth: saturating add, modutils.c:26); checks: depth sum == modimizers, index[] holds every entry once"}
+
+
+def write_mod(cx, ms):
+    """`modutils -a ... -w`: the config-2 set (already mirrored in the host arrays, index[] included: sync_to_host ran) written as a .mod
+    (modset.c:79-88) through the library's gzip writer -- independent members deflated by a team of threads (mg_pgzip.c), which gzread,
+    i.e. the reference, reads as one stream -- beside the rate of ONE zlib stream at the same level (what the reference's fzopen +
+    gzwrite is, utils.c:107-127) on a sample of the same bytes."""
+    import zlib
+    import numpy as np
+    L, mg = cx.L, cx.mg
+    m = ms.contents
+    n = m.max + 1
+    raw_bytes = 104 + (4 << m.tableBits) + 11 * n
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(shm, "modgpu_write_%d.mod" % os.getpid())
+    libc = C.CDLL(None); libc.fclose.argtypes = [C.c_void_p]
+    try:
+        t0 = time.perf_counter()
+        f = L.mgGzipOpenWrite(path.encode())
+        if not f:
+            raise RuntimeError("cannot create " + path)
+        L.modsetWrite(ms, C.c_void_p(f))
+        if libc.fclose(C.c_void_p(f)):
+            raise RuntimeError("write failed")
+        dt = time.perf_counter() - t0
+        zsize = os.path.getsize(path)
+        # the head of the file decompresses to the header + the head of index[]
+        idx = np.ctypeslib.as_array(m.index, (1 << m.tableBits,))
+        with open(path, "rb") as fh:
+            head = zlib.decompressobj(31).decompress(fh.read(64 << 20), 8 << 20)
+        ok = head[:8] == b"MSHSTv2\0" and head[104:] == idx[:(len(head) - 104) // 4 + 1].tobytes()[:len(head) - 104]
+        # one stream, one thread, level 6: 192 MiB of index[] from the middle + 64 MiB of value[]
+        val = np.ctypeslib.as_array(m.value, (n,))
+        sample = [idx[len(idx) // 2: len(idx) // 2 + (48 << 20)].tobytes(), val[1:1 + (8 << 20)].tobytes()]
+        z = zlib.compressobj(6, zlib.DEFLATED, 31)
+        t0 = time.perf_counter()
+        zs = sum(len(z.compress(b)) for b in sample) + len(z.flush())
+        dt1 = time.perf_counter() - t0
+        sb = sum(len(b) for b in sample)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    par, one = raw_bytes / dt / 1e6, sb / dt1 / 1e6
+    return {"entry": "modsetWrite through mgGzipOpenWrite", "raw_bytes": raw_bytes, "file_bytes": zsize, "seconds": round(dt, 2),
+            "MBps": round(par, 1), "single_stream_MBps": round(one, 1), "speedup_vs_single_stream": round(par / one, 1),
+            "single_stream_seconds_estimate": round(raw_bytes / (one * 1e6), 1), "single_stream_sample_bytes": sb,
+            "single_stream_sample_ratio": round(zs / sb, 3), "file_ratio": round(zsize / raw_bytes, 3),
+            "threads": min(int(os.environ.get("MODGPU_GZIP_THREADS", "0")) or len(os.sched_getaffinity(0)), 32), "head_decompresses_ok": bool(ok),
+            "what": "config 2's set, table bits 30: 104 + 4 * 2^30 + 11 * (max + 1) bytes -> gzip members of 16 MiB deflated in parallel (level 6), "
+                    "written in order into /dev/shm; single_stream: zlib level 6 on one thread over a 256 MiB sample of index[] and value[]"}
+
+
+def modmap_query_file_long(cx):
+    """BASELINE config 3 in its own shape, FROM FILES (modmap.c:93-134,188-281): a 24 x 125 Mbp FASTA reference (80 columns) through
+    mgReferenceFastaRead, then >= 5 Gbp of ONT-like reads drawn from it (FASTA, one line a read) through mgQueryFile -- text parsed on the
+    device, scan, lookups, tallies and chaining there, Q / M lines formatted and written by the host's threads.  The chaining kernels'
+    share (mg_chain.hip) is split out per 10 Gbp from the library's event timers."""
+    import numpy as np
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    scale = float(os.environ.get("MODGPU_BENCH_C3_SCALE", "1"))
+    n_seq, seq_len = 24, int(125_000_000 * scale) // 80 * 80
+    genome_bases = n_seq * seq_len
+    q_bases = int(float(os.environ.get("MODGPU_BENCH_LONG_QUERY_GBP", "5")) * 1e9 * min(1.0, scale * 4))
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    need = genome_bases * 81 // 80 + q_bases + (1 << 28)
+    free = __import__("shutil").disk_usage(shm).free
+    if free < need * 1.2:
+        return {"skipped": "%s has %.1f GB free, the two files need %.1f GB" % (shm, free / 1e9, need / 1e9)}
+    k, d, bits = 21, 64, 28
+    rpath = os.path.join(shm, "modgpu_long_%d_ref.fa" % os.getpid())
+    qpath = os.path.join(shm, "modgpu_long_%d_reads.fa" % os.getpid())
+    opath = os.path.join(shm, "modgpu_long_%d_out.txt" % os.getpid())
+
+    def letters_of(packed, n):                                     # bases 0..3 of a packed stream as ASCII, on the device
+        b = torch.empty(n, dtype=torch.uint8, device=cx.dev)
+        mg.check(L.mgUnpackDevice(packed.data_ptr(), n, b.data_ptr(), cx.stream))
+        torch.cuda.synchronize()
+        b += 65; b += (b > 65).to(torch.uint8); b += (b > 67).to(torch.uint8) * 3; b += (b > 71).to(torch.uint8) * 12      # 0 1 2 3 -> 65 67 71 84 = A C G T
+        return b
+    t_files = time.perf_counter()
+    try:
+        genome = make_genome(cx, genome_bases, 333)
+        nl = torch.full((seq_len // 80, 1), 10, dtype=torch.uint8, device=cx.dev)
+        with open(rpath, "wb") as f:
+            for i in range(n_seq):
+                # (sequence i starts on a word boundary: seq_len is a multiple of 16)
+                view = genome[i * seq_len // 16:]
+                t_ = torch.cat([letters_of(view, seq_len).view(-1, 80), nl], dim=1).cpu().numpy()
+                f.write(b">chr%d\n" % (i + 1)); f.write(t_.tobytes())
+        del nl
+        reads, d_offsets, offsets, n_reads = make_reads(cx, q_bases, genome, genome_bases, 4242, 0.05, 5252)
+        del genome
+        q_bases = int(offsets[n_reads])
+        h = letters_of(reads, q_bases).cpu().numpy()
+        del reads, d_offsets
+        torch.cuda.empty_cache()
+        mv = memoryview(h)
+        with open(qpath, "wb", buffering=1 << 24) as f:
+            for r in range(n_reads):
+                f.write(b">r%d\n" % r); f.write(mv[int(offsets[r]):int(offsets[r + 1])]); f.write(b"\n")
+        del mv, h
+        t_files = time.perf_counter() - t_files
+        sh = mg.seqhashCreate(k, d, 17); ms = mg.modsetCreate(sh, bits)
+        ref = L.mgReferenceCreate(ms, 1 << 26)
+        with mg.CFile(os.devnull, "w") as fo:
+            t0 = time.perf_counter()
+            if L.mgReferenceFastaRead(ref, rpath.encode(), True, fo):
+                raise RuntimeError("mgReferenceFastaRead failed")
+            t_ref = time.perf_counter() - t0
+        r_ = C.cast(ref, C.POINTER(mg.MgReference)).contents
+        best, lines, chain_ms = None, 0, None
+        for it in range(3):
+            if it == 2:
+                L.mgProfileOnly(-1); L.mgProfileEnable(1); L.mgProfileReset()
+            t0 = time.perf_counter()
+            with mg.CFile(opath, "w") as fo:
+                rc = L.mgQueryFile(ref, qpath.encode(), fo)
+            dt = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError("mgQueryFile failed")
+            if it == 2:
+                table = read_profile(L, mg); L.mgProfileEnable(0)
+                chain_ms = table.get("mgChainKernel", (0.0, 0))[0] + table.get("mgChainResolveKernel", (0.0, 0))[0]
+                kern_ms = {kn: round(v[0], 2) for kn, v in table.items() if v[0] >= 0.05}
+            elif it:
+                best = dt
+        with open(opath, "rb") as fo:
+            txt = fo.read()
+        n_q, n_m = txt.count(b"\nQ\t") + txt.startswith(b"Q\t"), txt.count(b"\nM\t")
+        res = {"entry": "mgReferenceFastaRead + mgQueryFile",
+               "reference": {"sequences": n_seq, "bases": genome_bases, "file_bytes": os.path.getsize(rpath), "read_s": round(t_ref, 3),
+                             "Gbp_per_s": round(genome_bases / t_ref / 1e9, 2), "occurrences": int(r_.max), "modset_entries": int(ms.contents.max)},
+               "query": {"reads": n_reads, "bases": q_bases, "file_bytes": os.path.getsize(qpath), "seconds": round(best, 3),
+                         "Gbp_per_s": round(q_bases / best / 1e9, 2), "Q_lines": int(n_q), "M_lines": int(n_m), "all_reads_reported": int(n_q) == n_reads,
+                         "chain_ms_per_10Gbp": round(chain_ms / q_bases * 1e10, 3) if chain_ms is not None else None,
+                         "chain_ms_total": round(chain_ms, 3) if chain_ms is not None else None, "kernel_ms_profiled_run": kern_ms},
+               "files_written_in_s": round(t_files, 1),
+               "what": "80-column FASTA reference and one-line-per-read FASTA reads in the page cache (/dev/shm); parse on the device, scan + insert + "
+                       "reference arrays on the device (mg_refpack.hip); queries: scan + lookups + tallies + chaining on the device a batch at a time"}
+        L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+        return res
+    finally:
+        for p_ in (rpath, qpath, opath):
+            if os.path.exists(p_):
+                os.remove(p_)
 
 
 def dropin_unmodified(h, shm):

@@ -86,6 +86,12 @@ MgStatus mgMemcpyH2D (void *dst, const void *src, size_t bytes, void *stream) ;
 MgStatus mgMemcpyD2H (void *dst, const void *src, size_t bytes, void *stream) ;
 MgStatus mgMemsetD (void *dst, int byte, size_t bytes, void *stream) ;
 MgStatus mgStreamSynchronize (void *stream) ;
+/* Whole arrays between the device and PAGEABLE host memory at the link's speed: a team of host threads (mgXferThreadCount) moves the
+ * array in 4 MiB pieces through page-locked blocks, one copy stream each (what modsetSyncToHost and mgReferenceRead mirror their
+ * results with; a plain copy into pageable memory goes through the runtime's staging at a few GB/s).  Both wait for the device to be
+ * idle first and return when the bytes are in place. */
+MgStatus mgCopyD2HBig (void *hostDst, const void *devSrc, size_t bytes) ;
+MgStatus mgCopyH2DBig (void *devDst, const void *hostSrc, size_t bytes) ;
 
 /* 2-bit packed read layout in HBM: base i of the concatenated batch lives in bits
  * [30-2*(i%16), 32-2*(i%16)) of 32-bit word i/16 (first base in the most significant bits, so a
@@ -160,7 +166,7 @@ MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, U32 *dIndex
  * depth[] += device counts (modutils.c:26), and (when wantIndex) the open-addressed index[] table
  * rebuilt exactly as the reference's sequence of inserts would have left it (modset.c:51-57). */
 MgStatus modsetSyncToHost (Modset *ms, int wantIndex) ;
-int      mgXferThreadCount (void) ;         /* host threads that move whole arrays between the device and the Modset's own arrays (modsetSyncToHost, device rebuilds): the CPUs the process may use, at most 16; MODGPU_XFER_THREADS overrides */
+int      mgXferThreadCount (void) ;         /* host threads that move whole arrays between the device and the Modset's own arrays (modsetSyncToHost, device rebuilds): 4 (measured best: tools/xfer_probe.py) or fewer if the process may use fewer CPUs; MODGPU_XFER_THREADS overrides, up to 16 */
 /* Drop the device table (host arrays untouched; pending device depth counts are synced first). */
 MgStatus mgModsetDeviceRelease (Modset *ms) ;
 /* Tell the library the caller changed ms->value/max/depth on the host behind its back. */

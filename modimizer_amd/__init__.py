@@ -69,7 +69,7 @@ EXPORTS = [
     "mgMemcpyH2D", "mgMemcpyD2H", "mgMemsetD", "mgStreamSynchronize",
     "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice", "mgUploadPack",
     "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch", "seqhashMinimizerBatchDevice", "seqhashMinimizerBatch",
-    "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgXferThreadCount", "mgModsetDeviceRelease",
+    "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgXferThreadCount", "mgCopyD2HBig", "mgCopyH2DBig", "mgModsetDeviceRelease",
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
@@ -137,6 +137,8 @@ def lib():
     SH, MS, IT = C.POINTER(Seqhash), C.POINTER(Modset), C.POINTER(SeqhashRCiterator)
 
     def sig(name, res, *args):
+        if os.environ.get("MODGPU_LIB") and not hasattr(L, name):      # a variant build of another round (A/B runs): what it lacks stays unbound
+            return
         f = getattr(L, name); f.restype = res; f.argtypes = list(args)
     sig("seqhashCreate", SH, i32, i32, i32)
     sig("seqhashWrite", None, SH, vp); sig("seqhashRead", SH, vp); sig("seqhashReport", None, SH, vp)
@@ -167,7 +169,7 @@ def lib():
     sig("seqhashMinimizerBatch", i64, SH, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
     sig("modsetAddBatchDevice", i32, MS, vp, u64, vp, i32, vp)
     sig("modsetFindBatchDevice", i32, MS, vp, u64, vp, vp)
-    sig("modsetSyncToHost", i32, MS, i32); sig("mgXferThreadCount", i32); sig("mgModsetDeviceRelease", i32, MS)
+    sig("modsetSyncToHost", i32, MS, i32); sig("mgXferThreadCount", i32); sig("mgCopyD2HBig", i32, vp, vp, C.c_size_t); sig("mgCopyH2DBig", i32, vp, vp, C.c_size_t); sig("mgModsetDeviceRelease", i32, MS)
     sig("mgModsetHostChanged", None, MS)
     sig("modsetDepthHistogramDevice", i32, MS, vp, vp)
     sig("mgAddReadsDevice", i32, MS, vp, u64, vp, u32, U64P, vp)

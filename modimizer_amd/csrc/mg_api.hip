@@ -88,7 +88,7 @@ static const char *gKernelNames[MG_K_COUNT] = {
   "mgTableExportDepthKernel", "mgTableHistKernel", "mgReplayIndexKernel", "mgIndexFinishKernel",
   "mgSynthGenomeKernel", "mgSynthReadsKernel", "memset", "mgSegScanKernel", "mgSegCompactKernel",
   "mgPartChunks+ScanKernel", "mgPartHistKernel", "mgPartScatterKernel", "mgRankCountKernel", "mgRankScanKernel", "mgBucketDedupKernel",
-  "mgBucketMergeKernel", "mgRankLookupKernel", "mgTableFindSegKernel", "mgHotPlan+ReduceKernel", "mgBucketFindKernel", "mgUnpartKernel" };
+  "mgBucketMergeKernel", "mgRankLookupKernel", "mgTableFindSegKernel", "mgHotPlan+ReduceKernel", "mgBucketFindKernel", "mgUnpartKernel", "mgChainKernel", "mgChainResolveKernel" };
 #define MG_PROF_POOL 8192
 struct MgProfRec { int id; hipEvent_t a, b; };
 static struct {
@@ -542,6 +542,7 @@ static MgStatus mgDevGet (Modset *ms, MgDev **out, hipStream_t st)
     { d = new MgDev (); d->built = false; d->hostIndexMax = 0; d->hPin = 0;
       if (hipHostMalloc ((void **) &d->hPin, 256, hipHostMallocDefault) != hipSuccess) { delete d; return mgHipFail (hipGetLastError (), "hipHostMalloc"); }
       if ((s = mgDevBuild (ms, d, st))) { mgDevFree (d); return s; }
+      mgXferWarm ();                                       /* what is built on the device comes back through mg_xfer.hip: its streams are made meanwhile */
       std::lock_guard<std::mutex> g (gRegLock); gReg[ms] = d; mgLiveDeviceModsets = (int) gReg.size ();
     }
   else if (ms->max > d->t.max)

@@ -12,6 +12,7 @@
 #include <sched.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <time.h>
 #include "modgpu.h"
 #include "mg_internal.h"
 
@@ -149,7 +150,10 @@ void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out)
 {
   Modset *ms = ref->ms;
   fprintf (out, "  %d hashes from %d reference sequences, total length %lld\n", ref->max, ref->nSeq, (long long) totLen);
+  const int timing = mgKnobs ()->seedTiming == 1;          /* dev */
+  struct timespec f0, f1, f2, f3; clock_gettime (CLOCK_MONOTONIC, &f0);
   if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");       /* value[] of the new entries */
+  clock_gettime (CLOCK_MONOTONIC, &f1);
   const U32 n = ref->max ? ref->max : 1, m = ms->max + 1;
   free (ref->index); free (ref->offset); free (ref->id); free (ref->depth); free (ref->rev); free (ref->loc);   /* (nothing was written into them: the occurrences are on the device) */
   ref->index = (U32 *) mgAllocBig ((size_t) n * sizeof (U32));
@@ -161,7 +165,12 @@ void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out)
   if (!ref->index || !ref->offset || !ref->id || !ref->rev || !ref->depth || !ref->loc) { fprintf (stderr, "FATAL ERROR: out of memory\n"); exit (-1); }
   ref->size = ref->max;
   U32 tal[3];
+  clock_gettime (CLOCK_MONOTONIC, &f2);
   if (mgRefBuildFinish (ref, ref->index, ref->offset, ref->id, ref->depth, ref->rev, ref->loc, ms->info, tal)) fatal ("reference pack");
+  clock_gettime (CLOCK_MONOTONIC, &f3);
+  if (timing) fprintf (stderr, "mgReferenceFinish: modset mirror %.1f ms, host arrays %.1f ms, classes + loc + rev + mirror %.1f ms\n",
+                       (f1.tv_sec - f0.tv_sec) * 1e3 + (f1.tv_nsec - f0.tv_nsec) * 1e-6, (f2.tv_sec - f1.tv_sec) * 1e3 + (f2.tv_nsec - f1.tv_nsec) * 1e-6,
+                       (f3.tv_sec - f2.tv_sec) * 1e3 + (f3.tv_nsec - f2.tv_nsec) * 1e-6);
   if ((size_t) ms->size > (size_t) m) memset (ref->depth + m, 0, ((size_t) ms->size - m) * sizeof (U32));      /* (the reference's resize keeps ms->size zeroed entries when the set is not packed) */
   fprintf (out, "  %d copy 1, %d copy 2, %d multiple\n", tal[0], tal[1], tal[2]);
   if (isAdd) modsetPack (ms);
@@ -170,10 +179,17 @@ void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out)
 int mgReferenceRead (MgReference *ref, const char *bases, const int64_t *offsets, int nSeq,
                      const char **names, bool isAdd, FILE *out)
 {
+  const int timing = mgKnobs ()->seedTiming == 1;          /* dev */
+  struct timespec c0, c1, c2, c3; clock_gettime (CLOCK_MONOTONIC, &c0);
   MgDevBatch b; mgBatchUpload (&b, bases, offsets, nSeq);
+  clock_gettime (CLOCK_MONOTONIC, &c1);
   mgReferenceAddDevice (ref, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, nSeq, names, isAdd);
   mgBatchFree (&b);
+  clock_gettime (CLOCK_MONOTONIC, &c2);
   mgReferenceFinish (ref, nSeq ? (U64) offsets[nSeq] : 0, isAdd, out);
+  clock_gettime (CLOCK_MONOTONIC, &c3);
+#define MSD_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+  if (timing) fprintf (stderr, "mgReferenceRead: pack + upload %.1f ms, scan + insert + append %.1f ms, finish (mirror, classes, pack) %.1f ms\n", MSD_ (c0, c1), MSD_ (c1, c2), MSD_ (c2, c3));
   return 0;
 }
 

@@ -35,10 +35,46 @@ __global__ void mgSeedStartKernel (const U32 *__restrict__ seedRead, U64 nSeeds,
     }
 }
 
-__device__ __forceinline__ bool mgBlockEnds (const MgRefDev &d, U32 loc, U32 loc0, U32 locN, U32 i0, U32 iN, bool withUnset)
+/* Chaining in two steps.  Walking a read's seeds is serial (every step looks at the block built so far), but what a step needs
+ * from the reference -- the seed's copy class, its first occurrence, its second one, the sequences they lie on -- depends on the seed
+ * alone.  A lane per read that fetched them on the way (info[x] -> loc[x] -> rev[..] -> id[..]: four dependent random loads a seed)
+ * spent 120 ms per 10 Gbp of ONT-like reads, the whole of it latency: the 3000 seeds of a 200 kb read one after the other.  So:
+ *   resolve   a lane per SEED: copy class and CSR offset from one 8-byte word (li[x] = loc | info << 32), the first two occurrences
+ *             with their sequence ids from one or two adjacent 8-byte words (revid[j] = rev[j] | id[rev[j]] << 32) -- two dependent
+ *             random loads, all seeds of the batch in flight at once -- left as ONE 16-byte record per seed:
+ *             {loc1, id1 | flags << 29, loc2, id2}, flags = copy class | hit << 2;
+ *   chain     a lane per READ walks its records, which lie one after the other: no load of a step depends on the step before
+ *             (the sequence id of the block's first occurrence travels in a register), so sixteen records are fetched at a time --
+ *             one memory round trip per sixteen seeds instead of four per seed. */
+#define MG_SEED_HIT 4u       /* flags of a seed: bits 0-1 copy class, bit 2 = the k-mer is in the modset */
+#define MG_SEED_FLAG_SHIFT 29
+__global__ __launch_bounds__ (256)
+void mgChainResolveKernel (const U32 *__restrict__ seedIx, U64 nSeeds, const U64 *__restrict__ li, const U64 *__restrict__ revid, U32 refMax,
+                           uint4 *__restrict__ rec)
+{
+  const U64 stride = (U64) gridDim.x * blockDim.x;
+  for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i < nSeeds ; i += stride)
+    { const U32 x = seedIx[i];
+      uint4 r = make_uint4 (0, 0, 0, 0);
+      if (x)
+        { const U64 v = li[x];
+          const U32 c = (U32) (v >> 32) & 3u, l = (U32) v;
+          r.y = (MG_SEED_HIT | c) << MG_SEED_FLAG_SHIFT;
+          if (c != 3)                                                /* (copy M: counted, never chained: modmap.c:216) */
+            { const U64 a = revid[l];
+              r.x = (U32) a; r.y |= (U32) (a >> 32);
+              if (c != 1) { const U64 b = revid[l + 1 < refMax ? l + 1 : refMax]; r.z = (U32) b; r.w = (U32) (b >> 32); }      /* the second copy, for the retry of modmap.c:242-254 (slot refMax is defined slack) */
+            }
+        }
+      rec[i] = r;
+    }
+}
+
+/* one end-of-block test, modmap.c:232-241 (repeated at :245-254 without the "no block" clause); idL / id0: the sequences of loc / loc0 */
+__device__ __forceinline__ bool mgBlockEnds (U32 idL, U32 id0, U32 loc, U32 loc0, U32 locN, U32 i0, U32 iN, bool withUnset)
 {
   if (withUnset && !loc0) return true;
-  if (d.id[loc] != d.id[loc0]) return true;
+  if (idL != id0) return true;
   bool end = false;
   if (loc0 < locN)
     { if (loc < locN) end = true;
@@ -51,45 +87,70 @@ __device__ __forceinline__ bool mgBlockEnds (const MgRefDev &d, U32 loc, U32 loc
   return end;
 }
 
+/* the walk's state and one step of it (modmap.c:213-258 for seed i of the read, its record in x y z w); both kernels below run this */
+struct MgChainState { MgChainQ qq; U32 loc0, locN, i0, iN, id0; int n1, n2; };
+struct MgChainOut { const U32 *seedPos; const U32 *refOffset; MgChainM *mine; U32 maxM; U32 *overflow; U64 s0; bool writer; };
+__device__ __forceinline__ void mgChainEmit (MgChainState &st, const MgChainOut &o)
+{
+  if (o.writer)
+    { if (st.qq.nM < o.maxM)
+        { MgChainM e; e.pos0 = o.seedPos[o.s0 + st.i0] & MG_POS_MASK; e.posN = o.seedPos[o.s0 + st.iN] & MG_POS_MASK;
+          e.id0 = st.id0; e.off0 = o.refOffset[st.loc0]; e.offN = o.refOffset[st.locN]; e.n1 = st.n1; e.n2 = st.n2;
+          e.span = st.locN > st.loc0 ? st.locN - st.loc0 : st.loc0 - st.locN; o.mine[st.qq.nM] = e;
+        }
+      else *o.overflow = 1;
+    }
+  ++st.qq.nM;
+}
+__device__ __forceinline__ void mgChainStep (MgChainState &st, const MgChainOut &o, U32 i, U32 x, U32 y, U32 z, U32 w)
+{
+  const U32 f = y >> MG_SEED_FLAG_SHIFT;
+  if (!(f & MG_SEED_HIT)) { ++st.qq.missed; return; }
+  const U32 c = f & 3u;
+  if (c == 1) ++st.qq.copy1; else if (c == 2) ++st.qq.copy2; else if (c == 3) ++st.qq.copyM;
+  if (c == 3) return;
+  U32 loc = x, idL = y & ((1u << MG_SEED_FLAG_SHIFT) - 1);
+  const bool is1 = c == 1;
+  bool end = mgBlockEnds (idL, st.id0, loc, st.loc0, st.locN, st.i0, st.iN, true);
+  if (end && st.loc0 && !is1)
+    { loc = z; idL = w;
+      end = mgBlockEnds (idL, st.id0, loc, st.loc0, st.locN, st.i0, st.iN, false);
+    }
+  if (end)
+    { if (st.n1 > 2) mgChainEmit (st, o);                           /* a block is reported when it ENDS only with more than two copy-1 seeds (modmap.c:256) */
+      st.n1 = st.n2 = 0; st.loc0 = loc; st.id0 = idL; st.i0 = i;
+    }
+  if (is1) ++st.n1; else ++st.n2;
+  st.locN = loc; st.iN = i;
+}
+__device__ __forceinline__ void mgChainBegin (MgChainState &st, U32 ns)
+{ st.qq.nSeeds = ns; st.qq.missed = 0; st.qq.copy1 = st.qq.copy2 = st.qq.copyM = 0; st.qq.nM = 0; st.loc0 = st.locN = st.i0 = st.iN = st.id0 = 0; st.n1 = st.n2 = 0; }
+
+/* a LANE per read.  (A wave per long read -- 64 records a fetch, the walk on wave-uniform values -- was built and measured: no
+   faster.  What a batch's chaining costs is the serial walk of its LONGEST read, 3000 dependent steps of ~0.15 us for 200 kb,
+   however the steps are issued; the file entry point therefore makes few, large batches of long reads: mg_seqio.c.) */
+#define MG_CHAIN_AHEAD 16
 __global__ __launch_bounds__ (256)
-void mgChainKernel (const U32 *__restrict__ seedIx, const U32 *__restrict__ seedPos, const U64 *__restrict__ seedStart,
-                    U32 nReads, const MgRefDev d, MgChainQ *__restrict__ q, MgChainM *__restrict__ mRec, U32 maxM,
+void mgChainKernel (const uint4 *__restrict__ rec, const U32 *__restrict__ seedPos,
+                    const U64 *__restrict__ seedStart, U32 nReads, const U32 *__restrict__ refOffset, MgChainQ *__restrict__ q, MgChainM *__restrict__ mRec, U32 maxM,
                     U32 *__restrict__ overflow)
 {
   const U32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nReads) return;
   const U64 s0 = seedStart[r], s1 = seedStart[r + 1];
   const U32 ns = (U32) (s1 - s0);
-  MgChainQ qq; qq.nSeeds = ns; qq.missed = 0; qq.copy1 = qq.copy2 = qq.copyM = 0; qq.nM = 0;
-  U32 loc0 = 0, locN = 0, i0 = 0, iN = 0;
-  int n1 = 0, n2 = 0;
-  MgChainM *mine = mRec + (U64) r * maxM;
-#define MG_EMIT() do { if (qq.nM < maxM) { MgChainM e; e.pos0 = seedPos[s0 + i0] & MG_POS_MASK; e.posN = seedPos[s0 + iN] & MG_POS_MASK; \
-      e.id0 = d.id[loc0]; e.off0 = d.offset[loc0]; e.offN = d.offset[locN]; e.n1 = n1; e.n2 = n2; \
-      e.span = locN > loc0 ? locN - loc0 : loc0 - locN; mine[qq.nM] = e; } else *overflow = 1; ++qq.nM; } while (0)
-  for (U32 i = 0 ; i < ns ; ++i)
-    { const U32 x = seedIx[s0 + i];
-      if (!x) { ++qq.missed; continue; }
-      const int c = d.info[x] & 3;
-      if (c == 1) ++qq.copy1; else if (c == 2) ++qq.copy2; else if (c == 3) ++qq.copyM;
-      if (c == 3) continue;
-      U32 loc = d.rev[d.loc[x]];
-      const bool is1 = c == 1;
-      bool end = mgBlockEnds (d, loc, loc0, locN, i0, iN, true);
-      if (end && loc0 && !is1)
-        { loc = d.rev[d.loc[x] + 1];
-          end = mgBlockEnds (d, loc, loc0, locN, i0, iN, false);
-        }
-      if (end)
-        { if (n1 > 2) MG_EMIT ();
-          n1 = n2 = 0; loc0 = loc; i0 = i;
-        }
-      if (is1) ++n1; else ++n2;
-      locN = loc; iN = i;
+  MgChainState st; mgChainBegin (st, ns);
+  MgChainOut o; o.seedPos = seedPos; o.refOffset = refOffset; o.mine = mRec + (U64) r * maxM; o.maxM = maxM; o.overflow = overflow; o.s0 = s0; o.writer = true;
+  const uint4 *mineRec = rec + s0;
+  for (U32 base = 0 ; base < ns ; base += MG_CHAIN_AHEAD)
+    { uint4 v[MG_CHAIN_AHEAD];
+#pragma unroll
+      for (int j = 0 ; j < MG_CHAIN_AHEAD ; ++j) v[j] = base + j < ns ? mineRec[base + j] : make_uint4 (0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0 ; j < MG_CHAIN_AHEAD ; ++j) if (base + j < ns) mgChainStep (st, o, base + j, v[j].x, v[j].y, v[j].z, v[j].w);
     }
-  if (n2 > 2) MG_EMIT ();
-#undef MG_EMIT
-  q[r] = qq;
+  if (st.n2 > 2) mgChainEmit (st, o);                               /* the block open at the end of the read: only with more than two copy-2 seeds (modmap.c:269) */
+  q[r] = st.qq;
 }
 
 /* the blocks of all reads, densely: read r's min (nM, maxM) blocks go to mStart[r] .. (the kernel above leaves them in slots of maxM per read:
@@ -111,7 +172,7 @@ void mgChainCompactKernel (const MgChainQ *__restrict__ q, const MgChainM *__res
    The scratch belongs to the calling HOST THREAD and to the device it was allocated on (like the iterator's scratch, mg_api.hip): a
    thread that has moved to another GPU (mgSetDevice) drops it and starts again there, two threads driving two GPUs share nothing
    and do not wait for each other, and a thread that ends gives its blocks back. */
-enum { CS_IX, CS_POS, CS_RID, CS_START, CS_Q, CS_M, CS_OV, CS_MC, CS_N };
+enum { CS_IX, CS_POS, CS_RID, CS_START, CS_Q, CS_M, CS_OV, CS_MC, CS_REC, CS_N };
 static bool gChainAlive = true;                            /* false once the library is being unloaded: thread-local destructors that run after that leave HIP alone */
 __attribute__ ((destructor)) static void mgChainDown (void) { gChainAlive = false; }
 struct MgChainScratch
@@ -171,11 +232,17 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
     if (!dIx) break;
     dStart = (U64 *) csGet (CS_START, ((size_t) nReads + 2) * 8); dQ = (MgChainQ *) csGet (CS_Q, (size_t) nReads * sizeof (MgChainQ));
     dM = (MgChainM *) csGet (CS_M, (size_t) nReads * maxM * sizeof (MgChainM)); dOv = (U32 *) csGet (CS_OV, 4);
-    if (!dStart || !dQ || !dM || !dOv) break;
+    uint4 *dRec = (uint4 *) csGet (CS_REC, ((size_t) n + 1) * sizeof (uint4));
+    if (!dStart || !dQ || !dM || !dOv || !dRec) break;
     if (hipMemset (dOv, 0, 4)) break;
     unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
+    mgProfBegin (MG_K_CHAIN_RESOLVE, 0);                   /* (bench.py: chain_ms_per_10Gbp = resolve + chain) */
     hipLaunchKernelGGL (mgSeedStartKernel, dim3 (grid), dim3 (256), 0, 0, dRid, n, nReads, dStart);
-    hipLaunchKernelGGL (mgChainKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, d, dQ, dM, maxM, dOv);
+    if (n) hipLaunchKernelGGL (mgChainResolveKernel, dim3 (grid), dim3 (256), 0, 0, dIx, n, d.li, d.revid, d.refMax, dRec);
+    mgProfEnd (MG_K_CHAIN_RESOLVE, 0);
+    mgProfBegin (MG_K_CHAIN, 0);
+    hipLaunchKernelGGL (mgChainKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, 0, dRec, dPos, dStart, nReads, d.offset, dQ, dM, maxM, dOv);
+    mgProfEnd (MG_K_CHAIN, 0);
     if (hipGetLastError () != hipSuccess) break;
     U32 ov = 0;
     if (hipMemcpy (&ov, dOv, 4, hipMemcpyDeviceToHost)) break;

@@ -37,7 +37,7 @@ enum MgKernelId {
   MG_K_TABLE_FLAG, MG_K_TABLE_FIND, MG_K_TABLE_LOAD, MG_K_TABLE_EXPORT, MG_K_TABLE_HIST,
   MG_K_INDEX_REPLAY, MG_K_INDEX_FINISH, MG_K_SYNTH_GENOME, MG_K_SYNTH_READS, MG_K_MEMSET,
   MG_K_SEG_SCAN, MG_K_SEG_COMPACT, MG_K_PART, MG_K_PART_HIST, MG_K_PART_SCATTER, MG_K_RANK_COUNT, MG_K_RANK_SCAN, MG_K_BUCKET_DEDUP,
-  MG_K_BUCKET_MERGE, MG_K_RANK_LOOKUP, MG_K_TABLE_FIND_SEG, MG_K_HOT_REDUCE, MG_K_BUCKET_FIND, MG_K_UNPART, MG_K_COUNT
+  MG_K_BUCKET_MERGE, MG_K_RANK_LOOKUP, MG_K_TABLE_FIND_SEG, MG_K_HOT_REDUCE, MG_K_BUCKET_FIND, MG_K_UNPART, MG_K_CHAIN, MG_K_CHAIN_RESOLVE, MG_K_COUNT
 };
 void mgProfBegin (int id, hipStream_t st);
 void mgProfEnd (int id, hipStream_t st);

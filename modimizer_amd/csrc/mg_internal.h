@@ -29,7 +29,7 @@ int  mgTextParseFileDevice (const char *filename, char **basesOut, int64_t **off
 /* the same parser for the callers that print record ids: every batch of complete records (device resident: packed bases, read
    offsets) with its ids (id r = idBytes + idOff[r], 0-terminated: seqio.c:303-304) to fn; a non-zero return of fn ends the file */
 typedef int (*MgTextBatchFn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, const char *idBytes, const U64 *idOff, void *stream);
-int  mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 batchBases, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine);   /* batchBases: a batch is handed on once it holds this many bases (0: the default, 1 Gbp) */
+int  mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 batchBases, U64 batchRecs, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine);   /* a batch is handed on (at a window's end) once it holds batchBases bases (0: the default, 1 Gbp) and batchRecs records, or the default's bases whatever the records */
 /* the device halves of the modmap callers (mg_callers.c): a batch that is already on the device */
 int  mgQueryProcessDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, int nReads, const char **names, FILE *out);
 /* mgQueryFile's batches: Push runs the device half now, one writer thread formats and writes the lines, in order, behind it */

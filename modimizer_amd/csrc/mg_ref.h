@@ -3,12 +3,15 @@
 #define MG_REF_H
 #include "mg_common.h"
 struct MgRefDev {
-  U8 *info = 0;                      /* [ms->max + 1] the modset's flag bytes, copy classes set (modmap.c:125-129) */
-  U32 *loc = 0, *rev = 0;            /* referencePack's CSR (modmap.c:74-91): occurrences of index x are rev[loc[x] .. loc[x] + depth[x]) */
-  U32 *id = 0, *offset = 0;          /* per occurrence: sequence, position in it */
+  /* what the chaining reads (mg_chain.hip), derived from the arrays of referencePack (modmap.c:74-91) and the modset's flag bytes: */
+  U64 *li = 0;                       /* [ms->max + 1] loc[x] | (U64) info[x] << 32: CSR offset and copy class (modmap.c:125-129) of modset index x in one word */
+  U64 *revid = 0;                    /* [ref->max + 1] rev[j] | (U64) id[rev[j]] << 32: the j-th occurrence in CSR order with the sequence it lies on; one slot of slack */
+  U32 *offset = 0;                   /* per occurrence: position in its sequence (read when an M block is reported) */
   U32 msMax = 0, refMax = 0;         /* what the arrays above were made for */
-  bool packed = false;               /* loc / rev / info are valid */
-  /* while the reference is being read (mgRefBuildAppend): */
+  int nSeq = 0;
+  bool packed = false;               /* they are valid */
+  /* while the reference is being read and packed (mg_refpack.hip): */
+  U8 *info = 0; U32 *loc = 0, *rev = 0, *id = 0;
   U32 *index = 0, *depth = 0;        /* per occurrence: modset index; per modset index: occurrences */
   size_t capOcc = 0, capMs = 0;
 };

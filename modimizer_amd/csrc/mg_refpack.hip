@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <mutex>
 #include <unordered_map>
 #include "mg_common.h"
@@ -33,7 +34,27 @@ static std::unordered_map<const MgReference *, MgRefDev> gRefDev;
 
 static void mgRefDevFree (MgRefDev &d)
 { (void) hipFree (d.info); (void) hipFree (d.loc); (void) hipFree (d.rev); (void) hipFree (d.id); (void) hipFree (d.offset);
-  (void) hipFree (d.index); (void) hipFree (d.depth); d = MgRefDev ();
+  (void) hipFree (d.index); (void) hipFree (d.depth); (void) hipFree (d.li); (void) hipFree (d.revid); d = MgRefDev ();
+}
+
+/* li[] and revid[] (mg_ref.h) from info / loc / rev / id; those four are freed: the chaining reads the derived words only */
+__global__ void mgRefDeriveLiKernel (const U8 *__restrict__ info, const U32 *__restrict__ loc, U64 m, U64 *__restrict__ li)
+{ for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i < m ; i += (U64) gridDim.x * blockDim.x) li[i] = (U64) loc[i] | ((U64) info[i] << 32); }
+__global__ void mgRefDeriveRevidKernel (const U32 *__restrict__ rev, const U32 *__restrict__ id, U64 n, U64 *__restrict__ revid)      /* n = ref->max; slot n: occurrence 0 */
+{ for (U64 j = (U64) blockIdx.x * blockDim.x + threadIdx.x ; j <= n ; j += (U64) gridDim.x * blockDim.x) { const U32 r = j < n ? rev[j] : 0u; revid[j] = (U64) r | ((U64) (n ? id[r] : 0u) << 32); } }
+static MgStatus mgRefDerive (MgRefDev &d, U32 msMax, U32 refMax, hipStream_t st)
+{
+  const U64 m = (U64) msMax + 1, n = refMax;
+  if (d.nSeq >= (1 << 29)) { mgSetError ("more than 2^29 reference sequences"); return MG_ERR_ARG; }      /* (the chaining's seed records keep three flag bits above the sequence id) */
+  (void) hipFree (d.li); d.li = 0; (void) hipFree (d.revid); d.revid = 0;
+  MG_HIP (hipMalloc ((void **) &d.li, m * 8));
+  MG_HIP (hipMalloc ((void **) &d.revid, (n + 1) * 8));
+  hipLaunchKernelGGL (mgRefDeriveLiKernel, dim3 (2048), dim3 (256), 0, st, d.info, d.loc, m, d.li);
+  hipLaunchKernelGGL (mgRefDeriveRevidKernel, dim3 (2048), dim3 (256), 0, st, d.rev, d.id, n, d.revid);
+  MG_HIP (hipGetLastError ());
+  MG_HIP (hipStreamSynchronize (st));
+  (void) hipFree (d.info); d.info = 0; (void) hipFree (d.loc); d.loc = 0; (void) hipFree (d.rev); d.rev = 0; (void) hipFree (d.id); d.id = 0;
+  return MG_OK;
 }
 
 extern "C" void mgChainForget (const MgReference *ref)
@@ -50,7 +71,7 @@ MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
   std::lock_guard<std::mutex> g (gRefLock);
   MgRefDev &d = gRefDev[ref];
   const U32 msMax = ref->ms->max, refMax = ref->max;
-  if (d.info && d.packed && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
+  if (d.li && d.packed && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
   mgRefDevFree (d);
   const size_t m = (size_t) msMax + 1, n = refMax ? refMax : 1;
   MG_HIP (hipMalloc ((void **) &d.info, m));
@@ -64,6 +85,8 @@ MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
   if ((s = mgXferH2D (d.info, ref->ms->info, m)) || (s = mgXferH2D (d.loc, ref->loc, m * 4))) return s;
   if (refMax && ((s = mgXferH2D (d.rev, ref->rev, (size_t) refMax * 4)) || (s = mgXferH2D (d.id, ref->id, (size_t) refMax * 4))
                  || (s = mgXferH2D (d.offset, ref->offset, (size_t) refMax * 4)))) return s;
+  d.nSeq = ref->nSeq;
+  if ((s = mgRefDerive (d, msMax, refMax, 0))) return s;
   d.msMax = msMax; d.refMax = refMax; d.packed = true;
   *out = d;
   return MG_OK;
@@ -339,6 +362,9 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
   const U32 msMax = ref->ms->max, n = ref->max;
   const size_t m = (size_t) msMax + 1;
   tallies[0] = tallies[1] = tallies[2] = 0;
+  struct timespec tq0; clock_gettime (CLOCK_MONOTONIC, &tq0);
+  const bool lapOn = mgKnobs ()->seedTiming == 1;
+#define MG_LAP(what) do { if (lapOn) { (void) hipStreamSynchronize (st); struct timespec q_; clock_gettime (CLOCK_MONOTONIC, &q_); fprintf (stderr, "mgRefBuildFinish: %s at %.1f ms\n", what, (q_.tv_sec - tq0.tv_sec) * 1e3 + (q_.tv_nsec - tq0.tv_nsec) * 1e-6); } } while (0)
   if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
   if (!d.depth)                                                      /* no batch ever came: an empty reference */
     { MG_HIP (hipMalloc ((void **) &d.depth, (m + 1) * 4)); MG_HIP (hipMemsetAsync (d.depth, 0, (m + 1) * 4, st)); d.capMs = m; }
@@ -354,10 +380,13 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
     /* info: the host's flag bytes up, the copy classes set, back down (and kept for the chaining) */
     (void) hipFree (d.info); d.info = 0; (void) hipFree (d.loc); d.loc = 0;
     if (hipMalloc ((void **) &d.info, m) || hipMalloc ((void **) &d.loc, (m + 1) * 4) || hipStreamSynchronize (st)) break;
-    if ((s = mgXferH2D (d.info, hInfo, m))) break;
+    MG_LAP ("allocations");
+    if ((s = mgXferH2DSparse (d.info, hInfo, m))) break;
+    MG_LAP ("info up");      /* (a new Modset's info[] has never been written: nothing is read, and the mirror below lands on fresh pages) */
     s = MG_ERR_HIP;
     if (msMax) hipLaunchKernelGGL (mgRefClassifyKernel, dim3 (2048), dim3 (256), 0, st, d.depth, msMax, d.info, dTal);
     if ((s = mgRefExclusiveScan (d.depth, d.loc, m, tiles, st))) break;
+    MG_LAP ("classes + loc");
     s = MG_ERR_HIP;
     if (hipMemcpyAsync (tallies, dTal, 12, hipMemcpyDeviceToHost, st)) break;
     /* rev: the occurrence ordinals sorted by index, stably */
@@ -367,6 +396,7 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
         const int passes = (keyBits + 7) / 8;
         if (hipMalloc ((void **) &hist, (histWords + 2) * 4) || hipMalloc ((void **) &v1, ((size_t) n + 1) * 4) || hipMalloc ((void **) &v2, ((size_t) n + 1) * 4)) break;
         if (passes > 1 && (hipMalloc ((void **) &k1, (size_t) n * 4) || (passes > 2 && hipMalloc ((void **) &k2, (size_t) n * 4)))) break;
+        MG_LAP ("sort allocations");
         const U32 *kin = d.index; const U32 *vin = 0;
         U32 *kout = k1, *vout = v1;
         bool bad = false;
@@ -380,19 +410,25 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
             kout = kout == k1 ? k2 : k1; vout = vout == v1 ? v2 : v1;
           }
         if (bad || hipGetLastError () != hipSuccess) break;
+        MG_LAP ("sort");
         d.rev = (U32 *) vin;                                         /* the last pass's output */
         if (d.rev == v1) v1 = 0; else v2 = 0;
         if (hipMemsetAsync (d.rev + n, 0, 4, st)) break;            /* (the chaining reads rev[loc[x] + 1] of a copy-2 seed: inside the array, but keep the slack defined) */
       }
     else { if (hipMalloc ((void **) &d.rev, 8) || hipMemsetAsync (d.rev, 0, 8, st)) break; }
     if (hipStreamSynchronize (st)) break;
+    if (mgKnobs ()->seedTiming == 1) { struct timespec q; clock_gettime (CLOCK_MONOTONIC, &q); fprintf (stderr, "mgRefBuildFinish: kernels done at %.1f ms\n", (q.tv_sec - tq0.tv_sec) * 1e3 + (q.tv_nsec - tq0.tv_nsec) * 1e-6); }
     /* mirror */
     if ((s = mgXferD2H (hInfo, d.info, m, MG_XFER_COPY)) || (s = mgXferD2H (hDepth, d.depth, m * 4, MG_XFER_COPY)) || (s = mgXferD2H (hLoc, d.loc, m * 4, MG_XFER_COPY))) break;
     if (n && ((s = mgXferD2H (hIndex, d.index, (size_t) n * 4, MG_XFER_COPY)) || (s = mgXferD2H (hOffset, d.offset, (size_t) n * 4, MG_XFER_COPY))
               || (s = mgXferD2H (hId, d.id, (size_t) n * 4, MG_XFER_COPY)) || (s = mgXferD2H (hRev, d.rev, (size_t) n * 4, MG_XFER_COPY)))) break;
     /* what the chaining does not read goes; the rest is the resident copy */
     (void) hipFree (d.index); d.index = 0; (void) hipFree (d.depth); d.depth = 0; d.capOcc = 0; d.capMs = 0;
-    if (!d.id) { if (hipMalloc ((void **) &d.id, 8) || hipMalloc ((void **) &d.offset, 8)) { s = MG_ERR_HIP; break; } }
+    if (!d.id) { if (hipMalloc ((void **) &d.id, 8) || hipMalloc ((void **) &d.offset, 8) || hipMemset (d.id, 0, 8)) { s = MG_ERR_HIP; break; } }
+    d.nSeq = ref->nSeq;
+    MG_LAP ("mirror");
+    if ((s = mgRefDerive (d, msMax, n, st))) break;
+    MG_LAP ("derive");
     d.msMax = msMax; d.refMax = n; d.packed = true;
     s = MG_OK;
   } while (0);

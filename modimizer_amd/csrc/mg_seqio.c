@@ -1073,7 +1073,7 @@ int mgReferenceFastaRead (MgReference *ref, const char *filename, bool isAdd, FI
     int first = -1;
     { FILE *f = fopen (filename, "rb"); if (f) { first = fgetc (f); fclose (f); } }
     if (first == '>')                                     /* (a FASTQ reference goes the host way: the hand-over in the middle of a file is not worth having here) */
-      { const int rc = mgTextForEachBatchDevice (filename, refDeviceBatch, &c, 0, &nSeq, &totLen, &resumeOff, &resumeLine);
+      { const int rc = mgTextForEachBatchDevice (filename, refDeviceBatch, &c, 0, 0, &nSeq, &totLen, &resumeOff, &resumeLine);
         if (rc == -1) return -1;
         if (rc == 0) { mgReferenceFinish (ref, totLen, isAdd, out); return 0; }
       }
@@ -1095,9 +1095,12 @@ static int queryBatch (MgSeqBatch *b, void *v)
 static int queryDeviceBatch (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, void *stream)
 { (void) stream; return mgQueryPipePush ((MgQueryPipe *) v, dPacked, total, dOff, (int) nReads, idBytes, idOff); }
 
-/* a query batch per window of the file (128 MiB of text; a batch is handed on at the first window's end at which it holds this
-   many bases): the lines of one batch are formatted and written while the next one is read, parsed and queried */
+/* short reads: a query batch per window of the file (128 MiB of text; a batch is handed on at the first window's end at which it holds
+   this many bases and records): the lines of one batch are formatted and written while the next one is read, parsed and queried.
+   Long reads (few lines): batches of the default size, 1 Gbp -- the chaining of a batch (mg_chain.hip) takes as long as the serial
+   walk of its longest read, whatever else it holds: 38 batches of 134 Mbp spent 17 ms there per 5 Gbp */
 #define MG_QUERY_FILE_BATCH 32000000ull
+#define MG_QUERY_FILE_BATCH_RECS 200000ull
 
 int mgQueryFile (MgReference *ref, const char *filename, FILE *out)            /* modmap.c:188-196 */
 {
@@ -1106,7 +1109,7 @@ int mgQueryFile (MgReference *ref, const char *filename, FILE *out)            /
      its newline, FASTQ that breaks a rule: the host parser (from the first record the device parser has not handed on) */
   U64 nSeq = 0, totLen = 0, resumeOff = 0, resumeLine = 1;
   MgQueryPipe *pipe = mgQueryPipeOpen (ref, out);
-  int rc = mgTextForEachBatchDevice (filename, queryDeviceBatch, pipe, MG_QUERY_FILE_BATCH, &nSeq, &totLen, &resumeOff, &resumeLine);
+  int rc = mgTextForEachBatchDevice (filename, queryDeviceBatch, pipe, MG_QUERY_FILE_BATCH, MG_QUERY_FILE_BATCH_RECS, &nSeq, &totLen, &resumeOff, &resumeLine);
   mgQueryPipeClose (pipe);                                 /* every line of the device parser's batches is out */
   if (rc == 0 || rc == -1) return rc;
   if (rc == -3) return forEachBatchFrom (filename, (size_t) resumeOff, resumeLine, nSeq, queryBatch, &c);

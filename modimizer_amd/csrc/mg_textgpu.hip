@@ -633,6 +633,7 @@ struct TxSink {                                            /* what is done with 
   int (*fn) (void *ctx, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st);
   void *ctx;
   U64 batchBases = 0;                                      /* != 0: a batch is handed on once it holds this many bases (the knobs, which tests set, come first) */
+  U64 batchRecs = 0;                                       /* != 0: ... and this many records -- or the default batch's bases whatever the records (long reads: few lines to format, and a batch's chaining costs its LONGEST read's serial walk: fewer, larger batches) */
   bool wantIds;                                            /* the records' ids (seqio.c:303-304: the header line after its '>' / '@' up to the first white space): id r = idBytes + idOff[r], 0-terminated */
 };
 
@@ -783,7 +784,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
       return rq;
     }
   const size_t window = txWindowBytes (fileSize);
-  const U64 batch = txBatchBases (sink.batchBases);
+  const U64 batch = txBatchBases (sink.batchBases), bigBatch = batch > txBatchBases (0) ? batch : txBatchBases (0);
   hipStream_t st = 0;
   int rc = -1;
   U64 nSeq = 0, totLen = 0;
@@ -850,7 +851,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
             ids.headers (t.hPin[cur], nCur, hdr, nThreads);
           }
         const bool eof = !nNext;
-        if (eof || accBases >= batch)
+        if (eof || accBases >= bigBatch || (accBases >= batch && accRecs >= sink.batchRecs))
           { /* complete records: all of them at the end of the file, otherwise all but the one still open */
             U64 nRec = eof ? accRecs : accRecs - 1, total = accBases;
             if (!eof && hipMemcpy (&total, t.dRecOff + nRec, 8, hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
@@ -893,7 +894,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
 static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink, U64 *nSeqOut, U64 *totLenOut, U64 *resumeOff, U64 *resumeLine)
 {
   const size_t window = txWindowBytes (fileSize);
-  const U64 batch = txBatchBases (sink.batchBases);
+  const U64 batch = txBatchBases (sink.batchBases), bigBatch = batch > txBatchBases (0) ? batch : txBatchBases (0);
   hipStream_t st = 0;
   int rc = -1;
   U64 nSeq = 0, totLen = 0, resume = 0;
@@ -979,7 +980,7 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
                         || hipMemcpy (&tail[2], t.dEndP + accRecs, 8, hipMemcpyDeviceToHost) != hipSuccess)) { failed = true; break; }
         if (bad || (eof && ((nlCount & 3) || accBases != (accRecs ? tail[0] : 0) || accQual != (accRecs ? tail[1] : 0))))
           { handOver = true; break; }                      /* nothing of the accumulator has been added: the host parser starts at its first record */
-        if ((eof || accBases >= batch) && accRecs)
+        if ((eof || accBases >= bigBatch || (accBases >= batch && accRecs >= sink.batchRecs)) && accRecs)
           { ck.lap (ck.flush);
             if (txFlush (t, sink, tail[0], accRecs, st, &ids)) { failed = true; break; }
             ck.lap (ck.sink);
@@ -1037,10 +1038,10 @@ extern "C" int mgAddSequenceFileDevice (Modset *ms, const char *filename, U64 *n
 struct TxCbCtx { MgTextBatchFn fn; void *ctx; };
 static int txCbSink (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, hipStream_t st)
 { TxCbCtx *c = (TxCbCtx *) v; return c->fn (c->ctx, dPacked, total, dOff, nReads, idBytes, idOff, (void *) st); }
-extern "C" int mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 batchBases, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine)
+extern "C" int mgTextForEachBatchDevice (const char *filename, MgTextBatchFn fn, void *ctx, U64 batchBases, U64 batchRecs, U64 *nSeq, U64 *totLen, U64 *resumeOff, U64 *resumeLine)
 {
   TxCbCtx c; c.fn = fn; c.ctx = ctx;
-  TxSink sink; sink.fn = txCbSink; sink.ctx = &c; sink.wantIds = true; sink.batchBases = batchBases;
+  TxSink sink; sink.fn = txCbSink; sink.ctx = &c; sink.wantIds = true; sink.batchBases = batchBases; sink.batchRecs = batchRecs;
   return txParseFile (filename, sink, nSeq, totLen, resumeOff, resumeLine);
 }
 

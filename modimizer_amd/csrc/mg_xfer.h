@@ -7,7 +7,9 @@
 /* both return when the bytes are where they go; the caller has synchronised whatever produced devSrc / reads devDst */
 MgStatus mgXferD2H (void *hostDst, const void *devSrc, size_t bytes, int op);
 MgStatus mgXferH2D (void *devDst, const void *hostSrc, size_t bytes);
+MgStatus mgXferH2DSparse (void *devDst, const void *hostSrc, size_t bytes);      /* the same for a calloc ()ed array of the library's that may be mostly untouched: never-written pages are not read (see mg_xfer.hip) */
 int      mgXferThreads (void);
+void     mgXferWarm (void);            /* make the team's streams and page-locked blocks now, on a thread of its own (a transfer is going to follow) */
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -11,6 +11,7 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -19,16 +20,24 @@
 #include "mg_xfer.h"
 
 #define MG_XFER_MAXT   16
-#define MG_XFER_PIECE  ((size_t) 4 << 20)              /* bytes per piece: 80 us on the link, long enough to hide a copy call */
+#define MG_XFER_PIECE_MAX ((size_t) 16 << 20)
+static size_t gPiece = (size_t) 4 << 20;                 /* bytes per piece: 80 us on the link, long enough to hide a copy call (measured, 4 threads with a stream each: 1 MiB 54 GB/s, 4 MiB 49 - 54, 16 MiB 52; MODGPU_XFER_PIECE_KB: dev) */
+#define MG_XFER_PIECE  gPiece
 
-struct MgXferLane { hipStream_t st; char *pin[2]; hipEvent_t ev[2]; };
+/* A lane has a copy stream of its own: four queues keep the link at 52 - 54 GB/s, all lanes on the device's default stream reach 46
+   (tools/xfer_probe.py) -- and a call that follows such a transfer on the default stream was seen to wait 30 ms for it to drain.
+   But the first streams a process creates cost 10 ms apiece (42 ms for four: half of a first mgReferenceRead's mirror), so they are
+   made AHEAD of their first use, by a thread started when a Modset gets its device table (mgXferWarm): by the time there is
+   something to mirror they exist.  MODGPU_XFER_STREAMS=0 puts the copies on the default stream (dev). */
+struct MgXferLane { hipStream_t st; bool own, made; char *pin[2]; hipEvent_t ev[2]; };
 static struct MgXferCtx { int dev = -1; int T = 0; MgXferLane lane[MG_XFER_MAXT]; std::mutex lock; } gX;
 
 static void mgXferDropLocked (void)
 {
   for (int t = 0 ; t < gX.T ; ++t)
     { MgXferLane &l = gX.lane[t];
-      if (l.st) { (void) hipStreamSynchronize (l.st); (void) hipStreamDestroy (l.st); }
+      if (l.made) (void) hipStreamSynchronize (l.st);
+      if (l.made && l.own) (void) hipStreamDestroy (l.st);
       for (int b = 0 ; b < 2 ; ++b) { if (l.pin[b]) (void) hipHostFree (l.pin[b]); if (l.ev[b]) (void) hipEventDestroy (l.ev[b]); }
       memset (&l, 0, sizeof (l));
     }
@@ -38,32 +47,52 @@ static void mgXferDropLocked (void)
 int mgXferThreads (void)
 {
   const long kv = mgKnobs ()->xferThreads;
-  long v = (kv != MG_KNOB_UNSET && kv > 0) ? kv : mgCpuBudget ();
+  long v = (kv != MG_KNOB_UNSET && kv > 0) ? kv : (mgCpuBudget () < 4 ? mgCpuBudget () : 4);      /* measured (tools/xfer_probe.py, 1 GiB, 16 CPUs granted): 4 threads 52 GB/s device to host, 8: 47, 16: 43 -- four memcpy streams keep up with the link, more get in each other's way; host to device 55 either way */
   if (v > MG_XFER_MAXT) v = MG_XFER_MAXT;
   if (v < 1) v = 1;
   return (int) v;
 }
 
 extern "C" int mgXferThreadCount (void) { return mgXferThreads (); }
-extern "C" void mgXferReleaseBuffers (void) { std::lock_guard<std::mutex> g (gX.lock); mgXferDropLocked (); }
+/* the thread that makes the lanes ahead of their first use; joined before another is started, on release, and when the library's
+   statics are destroyed (a std::thread that is destroyed while it can still be joined ends the process) */
+static std::mutex gWarmLock;
+static struct MgWarmThread { std::thread t; ~MgWarmThread () { if (t.joinable ()) t.join (); } } gWarmHolder;
+#define gWarm gWarmHolder.t
+static void mgXferWarmJoin (void) { std::lock_guard<std::mutex> g (gWarmLock); if (gWarm.joinable ()) gWarm.join (); }
+extern "C" void mgXferReleaseBuffers (void) { mgXferWarmJoin (); std::lock_guard<std::mutex> g (gX.lock); mgXferDropLocked (); }
 
-/* lanes 0 .. T-1 on the current device (gX.lock held) */
+/* the context for T lanes on the current device (gX.lock held): a lane's stream, blocks and events are made by the thread that runs
+   the lane, on its first piece (sixteen threads page-lock their blocks side by side instead of one after the other) */
 static MgStatus mgXferPrepareLocked (int T)
 {
   int dev = 0; MG_HIP (hipGetDevice (&dev));
-  if (gX.dev >= 0 && gX.dev != dev) mgXferDropLocked ();      /* streams and events belong to a device */
+  const long kb = mgKnobs ()->xferPieceKb;
+  size_t piece = (kb != MG_KNOB_UNSET && kb >= 64) ? (size_t) kb << 10 : (size_t) 4 << 20;
+  if (piece > MG_XFER_PIECE_MAX) piece = MG_XFER_PIECE_MAX;
+  if ((gX.dev >= 0 && gX.dev != dev) || piece != gPiece) mgXferDropLocked ();      /* streams and events belong to a device; the blocks are a piece long */
+  gPiece = piece;
   gX.dev = dev;
-  for (int t = gX.T ; t < T ; ++t)
-    { MgXferLane &l = gX.lane[t];
-      memset (&l, 0, sizeof (l));
-      gX.T = t + 1;                                           /* (a lane made by halves is still dropped whole) */
-      MG_HIP (hipStreamCreateWithFlags (&l.st, hipStreamNonBlocking));
-      for (int b = 0 ; b < 2 ; ++b)
-        { MG_HIP (hipHostMalloc ((void **) &l.pin[b], MG_XFER_PIECE, hipHostMallocPortable));
-          MG_HIP (hipEventCreateWithFlags (&l.ev[b], hipEventDisableTiming));
-        }
-    }
+  if (T > gX.T) { for (int t = gX.T ; t < T ; ++t) memset (&gX.lane[t], 0, sizeof (MgXferLane)); gX.T = T; }
   return MG_OK;
+}
+static hipError_t mgXferLaneMake (MgXferLane &l)
+{
+  if (l.made) return hipSuccess;
+  hipError_t e;
+  struct timespec a, b1, c; clock_gettime (CLOCK_MONOTONIC, &a);
+  if (mgKnobs ()->xferStreams != 0) { if ((e = hipStreamCreateWithFlags (&l.st, hipStreamNonBlocking)) != hipSuccess) return e; l.own = true; }
+  else { l.st = 0; l.own = false; }                       /* (dev) the device's default stream */
+  l.made = true;
+  clock_gettime (CLOCK_MONOTONIC, &b1);
+  for (int b = 0 ; b < 2 ; ++b)
+    { if (!l.pin[b] && (e = hipHostMalloc ((void **) &l.pin[b], MG_XFER_PIECE, hipHostMallocPortable)) != hipSuccess) return e;
+      if (!l.ev[b] && (e = hipEventCreateWithFlags (&l.ev[b], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+  clock_gettime (CLOCK_MONOTONIC, &c);
+  if (mgKnobs ()->uploadTiming == 1)
+    fprintf (stderr, "mgXferLaneMake: stream %.2f ms, blocks + events %.2f ms\n", (b1.tv_sec - a.tv_sec) * 1e3 + (b1.tv_nsec - a.tv_nsec) * 1e-6, (c.tv_sec - b1.tv_sec) * 1e3 + (c.tv_nsec - b1.tv_nsec) * 1e-6);
+  return hipSuccess;
 }
 
 static inline void mgXferApply (char *dst, const char *src, size_t bytes, int op)
@@ -78,7 +107,7 @@ static inline void mgXferApply (char *dst, const char *src, size_t bytes, int op
 static hipError_t mgXferLaneRun (int dev, MgXferLane &l, int t, int T, char *dst, const char *src, size_t bytes, int op)
 {
   hipError_t e = hipSetDevice (dev);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || (e = mgXferLaneMake (l)) != hipSuccess) return e;
   const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
   size_t p = (size_t) t; int b = 0;
   auto issue = [&] (size_t piece, int buf) -> hipError_t
@@ -100,6 +129,7 @@ static hipError_t mgXferLaneRun (int dev, MgXferLane &l, int t, int T, char *dst
 MgStatus mgXferD2H (void *hostDst, const void *devSrc, size_t bytes, int op)
 {
   if (!bytes) return MG_OK;
+  struct timespec q0; clock_gettime (CLOCK_MONOTONIC, &q0);
   std::lock_guard<std::mutex> g (gX.lock);
   const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
   int T = mgXferThreads ();
@@ -116,6 +146,7 @@ MgStatus mgXferD2H (void *hostDst, const void *devSrc, size_t bytes, int op)
   for (auto &x : th) x.join ();
   for (int t = started ; t < T ; ++t) err[t] = mgXferLaneRun (dev, gX.lane[t], t, T, (char *) hostDst, (const char *) devSrc, bytes, op);
   for (int t = 0 ; t < T ; ++t) if (err[t] != hipSuccess) return mgHipFail (err[t], "mgXferD2H");
+  if (mgKnobs ()->uploadTiming == 1) { struct timespec q1; clock_gettime (CLOCK_MONOTONIC, &q1); fprintf (stderr, "mgXferD2H: %zu bytes, %d threads, %.2f ms\n", bytes, T, (q1.tv_sec - q0.tv_sec) * 1e3 + (q1.tv_nsec - q0.tv_nsec) * 1e-6); }
   return MG_OK;
 }
 
@@ -124,7 +155,7 @@ MgStatus mgXferD2H (void *hostDst, const void *devSrc, size_t bytes, int op)
 static hipError_t mgXferLaneUp (int dev, MgXferLane &l, int t, int T, char *dDst, const char *hSrc, size_t bytes)
 {
   hipError_t e = hipSetDevice (dev);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || (e = mgXferLaneMake (l)) != hipSuccess) return e;
   const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
   int b = 0; size_t done = 0;
   for (size_t p = (size_t) t ; p < nPieces ; p += (size_t) T, b ^= 1, ++done)
@@ -157,4 +188,69 @@ MgStatus mgXferH2D (void *devDst, const void *hostSrc, size_t bytes)
   for (int t = started ; t < T ; ++t) err[t] = mgXferLaneUp (dev, gX.lane[t], t, T, (char *) devDst, (const char *) hostSrc, bytes);
   for (int t = 0 ; t < T ; ++t) if (err[t] != hipSuccess) return mgHipFail (err[t], "mgXferH2D");
   return MG_OK;
+}
+
+/* public forms (include/modgpu.h) */
+extern "C" MgStatus mgCopyD2HBig (void *hostDst, const void *devSrc, size_t bytes)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; MG_HIP (hipDeviceSynchronize ()); return mgXferD2H (hostDst, devSrc, bytes, MG_XFER_COPY); }
+extern "C" MgStatus mgCopyH2DBig (void *devDst, const void *hostSrc, size_t bytes)
+{ MgStatus s = mgEnsureDevice (); if (s) return s; MG_HIP (hipDeviceSynchronize ()); return mgXferH2D (devDst, hostSrc, bytes); }
+
+/* Host to device for an array most of which may never have been written: pages of an anonymous mapping that were never touched read as
+ * zero, and READING them maps the shared zero page -- after which the first write to each (the mirror coming back) is a copy-on-write
+ * fault per 4 KiB instead of a fresh huge page (ms->info of a new Modset, calloc ()ed by modsetCreate: 47 MB came back at 4 GB/s).
+ * /proc/self/pagemap says which pages exist (present or swapped); only those are read and sent, the rest of the device array is
+ * cleared.  Only for arrays the library allocated itself (anonymous memory); anything odd falls back to the plain copy. */
+#include <fcntl.h>
+#include <unistd.h>
+MgStatus mgXferH2DSparse (void *devDst, const void *hostSrc, size_t bytes)
+{
+  if (bytes < ((size_t) 4 << 20)) return mgXferH2D (devDst, hostSrc, bytes);
+  const size_t pg = (size_t) sysconf (_SC_PAGESIZE);
+  const size_t a0 = (size_t) hostSrc, firstPage = a0 / pg, lastPage = (a0 + bytes - 1) / pg, nPages = lastPage - firstPage + 1;
+  U64 *ent = (U64 *) malloc (nPages * 8);
+  const int fd = open ("/proc/self/pagemap", O_RDONLY);
+  bool ok = ent && fd >= 0;
+  for (size_t got = 0 ; ok && got < nPages * 8 ; )
+    { const ssize_t r = pread (fd, (char *) ent + got, nPages * 8 - got, (off_t) (firstPage * 8 + got));
+      if (r <= 0) ok = false; else got += (size_t) r;
+    }
+  if (fd >= 0) close (fd);
+  if (!ok) { free (ent); return mgXferH2D (devDst, hostSrc, bytes); }
+  MgStatus s = MG_OK;
+  if (hipMemset (devDst, 0, bytes) != hipSuccess || hipDeviceSynchronize () != hipSuccess) { free (ent); return mgHipFail (hipGetLastError (), "mgXferH2DSparse"); }
+  for (size_t p = 0 ; p < nPages && !s ; )
+    { if (!(ent[p] >> 62)) { ++p; continue; }              /* bit 63 present, bit 62 swapped: neither = never written */
+      size_t q = p; while (q < nPages && (ent[q] >> 62)) ++q;
+      size_t b0 = (firstPage + p) * pg, b1 = (firstPage + q) * pg;
+      if (b0 < a0) b0 = a0;
+      if (b1 > a0 + bytes) b1 = a0 + bytes;
+      s = mgXferH2D ((char *) devDst + (b0 - a0), (const char *) b0, b1 - b0);
+      p = q;
+    }
+  free (ent);
+  return s;
+}
+
+/* see MgXferLane: called where a transfer is certain to follow (a Modset's device table has just been made) */
+void mgXferWarm (void)
+{
+  int dev = 0;
+  if (hipGetDevice (&dev) != hipSuccess) { (void) hipGetLastError (); return; }
+  const int T = mgXferThreads ();
+  { std::unique_lock<std::mutex> g (gX.lock, std::try_to_lock);
+    if (!g.owns_lock ()) return;                          /* a transfer (or a warm-up) is running: the lanes exist or are being made */
+    if (gX.dev == dev && gX.T >= T) { bool all = true; for (int t = 0 ; t < T ; ++t) all = all && gX.lane[t].made; if (all) return; }
+  }
+  std::lock_guard<std::mutex> w (gWarmLock);
+  if (gWarm.joinable ()) gWarm.join ();
+  try
+    { gWarm = std::thread ([dev, T]
+        { if (hipSetDevice (dev) != hipSuccess) return;
+          std::lock_guard<std::mutex> g (gX.lock);          /* a transfer that comes before this is done waits here, and finds the lanes made */
+          if (mgXferPrepareLocked (T)) return;
+          for (int t = 0 ; t < T ; ++t) if (mgXferLaneMake (gX.lane[t]) != hipSuccess) { (void) hipGetLastError (); return; }
+        });
+    }
+  catch (...) { }                                          /* no thread to be had: the lanes are made when they are first used */
 }
