@@ -207,6 +207,26 @@ MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
  * per-GPU modsets in rank order reproduces the single-stream build exactly. */
 bool mgModsetMergeArrays (Modset *ms1, U64 *value2, U16 *depth2, U8 *info2, U32 n2) ;
 
+/* Multi-GPU from C, straight on RCCL (BASELINE config 4).  Reads shard over the GPUs, every GPU builds its own modset, no
+ * collective on the data path; these are the exchanges there are.  Communicators as RCCL has them: ONE PROCESS, N DEVICES, a host
+ * thread per device (mgCommInitAll; each thread calls mgSetDevice (device of its comm) and then uses the library as on one GPU) -- or ONE
+ * PROCESS PER DEVICE (rank 0 calls mgCommGetUniqueId and hands the 128 bytes to the others by its own means -- a file, a socket, MPI --,
+ * every rank calls mgCommInitRank).  librccl is loaded by the first of these calls, not before. */
+typedef struct MgComm MgComm ;
+MgStatus mgCommInitAll (MgComm **comms /* [nDev] out */, int nDev, const int *devices /* 0: 0 .. nDev-1 */) ;
+MgStatus mgCommGetUniqueId (void *id128) ;
+MgStatus mgCommInitRank (MgComm **comm, int nRanks, int rank, const void *id128, int device) ;
+int      mgCommRank (const MgComm *c) ;
+int      mgCommSize (const MgComm *c) ;
+void     mgCommDestroy (MgComm *c) ;
+/* config 4's collective: hist65536[d] (host, U64) = over all ranks, the number of modset entries of depth d (modutils.c:53-63 per rank,
+ * all-reduced with SUM: 512 KiB a rank over xGMI).  Every rank calls it with its own set and gets the sum. */
+MgStatus mgHistogramAllReduce (Modset *ms, U64 *hist65536, MgComm *c) ;
+/* the exact global set: on rank `root` ms becomes the merge of every rank's set in RANK order with modsetMerge semantics
+ * (modset.c:106-128): with contiguous blocks of reads per rank and root = 0 that is, bit for bit, the set one stream over all the reads
+ * builds.  Every rank calls it; the others' sets are sent (point to point, one rank at a time) and left as they are. */
+MgStatus mgModsetMergeRankOrder (Modset *ms, MgComm *c, int root) ;
+
 /* Host-side batch mirrors of the reference callers' loops. */
 /* modutils.c:19-31 over nReads reads; returns total hashes, -1 on error. ms->max updated. */
 int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads) ;

@@ -163,6 +163,8 @@ MgHashParams mgMakeParams (const Seqhash *sh)
   for (int i = 0 ; i < 6 ; ++i) x *= 2 - odd * x;
   p.dOddInv = x;
   p.dOddLim = ~(U64) 0 / odd;
+  p.small32 = (2 * sh->k <= 40 && odd < ((U64) 1 << 15)) ? 1u : 0u;
+  p.c24 = (U32) (((U64) 1 << 24) % odd); p.inv32 = (U32) x; p.lim32 = (U32) (0xffffffffull / odd);
   return p;
 }
 

@@ -25,6 +25,11 @@ struct MgHashParams {
   int dShift;      /* d = dOdd << dShift */
   U64 dOddInv;     /* inverse of dOdd mod 2^64 */
   U64 dOddLim;     /* floor((2^64-1) / dOdd) */
+  /* the same test in 32-bit arithmetic, for hashes of at most 40 bits (k <= 20) and d < 2^15 (mgDivisibleOdd32): */
+  U32 c24;         /* 2^24 mod dOdd */
+  U32 inv32;       /* inverse of dOdd mod 2^32 */
+  U32 lim32;       /* floor((2^32-1) / dOdd) */
+  U32 small32;     /* 1 when the 32-bit test applies */
 };
 
 void mgSetError (const char *fmt, ...);
@@ -52,6 +57,19 @@ __device__ __forceinline__ bool mgDivisible (U64 x, const MgHashParams &p)
 {
   if (x & (((U64) 1 << p.dShift) - 1)) return false;
   return ((x >> p.dShift) * p.dOddInv) <= p.dOddLim;
+}
+
+/* Exact "h % dOdd == 0" for h < 2^40 and odd dOdd < 2^15 in 32-bit arithmetic (seqhash.c:190 is `u % w`):
+ * h = a 2^24 + b with a < 2^16, b < 2^24, so h = a c24 + b (mod dOdd) with c24 = 2^24 mod dOdd, and t = a c24 + b < 2^16 2^15 + 2^24
+ * < 2^32 does not overflow; t is a multiple of the odd dOdd iff t dOdd^-1 mod 2^32 <= floor((2^32-1) / dOdd).
+ * v_alignbit + v_and + v_mad_u32_u24 + v_mul_lo_u32 + v_cmp, in the place of a 64-bit low product (2 v_mul_lo_u32 + the double-cost
+ * v_mad_u64_u32 + v_add3) and a 64-bit compare. */
+__device__ __forceinline__ bool mgDivisibleOdd32 (U64 h, const MgHashParams &p)
+{
+  const U32 lo = (U32) h, hi = (U32) (h >> 32);
+  const U32 a = __builtin_amdgcn_alignbit (hi, lo, 24);          /* h >> 24 */
+  const U32 t = __umul24 (a, p.c24) + (lo & 0xffffffu);
+  return t * p.inv32 <= p.lim32;
 }
 
 /* reverse complement of 16 bases in one word: reverse the bit order, swap the two bits of every base back, complement.

@@ -193,6 +193,8 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
 #define MG_MODE_POW2  1      /* d = 2^m: exact test in phase A via a mask */
 #define MG_MODE_FAST  2      /* d = 2^m, shift1+m <= 32, k >= 17: low-bits filter in phase A */
 #define MG_MODE_ODD   3      /* odd d (the reference's default w = 31): the exact test is the inverse's product alone */
+#define MG_MODE_ODD32 4      /* odd d < 2^15 and k <= 20 (the reference's defaults k = 19, w = 31): that test in 32-bit arithmetic (mgDivisibleOdd32) */
+#define MG_MODE_ANY32 5      /* d = odd 2^s, d < 2^15, k <= 20: low s bits zero and the 32-bit test on the rest */
 #define MG_LIST_UNROLL 4     /* candidates per half of a lane's mask listed by straight-line code */
 #define MG_CAND_CAP   320    /* candidate list entries (LDS, per wavefront): up to 63 waiting from the tile before + a pass of this tile's */
 #define MG_WAVES      (MG_SCAN_THREADS / 64)
@@ -389,6 +391,8 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
                   bool hit;
                   if (MODE == MG_MODE_POW2)     hit = (h & dMask) == 0;
                   else if (MODE == MG_MODE_ODD) hit = h * p.dOddInv <= p.dOddLim;
+                  else if (MODE == MG_MODE_ODD32) hit = mgDivisibleOdd32 (h, p);
+                  else if (MODE == MG_MODE_ANY32) hit = !((U32) h & (((U32) 1 << p.dShift) - 1u)) && mgDivisibleOdd32 (h >> p.dShift, p);
                   else                          hit = mgDivisible (h, p);
                   acc = (acc << 1) | (hit ? 1u : 0u);
                 }
@@ -494,6 +498,8 @@ __device__ __forceinline__ U64 mgScanWorker (const MgScanArgs &a, const U64 work
                     U64 h = fwd ? hF : hR;
                     if (MODE == MG_MODE_POW2)     surv = (h & dMask) == 0;
                     else if (MODE == MG_MODE_ODD) surv = h * p.dOddInv <= p.dOddLim;
+                    else if (MODE == MG_MODE_ODD32) surv = mgDivisibleOdd32 (h, p);
+                    else if (MODE == MG_MODE_ANY32) surv = !((U32) h & (((U32) 1 << p.dShift) - 1u)) && mgDivisibleOdd32 (h >> p.dShift, p);
                     else                          surv = mgDivisible (h, p);
                   }
                 if (!fwd) F = R;
@@ -804,7 +810,9 @@ static int mgScanMode (const MgHashParams &p, MgScanArgs *a)
       a->thresh = (U32) 1 << (32 - p.dShift);
       return MG_MODE_FAST;
     }
-  return pow2 ? MG_MODE_POW2 : (p.dShift == 0 ? MG_MODE_ODD : MG_MODE_ANY);
+  if (pow2) return MG_MODE_POW2;
+  const bool small = p.small32 && mgKnobs ()->scanDiv64 != 1;      /* (test knob: 1 = the 64-bit test whatever k and d) */
+  return p.dShift == 0 ? (small ? MG_MODE_ODD32 : MG_MODE_ODD) : (small ? MG_MODE_ANY32 : MG_MODE_ANY);
 }
 
 /* scan tiles [tile0, tile1) of the batch: the modimizers of those k-mer starts, dense and in order */
@@ -851,7 +859,8 @@ MgStatus mgLaunchScanRange (const MgHashParams &p, const U32 *dPacked, U64 total
 #define MG_SCAN_LAUNCH(M) do { if (where) MG_LAUNCH (MG_K_SCAN, st, (mgScanKernel<M, true>), dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a); \
                                else       MG_LAUNCH (MG_K_SCAN, st, (mgScanKernel<M, false>), dim3 (grid), dim3 (MG_SCAN_THREADS), 0, st, a); } while (0)
   if (mode == MG_MODE_FAST) MG_SCAN_LAUNCH (MG_MODE_FAST); else if (mode == MG_MODE_POW2) MG_SCAN_LAUNCH (MG_MODE_POW2);
-  else if (mode == MG_MODE_ODD) MG_SCAN_LAUNCH (MG_MODE_ODD); else MG_SCAN_LAUNCH (MG_MODE_ANY);
+  else if (mode == MG_MODE_ODD) MG_SCAN_LAUNCH (MG_MODE_ODD); else if (mode == MG_MODE_ODD32) MG_SCAN_LAUNCH (MG_MODE_ODD32);
+  else if (mode == MG_MODE_ANY32) MG_SCAN_LAUNCH (MG_MODE_ANY32); else MG_SCAN_LAUNCH (MG_MODE_ANY);
 #undef MG_SCAN_LAUNCH
   MG_HIP (hipGetLastError ());
   MG_LAUNCH (MG_K_SEG_SCAN, st, mgSegScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, g.nBlocks, g.segCap, capacity, segStart, dCount);
@@ -923,6 +932,8 @@ MgStatus mgLaunchIterScan (const MgHashParams &p, const U32 *dPacked, U64 totalB
   if (mode == MG_MODE_FAST)      hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_FAST>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   else if (mode == MG_MODE_POW2) hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_POW2>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   else if (mode == MG_MODE_ODD)  hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ODD>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
+  else if (mode == MG_MODE_ODD32) hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ODD32>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
+  else if (mode == MG_MODE_ANY32) hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ANY32>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   else                           hipLaunchKernelGGL (mgIterScanKernel<MG_MODE_ANY>, dim3 (1), dim3 (MG_ITER_WAVES * 64), 0, st, a, o);
   MG_HIP (hipGetLastError ());
   return MG_OK;

@@ -187,6 +187,37 @@ def test_bench_multi_rank_path_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_c_comm_entry_points_world1():
+    """the one-process-per-device way into RCCL from the C ABI (mgCommGetUniqueId + mgCommInitRank) at world size 1: the all-reduced
+    histogram is modsetDepthHistogramDevice's, mgModsetMergeRankOrder with nobody to merge leaves the set as it is.  Run in a process of
+    its own (librccl is dlopen()ed into it)."""
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import modimizer_amd as mg
+from modimizer_amd import synth
+L = mg.lib(); mg.check(L.mgSetDevice(0))
+ident = (C.c_ubyte * 128)(); mg.check(L.mgCommGetUniqueId(ident))
+comm = C.c_void_p(); mg.check(L.mgCommInitRank(C.byref(comm), 1, 0, ident, 0))
+assert L.mgCommRank(comm) == 0 and L.mgCommSize(comm) == 1
+sh = mg.seqhashCreate(21, 64, 17); ms = mg.modsetCreate(sh, 24)
+bases = synth.iid_bases(3_000_000, 5); bases = np.concatenate([bases, bases[:1_000_000]])      # depths 1 and 2
+off = np.array([0, len(bases)], np.int64)
+n = mg.add_sequence_batch(ms, bases, off)
+hist = np.zeros(65536, np.uint64); mg.check(L.mgHistogramAllReduce(ms, hist.ctypes.data, comm))
+d = mg.DeviceBuffer(65536 * 8); mg.check(L.mgMemsetD(d.ptr, 0, 65536 * 8, None)); mg.check(L.modsetDepthHistogramDevice(ms, d.ptr, None))
+own = d.to_numpy(np.uint64, 65536)
+assert np.array_equal(hist, own) and int(hist.sum()) == ms.contents.max and hist[2] > 0 and int((hist * np.arange(65536, dtype=np.uint64)).sum()) == n
+before = ms.contents.max
+mg.check(L.mgModsetMergeRankOrder(ms, comm, 0)); assert ms.contents.max == before
+L.mgCommDestroy(comm); L.modsetDestroy(ms)
+print("COMM_OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "COMM_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
 def test_bench_world2_code_path_on_one_gpu():
     """`python bench.py --gpus 2` with both ranks on cuda:0 (MODGPU_BENCH_ONE_GPU=1: gloo instead of RCCL, which refuses two
     ranks on one device): the world > 1 branches a one-GPU box cannot otherwise reach -- block r on rank r, the summed histogram
@@ -235,3 +266,12 @@ def test_bench_on_every_gpu_of_the_box(n):
     assert j["value"] >= 0.8 * n * j["single_gpu_block_gbps"], (j["value"], j["single_gpu_block_gbps"])
     c3 = j["other_configs"]["c3_sharded"]
     assert "error" not in c3 and c3["n_gpus"] == n and c3["value"] > 0
+    # the same from C: examples/multi_gpu.c (one process, a host thread per GPU, mgCommInitAll / mgHistogramAllReduce /
+    # mgModsetMergeRankOrder on librccl): the all-reduced histogram is the sum of the GPUs' own, and the per-GPU sets merged in rank
+    # order are, bit for bit, the set one stream over all the blocks builds
+    import tempfile, pathlib
+    from tests.test_example import build_multi_gpu
+    with tempfile.TemporaryDirectory() as td:
+        exe = build_multi_gpu(pathlib.Path(td))
+        r = subprocess.run([exe, str(n), "200"], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0 and "MULTI_GPU_OK" in r.stdout, r.stdout[-800:] + r.stderr[-800:]

@@ -7,13 +7,36 @@ import pytest
 from tests import util
 
 SRC = os.path.join(util.ROOT, "examples", "sketch_file.c")
+SRC_MULTI = os.path.join(util.ROOT, "examples", "multi_gpu.c")
 
 
-def test_example_is_plain_c99(tmp_path):
-    """the header and the example compile as C99 with warnings on (no C++-isms, no HIP types in the ABI)"""
+@pytest.mark.parametrize("src", [SRC, SRC_MULTI])
+def test_example_is_plain_c99(src, tmp_path):
+    """the header and the examples compile as C99 with warnings on (no C++-isms, no HIP types in the ABI)"""
     r = subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-std=c99", "-I", os.path.join(util.ROOT, "include"),
-                        "-c", SRC, "-o", str(tmp_path / "x.o")], capture_output=True, text=True)
+                        "-c", src, "-o", str(tmp_path / "x.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def build_multi_gpu(tmp_path):
+    exe = str(tmp_path / "multi_gpu")
+    libdir = os.path.join(util.ROOT, "modimizer_amd")
+    r = subprocess.run(["gcc", "-O2", "-pthread", "-I", os.path.join(util.ROOT, "include"), SRC_MULTI, "-o", exe, "-L", libdir, "-lmodgpu", "-lm",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.gpu
+def test_multi_gpu_example_on_one_gpu(tmp_path):
+    """examples/multi_gpu.c = BASELINE config 4 in C (mgCommInitAll on librccl, a host thread per GPU, mgHistogramAllReduce,
+    mgModsetMergeRankOrder) at N = 1: the all-reduced histogram is the GPU's own (modsetDepthHistogramDevice), the merged set is the
+    single-stream set.  N > 1 runs where the box has more GPUs (tests/test_dist.py::test_bench_on_every_gpu_of_the_box)."""
+    exe = build_multi_gpu(tmp_path)
+    r = subprocess.run([exe, "1", "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
+    assert "MULTI_GPU_OK" in r.stdout and "histogram: all-reduced == sum of the ranks' own on every rank: yes" in r.stdout
+    assert "identical to the single-stream build over all blocks (value[], depth[]): yes" in r.stdout
 
 
 @pytest.mark.gpu
