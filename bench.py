@@ -804,31 +804,67 @@ def bench_c3(cx, args, shard=None):
     mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
                                   q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
     torch.cuda.synchronize()
+    if not shard and os.environ.get("MODGPU_BENCH_C3_PIPE", "1") != "0":        # ... and of the pipeline's second arena and stream
+        tk = [C.c_void_p(), C.c_void_p()]
+        for j in (0, 1):
+            mg.check(L.mgQueryReadsDeviceAsync(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads, q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(tk[j]), cx.stream))
+        for j in (0, 1):
+            mg.check(L.mgQueryReadsDeviceWait(tk[j], C.byref(n_seeds), cx.stream))
+        torch.cuda.synchronize()
     L.mgProfileReset()
-    tot_bases = tot_seeds = tot_hits = 0
-    per, seeds_each = [], []
-    torch.cuda.synchronize()
-    if shard:
-        cx.dist.barrier()
-    t_all = time.perf_counter()
-    for reads, d_offsets, n_reads, q_idx in batches:
-        t0 = time.perf_counter()
-        mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
-                                      q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
-        per.append(round((time.perf_counter() - t0) * 1e3, 2))      # the call returns when its seeds are complete (it synchronises)
-        seeds_each.append(n_seeds.value)
-        tot_bases += batch; tot_seeds += n_seeds.value
-    torch.cuda.synchronize()
-    if shard:
-        cx.dist.barrier()
-    t_query = time.perf_counter() - t_all
+    # batches that follow one another, two ways: one synchronous call a batch (the headline of this config), and pipelined -- the scan of
+    # batch i + 1 started (mgQueryReadsDeviceAsync: the library's own stream, the other of two scratch arenas) before the lookups of batch i
+    # are run (mgQueryReadsDeviceWait) -- reported beside it (profiles/r05_c3_pipe_trace.txt says why it gains nothing)
+    q_pos2 = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
+    q_rd2 = torch.empty(qcap, dtype=torch.int32, device=cx.dev)
+
+    def run_batches(pipe):
+        per_, seeds_ = [], []
+        torch.cuda.synchronize()
+        if shard:
+            cx.dist.barrier()
+        t_all = time.perf_counter()
+        if pipe:
+            def start(i):
+                reads, d_offsets, n_reads, q_idx = batches[i]
+                t = C.c_void_p()
+                mg.check(L.mgQueryReadsDeviceAsync(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads, q_idx.data_ptr(),
+                                                   (q_pos2 if i & 1 else q_pos).data_ptr(), (q_rd2 if i & 1 else q_rd).data_ptr(), qcap, C.byref(t), cx.stream))
+                return t
+            nxt = start(0)
+            for i in range(len(batches)):
+                t0 = time.perf_counter()
+                cur, nxt = nxt, (start(i + 1) if i + 1 < len(batches) else None)
+                mg.check(L.mgQueryReadsDeviceWait(cur, C.byref(n_seeds), cx.stream))
+                per_.append(round((time.perf_counter() - t0) * 1e3, 2)); seeds_.append(n_seeds.value)
+        else:
+            for reads, d_offsets, n_reads, q_idx in batches:
+                t0 = time.perf_counter()
+                mg.check(L.mgQueryReadsDevice(ms, reads.data_ptr(), batch, d_offsets.data_ptr(), n_reads,
+                                              q_idx.data_ptr(), q_pos.data_ptr(), q_rd.data_ptr(), qcap, C.byref(n_seeds), cx.stream))
+                per_.append(round((time.perf_counter() - t0) * 1e3, 2))      # the call returns when its seeds are complete (it synchronises)
+                seeds_.append(n_seeds.value)
+        torch.cuda.synchronize()
+        if shard:
+            cx.dist.barrier()
+        return time.perf_counter() - t_all, per_, seeds_
+    pipelined = None
+    if not shard and os.environ.get("MODGPU_BENCH_C3_PIPE", "1") != "0":
+        L.mgProfileEnable(0)
+        tp, perp, seedsp = run_batches(True)
+        pipelined = {"value": round(n_batches * batch / tp / 1e9, 2), "ms_per_batch": round(tp / n_batches * 1e3, 3), "ms_each_batch": perp}
+        L.mgProfileEnable(1); L.mgProfileReset()
+    t_query, per, seeds_each = run_batches(False)
+    if pipelined is not None:
+        pipelined["same_seed_counts"] = seedsp == seeds_each
+    tot_bases, tot_seeds, tot_hits = n_batches * batch, sum(seeds_each), 0
     for (reads, d_offsets, n_reads, q_idx), ns in zip(batches, seeds_each):
         tot_hits += int((q_idx[:ns] != 0).sum().item())
     if shard:                                          # whole job: all ranks' bases over the slowest rank's time
         tm = torch.tensor([t_query], dtype=torch.float64, device=cx.dev); cx.dist.all_reduce(tm, op=cx.dist.ReduceOp.MAX)
         tot = torch.tensor([tot_bases, tot_seeds, tot_hits], dtype=torch.int64, device=cx.dev); cx.dist.all_reduce(tot)
         t_job = float(tm.item()); job_bases, job_seeds, job_hits = (int(x) for x in tot.tolist())
-    del batches, reads, d_offsets, q_idx
+    del batches, reads, d_offsets, q_idx, q_pos2, q_rd2
     table = read_profile(L, mg)
     L.mgProfileEnable(0)
     per_batch = {kname: (v[0] / n_batches, 1, v[2]) for kname, v in table.items()}
@@ -852,7 +888,7 @@ def bench_c3(cx, args, shard=None):
                        "%d query batches of %g Gbp ONT-like reads from it (5%% subs): scan + lookup, seeds (index,pos,read) out"
                        % (n_seq, seq_len // 1_000_000, genome_bases / 1e9, bits, ref_occ, ref_entries, n_batches, batch / 1e9),
            "value": round(tot_bases / t_query / 1e9, 2), "unit": "Gbp/s", "ms_per_batch": round(t_query / n_batches * 1e3, 3),
-           "ms_each_batch": per, "query_bases": tot_bases, "seeds": tot_seeds, "seed_hit_fraction": round(tot_hits / max(tot_seeds, 1), 4),
+           "pipelined": pipelined, "ms_each_batch": per, "query_bases": tot_bases, "seeds": tot_seeds, "seed_hit_fraction": round(tot_hits / max(tot_seeds, 1), 4),
            "reference_insert_device_s": round(t_ref, 3), "reference_insert_device_Gbp_per_s": round(genome_bases / t_ref / 1e9, 1),
            "reference_read": ref_read, "reference_read_s": (ref_read or {}).get("whole_call_s"),
            "whole_batch": {"bytes_per_base": 0.25 + 36.0 / d, "GBps": round((0.25 + 36.0 / d) * tot_bases / t_query / 1e9, 1),

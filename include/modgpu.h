@@ -196,6 +196,17 @@ MgStatus mgQueryReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
                              U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
                              U64 *nSeeds, void *stream) ;
 
+/* mgQueryReadsDevice in two halves, for batches that follow one another (config 3: 90 Gbp of reads in batches of 10): Async starts the
+ * batch's scan on a stream of the library's own, into the other of two scratch arenas, and returns at once; Wait runs the lookups on
+ * `stream` and returns when the seeds are complete.  Called as   Async (0); for every i: { Async (i + 1); Wait (i); }   the scan of batch
+ * i + 1 (bound by instruction issue) runs beside the lookups of batch i (bound by memory requests).  At most two batches in flight,
+ * waited for in the order they were started, each with output arrays of its own; the batch on `stream` must be complete there when
+ * Async is called (the scan waits for what that stream holds at that moment); until the last ticket has been waited for the modset takes
+ * no other batch call (they fail with MG_ERR_ARG).  The results are those of mgQueryReadsDevice, bit for bit. */
+MgStatus mgQueryReadsDeviceAsync (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                  U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity, void **ticket, void *stream) ;
+MgStatus mgQueryReadsDeviceWait (void *ticket, U64 *nSeeds, void *stream) ;      /* frees the ticket, also on error */
+
 /* mgInsertReadsDevice = the insert loop of referenceFastaRead (modmap.c:106-118, isAdd true): every
  * modimizer is inserted WITHOUT touching depth and its (index,pos,read) returned. */
 MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,

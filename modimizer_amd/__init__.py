@@ -70,7 +70,7 @@ EXPORTS = [
     "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice", "mgUploadPack",
     "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch", "seqhashMinimizerBatchDevice", "seqhashMinimizerBatch",
     "modsetAddBatchDevice", "modsetFindBatchDevice", "modsetSyncToHost", "mgXferThreadCount", "mgCopyD2HBig", "mgCopyH2DBig", "mgModsetDeviceRelease",
-    "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice",
+    "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice", "mgQueryReadsDeviceAsync", "mgQueryReadsDeviceWait",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgGzipOpenWrite", "mgReferenceLoad",
@@ -175,6 +175,7 @@ def lib():
     sig("modsetDepthHistogramDevice", i32, MS, vp, vp)
     sig("mgAddReadsDevice", i32, MS, vp, u64, vp, u32, U64P, vp)
     sig("mgQueryReadsDevice", i32, MS, vp, u64, vp, u32, vp, vp, vp, u64, U64P, vp)
+    sig("mgQueryReadsDeviceAsync", i32, MS, vp, u64, vp, u32, vp, vp, vp, u64, C.POINTER(vp), vp); sig("mgQueryReadsDeviceWait", i32, vp, U64P, vp)
     sig("mgAddSequenceBatch", i64, MS, vp, vp, i32); sig("mgDepthHistogram", None, MS, vp)
     sig("mgSynthGenome", i32, vp, u64, u64, vp)
     sig("mgSynthReads", i32, vp, u64, vp, vp, vp, u32, u64, C.c_double, u64, vp, vp)

@@ -473,7 +473,11 @@ extern "C" int mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U6
 
 struct MgDev {
   MgTable t;
-  MgArena arena;
+  MgArena arena;           /* the scratch of the call in flight (slot 0 of the query pipeline) */
+  MgArena arena2;          /* slot 1: the scan of the NEXT query batch runs into it while the lookups of this one read slot 0's segments (mgQueryReadsDeviceAsync) */
+  hipStream_t side = 0;    /* the stream those scans run on */
+  hipEvent_t scanned[2] = { 0, 0 }, inputReady = 0;
+  int ticketsOut = 0, nextSlot = 0; bool slotBusy[2] = { false, false };
   U64 *hPin;               /* pinned host words the per-call counters come back into: a device-to-host copy into pageable memory
                               goes through the runtime's staging path, whose wake-up was seen to take 10 - 25 ms now and then */
   U32 hostIndexMax;        /* entries 1..hostIndexMax are present in the host index[] table */
@@ -495,7 +499,10 @@ static void mgDevFree (MgDev *d)
     { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
       (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters); (void) hipFree (d->t.liveHist);
     }
-  d->arena.release ();
+  d->arena.release (); d->arena2.release ();
+  if (d->side) { (void) hipStreamSynchronize (d->side); (void) hipStreamDestroy (d->side); }
+  for (int i = 0 ; i < 2 ; ++i) if (d->scanned[i]) (void) hipEventDestroy (d->scanned[i]);
+  if (d->inputReady) (void) hipEventDestroy (d->inputReady);
   delete d;
 }
 
@@ -774,6 +781,7 @@ static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *
                             bool arenaLive, hipStream_t st, const MgHistReq *counted, const MgSegSrc *segSrc)
 {
   if (!n) return MG_OK;
+  if (d->ticketsOut) { mgSetError ("a query batch of this modset is in flight (mgQueryReadsDeviceAsync without its mgQueryReadsDeviceWait)"); return MG_ERR_ARG; }
   U64 chunk = n < MG_ADD_CHUNK ? n : MG_ADD_CHUNK;
   MgStatus s = mgTableEnsure (&d->t, chunk, st); if (s) return s;
   size_t need = mgTableAddScratchBytes (&d->t, chunk) + 4096;
@@ -825,6 +833,8 @@ extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
   hipStream_t st = 0;
   MgStatus s;
   MG_HIP (hipDeviceSynchronize ());
+  if (d->ticketsOut && (t.pendingDepth || (wantIndex && d->hostIndexMax < t.max)))
+    { mgSetError ("a query batch of this modset is in flight (its scratch is what a sync would use)"); return MG_ERR_ARG; }
   if (t.max > t.syncedMax)
     { const U32 first = t.syncedMax + 1;
       if ((s = mgXferD2H (ms->value + first, t.value + first, (size_t) (t.max - first + 1) * sizeof (U64), MG_XFER_COPY))) return s;
@@ -871,19 +881,71 @@ struct MgScanBufs { U64 *kmer; U32 *posF; U32 *rid; void *work; U64 *count; U64 
 /* outPosF / outRid (with room for outCap entries): the caller's own arrays; when they are large enough for the scan's
  * capacity the compaction writes pos / read straight into them (a device-to-device copy of 1.2 GB per 10 Gbp batch
  * took longer than the scan itself) */
+struct MgScanReq { const Seqhash *sh; const U32 *dPacked; U64 totalBases; const U64 *dReadOffsets; U32 nReads; bool wantPos; size_t extraPerSurvivor;
+                   U32 *outPosF, *outRid; U64 outCap; bool lazy; };
+static inline MgArena &mgArenaOf (MgDev *d, int slot) { return slot ? d->arena2 : d->arena; }
+static inline U64 *mgCountPin (MgDev *d, int slot) { return d->hPin + 8 + 8 * slot; }
+
+/* launch: buffers out of the slot's arena for `cap` modimizers, the scan, its counters on their way to the slot's pinned words.  No
+   wait: mgScanFinish does that */
+static MgStatus mgScanStart (MgDev *d, int slot, const MgScanReq &q, U64 cap, MgScanBufs *b, hipStream_t st)
+{
+  b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0; b->findScratch = 0; b->findScratch2 = 0;
+  MgArena &ar = mgArenaOf (d, slot);
+  /* a lookup batch whose k-mers stay in the segments may take the partitioned path (mgTableFindPartitioned): it needs the first digit's counts */
+  const long fp = mgKnobs ()->findPath;
+  const bool lookupHist = q.lazy && q.wantPos && !q.extraPerSurvivor && d->t.slots && fp != 'd'
+                          && (fp == 'p' || fp == '2' || (cap >= ((U64) 1 << 24) && d->t.nSlots >= ((U64) 1 << 24) && d->t.log2NB > 9));
+  const bool lookup2 = lookupHist && fp != 'p';
+  MgHashParams p = mgMakeParams (q.sh);
+  const size_t perS = 8 + (q.wantPos ? 8 : 0) + q.extraPerSurvivor;
+  const size_t need = al256 (cap * perS) + 4 * 4096 + 512 * MG_HIST_STRIDE * 4 + al256 (mgScanWorkBytes (q.totalBases, q.nReads, cap))
+                      + (q.extraPerSurvivor ? mgTableAddScratchBytes (&d->t, cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK) + 8192 : 0) + 8 * 256
+                      + (lookupHist ? mgTableFindPartScratchBytes (cap) + 8192 : 0) + (lookup2 ? mgTableFindPart2ScratchBytes (cap) + 8192 : 0);
+  MgStatus s = ar.reserve (need); if (s) return s;
+  ar.reset ();
+  b->cap = cap;
+  b->kmer = (U64 *) ar.take (cap * 8);
+  const bool direct = q.wantPos && q.outPosF && q.outRid && q.outCap >= cap;
+  b->posF = !q.wantPos ? 0 : (direct ? q.outPosF : (U32 *) ar.take (cap * 4));
+  b->rid = !q.wantPos ? 0 : (direct ? q.outRid : (U32 *) ar.take (cap * 4));
+  b->work = ar.take (mgScanWorkBytes (q.totalBases, q.nReads, cap));
+  b->count = (U64 *) ar.take (8 * MG_COUNT_WORDS);
+  b->counted.log2NB = 0; b->counted.kbits = 64; b->counted.binCount = 0; b->counted.hiB = 0;
+  if (q.extraPerSurvivor || lookupHist)              /* the survivors go into the modset, or through the partitioned lookup: have the scan count the first partition digit */
+    { b->counted.binCount = (U32 *) ar.take (512 * MG_HIST_STRIDE * sizeof (U32));
+      b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
+      if (lookupHist) b->counted.hiB = mgTableFindDigitBits (&d->t);
+    }
+  b->findScratch = lookupHist ? ar.take (mgTableFindPartScratchBytes (cap)) : 0;
+  b->findScratch2 = lookup2 ? ar.take (mgTableFindPart2ScratchBytes (cap)) : 0;
+  const bool lz = q.lazy && (q.wantPos ? q.extraPerSurvivor == 0 : b->counted.binCount != 0);   /* a build needs the digit counts; a pure lookup just the segments */
+  if ((s = mgLaunchScan (p, q.dPacked, q.totalBases, q.dReadOffsets, q.nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
+                         b->counted.binCount ? &b->counted : 0, lz ? &b->seg : 0))) return s;
+  b->lazy = lz;
+  MG_HIP (hipMemcpyAsync (mgCountPin (d, slot), b->count, MG_COUNT_WORDS * sizeof (U64), hipMemcpyDeviceToHost, st));
+  return MG_OK;
+}
+/* wait for the scan; *nOut = its modimizers, or *retryCap != 0: the capacity was too small, start again with that one */
+static MgStatus mgScanFinish (MgDev *d, int slot, const MgScanBufs *b, U64 *nOut, U64 *retryCap, hipStream_t st, hipEvent_t done = 0)
+{
+  volatile U64 *c = mgCountPin (d, slot);
+  if (done) MG_HIP (hipEventSynchronize (done));           /* (this scan alone: the stream may hold the next batch's scan behind it) */
+  else MG_HIP (hipStreamSynchronize (st));
+  *retryCap = 0;
+  if (!c[1] && c[0] <= b->cap) { *nOut = c[0]; return MG_OK; }
+  *nOut = c[0]; *retryCap = c[3];
+  return MG_OK;
+}
+
 static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked, U64 totalBases,
                                  const U64 *dReadOffsets, U32 nReads, bool wantPos, size_t extraPerSurvivor,
                                  MgScanBufs *b, U64 *nOut, hipStream_t st,
                                  U32 *outPosF = 0, U32 *outRid = 0, U64 outCap = 0, bool lazy = false)
 {
-  b->lazy = false; b->seg.nSegs = 0; b->seg.segKmer = 0; b->findScratch = 0; b->findScratch2 = 0;
+  if (d->ticketsOut) { mgSetError ("a query batch of this modset is in flight (mgQueryReadsDeviceAsync without its mgQueryReadsDeviceWait)"); return MG_ERR_ARG; }
+  MgScanReq q = { sh, dPacked, totalBases, dReadOffsets, nReads, wantPos, extraPerSurvivor, outPosF, outRid, outCap, lazy };
   U64 cap = mgSurvivorGuess (sh, totalBases);
-  /* a lookup batch whose k-mers stay in the segments may take the partitioned path (mgTableFindPartitioned): it needs the first digit's counts */
-  const long fp = mgKnobs ()->findPath;
-  const bool lookupHist = lazy && wantPos && !extraPerSurvivor && d->t.slots && fp != 'd'
-                          && (fp == 'p' || fp == '2' || (cap >= ((U64) 1 << 24) && d->t.nSlots >= ((U64) 1 << 24) && d->t.log2NB > 9));
-  const bool lookup2 = lookupHist && fp != 'p';
-  MgHashParams p = mgMakeParams (sh);
   if (extraPerSurvivor)
     { /* size the table now for the expected number of modimizers (N/d): the insert would do it anyway once the
          count is known, and with the geometry fixed the scan (or, for 2k < 24, the compaction kernel) can count for the first partition pass */
@@ -892,36 +954,11 @@ static MgStatus mgScanIntoArena (MgDev *d, const Seqhash *sh, const U32 *dPacked
       MgStatus es = mgTableEnsure (&d->t, expect, st); if (es) return es;
     }
   for (int attempt = 0 ; attempt < 3 ; ++attempt)
-    { size_t perS = 8 + (wantPos ? 8 : 0) + extraPerSurvivor;
-      size_t need = al256 (cap * perS) + 4 * 4096 + 512 * MG_HIST_STRIDE * 4 + al256 (mgScanWorkBytes (totalBases, nReads, cap))
-                    + (extraPerSurvivor ? mgTableAddScratchBytes (&d->t, cap < MG_ADD_CHUNK ? cap : MG_ADD_CHUNK) + 8192 : 0) + 8 * 256
-                    + (lookupHist ? mgTableFindPartScratchBytes (cap) + 8192 : 0) + (lookup2 ? mgTableFindPart2ScratchBytes (cap) + 8192 : 0);
-      MgStatus s = d->arena.reserve (need); if (s) return s;
-      d->arena.reset ();
-      b->cap = cap;
-      b->kmer = (U64 *) d->arena.take (cap * 8);
-      const bool direct = wantPos && outPosF && outRid && outCap >= cap;
-      b->posF = !wantPos ? 0 : (direct ? outPosF : (U32 *) d->arena.take (cap * 4));
-      b->rid = !wantPos ? 0 : (direct ? outRid : (U32 *) d->arena.take (cap * 4));
-      b->work = d->arena.take (mgScanWorkBytes (totalBases, nReads, cap));
-      b->count = (U64 *) d->arena.take (8 * MG_COUNT_WORDS);
-      b->counted.log2NB = 0; b->counted.kbits = 64; b->counted.binCount = 0; b->counted.hiB = 0;
-      if (extraPerSurvivor || lookupHist)              /* the survivors go into the modset, or through the partitioned lookup: have the scan count the first partition digit */
-        { b->counted.binCount = (U32 *) d->arena.take (512 * MG_HIST_STRIDE * sizeof (U32));
-          b->counted.log2NB = d->t.log2NB; b->counted.kbits = d->t.kbits;
-          if (lookupHist) b->counted.hiB = mgTableFindDigitBits (&d->t);
-        }
-      b->findScratch = lookupHist ? d->arena.take (mgTableFindPartScratchBytes (cap)) : 0;
-      b->findScratch2 = lookup2 ? d->arena.take (mgTableFindPart2ScratchBytes (cap)) : 0;
-      const bool lz = lazy && (wantPos ? extraPerSurvivor == 0 : b->counted.binCount != 0);   /* a build needs the digit counts; a pure lookup just the segments */
-      if ((s = mgLaunchScan (p, dPacked, totalBases, dReadOffsets, nReads, b->kmer, b->posF, b->rid, cap, b->count, b->work, st,
-                             b->counted.binCount ? &b->counted : 0, lz ? &b->seg : 0))) return s;
-      b->lazy = lz;
-      volatile U64 *c = d->hPin + 8;
-      MG_HIP (hipMemcpyAsync (d->hPin + 8, b->count, MG_COUNT_WORDS * sizeof (U64), hipMemcpyDeviceToHost, st));
-      MG_HIP (hipStreamSynchronize (st));
-      if (!c[1] && c[0] <= cap) { *nOut = c[0]; return MG_OK; }
-      cap = c[3];
+    { MgStatus s = mgScanStart (d, 0, q, cap, b, st); if (s) return s;
+      U64 retry = 0;
+      if ((s = mgScanFinish (d, 0, b, nOut, &retry, st))) return s;
+      if (!retry) return MG_OK;
+      cap = retry;
     }
   mgSetError ("scan capacity could not be established");
   return MG_ERR_CAPACITY;
@@ -1002,6 +1039,89 @@ extern "C" MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 tot
                                          U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity,
                                          U64 *nSeeds, void *stream)
 { return mgSeedReads (ms, 1, dPacked, totalBases, dReadOffsets, nReads, dSeedIndex, dSeedPosF, dSeedRead, capacity, nSeeds, (hipStream_t) stream); }
+
+/* The lookup loop of queryProcess (modmap.c:197-206) for batches that follow one another, in two halves: Async starts the batch's SCAN
+ * on a stream of the library's own, into the other of two scratch arenas, and returns; Wait runs its LOOKUPS on the caller's stream and
+ * returns when the seeds are complete.  Called as  Async (0); for i: Async (i + 1); Wait (i)  the scan of batch i + 1 -- bound by
+ * instruction issue -- runs beside the lookups of batch i -- bound by memory requests (profiles/r03_corun_matrix.txt: 7 - 8 % on the
+ * pair).  At most two batches in flight, waited for in the order they were started; each needs its own output arrays; until the last
+ * ticket is waited for, the modset takes no other batch call. */
+struct MgQueryTicket { Modset *ms; MgDev *d; int slot; MgScanReq q; MgScanBufs b; U32 *dSeedIndex, *dSeedPosF, *dSeedRead; U64 capacity; };
+
+extern "C" MgStatus mgQueryReadsDeviceAsync (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
+                                             U32 *dSeedIndex, U32 *dSeedPosF, U32 *dSeedRead, U64 capacity, void **ticket, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  if (!ticket) { mgSetError ("mgQueryReadsDeviceAsync: null ticket"); return MG_ERR_ARG; }
+  *ticket = 0;
+  MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
+  if (d->ticketsOut >= 2) { mgSetError ("two query batches are in flight already"); return MG_ERR_ARG; }
+  d->t.loadPct = 60;
+  if (d->t.slots && !d->ticketsOut && (s = mgTableEnsure (&d->t, 0, st))) return s;      /* (with a batch in flight the table has its lookup shape already) */
+  if (!d->side)
+    { /* lowest priority: the lookups are a chain of short kernels that should not queue behind the scan's workgroups; the scan fills what they leave */
+      int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange (&lo, &hi);
+      const long pk = mgKnobs ()->sidePriority;           /* dev: 0 = default priority */
+      if (pk == 0) MG_HIP (hipStreamCreateWithFlags (&d->side, hipStreamNonBlocking));
+      else MG_HIP (hipStreamCreateWithPriority (&d->side, hipStreamNonBlocking, lo));
+      for (int i = 0 ; i < 2 ; ++i) MG_HIP (hipEventCreateWithFlags (&d->scanned[i], hipEventDisableTiming));
+      MG_HIP (hipEventCreateWithFlags (&d->inputReady, hipEventDisableTiming));
+    }
+  const int slot = d->slotBusy[d->nextSlot] ? d->nextSlot ^ 1 : d->nextSlot;
+  MgQueryTicket *t = new MgQueryTicket ();
+  t->ms = ms; t->d = d; t->slot = slot; t->dSeedIndex = dSeedIndex; t->dSeedPosF = dSeedPosF; t->dSeedRead = dSeedRead; t->capacity = capacity;
+  t->q = MgScanReq { ms->hasher, dPacked, totalBases, dReadOffsets, nReads, true, 0, dSeedPosF, dSeedRead, capacity, true };
+  t->b = MgScanBufs (); t->b.cap = 0;
+  if (totalBases && nReads)
+    { /* the batch (and a table that has just been reshaped) is ready when the caller's stream gets here: the scan's stream waits for that */
+      hipError_t e = hipEventRecord (d->inputReady, st);
+      if (e == hipSuccess) e = hipStreamWaitEvent (d->side, d->inputReady, 0);
+      if (e != hipSuccess) { delete t; return mgHipFail (e, "mgQueryReadsDeviceAsync"); }
+      if ((s = mgScanStart (d, slot, t->q, mgSurvivorGuess (ms->hasher, totalBases), &t->b, d->side))) { delete t; return s; }
+      if ((e = hipEventRecord (d->scanned[slot], d->side)) != hipSuccess) { delete t; return mgHipFail (e, "mgQueryReadsDeviceAsync"); }
+    }
+  d->slotBusy[slot] = true; d->nextSlot = slot ^ 1; ++d->ticketsOut;
+  *ticket = t;
+  return MG_OK;
+}
+
+extern "C" MgStatus mgQueryReadsDeviceWait (void *ticket, U64 *nSeeds, void *stream)
+{
+  hipStream_t st = (hipStream_t) stream;
+  MgQueryTicket *t = (MgQueryTicket *) ticket;
+  if (!t) { mgSetError ("mgQueryReadsDeviceWait: null ticket"); return MG_ERR_ARG; }
+  MgDev *d = t->d;
+  if (nSeeds) *nSeeds = 0;
+  MgStatus s = MG_OK;
+  U64 n = 0;
+  if (t->q.totalBases && t->q.nReads)
+    do {
+      U64 retry = 0;
+      if ((s = mgScanFinish (d, t->slot, &t->b, &n, &retry, d->side, d->scanned[t->slot]))) break;
+      for (int attempt = 0 ; retry && attempt < 2 && !s ; ++attempt)      /* the guess was too small: again, with what the scan asked for */
+        { if ((s = mgScanStart (d, t->slot, t->q, retry, &t->b, d->side))) break;
+          s = mgScanFinish (d, t->slot, &t->b, &n, &retry, d->side);
+        }
+      if (s) break;
+      if (retry) { mgSetError ("scan capacity could not be established"); s = MG_ERR_CAPACITY; break; }
+      if (nSeeds) *nSeeds = n;
+      if (n > t->capacity) { mgSetError ("%llu seeds exceed the caller's capacity %llu", (unsigned long long) n, (unsigned long long) t->capacity); s = MG_ERR_CAPACITY; break; }
+      /* (the scan is complete: the host has waited for it, so the caller's stream need not) */
+      MgScanBufs &b = t->b;
+      if (b.lazy && b.findScratch && mgTableFindTakesPartition (&d->t, n, &b.counted))
+        s = mgTableFindPartitioned (&d->t, b.seg, n, &b.counted, t->dSeedIndex, b.kmer, b.findScratch, st, b.findScratch2);
+      else s = b.lazy ? mgTableFindSegments (&d->t, b.seg, n, t->dSeedIndex, st) : mgTableFind (&d->t, b.kmer, n, t->dSeedIndex, st);
+      if (s) break;
+      hipError_t e = hipSuccess;
+      if (t->dSeedPosF && b.posF != t->dSeedPosF) e = hipMemcpyAsync (t->dSeedPosF, b.posF, n * 4, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess && t->dSeedRead && b.rid != t->dSeedRead) e = hipMemcpyAsync (t->dSeedRead, b.rid, n * 4, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize (st);
+      if (e != hipSuccess) s = mgHipFail (e, "mgQueryReadsDeviceWait");
+    } while (0);
+  d->slotBusy[t->slot] = false; --d->ticketsOut;
+  delete t;
+  return s;
+}
 
 /* ---------------------------------------------------------------------------------------- */
 /* host-buffer mirrors of the reference callers' loops                                        */

@@ -48,6 +48,7 @@ typedef struct {
   long gzipThreads;        /* MODGPU_GZIP_THREADS: threads that deflate the members of a .mod / .ref / .readset file (mg_pgzip.c) */
   long xferPieceKb;        /* MODGPU_XFER_PIECE_KB: dev, bytes per piece of the array transfers (default 4096) */
   long xferStreams;        /* MODGPU_XFER_STREAMS: dev, 1 = a copy stream per transfer thread instead of the device's default stream */
+  long sidePriority;       /* MODGPU_SIDE_PRIORITY: dev, 0 = the pipelined query's scan stream at default priority (else lowest) */
   long xferThreads;        /* MODGPU_XFER_THREADS: host threads of the array transfers (mg_xfer.hip) */
   long seedTiming, uploadTiming, textTiming, parseTiming;   /* MODGPU_*_TIMING prints */
   long scanDebug, bucketDebug;                               /* only read by -DMG_ABLATE builds */

@@ -236,14 +236,18 @@ __device__ __forceinline__ U64 mgKmerAt (const U32 *sWords, U32 q, int sh1)
  * Latency: the next tile's words, halo and metadata are fetched while the current tile is processed
  * (registers), and the tile staging in LDS is double-buffered.
  */
-/* a wave has made its last count: the workgroup's last wave adds the LDS counts to the global ones.  (The LDS unit takes a
- * CU's operations in order, so once the other waves' ticks on sDone are in, so are their counts.) */
+/* a wave has made its last count: the workgroup's last wave adds the LDS counts to the global ones.  The tick on sDone is a
+ * RELEASE at workgroup scope -- neither the compiler nor the hardware may let a wave's counts on sHist sink below it -- and the wave
+ * that finds itself last makes an ACQUIRE before it reads sHist, so that what it reads are the other waves' finished counts.  (Rounds
+ * 1 - 4 used a relaxed atomicAdd and leaned on the LDS unit taking a CU's operations in order: true of the hardware, a promise the
+ * compiler never made.) */
 __device__ __forceinline__ void mgScanHistDone (const MgScanArgs &a, U32 *sHist, U32 *sDone, int lane)
 {
   U32 before = 0;
-  if (lane == 0) before = atomicAdd (sDone, 1u);
+  if (lane == 0) before = __hip_atomic_fetch_add (sDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   before = (U32) __builtin_amdgcn_readfirstlane ((int) before);
   if (before != MG_WAVES - 1) return;
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
   const U32 bins = (U32) 1 << a.histHiB;
   for (U32 b = (U32) lane ; b < bins ; b += 64) { const U32 v = sHist[b]; if (v) atomicAdd (&a.histCount[b * MG_HIST_STRIDE], v); }
 }
@@ -753,14 +757,19 @@ static MgScanGeom mgScanGeometryTiles (U64 nTiles, U64 capacity)
      the scan 0.72 instead of 0.36 ms per Gbp) */
   /* Footprint (what mgScanWorkBytes asks for): 16 bytes per segment entry (k-mer 8, pos 4, read 4), segments three times the
      fair share of the caller's capacity, capacity itself 1.25 N / d + 65536: 60 N / d bytes -- 9.4 GB for a 10 Gbp batch at d = 64;
-     at small d the cap below binds (a segment never holds more than its range's k-mer starts) and the scratch approaches 16 bytes
-     per base of the batch (config 5, d = 4, 1 Gbp: 16 GB).  Memory only: a segment is read up to its count.  Callers that scan
+     at small d the factor is 1.5 (below): 7.5 bytes per base of the batch at d = 4 (config 5, 1 Gbp: 7.5 GB; rounds 1 - 4: 16).  Memory only: a segment is read up to its count.  Callers that scan
      several large batches at once on one device should size for that (MODGPU_SEG_SLACK, 1..8: the factor, default 3; 1 = an
      eighth of slack as in round 2, at the price of a second scan when a worker overflows). */
+  /* Dense selections (round 5): where more than one start in sixteen is expected to be a modimizer (d < 16: capacity is 1.25 N / d) the
+     factor is 1.5, not 3 -- at d = 4 three times the share IS every start of the range (16 bytes per base: a 10 Gbp batch of config 5's
+     shape asked for 160 GB), while the spread of a range's count around its share shrinks with density (32 768 starts at 1/4: 8192 +- 78):
+     7.5 bytes per base instead.  What does overflow -- a homopolymer run whose one k-mer is a modimizer -- takes the second scan. */
   U64 share = capacity / g.nBlocks;
   const long slackKnob = mgKnobs ()->segSlack;
+  const bool dense = capacity > (g.nTiles * (U64) MG_TILE_BASES) / 16;
   const U64 slack = slackKnob != MG_KNOB_UNSET && slackKnob >= 1 && slackKnob <= 8 ? (U64) slackKnob : 3;
   U64 seg = slack > 1 ? slack * share + 64 : share + share / 8 + 64;
+  if (dense && (slackKnob == MG_KNOB_UNSET || slackKnob < 1 || slackKnob > 8)) seg = share + share / 2 + 64;
   U64 most = g.tilesPerBlock * (U64) MG_TILE_BASES;
   g.segCap = seg < most ? seg : most;
   return g;

@@ -294,6 +294,71 @@ def _seed_lists_vs_oracle(L, k, w, bits):
         assert n.value == len(qk) and np.array_equal(d_ix.to_numpy(np.uint32, n.value), want), rep
 
 
+@pytest.mark.parametrize("path", ["direct", "2 levels", None])
+def test_query_batches_pipelined_equal_synchronous(path):
+    """mgQueryReadsDeviceAsync / Wait (the scan of batch i + 1 beside the lookups of batch i, two scratch arenas): five batches of
+    different sizes -- one of them empty, one whose survivor guess is too small (d = 4 reads full of one k-mer would do; here a
+    capacity the caller under-sizes is the error case) -- give, seed for seed, what mgQueryReadsDevice gives; while a ticket is out
+    the modset refuses other batch calls; tickets are waited for in order."""
+    L = mg.lib()
+    k, w, bits = 21, 32, 22
+    sh = mg.seqhashCreate(k, w, 17)
+    ms = mg.modsetCreate(sh, bits)
+    refb = synth_batch(300_000, 300_000, 41, err=0.0, n50=50_000)
+    d_rp = mg.DeviceBuffer.from_numpy(mg.pack_host(refb[0])); d_ro = mg.DeviceBuffer.from_numpy(refb[1].astype(np.uint64))
+    nh = C.c_uint64()
+    mg.check(L.mgAddReadsDevice(ms, d_rp.ptr, int(refb[1][-1]), d_ro.ptr, len(refb[1]) - 1, C.byref(nh), None))
+    with mg.knobs(FIND_PATH=path):
+        batches = []
+        for i, (nb, n50, err) in enumerate([(400_000, 6000, 0.03), (1_200_000, 3000, 0.02), (0, 1, 0), (150_000, 800, 0.05), (900_000, 20_000, 0.01)]):
+            if nb:
+                q = synth_batch(nb, 300_000, 41, err=err, n50=n50)
+                d_p = mg.DeviceBuffer.from_numpy(mg.pack_host(q[0])); d_o = mg.DeviceBuffer.from_numpy(q[1].astype(np.uint64))
+                total, nr = int(q[1][-1]), len(q[1]) - 1
+            else:
+                d_p = mg.DeviceBuffer(64); d_o = mg.DeviceBuffer.from_numpy(np.zeros(1, np.uint64)); total, nr = 0, 0
+            cap = total // w * 2 + 1000
+            outs = [mg.DeviceBuffer(cap * 4) for _ in range(3)]
+            n = C.c_uint64()
+            mg.check(L.mgQueryReadsDevice(ms, d_p.ptr, total, d_o.ptr, nr, outs[0].ptr, outs[1].ptr, outs[2].ptr, cap, C.byref(n), None))
+            want = [o.to_numpy(np.uint32, n.value) for o in outs]
+            batches.append((d_p, d_o, total, nr, cap, want))
+        tickets, outs_all = [], []
+
+        def start(i):
+            d_p, d_o, total, nr, cap, _ = batches[i]
+            outs = [mg.DeviceBuffer(cap * 4) for _ in range(3)]
+            t = C.c_void_p()
+            mg.check(L.mgQueryReadsDeviceAsync(ms, d_p.ptr, total, d_o.ptr, nr, outs[0].ptr, outs[1].ptr, outs[2].ptr, cap, C.byref(t), None))
+            tickets.append(t); outs_all.append(outs)
+        start(0)
+        for i in range(len(batches)):
+            if i + 1 < len(batches):
+                start(i + 1)
+                if i == 0:                                    # two in flight: a third is refused, and so is any other batch call
+                    t3 = C.c_void_p()
+                    assert L.mgQueryReadsDeviceAsync(ms, batches[0][0].ptr, batches[0][2], batches[0][1].ptr, batches[0][3], outs_all[0][0].ptr,
+                                                     None, None, batches[0][4], C.byref(t3), None) != 0
+                    assert L.mgQueryReadsDevice(ms, batches[0][0].ptr, batches[0][2], batches[0][1].ptr, batches[0][3], outs_all[0][0].ptr,
+                                                None, None, batches[0][4], C.byref(nh), None) != 0 and b"in flight" in L.mgLastError()
+            n = C.c_uint64()
+            mg.check(L.mgQueryReadsDeviceWait(tickets[i], C.byref(n), None))
+            want = batches[i][5]
+            assert n.value == len(want[0]), i
+            for o, w_ in zip(outs_all[i], want):
+                assert np.array_equal(o.to_numpy(np.uint32, n.value), w_), i
+        # a capacity too small for the batch's seeds: the error of the synchronous call, and the modset is free again afterwards
+        d_p, d_o, total, nr, cap, want = batches[1]
+        t = C.c_void_p(); o = mg.DeviceBuffer(400)
+        mg.check(L.mgQueryReadsDeviceAsync(ms, d_p.ptr, total, d_o.ptr, nr, o.ptr, None, None, 100, C.byref(t), None))
+        n = C.c_uint64()
+        assert L.mgQueryReadsDeviceWait(t, C.byref(n), None) != 0 and n.value == len(want[0])
+        o3 = [mg.DeviceBuffer(cap * 4) for _ in range(3)]
+        mg.check(L.mgQueryReadsDevice(ms, d_p.ptr, total, d_o.ptr, nr, o3[0].ptr, o3[1].ptr, o3[2].ptr, cap, C.byref(n), None))
+        assert np.array_equal(o3[0].to_numpy(np.uint32, n.value), want[0])
+    L.modsetDestroy(ms)
+
+
 def test_full_size_build_properties():
     """BASELINE config 2 at full size (10 Gbp, table bits 30) plus a 1 Gbp run: properties that
     hold for any correct modset build — sum of depths == number of modimizers (no saturation here),
