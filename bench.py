@@ -649,8 +649,8 @@ def bench_c5(cx, args):
 
 def bench_ref_default(cx, args):
     """The reference's OWN default parameters (modmap.c:314-317, modutils.c:140: k = 19, w = 31, seed 17) on config 2's reads:
-    w is not a power of two, so the scan is the exact-mode kernel (mgScanKernel<MG_MODE_ANY>: both 64-bit hashes at every
-    start, divisibility by 31 without a division).  Step = clear + scan + build, as the headline."""
+    w is not a power of two, so the scan is the exact-mode kernel for an odd modulus (mgScanKernel<MG_MODE_ODD32>: both 64-bit
+    hashes at every start; divisibility by 31 without a division, in 32-bit arithmetic because the hash is 38 bits: mgDivisibleOdd32).  Step = clear + scan + build, as the headline."""
     torch, L, mg = cx.torch, cx.L, cx.mg
     k, w, bits = 19, 31, int(os.environ.get("MODGPU_BENCH_BITS", "30"))
     total = int(float(os.environ.get("MODGPU_BENCH_GBP", "10")) * 1e9)
@@ -702,7 +702,7 @@ def bench_realistic(cx, args):
     """What repeats cost: 1 Gbp of ONT-like reads (N50 20 kb, 5 % subs, 10x) from a 100 Mbp genome with the repeat
     structure of a real one (synth.repeat_genome: an Alu-like family with poly-A tails, satellite arrays, (CA)n) beside the same
     from an iid genome, and 0.5 Gbp of nothing but poly-A -- every start a modimizer of ONE k-mer at k=21 d=64 seed 17.  A
-    k-mer's occurrences all fall into one table bucket; buckets beyond 32768 occurrences are reduced chunk by chunk by many
+    k-mer's occurrences all fall into one table bucket; buckets beyond 16384 occurrences (MG_HOT_SPLIT_DEFAULT) are reduced chunk by chunk by many
     workgroups first (mgHotReduceKernel).  Step = clear + scan + build, k=21 d=64, table bits 28."""
     import numpy as np
     torch, L, mg, synth = cx.torch, cx.L, cx.mg, cx.synth
@@ -1063,18 +1063,21 @@ def end_to_end(cx, reads, offsets, k, d, seed):
                         dt = time.perf_counter() - t0
                         if rc:
                             raise RuntimeError("mgQueryFile failed")
-                        lines = os.path.getsize(outp); os.remove(outp)
+                        lines = os.path.getsize(outp)
+                        with open(outp, "rb") as fo_:
+                            sha = __import__("hashlib").sha1(fo_.read()).hexdigest()
+                        os.remove(outp)
                         if it:
                             best_ = dt if best_ is None else min(best_, dt)
                     L.mgReferenceDestroy(ref); L.modsetDestroy(ms2)
-                    return best_, lines
+                    return best_, lines, sha
                 finally:
                     del os.environ["MODGPU_TEXT_HOST"]
                     L.mgReloadKnobs()
-            (t_dev, out_bytes), (t_host, out_bytes_h) = time_query(False), time_query(True)
+            (t_dev, out_bytes, sha_dev), (t_host, out_bytes_h, sha_host) = time_query(False), time_query(True)
             res["modmap_query_file"] = {"entry": "mgReferenceFastaRead + mgQueryFile", "Gbp_per_s": round(nq * 150 / t_dev / 1e9, 2),
                                         "Gbp_per_s_host_parser": round(nq * 150 / t_host / 1e9, 2), "reads": nq, "bases": nq * 150,
-                                        "reference_bases": rb, "output_bytes": out_bytes, "same_output_size": out_bytes == out_bytes_h,
+                                        "reference_bases": rb, "output_bytes": out_bytes, "same_output": sha_dev == sha_host and out_bytes == out_bytes_h, "output_sha1": sha_dev,
                                         "lines_per_s": round(nq / t_dev / 1e6, 1),
                                         "what": "150-base reads, four-line FASTQ in the page cache -> parsed on the device (record ids copied out of the pinned windows) -> scan + "
                                                 "lookup + tallies + chaining on the device, a batch per 128 MiB window -> one Q line per read (M lines where blocks chain) formatted by a "
@@ -1284,7 +1287,8 @@ def dropin_unmodified(h, shm):
     """The reference's UNMODIFIED modutils.c (its own main(), seqio and per-read loop modutils.c:19-51: modRCiterator /
     modRCnext / modsetIndexFind per read) linked on libmodgpu.so (oracle/_ref/modutils_dropin) beside the reference program
     itself (oracle/_ref/modutils_ref) and the batch-patched one (oracle/_ref/modutils_batch, examples/modutils_batch.patch)
-    on the same FASTA files: 10 kb reads and 150 b reads cut from the bench's reads.  Wall clock of the whole program, and the
+    on the same FASTA files: 10 kb, 150 b and 24 kb reads cut from the bench's reads (the first two are scanned by modRCiterator's host leg, the
+    third by its kernel leg: every row says which).  Wall clock of the whole program, and the
     marginal rate (big file minus a 1/20 file: start-up, HIP initialisation and table allocation cancel)."""
     import numpy as np
     refdir = os.path.join(HERE, "oracle", "_ref")
@@ -1296,7 +1300,8 @@ def dropin_unmodified(h, shm):
            "iterator_crossover_bases": int(__import__("modimizer_amd").lib().mgIterHostBelow(-1)),
            "crossover_note": "modRCiterator scans reads shorter than this with the library's own scalar loop (a synchronous call cannot hide "
                              "the 13-15 us of a kernel launch + poll), longer ones with one kernel launch (mg_host.c)"}
-    for tag, rl, mbp in (("reads_10kb", 10000, 400), ("reads_150b", 150, 400)):
+    crossover = out["iterator_crossover_bases"]
+    for tag, rl, mbp in (("reads_10kb", 10000, 400), ("reads_150b", 150, 400), ("reads_24kb", 24000, 400)):
         paths = []
         for frac in (20, 1):
             nb = min(len(h), int(mbp * 1e6) // frac) // rl * rl
@@ -1307,7 +1312,10 @@ def dropin_unmodified(h, shm):
                 rec = np.concatenate([np.tile(hdr, (len(seq), 1)), seq, np.full((len(seq), 1), 10, np.uint8)], axis=1)
                 f.write(rec.tobytes())
             paths.append((path, nb))
-        row = {"read_length": rl, "bases": paths[1][1], "reads": paths[1][1] // rl}
+        # say which leg of modRCiterator a row measures -- below the crossover the drop-in's scan is the library's scalar HOST loop
+        # (the GPU is required but idle); the 24 kb row is the one that runs the one-launch-per-read kernel
+        row = {"read_length": rl, "bases": paths[1][1], "reads": paths[1][1] // rl,
+               "iterator_leg_of_modutils_dropin": "host scalar loop (read shorter than the crossover: no kernel runs)" if rl < crossover else "GPU kernel, one launch per read"}
         try:
             for name, prog in progs.items():
                 t = []

@@ -118,25 +118,29 @@ static SeqhashRCiterator *iterAlloc (Seqhash *sh, char *s, int len)
  * scalar loop more per base (stores, mispredicted branches), so their crossover is lower. */
 #define MG_ITER_HOST_BELOW_DEFAULT 12288
 #define MG_ITER_HOST_BELOW_DENSE    8192
-static int gIterHostBelow = -1;           /* -1: not looked up yet, -2: the defaults by w, >= 0: set (knob or mgIterHostBelow) */
+static int gIterHostBelow = -1;           /* -1: not looked up yet, -2: the defaults by w, >= 0: set (knob or mgIterHostBelow); relaxed atomics: iterators run on any thread */
 static int iterHostBelow (const Seqhash *sh)
 {
-  if (gIterHostBelow == -1)
-    { const long v = mgKnobs ()->iterHostBelow;              /* tuning knob: 0 = every read through the kernel */
-      gIterHostBelow = v != MG_KNOB_UNSET ? (v < 0 ? 0 : (int) v) : -2;
+  int v = __atomic_load_n (&gIterHostBelow, __ATOMIC_RELAXED);
+  if (v == -1)
+    { const long kv = mgKnobs ()->iterHostBelow;             /* tuning knob: 0 = every read through the kernel */
+      v = kv != MG_KNOB_UNSET ? (kv < 0 ? 0 : (int) kv) : -2;
+      __atomic_store_n (&gIterHostBelow, v, __ATOMIC_RELAXED);
     }
-  if (gIterHostBelow >= 0) return gIterHostBelow;
+  if (v >= 0) return v;
   return sh && sh->w < 16 ? MG_ITER_HOST_BELOW_DENSE : MG_ITER_HOST_BELOW_DEFAULT;
 }
+/* mgReloadKnobs () (mg_knobs.c) calls this: the crossover is looked up again, so a MODGPU_ITER_HOST_BELOW set between two calls counts */
+void mgIterKnobsReloaded (void) { __atomic_store_n (&gIterHostBelow, -1, __ATOMIC_RELAXED); }
 
 /* the crossover in bases; below < 0 asks (the value for sparse selections when the defaults are in force), below >= 0
-   sets it for every hasher, MG_ITER_BELOW_DEFAULTS (1 << 30 and above) puts the defaults by w back.  Returns the value in
-   force before the call. */
+   sets it for every hasher, MG_ITER_BELOW_DEFAULTS (1 << 30 and above) goes back to what the environment says (the knob, or the
+   defaults by w).  Returns the value in force before the call. */
 int mgIterHostBelow (int below)
 {
   const int was = iterHostBelow (0);
-  if (below >= (1 << 30)) gIterHostBelow = -2;
-  else if (below >= 0) gIterHostBelow = below;
+  if (below >= (1 << 30)) __atomic_store_n (&gIterHostBelow, -1, __ATOMIC_RELAXED);
+  else if (below >= 0) __atomic_store_n (&gIterHostBelow, below, __ATOMIC_RELAXED);
   return was;
 }
 

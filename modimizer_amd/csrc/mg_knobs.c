@@ -53,7 +53,8 @@ static void readAll (void)
 }
 
 const MgKnobs *mgKnobs (void) { pthread_once (&gOnce, readAll); return &gKnobs; }
-void mgReloadKnobs (void) { pthread_once (&gOnce, readAll); readAll (); }
+void mgIterKnobsReloaded (void) __attribute__ ((weak));      /* mg_host.c: a value cached from a knob */
+void mgReloadKnobs (void) { pthread_once (&gOnce, readAll); readAll (); if (mgIterKnobsReloaded) mgIterKnobsReloaded (); }
 
 static int gCpuBudget;
 static pthread_once_t gCpuOnce = PTHREAD_ONCE_INIT;

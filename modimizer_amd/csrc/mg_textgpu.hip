@@ -650,7 +650,7 @@ struct TxIds {
   void feed (const unsigned char *p, size_t n)
   { if (skipOne) { if (!n) return; ++p; --n; skipOne = false; }
     size_t i = 0;
-    while (i < n && !isspace (p[i])) ++i;
+    while (i < n && !space (p[i])) ++i;                      /* (not isspace (): that one follows the process's locale; the reference's ids end where the C locale's white space is, seqio.c:303) */
     bytes.insert (bytes.end (), (const char *) p, (const char *) p + i);
     if (i < n) { bytes.push_back (0); open = false; }
   }

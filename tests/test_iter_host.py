@@ -108,3 +108,16 @@ def test_vs_compiled_reference(k, w, seed):
         if n > 100:
             b[n // 3:n // 3 + 50] = 0
         assert all(np.array_equal(x, y) for x, y in zip(host_scan(sh, b), po.ref_scan(rsh, b))), (k, w, n)
+
+
+def test_crossover_knob_counts_after_the_first_use():
+    """MODGPU_ITER_HOST_BELOW set between two calls of one process (mg.knobs -> mgReloadKnobs) is looked up again (the value was
+    cached on first use and the knob silently ignored afterwards); 1 << 30 goes back to what the environment says, not to the built-in
+    defaults over its head"""
+    L = mg.lib()
+    was = L.mgIterHostBelow(-1)                      # (looked up: cached from here on)
+    with mg.knobs(ITER_HOST_BELOW="777"):
+        assert L.mgIterHostBelow(-1) == 777
+        assert L.mgIterHostBelow(5) == 777 and L.mgIterHostBelow(-1) == 5
+        assert L.mgIterHostBelow(1 << 30) == 5 and L.mgIterHostBelow(-1) == 777
+    assert L.mgIterHostBelow(-1) == was
