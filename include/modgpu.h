@@ -280,6 +280,12 @@ void mgReferenceWrite (MgReference *ref, const char *root) ;
  * reference's fzopen "r" (utils.c:107-127) -- and gunzip read such a file as the one stream the reference's single gzwrite would have
  * made; fclose () finishes it.  0 if `name` cannot be created. */
 FILE *mgGzipOpenWrite (const char *name) ;
+/* ... and its counterpart for modsetRead (modset.c:90-104): every member the writer makes carries its compressed and uncompressed size
+ * in a gzip extra field (RFC 1952 2.3.1.1, subfield 'M' 'G'; gzread and gunzip skip it), so the members are found without inflating
+ * anything and inflated by the team -- whole members straight into the array a large fread hands over.  0 if `name` is not such a file
+ * from its first byte to its last (any other gzip file, a plain file): the caller then takes the reference's fzopen / gzopen, as
+ * mgReferenceLoad and mgReadsetLoad do by themselves. */
+FILE *mgGzipOpenRead (const char *name) ;
 MgReference *mgReferenceLoad (const char *root) ;
 /* modmap.c:188-281: "Q" line and "M" lines for every read. */
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,

@@ -207,7 +207,7 @@ FILE *mgTagOpen (const char *root, const char *tag, const char *mode)      /* ut
   sprintf (name, "%s.%s", root, tag);
   FILE *f = 0;
   if (mode[0] == 'w') f = mgGzipOpenWrite (name);                  /* a gzip file of independent members, deflated by a team of threads (mg_pgzip.c) */
-  else
+  else if (!(f = mgGzipOpenRead (name)))                            /* a file of this library's members: they are found by their size fields and inflated in parallel */
     { gzFile z = gzopen (name, mode);
       if (z)
         { (void) gzbuffer (z, 1 << 20);

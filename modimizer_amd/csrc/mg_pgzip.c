@@ -29,19 +29,31 @@ typedef struct
   unsigned long long members, rawBytes, zBytes;
 } MgPgz;
 
-/* one member: gzip header + deflate + crc32 + length, into a malloc ()ed block */
+/* Every member says how long it is: its gzip header carries an extra field (RFC 1952 2.3.1.1, as bgzip's blocks do) with the subfield
+   'M' 'G': the member's compressed size in the file and its uncompressed size, 4 bytes each.  gzread and gunzip skip extra fields; the
+   library's own reader (mgGzipOpenRead) walks them to find every member without inflating any, and inflates them in parallel. */
+#define PGZ_HDR 24                                /* 10 fixed bytes, XLEN (2), subfield id (2) + length (2) + 8 bytes of sizes */
+static void put32 (unsigned char *p, unsigned v) { p[0] = (unsigned char) v; p[1] = (unsigned char) (v >> 8); p[2] = (unsigned char) (v >> 16); p[3] = (unsigned char) (v >> 24); }
+static unsigned get32 (const unsigned char *p) { return (unsigned) p[0] | (unsigned) p[1] << 8 | (unsigned) p[2] << 16 | (unsigned) p[3] << 24; }
+
+/* one member: gzip header (with the sizes) + deflate + crc32 + length, into a malloc ()ed block */
 static unsigned char *pgzMember (const unsigned char *src, size_t n, int level, size_t *outLen)
 {
   z_stream z; memset (&z, 0, sizeof (z));
   if (deflateInit2 (&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
-  const size_t cap = deflateBound (&z, (uLong) n) + 64;
+  unsigned char extra[12] = { 'M', 'G', 8, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  gz_header gh; memset (&gh, 0, sizeof (gh));
+  gh.os = 3; gh.extra = extra; gh.extra_len = sizeof (extra);
+  if (deflateSetHeader (&z, &gh) != Z_OK) { deflateEnd (&z); return 0; }
+  const size_t cap = deflateBound (&z, (uLong) n) + 64 + PGZ_HDR;
   unsigned char *out = (unsigned char *) malloc (cap);
   if (!out) { deflateEnd (&z); return 0; }
   z.next_in = (Bytef *) src; z.avail_in = (uInt) n; z.next_out = out; z.avail_out = (uInt) cap;
   const int rc = deflate (&z, Z_FINISH);
   *outLen = cap - z.avail_out;
   deflateEnd (&z);
-  if (rc != Z_STREAM_END) { free (out); return 0; }
+  if (rc != Z_STREAM_END || *outLen < PGZ_HDR + 8 || out[3] != 4 || out[12] != 'M' || out[13] != 'G') { free (out); return 0; }
+  put32 (out + 16, (unsigned) *outLen); put32 (out + 20, (unsigned) n);      /* (no header CRC: the field can be filled in afterwards) */
   return out;
 }
 
@@ -169,5 +181,143 @@ FILE *mgGzipOpenWrite (const char *name)
   cookie_io_functions_t io = { 0, pgzCookieWrite, 0, pgzCookieClose };
   FILE *f = fopencookie (p, "w", io);
   if (!f) { free (p->pend); free (p); close (fd); return 0; }
+  return f;
+}
+
+
+/* ---- reading: the members found by their extra fields, inflated by the team ----
+ * modsetRead (modset.c:90-104) is a few small freads and then index[] / value[] / depth[] / info[] in one fread each: gigabytes that one
+ * inflate stream delivers at a few hundred MB/s.  A file the writer above made lists its members' sizes, so: the table of members is
+ * built by walking the headers (24 bytes read per member), a read that covers whole members has them inflated straight into the
+ * caller's array by the team, and what is left of a read -- the head and tail of a large one, all of a small one -- is served from
+ * one member inflated into a buffer of the reader's.  Any other gzip file (or plain file) goes through gzopen as before. */
+typedef struct { off_t off; unsigned csize, usize; } PgzMem;
+typedef struct
+{ int fd; int T; PgzMem *mem; size_t nMem; unsigned most;
+  size_t cur; unsigned at;                        /* the position: member, byte inside it */
+  unsigned char *win; size_t winFirst, winCount;  /* members winFirst .. winFirst + winCount - 1 inflated, `most` bytes apart: the read-ahead window, a member per thread */
+  int err;
+} MgPgzIn;
+
+static int pgzInflateMember (int fd, const PgzMem *m, unsigned char *dst)
+{
+  unsigned char *z = (unsigned char *) malloc (m->csize);
+  if (!z) return -1;
+  size_t got = 0;
+  while (got < m->csize)
+    { const ssize_t r = pread (fd, z + got, m->csize - got, m->off + (off_t) got);
+      if (r <= 0) { if (r < 0 && errno == EINTR) continue; free (z); return -1; }
+      got += (size_t) r;
+    }
+  z_stream s; memset (&s, 0, sizeof (s));
+  int rc = -1;
+  if (inflateInit2 (&s, 15 + 16) == Z_OK)
+    { s.next_in = z; s.avail_in = m->csize; s.next_out = dst; s.avail_out = m->usize;
+      const int r = inflate (&s, Z_FINISH);       /* (the gzip wrapper: zlib checks the member's CRC and length itself) */
+      if (r == Z_STREAM_END && s.avail_out == 0) rc = 0;
+      inflateEnd (&s);
+    }
+  free (z);
+  return rc;
+}
+
+/* members first .. first + n - 1 inflated by the team: one after the other into dst (stride 0), or `stride` bytes apart */
+typedef struct { MgPgzIn *p; size_t first, n; unsigned char *dst; size_t stride; size_t next; pthread_mutex_t mu; int failed; } PgzInRun;
+static void *pgzInWorker (void *v)
+{
+  PgzInRun *r = (PgzInRun *) v;
+  for (;;)
+    { pthread_mutex_lock (&r->mu);
+      const size_t j = r->next++;
+      pthread_mutex_unlock (&r->mu);
+      if (j >= r->n || r->failed) return 0;
+      size_t at = j * r->stride;
+      if (!r->stride) for (size_t q = 0 ; q < j ; ++q) at += r->p->mem[r->first + q].usize;
+      if (pgzInflateMember (r->p->fd, &r->p->mem[r->first + j], r->dst + at)) r->failed = 1;
+    }
+}
+static int pgzInRun (MgPgzIn *p, size_t first, size_t n, unsigned char *dst, size_t stride)
+{
+  PgzInRun r; memset (&r, 0, sizeof (r));
+  r.p = p; r.first = first; r.n = n; r.dst = dst; r.stride = stride;
+  pthread_mutex_init (&r.mu, 0);
+  int T = p->T; if ((size_t) T > n) T = (int) n;
+  pthread_t th[MG_PGZ_MAXT]; int started = 0;
+  for (int t = 1 ; t < T ; ++t) if (pthread_create (&th[started], 0, pgzInWorker, &r) == 0) ++started;
+  pgzInWorker (&r);
+  for (int t = 0 ; t < started ; ++t) pthread_join (th[t], 0);
+  pthread_mutex_destroy (&r.mu);
+  return r.failed ? -1 : 0;
+}
+
+/* (glibc hands a cookie's read function its own buffer's worth at a time -- fread on such a FILE goes through the buffer whatever
+   the size asked for -- so the reads that arrive here are small: what makes the team useful is the window, a member per thread
+   inflated ahead; a read that does cover whole members, e.g. with a large setvbuf, has them inflated in place) */
+static ssize_t pgzCookieRead (void *c, char *out, size_t n)
+{
+  MgPgzIn *p = (MgPgzIn *) c;
+  if (p->err) return -1;
+  size_t done = 0;
+  while (done < n && p->cur < p->nMem)
+    { const PgzMem *m = &p->mem[p->cur];
+      const int inWin = p->cur >= p->winFirst && p->cur < p->winFirst + p->winCount;
+      if (!inWin && p->at == 0)
+        { size_t k = 0, bytes = 0;
+          while (p->cur + k < p->nMem && bytes + p->mem[p->cur + k].usize <= n - done) { bytes += p->mem[p->cur + k].usize; ++k; }
+          if (k)
+            { if (pgzInRun (p, p->cur, k, (unsigned char *) out + done, 0)) { p->err = 1; return -1; }
+              done += bytes; p->cur += k;
+              continue;
+            }
+        }
+      if (!inWin)
+        { const size_t k = p->nMem - p->cur < (size_t) p->T ? p->nMem - p->cur : (size_t) p->T;
+          if (pgzInRun (p, p->cur, k, p->win, p->most)) { p->err = 1; return -1; }
+          p->winFirst = p->cur; p->winCount = k;
+        }
+      const unsigned char *src = p->win + (p->cur - p->winFirst) * (size_t) p->most;
+      const size_t take = m->usize - p->at < n - done ? m->usize - p->at : n - done;
+      memcpy (out + done, src + p->at, take);
+      done += take; p->at += (unsigned) take;
+      if (p->at == m->usize) { ++p->cur; p->at = 0; }
+    }
+  return (ssize_t) done;
+}
+static int pgzInClose (void *c)
+{ MgPgzIn *p = (MgPgzIn *) c; const int rc = p->err ? -1 : 0; close (p->fd); free (p->mem); free (p->win); free (p); return rc; }
+
+/* `name` opened for reading if it is a file of this writer's members from its first byte to its last; 0 otherwise (the caller then takes gzopen) */
+FILE *mgGzipOpenRead (const char *name)
+{
+  const int fd = open (name, O_RDONLY);
+  if (fd < 0) return 0;
+  const off_t end = lseek (fd, 0, SEEK_END);
+  PgzMem *mem = 0; size_t nMem = 0, cap = 0; unsigned most = 0;
+  off_t at = 0;
+  int ok = end >= PGZ_HDR;
+  while (ok && at < end)
+    { unsigned char h[PGZ_HDR];
+      if (pread (fd, h, PGZ_HDR, at) != PGZ_HDR) { ok = 0; break; }
+      if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[10] != 12 || h[11] != 0 || h[12] != 'M' || h[13] != 'G' || h[14] != 8 || h[15] != 0) { ok = 0; break; }
+      const unsigned cs = get32 (h + 16), us = get32 (h + 20);
+      if (cs < PGZ_HDR + 8 || at + (off_t) cs > end) { ok = 0; break; }
+      if (nMem == cap) { cap = cap ? 2 * cap : 256; PgzMem *q = (PgzMem *) realloc (mem, cap * sizeof (PgzMem)); if (!q) { ok = 0; break; } mem = q; }
+      mem[nMem].off = at; mem[nMem].csize = cs; mem[nMem].usize = us; ++nMem;
+      if (us > most) most = us;
+      at += cs;
+    }
+  if (!ok || at != end || !nMem) { free (mem); close (fd); return 0; }
+  MgPgzIn *p = (MgPgzIn *) calloc (1, sizeof (MgPgzIn));
+  if (!p) { free (mem); close (fd); return 0; }
+  long t = mgKnobs ()->gzipThreads; if (t == MG_KNOB_UNSET || t <= 0) t = mgCpuBudget ();
+  p->T = t > MG_PGZ_MAXT ? MG_PGZ_MAXT : (int) t;
+  if ((size_t) p->T > nMem) p->T = (int) nMem;
+  p->fd = fd; p->mem = mem; p->nMem = nMem; p->most = most ? most : 1;
+  p->win = (unsigned char *) malloc ((size_t) p->T * p->most);       /* (virtual until a window is inflated into it) */
+  if (!p->win) { free (p); free (mem); close (fd); return 0; }
+  cookie_io_functions_t io = { pgzCookieRead, 0, 0, pgzInClose };
+  FILE *f = fopencookie (p, "r", io);
+  if (!f) { free (p->win); free (p); free (mem); close (fd); return 0; }
+  (void) setvbuf (f, 0, _IOFBF, (size_t) 1 << 20);                  /* a megabyte a call instead of glibc's 4 KiB */
   return f;
 }

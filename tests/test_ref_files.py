@@ -243,8 +243,35 @@ def test_multi_member_gzip_is_the_single_stream(tmp_path):
             L.modsetWrite(ms, C.c_void_p(f))
             assert libc.fclose(C.c_void_p(f)) == 0
         raw = open(gz, "rb").read()
-        assert raw.count(b"\x1f\x8b\x08\x00\x00\x00\x00\x00") >= 4          # 64 MiB of index[] in members of 16 MiB
+        assert raw.count(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\x03\x0c\x00MG\x08\x00") >= 4      # 64 MiB of index[] in members of 16 MiB, each with its sizes in the extra field
         assert gzip.decompress(raw) == open(plain, "rb").read()
+    # ... and read back by the team (mgGzipOpenRead: the members found by the sizes in their extra fields): modsetRead gets the same set
+    f = L.mgGzipOpenRead(gz.encode())
+    assert f
+    L.modsetRead.restype = C.POINTER(mg.Modset)
+    ms2 = L.modsetRead(C.c_void_p(f))
+    assert libc.fclose(C.c_void_p(f)) == 0
+    a, b = ms.contents, ms2.contents
+    assert (a.max, a.tableBits) == (b.max, b.tableBits)
+    for name, n, dt in (("index", 1 << a.tableBits, np.uint32), ("value", a.max + 1, np.uint64), ("depth", a.max + 1, np.uint16), ("info", a.max + 1, np.uint8)):
+        x, y = arr(getattr(a, name), n, dt), arr(getattr(b, name), n, dt)
+        assert np.array_equal(x[1:] if name == "value" else x, y[1:] if name == "value" else y), name
+    L.modsetDestroy(ms2)
+    # reads of every size across member boundaries: the bytes are the plain file's
+    want = open(plain, "rb").read()
+    libc.fread.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]; libc.fread.restype = C.c_size_t
+    for sizes in ([7, 104, (16 << 20) - 50, 1, 33 << 20, 5], [len(want) + 10], [1 << 20] * 70):
+        f = L.mgGzipOpenRead(gz.encode()); got = b""
+        for n in sizes:
+            buf = C.create_string_buffer(n)
+            k = libc.fread(buf, 1, n, C.c_void_p(f)); got += buf.raw[:k]
+        assert libc.fclose(C.c_void_p(f)) == 0
+        assert got == want[:len(got)] and len(got) == min(sum(sizes), len(want))
+    # a gzip file somebody else wrote, a plain file: not this reader's (the callers then take gzopen)
+    other = str(tmp_path / "other.gz")
+    with gzip.open(other, "wb") as g:
+        g.write(b"hello" * 1000)
+    assert not L.mgGzipOpenRead(other.encode()) and not L.mgGzipOpenRead(plain.encode())
     # small writes only: they collect and still come out as one valid stream; an empty file is one empty member
     f = L.mgGzipOpenWrite(gz.encode())
     libc.fputs.argtypes = [C.c_char_p, C.c_void_p]
