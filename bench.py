@@ -1094,6 +1094,35 @@ def end_to_end(cx, reads, offsets, k, d, seed):
     finally:
         if os.path.exists(path):
             os.remove(path)
+    # SURVEY §8(f) N3, modasm's read ingest (modasm.c:151-191 + 258-287): the same reads against the modset built from them -- scan + lookups +
+    # hit lists with distances on the device per batch, the hits per mod counted there, and at the end depth[], the inverse lists (a stable sort
+    # of the hits' read numbers by mod) and the reads' copy-class tallies made on the device and mirrored into the caller's MgReadset
+    try:
+        mg.check(L.mgModsetClear(ms, None))
+        if L.mgAddSequenceBatch(ms, h.ctypes.data, off.ctypes.data, n) < 0:
+            raise RuntimeError(L.mgLastError().decode())
+        best_rs, info_rs = None, None
+        for it in range(2):
+            rs = L.mgReadsetCreate(ms)
+            t0 = time.perf_counter()
+            rc = L.mgReadsetRead(rs, h.ctypes.data, off.ctypes.data, n)
+            dt = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError("mgReadsetRead failed")
+            R = C.cast(rs, C.POINTER(mg.MgReadset)).contents
+            mmax = ms.contents.max
+            inv_total = int(np.ctypeslib.as_array(R.invStart, (mmax + 2,))[mmax + 1])
+            dep = np.ctypeslib.as_array(ms.contents.depth, (mmax + 1,))
+            nhit = np.ctypeslib.as_array(R.nHit, (R.nReads + 1,))
+            ok = (int(nhit[1:].sum()) == R.totHit and inv_total == int(dep[(dep > 0) & (dep < 65535)].astype(np.int64).sum()) and R.nReads == n)
+            info_rs = {"reads": int(R.nReads), "hits": int(R.totHit), "inverse_list_entries": inv_total, "checks_ok": bool(ok)}
+            L.mgReadsetDestroy(rs)
+            best_rs = dt if best_rs is None else min(best_rs, dt)
+        res["readset_ingest"] = dict(info_rs, entry="mgReadsetRead", Gbp_per_s=round(nb / best_rs / 1e9, 1), seconds=round(best_rs, 3), bases=nb,
+                                     what="modasm's readsetFileRead + invBuild from host bytes: pack + H2D, scan + lookups + hit lists (index | strand, 16-bit distances) on the device, "
+                                          "hits per mod counted on the device across batches, depth[] / invStart[] / invSpace[] / nCopy[] made there and mirrored")
+    except Exception as e:
+        res["readset_ingest"] = {"error": str(e)[:300]}
     L.modsetDestroy(ms)
     try:
         res["dropin_unmodified"] = dropin_unmodified(h, shm)

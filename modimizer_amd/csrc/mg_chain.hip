@@ -329,17 +329,17 @@ void mgChainScanKernel (U64 *__restrict__ a, U32 n)
   if (tid == 1023) a[n] = sPart[1023];
 }
 
-/* hHitStart[nReads+1], hNMiss[nReads], *hHit / *hDx malloc()ed here (totHit entries), hDepthCount[ms->max+1]
- * (hits per mod, unsaturated).  Returns 0, -1 on error. */
+/* hHitStart[nReads+1], hNMiss[nReads]: host, filled here.  *dHitOut / *dDxOut: DEVICE arrays of hHitStart[nReads] entries, hipMalloc ()ed here (the
+ * caller copies them where they go and frees them with mgDeviceFree).  dDepthAccum: device U32[ms->max + 1], the hits per mod of the file so
+ * far (mg_refpack.hip keeps it across the batches): this batch's are added.  Returns 0, -1 on error. */
 extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
-                                     U64 *hHitStart, U32 *hNMiss, U32 **hHit, unsigned short **hDx, U32 *hDepthCount)
+                                     U64 *hHitStart, U32 *hNMiss, U32 **dHitOut, unsigned short **dDxOut, U32 *dDepthAccum)
 {
-  *hHit = 0; *hDx = 0;
+  *dHitOut = 0; *dDxOut = 0;
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
-  U32 *dIx = 0, *dPos = 0, *dRid = 0, *dMiss = 0, *dHit = 0, *dDepth = 0; unsigned short *dDx = 0; U64 *dStart = 0, *dHitStart = 0;
+  U32 *dIx = 0, *dPos = 0, *dRid = 0, *dMiss = 0, *dHit = 0; unsigned short *dDx = 0; U64 *dStart = 0, *dHitStart = 0;
   U64 n = 0;
   int rc = -1;
-  const size_t m = (size_t) ms->max + 1;
   do {
     for (int attempt = 0 ; attempt < 2 ; ++attempt)
       { if (hipMalloc ((void **) &dIx, guess * 4) || hipMalloc ((void **) &dPos, guess * 4) || hipMalloc ((void **) &dRid, guess * 4)) break;
@@ -351,8 +351,7 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
       }
     if (!dIx) break;
     if (hipMalloc ((void **) &dStart, ((size_t) nReads + 2) * 8) || hipMalloc ((void **) &dHitStart, ((size_t) nReads + 2) * 8)
-        || hipMalloc ((void **) &dMiss, ((size_t) nReads + 1) * 4) || hipMalloc ((void **) &dDepth, m * 4)) break;
-    if (hipMemset (dDepth, 0, m * 4)) break;
+        || hipMalloc ((void **) &dMiss, ((size_t) nReads + 1) * 4)) break;
     unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
     const unsigned rgrid = (nReads + 255) / 256;
     hipLaunchKernelGGL (mgSeedStartKernel, dim3 (grid), dim3 (256), 0, 0, dRid, n, nReads, dStart);
@@ -362,16 +361,14 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
     U64 totHit = 0;
     if (hipMemcpy (&totHit, dHitStart + nReads, 8, hipMemcpyDeviceToHost)) break;
     if (hipMalloc ((void **) &dHit, (totHit + 1) * 4) || hipMalloc ((void **) &dDx, (totHit + 1) * 2)) break;
-    hipLaunchKernelGGL (mgReadsetKernel<true>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss, dHit, dDx, dDepth);
+    hipLaunchKernelGGL (mgReadsetKernel<true>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss, dHit, dDx, dDepthAccum);
     if (hipGetLastError () != hipSuccess) break;
-    *hHit = (U32 *) malloc ((size_t) (totHit + 1) * 4); *hDx = (unsigned short *) malloc ((size_t) (totHit + 1) * 2);
-    if (hipMemcpy (hHitStart, dHitStart, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) || hipMemcpy (hNMiss, dMiss, (size_t) nReads * 4, hipMemcpyDeviceToHost)
-        || (totHit && (hipMemcpy (*hHit, dHit, totHit * 4, hipMemcpyDeviceToHost) || hipMemcpy (*hDx, dDx, totHit * 2, hipMemcpyDeviceToHost)))
-        || hipMemcpy (hDepthCount, dDepth, m * 4, hipMemcpyDeviceToHost)) break;
+    if (hipMemcpy (hHitStart, dHitStart, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) || hipMemcpy (hNMiss, dMiss, (size_t) nReads * 4, hipMemcpyDeviceToHost)) break;
+    *dHitOut = dHit; *dDxOut = dDx; dHit = 0; dDx = 0;
     rc = 0;
   } while (0);
   (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dHitStart);
-  (void) hipFree (dMiss); (void) hipFree (dHit); (void) hipFree (dDx); (void) hipFree (dDepth);
-  if (rc < 0) { free (*hHit); free (*hDx); *hHit = 0; *hDx = 0; if (!mgLastError ()[0]) mgSetError ("readset seeds on the device failed"); }
+  (void) hipFree (dMiss); (void) hipFree (dHit); (void) hipFree (dDx);
+  if (rc < 0 && !mgLastError ()[0]) mgSetError ("readset seeds on the device failed");
   return rc;
 }

@@ -63,7 +63,12 @@ MG_HIDDEN void mgQueryReleaseBuffers (void);           /* the query path's cache
 MG_HIDDEN void mgChainScratchKeep (int on);      /* 1: the query's device arrays stay allocated between batches; 0: ends that (and frees them) */
 /* readsetFileRead's per-read loop on the device (mg_chain.hip): hit lists, distances, counts, hits per mod */
 MG_HIDDEN int  mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBases, const U64 *dReadOffsets, U32 nReads,
-                                     U64 *hHitStart, U32 *hNMiss, U32 **hHit, unsigned short **hDx, U32 *hDepthCount);      /* drop the device copies of the reference's arrays */
+                                     U64 *hHitStart, U32 *hNMiss, U32 **dHitOut, unsigned short **dDxOut, U32 *dDepthAccum);
+/* the per-mod side of the read set on the device (mg_refpack.hip): hit counts kept across a file's batches; depth[], invStart[], invSpace[], nCopy[] at its end */
+MG_HIDDEN MgStatus mgReadsetDevBegin (const void *rs, U32 msMax, U32 **dDepth);
+MG_HIDDEN MgStatus mgReadsetFinishDevice (const void *rs, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
+                                          U16 *hDepth16, U64 *hInvStart, U32 **hInvSpace, int *hNCopy);
+MG_HIDDEN void mgReadsetDevForget (const void *rs);
 /* element count of the reference's Array after appending elements 0..n-1 (array.c:144-170,180-183) */
 MG_HIDDEN int mgRefArrayDim (int first, int size, int n);
 #ifdef __cplusplus

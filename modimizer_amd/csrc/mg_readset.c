@@ -37,6 +37,7 @@ void mgReadsetDestroy (MgReadset *rs)
 {
   if (!rs) return;
   free (rs->len); free (rs->nHit); free (rs->nMiss); free (rs->nCopy); free (rs->hitStart);
+  mgReadsetDevForget (rs);
   free (rs->hit); free (rs->dx); free (rs->invStart); free (rs->invSpace); free (rs);
 }
 
@@ -53,15 +54,22 @@ static void reserveReads (MgReadset *rs, int more)
   rs->capReads = cap;
 }
 
-/* modasm.c:158: depth is rebuilt from the reads that follow */
-static void readsetBegin (MgReadset *rs)
+/* modasm.c:158: depth is rebuilt from the reads that follow.  The hits per mod are counted on the device across the batches of the
+   file (mg_refpack.hip); depth[] comes back, saturated, when the file is done */
+static U32 *gDepthAccum (MgReadset *rs)
+{
+  U32 *d = 0;
+  if (mgReadsetDevBegin (rs, rs->ms->max, &d)) fatal ("read set on the device");
+  return d;
+}
+static U32 *readsetBegin (MgReadset *rs)
 {
   if (modsetSyncToHost (rs->ms, 0)) fatal ("modsetSyncToHost");
-  memset (rs->ms->depth, 0, ((size_t) rs->ms->max + 1) * sizeof (U16));
+  return gDepthAccum (rs);
 }
 
 /* modasm.c:161-188 for a batch of reads */
-static void readsetAddBatch (MgReadset *rs, const char *bases, const int64_t *offsets, int nReads)
+static void readsetAddBatch (MgReadset *rs, U32 *dDepth, const char *bases, const int64_t *offsets, int nReads)
 {
   Modset *ms = rs->ms;
   if (nReads <= 0) return;
@@ -70,18 +78,18 @@ static void readsetAddBatch (MgReadset *rs, const char *bases, const int64_t *of
   /* scan, lookup, hit lists, distances and counts on the device (mg_chain.hip) */
   U64 *hStart = (U64 *) malloc (((size_t) nReads + 1) * sizeof (U64));
   U32 *hMiss = (U32 *) malloc (((size_t) nReads + 1) * sizeof (U32));
-  U32 *hDepth = (U32 *) malloc (((size_t) ms->max + 1) * sizeof (U32));
-  U32 *hHit = 0; U16 *hDx = 0;
-  if (mgReadsetSeedsDevice (ms, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, hStart, hMiss, &hHit, &hDx, hDepth)) fatal ("read scan");
+  U32 *dHit = 0; U16 *dDx = 0;
+  if (mgReadsetSeedsDevice (ms, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, hStart, hMiss, &dHit, &dDx, dDepth)) fatal ("read scan");
   mgBatchFree (&b);
   const U64 n = hStart[nReads];
   if (rs->totHit + n + 1 > rs->capHit)
     { rs->capHit = (rs->totHit + n + 1) * 2;
       rs->hit = (U32 *) realloc (rs->hit, rs->capHit * sizeof (U32));
       rs->dx = (U16 *) realloc (rs->dx, rs->capHit * sizeof (U16));
+      if (!rs->hit || !rs->dx) { fprintf (stderr, "FATAL ERROR: out of memory\n"); exit (-1); }
     }
-  memcpy (rs->hit + rs->totHit, hHit, (size_t) n * sizeof (U32));
-  memcpy (rs->dx + rs->totHit, hDx, (size_t) n * sizeof (U16));
+  if (n && (mgCopyD2HBig (rs->hit + rs->totHit, dHit, (size_t) n * sizeof (U32)) || mgCopyD2HBig (rs->dx + rs->totHit, dDx, (size_t) n * sizeof (U16)))) fatal ("hit lists");
+  mgDeviceFree (dHit); mgDeviceFree (dDx);
   const int first = rs->nReads + 1;                   /* reads are numbered from 1 (modasm.c:95) */
   for (int r = 0 ; r < nReads ; ++r)
     { const int id = first + r;
@@ -91,22 +99,34 @@ static void readsetAddBatch (MgReadset *rs, const char *bases, const int64_t *of
       memset (rs->nCopy[id], 0, sizeof (int[4]));
       rs->hitStart[id] = rs->totHit + hStart[r];
     }
-  /* ++depth per hit with the wrap to 65535 (modasm.c:174): a saturating add of the hits per mod */
-  for (U32 i = 1 ; i <= ms->max ; ++i)
-    if (hDepth[i]) { U32 v = (U32) ms->depth[i] + hDepth[i]; ms->depth[i] = (U16) (v > 0xffffu ? 0xffffu : v); }
   rs->totHit += n;
   rs->nReads += nReads;
   rs->hitStart[rs->nReads + 1] = rs->totHit;
-  free (hStart); free (hMiss); free (hDepth); free (hHit); free (hDx);
+  free (hStart); free (hMiss);
 }
 
-/* invBuild (modasm.c:258-287): lists only for mods hit at least once and not saturated */
+/* invBuild (modasm.c:258-287) and the file's depth[] (modasm.c:174): on the device (mg_refpack.hip: counts saturated, the lists a stable sort
+   of the hits' read numbers by mod, a read's copy-class tallies a lane per read); a set of 2^32 hits or more takes the loops below */
+static void readsetFinishHost (MgReadset *rs);
 static void readsetFinish (MgReadset *rs)
 {
   Modset *ms = rs->ms;
-  mgModsetHostChanged (ms);                            /* depth[] was rewritten on the host */
-  free (rs->invStart); free (rs->invSpace);
+  free (rs->invStart); free (rs->invSpace); rs->invSpace = 0;
   rs->invStart = (U64 *) calloc ((size_t) ms->max + 2, sizeof (U64));
+  if (rs->totHit >= 0xfffffff0ull) { readsetFinishHost (rs); return; }
+  if (mgReadsetFinishDevice (rs, ms->max, rs->hit, rs->totHit, rs->hitStart, (U32) rs->nReads, ms->info, ms->depth, rs->invStart, &rs->invSpace, (int *) rs->nCopy))
+    fatal ("read set on the device");
+  mgModsetHostChanged (ms);                            /* depth[] was rewritten on the host */
+}
+
+/* the same by the reference's loops, for a set too large for 32-bit places (depth[] from the hits themselves) */
+static void readsetFinishHost (MgReadset *rs)
+{
+  Modset *ms = rs->ms;
+  memset (ms->depth, 0, ((size_t) ms->max + 1) * sizeof (U16));
+  for (U64 h = 0 ; h < rs->totHit ; ++h)
+    { U16 *dp = &ms->depth[rs->hit[h] & TOPMASK]; if (*dp < 0xffff) ++*dp; }      /* modasm.c:174 */
+  mgModsetHostChanged (ms);
   rs->invSpace = (U32 *) malloc ((rs->totHit ? rs->totHit : 1) * sizeof (U32));
   U64 off = 0;
   for (U32 i = 1 ; i <= ms->max ; ++i)
@@ -130,8 +150,8 @@ static void readsetFinish (MgReadset *rs)
 
 int mgReadsetRead (MgReadset *rs, const char *bases, const int64_t *offsets, int nReads)
 {
-  readsetBegin (rs);
-  readsetAddBatch (rs, bases, offsets, nReads);
+  U32 *dDepth = readsetBegin (rs);
+  readsetAddBatch (rs, dDepth, bases, offsets, nReads);
   readsetFinish (rs);
   return 0;
 }
@@ -140,13 +160,13 @@ int mgReadsetFileRead (MgReadset *rs, const char *filename)       /* modasm.c:15
 {
   MgSeqReader *r = mgSeqOpen (filename);
   if (!r) return -1;
-  readsetBegin (rs);
+  U32 *dDepth = readsetBegin (rs);
   const MgKnobs *kn = mgKnobs ();                          /* FILE_BATCH_BASES: tests */
   int64_t maxBases = (int64_t) (kn->fileBatchMbp != MG_KNOB_UNSET && kn->fileBatchMbp > 0 ? kn->fileBatchMbp : 512) * 1000000;
   if (kn->fileBatchBases != MG_KNOB_UNSET && kn->fileBatchBases > 0) maxBases = kn->fileBatchBases;
   MgSeqBatch b;
   while (mgSeqNextBatch (r, maxBases, &b) > 0)
-    { readsetAddBatch (rs, b.bases, b.offsets, b.nSeq);
+    { readsetAddBatch (rs, dDepth, b.bases, b.offsets, b.nSeq);
       mgSeqBatchFree (&b);
     }
   mgSeqClose (r);

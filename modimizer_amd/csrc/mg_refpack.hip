@@ -296,6 +296,42 @@ void mgRefSortScatterKernel (const U32 *__restrict__ keys, const U32 *__restrict
 
 /* ---------------------------------------------------------------------------------------- */
 
+/* values (vals, or the positions 0 .. n-1 when vals == 0) in the order of their keys, equal keys in their original order: LSD passes of
+   8 bits over keyBits bits.  *out: a fresh device array of n + 1 words (the caller frees it); tiles: scratch for the scans, at least
+   256 * ceil (n / 8192) / 4096 + 4 words. */
+static MgStatus mgRefStableSort (const U32 *keys, const U32 *vals, U32 n, int keyBits, U32 **out, U32 *tiles, hipStream_t st)
+{
+  *out = 0;
+  const int passes = (keyBits + 7) / 8 > 0 ? (keyBits + 7) / 8 : 1;
+  const U32 nSortTiles = (U32) (((U64) n + MG_RSORT_TILE - 1) / MG_RSORT_TILE);
+  const size_t histWords = (size_t) 256 * (nSortTiles ? nSortTiles : 1);
+  U32 *k1 = 0, *k2 = 0, *v1 = 0, *v2 = 0, *hist = 0;
+  MgStatus s = MG_ERR_HIP;
+  do {
+    if (hipMalloc ((void **) &hist, (histWords + 2) * 4) || hipMalloc ((void **) &v1, ((size_t) n + 1) * 4) || hipMalloc ((void **) &v2, ((size_t) n + 1) * 4)) break;
+    if (passes > 1 && (hipMalloc ((void **) &k1, (size_t) n * 4) || (passes > 2 && hipMalloc ((void **) &k2, (size_t) n * 4)))) break;
+    const U32 *kin = keys; const U32 *vin = vals;
+    U32 *kout = k1, *vout = v1;
+    bool bad = false;
+    for (int p = 0 ; p < passes ; ++p)
+      { const bool last = p + 1 == passes;
+        hipLaunchKernelGGL (mgRefSortHistKernel, dim3 (nSortTiles), dim3 (256), 0, st, kin, (U64) n, 8 * p, hist, nSortTiles);
+        if (mgRefExclusiveScan (hist, hist, histWords, tiles, st)) { bad = true; break; }
+        if (!vin) hipLaunchKernelGGL (mgRefSortScatterKernel<true>, dim3 (nSortTiles), dim3 (256), 0, st, kin, vin, (U64) n, 8 * p, hist, nSortTiles, last ? (U32 *) 0 : kout, vout);
+        else hipLaunchKernelGGL (mgRefSortScatterKernel<false>, dim3 (nSortTiles), dim3 (256), 0, st, kin, vin, (U64) n, 8 * p, hist, nSortTiles, last ? (U32 *) 0 : kout, vout);
+        kin = kout; vin = vout;
+        kout = kout == k1 ? k2 : k1; vout = vout == v1 ? v2 : v1;
+      }
+    if (bad || hipGetLastError () != hipSuccess || hipStreamSynchronize (st) != hipSuccess) break;
+    *out = (U32 *) vin;                                             /* the last pass's output */
+    if (*out == v1) v1 = 0; else v2 = 0;
+    s = MG_OK;
+  } while (0);
+  (void) hipFree (k1); (void) hipFree (k2); (void) hipFree (v1); (void) hipFree (v2); (void) hipFree (hist);
+  if (s == MG_ERR_HIP && !mgLastError ()[0]) mgHipFail (hipGetLastError (), "stable sort on the device");
+  return s;
+}
+
 static MgStatus mgRefGrow (U32 **p, size_t have, size_t keep, size_t want)      /* device array of `want` words holding the first `keep` of the old one */
 {
   (void) have;
@@ -370,7 +406,7 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
     { MG_HIP (hipMalloc ((void **) &d.depth, (m + 1) * 4)); MG_HIP (hipMemsetAsync (d.depth, 0, (m + 1) * 4, st)); d.capMs = m; }
   if (m > d.capMs + 1) { mgSetError ("modset grew beyond its size"); return MG_ERR_CAPACITY; }
   MgStatus s;
-  U32 *tiles = 0, *dTal = 0, *k1 = 0, *k2 = 0, *v1 = 0, *v2 = 0, *hist = 0;
+  U32 *tiles = 0, *dTal = 0;
   do {
     s = MG_ERR_HIP;
     const U32 nSortTiles = (U32) (((U64) n + MG_RSORT_TILE - 1) / MG_RSORT_TILE);
@@ -393,26 +429,10 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
     (void) hipFree (d.rev); d.rev = 0;
     if (n)
       { int keyBits = 1; while (keyBits < 32 && ((U64) 1 << keyBits) <= msMax) ++keyBits;
-        const int passes = (keyBits + 7) / 8;
-        if (hipMalloc ((void **) &hist, (histWords + 2) * 4) || hipMalloc ((void **) &v1, ((size_t) n + 1) * 4) || hipMalloc ((void **) &v2, ((size_t) n + 1) * 4)) break;
-        if (passes > 1 && (hipMalloc ((void **) &k1, (size_t) n * 4) || (passes > 2 && hipMalloc ((void **) &k2, (size_t) n * 4)))) break;
         MG_LAP ("sort allocations");
-        const U32 *kin = d.index; const U32 *vin = 0;
-        U32 *kout = k1, *vout = v1;
-        bool bad = false;
-        for (int p = 0 ; p < passes ; ++p)
-          { const bool last = p + 1 == passes;
-            hipLaunchKernelGGL (mgRefSortHistKernel, dim3 (nSortTiles), dim3 (256), 0, st, kin, (U64) n, 8 * p, hist, nSortTiles);
-            if (mgRefExclusiveScan (hist, hist, histWords, tiles, st)) { bad = true; break; }
-            if (p == 0) hipLaunchKernelGGL (mgRefSortScatterKernel<true>, dim3 (nSortTiles), dim3 (256), 0, st, kin, vin, (U64) n, 8 * p, hist, nSortTiles, last ? (U32 *) 0 : kout, vout);
-            else hipLaunchKernelGGL (mgRefSortScatterKernel<false>, dim3 (nSortTiles), dim3 (256), 0, st, kin, vin, (U64) n, 8 * p, hist, nSortTiles, last ? (U32 *) 0 : kout, vout);
-            kin = kout; vin = vout;
-            kout = kout == k1 ? k2 : k1; vout = vout == v1 ? v2 : v1;
-          }
-        if (bad || hipGetLastError () != hipSuccess) break;
+        if ((s = mgRefStableSort (d.index, 0, n, keyBits, &d.rev, tiles, st))) break;
+        s = MG_ERR_HIP;
         MG_LAP ("sort");
-        d.rev = (U32 *) vin;                                         /* the last pass's output */
-        if (d.rev == v1) v1 = 0; else v2 = 0;
         if (hipMemsetAsync (d.rev + n, 0, 4, st)) break;            /* (the chaining reads rev[loc[x] + 1] of a copy-2 seed: inside the array, but keep the slack defined) */
       }
     else { if (hipMalloc ((void **) &d.rev, 8) || hipMemsetAsync (d.rev, 0, 8, st)) break; }
@@ -432,7 +452,125 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
     d.msMax = msMax; d.refMax = n; d.packed = true;
     s = MG_OK;
   } while (0);
-  (void) hipFree (tiles); (void) hipFree (dTal); (void) hipFree (k1); (void) hipFree (k2); (void) hipFree (v1); (void) hipFree (v2); (void) hipFree (hist);
+  (void) hipFree (tiles); (void) hipFree (dTal);
   if (s == MG_ERR_HIP && !mgLastError ()[0]) mgHipFail (hipGetLastError (), "reference pack on the device");
+  return s;
+}
+
+
+/* ---------------------------------------------------------------------------------------- */
+/* modasm's read ingest: what readsetFileRead + invBuild (modasm.c:151-191,258-287) leave per MOD, on the device.
+ *
+ * Per batch the hit lists are made by mg_chain.hip (mgReadsetSeedsDevice); the hits per mod are counted THERE into an array that lives
+ * here across the batches of a file (rounds 1-4: copied back and folded into ms->depth by a host loop over every mod, per batch).
+ * At the end of the file: depth[] = the counts saturated at 65 535 (modasm.c:174); the inverse lists -- for every mod that was hit and
+ * did not saturate, the reads that hit it, in read order (modasm.c:266,278) -- are a stable sort of the hits' read numbers by mod
+ * (mgRefStableSort: the sort of referencePack), hits on saturated mods keyed past the last mod so that they fall off the end;
+ * invStart[] is the exclusive scan of the lists' lengths; a read's copy-class tallies (modasm.c:276-277) are a lane per read. */
+#define MG_RS_TOPMASK 0x7fffffffu
+struct MgReadsetDev { U32 *depth = 0; size_t cap = 0; };
+static std::mutex gRsLock;
+static std::unordered_map<const void *, MgReadsetDev> gRsDev;
+
+extern "C" void mgReadsetDevForget (const void *rs)
+{ std::lock_guard<std::mutex> g (gRsLock); auto it = gRsDev.find (rs); if (it != gRsDev.end ()) { (void) hipFree (it->second.depth); gRsDev.erase (it); } }
+
+/* the per-mod hit counts of the file that follows: device U32[msMax + 2], zero (modasm.c:158) */
+extern "C" MgStatus mgReadsetDevBegin (const void *rs, U32 msMax, U32 **dDepth)
+{
+  std::lock_guard<std::mutex> g (gRsLock);
+  MgReadsetDev &d = gRsDev[rs];
+  const size_t want = (size_t) msMax + 2;
+  if (d.cap < want) { (void) hipFree (d.depth); d.depth = 0; d.cap = 0; MG_HIP (hipMalloc ((void **) &d.depth, want * 4)); d.cap = want; }
+  MG_HIP (hipMemset (d.depth, 0, want * 4));
+  *dDepth = d.depth;
+  return MG_OK;
+}
+
+__global__ void mgRsCountKernel (const U32 *__restrict__ depth32, U32 msMax, U32 *__restrict__ cnt, unsigned short *__restrict__ depth16)
+{
+  for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i <= (U64) msMax + 1 ; i += (U64) gridDim.x * blockDim.x)
+    { const U32 dp = (i >= 1 && i <= msMax) ? depth32[i] : 0u;
+      cnt[i] = (dp && dp < 0xffffu) ? dp : 0u;                       /* a list only for a mod that was hit and did not saturate (modasm.c:266) */
+      if (i <= msMax) depth16[i] = (unsigned short) (dp > 0xffffu ? 0xffffu : dp);
+    }
+}
+__global__ void mgRsWidenKernel (const U32 *__restrict__ a, U64 n, U64 *__restrict__ out)
+{ for (U64 i = (U64) blockIdx.x * blockDim.x + threadIdx.x ; i < n ; i += (U64) gridDim.x * blockDim.x) out[i] = a[i]; }
+/* per hit: key = its mod (past the last mod if that one saturated), value = its read: the one whose hitStart range holds it (reads from 1) */
+__global__ void mgRsKeyValKernel (const U32 *__restrict__ hit, U64 nHit, const U64 *__restrict__ hitStart, U32 nReads, const U32 *__restrict__ depth32, U32 msMax,
+                                  U32 *__restrict__ key, U32 *__restrict__ val)
+{
+  for (U64 h = (U64) blockIdx.x * blockDim.x + threadIdx.x ; h < nHit ; h += (U64) gridDim.x * blockDim.x)
+    { const U32 y = hit[h] & MG_RS_TOPMASK;
+      key[h] = depth32[y] < 0xffffu ? y : msMax + 1;
+      U32 lo = 1, hi = nReads;                                       /* the last r with hitStart[r] <= h */
+      while (lo < hi) { const U32 mid = lo + (hi - lo + 1) / 2; if (hitStart[mid] <= h) lo = mid; else hi = mid - 1; }
+      val[h] = lo;
+    }
+}
+__global__ __launch_bounds__ (256)
+void mgRsCopyTallyKernel (const U32 *__restrict__ hit, const U64 *__restrict__ hitStart, U32 nReads, const U8 *__restrict__ info, int4 *__restrict__ nCopy)
+{
+  const U32 r = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nReads) return;
+  int c[4] = { 0, 0, 0, 0 };
+  const U64 h0 = hitStart[r], h1 = hitStart[r + 1];
+  for (U64 h = h0 ; h < h1 ; h += 8)
+    { U32 cl[8];
+#pragma unroll
+      for (int j = 0 ; j < 8 ; ++j) cl[j] = h + j < h1 ? (U32) info[hit[h + j] & MG_RS_TOPMASK] & 3u : 4u;      /* eight gathers in flight */
+#pragma unroll
+      for (int j = 0 ; j < 8 ; ++j) { c[0] += cl[j] == 0; c[1] += cl[j] == 1; c[2] += cl[j] == 2; c[3] += cl[j] == 3; }
+    }
+  nCopy[r] = make_int4 (c[0], c[1], c[2], c[3]);
+}
+
+/* hHit[totHit], hHitStart[nReads + 2] (reads from 1; [nReads + 1] = totHit), hInfo[msMax + 1]: in.  hDepth16[msMax + 1], hInvStart[msMax + 2],
+   *hInvSpace (malloc ()ed here, the lists' total length words), hNCopy[(nReads + 1) * 4]: out.  totHit < 2^32 - 1. */
+extern "C" MgStatus mgReadsetFinishDevice (const void *rs, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
+                                           U16 *hDepth16, U64 *hInvStart, U32 **hInvSpace, int *hNCopy)
+{
+  *hInvSpace = 0;
+  MgReadsetDev d;
+  { std::lock_guard<std::mutex> g (gRsLock); auto it = gRsDev.find (rs); if (it == gRsDev.end ()) { mgSetError ("mgReadsetFinishDevice: no read set in progress"); return MG_ERR_ARG; } d = it->second; }
+  hipStream_t st = 0;
+  const size_t m = (size_t) msMax + 1;
+  U32 *dHit = 0, *dCnt = 0, *dKey = 0, *dVal = 0, *dSorted = 0, *tiles = 0; U64 *dStart = 0, *dInv64 = 0; U8 *dInfo = 0; unsigned short *dD16 = 0; int4 *dNc = 0;
+  MgStatus s = MG_ERR_HIP;
+  do {
+    const size_t histWords = (size_t) 256 * ((totHit + MG_RSORT_TILE - 1) / MG_RSORT_TILE + 1);
+    const size_t scanTiles = ((m + 2) > histWords ? (m + 2) : histWords) / MG_SCAN_TILE + 4;
+    if (hipMalloc ((void **) &tiles, scanTiles * 4) || hipMalloc ((void **) &dCnt, (m + 2) * 4) || hipMalloc ((void **) &dD16, (m + 1) * 2) || hipMalloc ((void **) &dInv64, (m + 2) * 8)
+        || hipMalloc ((void **) &dInfo, m) || hipMalloc ((void **) &dStart, ((size_t) nReads + 3) * 8) || hipMalloc ((void **) &dNc, ((size_t) nReads + 2) * sizeof (int4))
+        || hipMalloc ((void **) &dHit, (totHit + 1) * 4) || hipMalloc ((void **) &dKey, (totHit + 1) * 4) || hipMalloc ((void **) &dVal, (totHit + 1) * 4) || hipDeviceSynchronize ()) break;
+    if ((s = mgXferH2DSparse (dInfo, hInfo, m)) || (s = mgXferH2D (dStart, hHitStart, ((size_t) nReads + 2) * 8)) || (totHit && (s = mgXferH2D (dHit, hHit, totHit * 4)))) break;
+    s = MG_ERR_HIP;
+    hipLaunchKernelGGL (mgRsCountKernel, dim3 (2048), dim3 (256), 0, st, d.depth, msMax, dCnt, dD16);
+    if ((s = mgRefExclusiveScan (dCnt, dCnt, m + 1, tiles, st))) break;      /* dCnt[i] = first place of mod i's list; [msMax + 1] = the lists' total */
+    s = MG_ERR_HIP;
+    hipLaunchKernelGGL (mgRsWidenKernel, dim3 (2048), dim3 (256), 0, st, dCnt, (U64) m + 1, dInv64);
+    if (nReads) hipLaunchKernelGGL (mgRsCopyTallyKernel, dim3 ((nReads + 255) / 256), dim3 (256), 0, st, dHit, dStart, nReads, dInfo, dNc);
+    U32 listed = 0;
+    if (hipMemcpyAsync (&listed, dCnt + m, 4, hipMemcpyDeviceToHost, st) || hipStreamSynchronize (st)) break;
+    if (totHit)
+      { hipLaunchKernelGGL (mgRsKeyValKernel, dim3 (4096), dim3 (256), 0, st, dHit, totHit, dStart, nReads, d.depth, msMax, dKey, dVal);
+        int keyBits = 1; while (keyBits < 32 && ((U64) 1 << keyBits) <= (U64) msMax + 1) ++keyBits;
+        if ((s = mgRefStableSort (dKey, dVal, (U32) totHit, keyBits, &dSorted, tiles, st))) break;
+        s = MG_ERR_HIP;
+      }
+    if (hipGetLastError () != hipSuccess || hipStreamSynchronize (st)) break;
+    U32 *inv = (U32 *) mgAllocBig (((size_t) listed ? listed : 1) * 4);
+    if (!inv) { s = MG_ERR_NOMEM; break; }
+    *hInvSpace = inv;
+    if ((s = mgXferD2H (hDepth16, dD16, m * 2, MG_XFER_COPY)) || (s = mgXferD2H (hInvStart, dInv64, (m + 1) * 8, MG_XFER_COPY))
+        || (listed && (s = mgXferD2H (inv, dSorted, (size_t) listed * 4, MG_XFER_COPY)))
+        || (nReads && (s = mgXferD2H (hNCopy + 4, dNc + 1, (size_t) nReads * sizeof (int4), MG_XFER_COPY)))) break;
+    s = MG_OK;
+  } while (0);
+  (void) hipFree (dHit); (void) hipFree (dCnt); (void) hipFree (dKey); (void) hipFree (dVal); (void) hipFree (dSorted); (void) hipFree (tiles);
+  (void) hipFree (dStart); (void) hipFree (dInv64); (void) hipFree (dInfo); (void) hipFree (dD16); (void) hipFree (dNc);
+  if (s == MG_ERR_HIP && !mgLastError ()[0]) mgHipFail (hipGetLastError (), "read set on the device");
+  if (s && *hInvSpace) { free (*hInvSpace); *hInvSpace = 0; }
   return s;
 }
