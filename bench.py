@@ -506,6 +506,12 @@ def gpu_rank(args):
         except Exception as e:
             out["end_to_end"]["write_mod"] = {"error": str(e)[:300]}
 
+    n4 = None
+    if rank == 0 and world == 1 and not multi and not args.no_other:
+        try:
+            n4 = bench_minimizers(cx, reads, d_offsets, offsets, n_reads)
+        except Exception as e:
+            n4 = {"error": str(e)[:300]}
     L.modsetDestroy(ms)
     del reads, d_offsets
     torch.cuda.empty_cache()
@@ -524,6 +530,8 @@ def gpu_rank(args):
                 other[name] = fn(cx, args)
             except Exception as e:                                # the headline line must still go out
                 other[name] = {"error": str(e)[:300]}
+        if n4 is not None:
+            other["n4_minimizers"] = n4
         out["other_configs"] = other
 
     if multi and not args.no_other:
@@ -566,6 +574,41 @@ def rank_parity(cx, ms, reads, d_offsets, offsets, n_reads, S, k, d, seed):
 
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs 5 and 3 (N = 1)
+
+def bench_minimizers(cx, reads, d_offsets, offsets, n_reads):
+    """minimizerRCiterator / minimizerRCnext (seqhash.c:83-152; no caller in the reference) run to exhaustion on every read of
+    the first ~2 Gbp of the headline's batch, device resident, at the reference's default k = 19, w = 31: count pass + scan + write pass."""
+    import numpy as np
+    torch, L, mg = cx.torch, cx.L, cx.mg
+    want = int(float(os.environ.get("MODGPU_BENCH_MIN_GBP", "2")) * 1e9)
+    n = max(1, min(int(np.searchsorted(offsets, want, side="right")) - 1, n_reads))
+    total = int(offsets[n])
+    k, w = 19, 31
+    sh = mg.seqhashCreate(k, w, 17)
+    cap = int(total / (w / 2 + 1) + total / 8 + n + 1024)
+    dH = torch.empty(cap, dtype=torch.int64, device=cx.dev); dP = torch.empty(cap, dtype=torch.int32, device=cx.dev)
+    dS = torch.empty(n + 2, dtype=torch.int64, device=cx.dev)
+    nm = C.c_uint64()
+    best = None
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        mg.check(L.seqhashMinimizerBatchDevice(sh, reads.data_ptr(), total, d_offsets.data_ptr(), n, dH.data_ptr(), dP.data_ptr(), dS.data_ptr(), cap, C.byref(nm), cx.stream))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if it:
+            best = dt if best is None else min(best, dt)
+    m = nm.value
+    pos = (dP[:m] & 0x7fffffff).to(torch.int64)
+    st = dS[:n + 1]
+    # every read's positions strictly increase, and no step is longer than w (the next window starts right behind the last minimum)
+    d = pos[1:] - pos[:-1]
+    first = torch.zeros(m, dtype=torch.bool, device=cx.dev); first[st[:-1][st[:-1] < m]] = True
+    inner = ~first[1:]
+    ok = bool((d[inner] > 0).all().item()) and bool((d[inner] <= w).all().item()) and int(st[-1].item()) == m
+    return {"entry": "seqhashMinimizerBatchDevice", "k": k, "w": w, "bases": total, "reads": n, "minimizers": int(m), "ms": round(best * 1e3, 2),
+            "Gbp_per_s": round(total / best / 1e9, 1), "bases_per_minimizer": round(total / max(m, 1), 2), "checks_ok": ok,
+            "what": "a wave per read; tiles of 496 positions staged in LDS (hashes by all lanes, prefix / suffix arg-minima per block of w, next[] per position), "
+                    "the chain walked one LDS read a link and written by all lanes; two passes (count, write). Round 4: 24 Gbp/s, every link a wave-wide window scan from global memory"}
+
 
 def bench_c4_block(cx, args):
     """What ONE GPU does at N > 1 (configs[3]): block 0 of the 100 Gbp set — 12.5 Gbp of reads from the 3.33 Gbp genome —

@@ -25,7 +25,8 @@ static void readAll (void)
   k.partPacked = num ("MODGPU_PART_PACKED");       k.partBig = num ("MODGPU_PART_BIG");
   k.addChunk = num ("MODGPU_ADD_CHUNK");           k.scanGrid = num ("MODGPU_SCAN_GRID");
   k.scanGeneric = num ("MODGPU_SCAN_GENERIC");     k.scanHist = num ("MODGPU_SCAN_HIST");
-  k.scanDiv64 = num ("MODGPU_SCAN_DIV64");
+  k.scanDiv64 = num ("MODGPU_SCAN_DIV64");        k.minTiled = num ("MODGPU_MIN_TILED");
+  k.minTile = num ("MODGPU_MIN_TILE");
   k.noSegmentInput = num ("MODGPU_NO_SEGMENT_INPUT");
   k.rankSliceShift = num ("MODGPU_RANK_SLICE_SHIFT");
   k.flagPolarity = num ("MODGPU_FLAG_POLARITY");   k.mergeSlots = num ("MODGPU_MERGE_SLOTS");

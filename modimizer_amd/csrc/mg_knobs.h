@@ -21,6 +21,8 @@ typedef struct {
   long addChunk;           /* MODGPU_ADD_CHUNK: modimizers per insert pass */
   long scanGrid;           /* MODGPU_SCAN_GRID: workers per scan launch */
   long scanGeneric;        /* MODGPU_SCAN_GENERIC: 1 = no filter mode */
+  long minTile;            /* MODGPU_MIN_TILE: dev, positions per tile of the minimizer scan (default 512) */
+  long minTiled;           /* MODGPU_MIN_TILED: 0 = the minimizer scan walks every window one link at a time (the path of windows wider than 256) */
   long scanDiv64;          /* MODGPU_SCAN_DIV64: 1 = the exact modes test divisibility in 64-bit arithmetic whatever k and d */
   long scanHist;           /* MODGPU_SCAN_HIST: 0 = the compaction kernel counts the first partition digit */
   long noSegmentInput;     /* MODGPU_NO_SEGMENT_INPUT: 1 = the build always gets a dense copy */

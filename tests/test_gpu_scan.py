@@ -321,9 +321,18 @@ def test_minimizer_iterator_vs_golden(ci):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,w,seed", [(21, 31, 17), (15, 5, 3), (31, 64, 17), (19, 100, 9), (12, 1, 2), (21, 2, 17)])
-def test_minimizer_batch_vs_oracle(k, w, seed):
-    """a ragged batch (empty, shorter than k, shorter than k+w, monotone runs, homopolymers, long reads)"""
+@pytest.mark.parametrize("k,w,seed", [(21, 31, 17), (15, 5, 3), (31, 64, 17), (19, 100, 9), (12, 1, 2), (21, 2, 17),
+                                      (21, 256, 17), (21, 257, 17), (15, 7, 3), (9, 3, 5), (19, 1023, 9)])
+@pytest.mark.parametrize("tiled", [None, "0"])
+def test_minimizer_batch_vs_oracle(k, w, seed, tiled):
+    """a ragged batch (empty, shorter than k, shorter than k+w, monotone runs, homopolymers, long reads); through the tiles (windows
+    up to 256: suffix / prefix arg-minima per block of w) and one link at a time (MODGPU_MIN_TILED=0, and every w > 256); k = 9 with
+    w = 3 on 200 kb makes thousands of equal hashes per window: the tie rule (smallest position mod w) on every link"""
+    with mg.knobs(MIN_TILED=tiled):
+        _minimizer_batch_vs_oracle(k, w, seed)
+
+
+def _minimizer_batch_vs_oracle(k, w, seed):
     from oracle import pyoracle as orc
     rng = np.random.default_rng(k * 1000 + w)
     reads = [np.zeros(0, np.uint8), rng.integers(0, 4, k - 1).astype(np.uint8), rng.integers(0, 4, k).astype(np.uint8),
