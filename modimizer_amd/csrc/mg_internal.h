@@ -43,6 +43,7 @@ void mgTextReleaseBuffers (void);
 /* shared by the caller mirrors (mg_callers.c, mg_readset.c): not exported */
 #define MG_HIDDEN __attribute__ ((visibility ("hidden")))
 typedef struct { void *dPacked, *dOff; U64 total; U32 nReads; } MgDevBatch;     /* host bytes -> 2-bit words in HBM */
+MG_HIDDEN int mgSeqForEachBatchFrom (const char *filename, size_t startOff, U64 startLine, U64 startSeq, int (*fn) (MgSeqBatch *, void *), void *ctx);   /* the host parser's batches (the next one parsed while fn works), from a record start on */
 MG_HIDDEN void mgBatchUpload (MgDevBatch *b, const char *bases, const int64_t *offsets, int nReads);
 MG_HIDDEN void mgBatchFree (MgDevBatch *b);
 MG_HIDDEN FILE *mgTagOpen (const char *root, const char *tag, const char *mode);

@@ -68,19 +68,19 @@ static U32 *readsetBegin (MgReadset *rs)
   return gDepthAccum (rs);
 }
 
-/* modasm.c:161-188 for a batch of reads */
-static void readsetAddBatch (MgReadset *rs, U32 *dDepth, const char *bases, const int64_t *offsets, int nReads)
+/* modasm.c:161-188 for a batch of reads that is on the device (2-bit packed, offsets in bases) */
+static void readsetAddBatchDevice (MgReadset *rs, U32 *dDepth, const void *dPacked, U64 total, const void *dOff, int nReads)
 {
   Modset *ms = rs->ms;
   if (nReads <= 0) return;
   reserveReads (rs, nReads);
-  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
+  int64_t *offsets = (int64_t *) malloc (((size_t) nReads + 1) * sizeof (int64_t));
+  if (mgMemcpyD2H (offsets, dOff, ((size_t) nReads + 1) * 8, 0)) fatal ("D2H");
   /* scan, lookup, hit lists, distances and counts on the device (mg_chain.hip) */
   U64 *hStart = (U64 *) malloc (((size_t) nReads + 1) * sizeof (U64));
   U32 *hMiss = (U32 *) malloc (((size_t) nReads + 1) * sizeof (U32));
   U32 *dHit = 0; U16 *dDx = 0;
-  if (mgReadsetSeedsDevice (ms, (const U32 *) b.dPacked, b.total, (const U64 *) b.dOff, (U32) nReads, hStart, hMiss, &dHit, &dDx, dDepth)) fatal ("read scan");
-  mgBatchFree (&b);
+  if (mgReadsetSeedsDevice (ms, (const U32 *) dPacked, total, (const U64 *) dOff, (U32) nReads, hStart, hMiss, &dHit, &dDx, dDepth)) fatal ("read scan");
   const U64 n = hStart[nReads];
   if (rs->totHit + n + 1 > rs->capHit)
     { rs->capHit = (rs->totHit + n + 1) * 2;
@@ -102,7 +102,16 @@ static void readsetAddBatch (MgReadset *rs, U32 *dDepth, const char *bases, cons
   rs->totHit += n;
   rs->nReads += nReads;
   rs->hitStart[rs->nReads + 1] = rs->totHit;
-  free (hStart); free (hMiss);
+  free (hStart); free (hMiss); free (offsets);
+}
+
+/* ... from host bytes */
+static void readsetAddBatch (MgReadset *rs, U32 *dDepth, const char *bases, const int64_t *offsets, int nReads)
+{
+  if (nReads <= 0) return;
+  MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
+  readsetAddBatchDevice (rs, dDepth, b.dPacked, b.total, b.dOff, nReads);
+  mgBatchFree (&b);
 }
 
 /* invBuild (modasm.c:258-287) and the file's depth[] (modasm.c:174): on the device (mg_refpack.hip: counts saturated, the lists a stable sort
@@ -156,20 +165,26 @@ int mgReadsetRead (MgReadset *rs, const char *bases, const int64_t *offsets, int
   return 0;
 }
 
+typedef struct { MgReadset *rs; U32 *dDepth; } RsFileCtx;
+static int rsDeviceBatch (void *v, const U32 *dPacked, U64 total, const U64 *dOff, U32 nReads, const char *idBytes, const U64 *idOff, void *stream)
+{ RsFileCtx *c = (RsFileCtx *) v; (void) idBytes; (void) idOff; (void) stream; readsetAddBatchDevice (c->rs, c->dDepth, dPacked, total, dOff, (int) nReads); return 0; }
+static int rsHostBatch (MgSeqBatch *b, void *v)
+{ RsFileCtx *c = (RsFileCtx *) v; readsetAddBatch (c->rs, c->dDepth, b->bases, b->offsets, b->nSeq); return 0; }
+
 int mgReadsetFileRead (MgReadset *rs, const char *filename)       /* modasm.c:151-191 */
 {
-  MgSeqReader *r = mgSeqOpen (filename);
-  if (!r) return -1;
-  U32 *dDepth = readsetBegin (rs);
-  const MgKnobs *kn = mgKnobs ();                          /* FILE_BATCH_BASES: tests */
-  int64_t maxBases = (int64_t) (kn->fileBatchMbp != MG_KNOB_UNSET && kn->fileBatchMbp > 0 ? kn->fileBatchMbp : 512) * 1000000;
-  if (kn->fileBatchBases != MG_KNOB_UNSET && kn->fileBatchBases > 0) maxBases = kn->fileBatchBases;
-  MgSeqBatch b;
-  while (mgSeqNextBatch (r, maxBases, &b) > 0)
-    { readsetAddBatch (rs, dDepth, b.bases, b.offsets, b.nSeq);
-      mgSeqBatchFree (&b);
-    }
-  mgSeqClose (r);
+  { FILE *f = fopen (filename, "rb"); if (!f) return -1; fclose (f); }
+  RsFileCtx c; c.rs = rs; c.dDepth = readsetBegin (rs);
+  /* plain FASTA / FASTQ text: parsed on the device (mg_textgpu.hip), the batches never exist as host bytes; gzip, a last line without
+     its newline, FASTQ that breaks a rule: the host parser, from the first record the device parser has not handed on */
+  const MgKnobs *kn = mgKnobs ();
+  U64 nSeq = 0, totLen = 0, resumeOff = 0, resumeLine = 1;
+  U64 batch = (U64) (kn->fileBatchMbp != MG_KNOB_UNSET && kn->fileBatchMbp > 0 ? kn->fileBatchMbp : 512) * 1000000;
+  int rc = mgTextForEachBatchDevice (filename, rsDeviceBatch, &c, batch, 0, &nSeq, &totLen, &resumeOff, &resumeLine);
+  if (rc == -1) return -1;
+  if (rc == -2) rc = mgSeqForEachBatchFrom (filename, 0, 1, 0, rsHostBatch, &c);
+  else if (rc == -3) rc = mgSeqForEachBatchFrom (filename, (size_t) resumeOff, resumeLine, nSeq, rsHostBatch, &c);
+  if (rc) return rc;
   readsetFinish (rs);
   return 0;
 }

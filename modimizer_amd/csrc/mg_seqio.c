@@ -1018,6 +1018,9 @@ static int forEachBatchFrom (const char *filename, size_t startOff, U64 startLin
 
 static int forEachBatch (const char *filename, int (*fn) (MgSeqBatch *, void *), void *ctx)
 { return forEachBatchFrom (filename, 0, 1, 0, fn, ctx); }
+/* for the callers in other files (mg_readset.c): the host parser from byte startOff on (0, line 1, no sequence before: the whole file) */
+int mgSeqForEachBatchFrom (const char *filename, size_t startOff, U64 startLine, U64 startSeq, int (*fn) (MgSeqBatch *, void *), void *ctx)
+{ return forEachBatchFrom (filename, startOff, startLine, startSeq, fn, ctx); }
 
 typedef struct { Modset *ms; U64 nSeq, totLen, totHash; } AddCtx;
 static int addBatch (MgSeqBatch *b, void *v)
