@@ -862,6 +862,20 @@ extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
   return MG_OK;
 }
 
+/* depth[] of ms has been remade from what the device counted elsewhere (modasm's read ingest, mg_refpack.hip): the device table's own copy
+   follows -- dDepth16[0 .. max] on the device -- instead of the whole table being dropped and rebuilt from the host arrays on its next use.
+   No count is pending in the table (the caller synced before it started).  0 if there is no device table (nothing to do). */
+extern "C" MgStatus mgModsetAdoptDepthDevice (Modset *ms, const U16 *dDepth16)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d || !d->built) return MG_OK;
+  MgTable &t = d->t;
+  if (t.pendingDepth || t.max != ms->max) { mgModsetHostChanged (ms); return MG_OK; }      /* (not in step with the host: start again from its arrays) */
+  MG_HIP (hipMemcpy (t.baseDepth, dDepth16, ((size_t) t.max + 1) * sizeof (U16), hipMemcpyDeviceToDevice));
+  t.baseZero = false; t.liveHistValid = false;
+  return MG_OK;
+}
+
 extern "C" U64 mgModsetDeviceSlots (Modset *ms) { MgDev *d = mgDevLookup (ms); return d && d->built ? d->t.nSlots : 0; }
 
 extern "C" MgStatus modsetDepthHistogramDevice (Modset *ms, U64 *dHist, void *stream)

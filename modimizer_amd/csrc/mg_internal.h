@@ -67,9 +67,10 @@ MG_HIDDEN int  mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
                                      U64 *hHitStart, U32 *hNMiss, U32 **dHitOut, unsigned short **dDxOut, U32 *dDepthAccum);
 /* the per-mod side of the read set on the device (mg_refpack.hip): hit counts kept across a file's batches; depth[], invStart[], invSpace[], nCopy[] at its end */
 MG_HIDDEN MgStatus mgReadsetDevBegin (const void *rs, U32 msMax, U32 **dDepth);
-MG_HIDDEN MgStatus mgReadsetFinishDevice (const void *rs, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
+MG_HIDDEN MgStatus mgReadsetFinishDevice (const void *rs, Modset *ms, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
                                           U16 *hDepth16, U64 *hInvStart, U32 **hInvSpace, int *hNCopy);
 MG_HIDDEN void mgReadsetDevForget (const void *rs);
+MG_HIDDEN MgStatus mgModsetAdoptDepthDevice (Modset *ms, const U16 *dDepth16);      /* the device table's depth copy = dDepth16[0 .. max] (mg_api.hip) */
 /* element count of the reference's Array after appending elements 0..n-1 (array.c:144-170,180-183) */
 MG_HIDDEN int mgRefArrayDim (int first, int size, int n);
 #ifdef __cplusplus

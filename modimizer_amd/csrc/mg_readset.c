@@ -123,9 +123,8 @@ static void readsetFinish (MgReadset *rs)
   free (rs->invStart); free (rs->invSpace); rs->invSpace = 0;
   rs->invStart = (U64 *) calloc ((size_t) ms->max + 2, sizeof (U64));
   if (rs->totHit >= 0xfffffff0ull) { readsetFinishHost (rs); return; }
-  if (mgReadsetFinishDevice (rs, ms->max, rs->hit, rs->totHit, rs->hitStart, (U32) rs->nReads, ms->info, ms->depth, rs->invStart, &rs->invSpace, (int *) rs->nCopy))
-    fatal ("read set on the device");
-  mgModsetHostChanged (ms);                            /* depth[] was rewritten on the host */
+  if (mgReadsetFinishDevice (rs, ms, ms->max, rs->hit, rs->totHit, rs->hitStart, (U32) rs->nReads, ms->info, ms->depth, rs->invStart, &rs->invSpace, (int *) rs->nCopy))
+    fatal ("read set on the device");                  /* (the device table's depth copy was set there too) */
 }
 
 /* the same by the reference's loops, for a set too large for 32-bit places (depth[] from the hits themselves) */

@@ -528,7 +528,7 @@ void mgRsCopyTallyKernel (const U32 *__restrict__ hit, const U64 *__restrict__ h
 
 /* hHit[totHit], hHitStart[nReads + 2] (reads from 1; [nReads + 1] = totHit), hInfo[msMax + 1]: in.  hDepth16[msMax + 1], hInvStart[msMax + 2],
    *hInvSpace (malloc ()ed here, the lists' total length words), hNCopy[(nReads + 1) * 4]: out.  totHit < 2^32 - 1. */
-extern "C" MgStatus mgReadsetFinishDevice (const void *rs, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
+extern "C" MgStatus mgReadsetFinishDevice (const void *rs, Modset *ms, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
                                            U16 *hDepth16, U64 *hInvStart, U32 **hInvSpace, int *hNCopy)
 {
   *hInvSpace = 0;
@@ -566,6 +566,7 @@ extern "C" MgStatus mgReadsetFinishDevice (const void *rs, U32 msMax, const U32 
     if ((s = mgXferD2H (hDepth16, dD16, m * 2, MG_XFER_COPY)) || (s = mgXferD2H (hInvStart, dInv64, (m + 1) * 8, MG_XFER_COPY))
         || (listed && (s = mgXferD2H (inv, dSorted, (size_t) listed * 4, MG_XFER_COPY)))
         || (nReads && (s = mgXferD2H (hNCopy + 4, dNc + 1, (size_t) nReads * sizeof (int4), MG_XFER_COPY)))) break;
+    if ((s = mgModsetAdoptDepthDevice (ms, (const U16 *) dD16))) break;      /* the device table keeps up with the depth[] just mirrored (no rebuild on its next use) */
     s = MG_OK;
   } while (0);
   (void) hipFree (dHit); (void) hipFree (dCnt); (void) hipFree (dKey); (void) hipFree (dVal); (void) hipFree (dSorted); (void) hipFree (tiles);
