@@ -218,6 +218,51 @@ print("COMM_OK")
 
 
 @pytest.mark.gpu
+def test_query_scratch_follows_the_thread_to_another_gpu(tmp_path):
+    """mgQueryFile on device 0 leaves the calling thread's query scratch allocated there (it is kept between the batches of a
+    file); the same thread then moves to device 1 (mgSetDevice) and queries there -- the scratch is the thread's and its device's, so it
+    is dropped and made again on device 1 instead of device-0 blocks being handed to kernels on device 1.  Needs two GPUs."""
+    same = os.environ.get("MODGPU_TEST_TWO_GPU_ON_ONE") == "1"        # (dev: both halves on device 0, to check the script itself on a one-GPU box)
+    if _gpu_count() < 2 and not same:
+        pytest.skip("needs 2 GPUs, this box has %d" % _gpu_count())
+    code = r"""
+import ctypes as C, numpy as np, os, sys
+sys.path.insert(0, %r)
+import modimizer_amd as mg
+from modimizer_amd import synth
+L = mg.lib()
+genome = synth.iid_bases(2_000_000, 5)
+reads = [genome[i * 7000:i * 7000 + 6000] for i in range(200)]
+fa = os.path.join(%r, "q.fa")
+with open(fa, "w") as f:
+    for i, r in enumerate(reads):
+        f.write(">r%%d\n%%s\n" %% (i, "".join("ACGT"[b] for b in r)))
+outs = []
+for half, dev in enumerate(%r):
+    mg.check(L.mgSetDevice(dev))
+    sh = mg.seqhashCreate(21, 64, 17); ms = mg.modsetCreate(sh, 22)
+    ref = L.mgReferenceCreate(ms, 1 << 22)
+    off = np.array([0, len(genome)], np.int64); names = (C.c_char_p * 1)(b"g")
+    with mg.CFile(os.devnull, "w") as fo:
+        assert L.mgReferenceRead(ref, genome.ctypes.data, off.ctypes.data, 1, names, True, fo) == 0
+    out = os.path.join(%r, "o%%d.txt" %% half)
+    with mg.CFile(out, "w") as fo:
+        if half == 0:
+            assert L.mgQueryFile(ref, fa.encode(), fo) == 0                  # leaves the scratch of this thread on device 0
+        else:
+            b = np.concatenate(reads); o = np.arange(len(reads) + 1, dtype=np.int64) * 6000
+            nm = (C.c_char_p * len(reads))(*[b"r%%d" %% i for i in range(len(reads))])
+            assert L.mgQueryProcess(ref, b.ctypes.data, o.ctypes.data, len(reads), nm, fo) == 0
+    outs.append(open(out).read())
+    L.mgReferenceDestroy(ref); L.modsetDestroy(ms)
+assert outs[0] == outs[1] and outs[0].count("Q\t") == len(reads)
+print("TWO_GPU_OK")
+""" % (ROOT, str(tmp_path), (0, 0) if same else (0, 1), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "TWO_GPU_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
 def test_bench_world2_code_path_on_one_gpu():
     """`python bench.py --gpus 2` with both ranks on cuda:0 (MODGPU_BENCH_ONE_GPU=1: gloo instead of RCCL, which refuses two
     ranks on one device): the world > 1 branches a one-GPU box cannot otherwise reach -- block r on rank r, the summed histogram
