@@ -499,8 +499,8 @@ static void mgDevFree (MgDev *d)
     { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
       (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters); (void) hipFree (d->t.liveHist);
     }
+  if (d->side) { (void) hipStreamSynchronize (d->side); (void) hipStreamDestroy (d->side); }      /* (a scan started by mgQueryReadsDeviceAsync and never waited for still writes into an arena) */
   d->arena.release (); d->arena2.release ();
-  if (d->side) { (void) hipStreamSynchronize (d->side); (void) hipStreamDestroy (d->side); }
   for (int i = 0 ; i < 2 ; ++i) if (d->scanned[i]) (void) hipEventDestroy (d->scanned[i]);
   if (d->inputReady) (void) hipEventDestroy (d->inputReady);
   delete d;

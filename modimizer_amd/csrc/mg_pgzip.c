@@ -300,7 +300,7 @@ FILE *mgGzipOpenRead (const char *name)
       if (pread (fd, h, PGZ_HDR, at) != PGZ_HDR) { ok = 0; break; }
       if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[10] != 12 || h[11] != 0 || h[12] != 'M' || h[13] != 'G' || h[14] != 8 || h[15] != 0) { ok = 0; break; }
       const unsigned cs = get32 (h + 16), us = get32 (h + 20);
-      if (cs < PGZ_HDR + 8 || at + (off_t) cs > end) { ok = 0; break; }
+      if (cs < PGZ_HDR + 8 || at + (off_t) cs > end || us > 8 * MG_PGZ_MEMBER) { ok = 0; break; }      /* (a size this writer never makes: not a file of its own) */
       if (nMem == cap) { cap = cap ? 2 * cap : 256; PgzMem *q = (PgzMem *) realloc (mem, cap * sizeof (PgzMem)); if (!q) { ok = 0; break; } mem = q; }
       mem[nMem].off = at; mem[nMem].csize = cs; mem[nMem].usize = us; ++nMem;
       if (us > most) most = us;
