@@ -36,11 +36,36 @@ typedef struct
 static void put32 (unsigned char *p, unsigned v) { p[0] = (unsigned char) v; p[1] = (unsigned char) (v >> 8); p[2] = (unsigned char) (v >> 16); p[3] = (unsigned char) (v >> 24); }
 static unsigned get32 (const unsigned char *p) { return (unsigned) p[0] | (unsigned) p[1] << 8 | (unsigned) p[2] << 16 | (unsigned) p[3] << 24; }
 
+/* What these files hold -- index[]: a 4 * 2^bits byte table nine tenths zero; value[]: k-mers of 2k bits in 64-bit words; counts, offsets
+   -- is runs of zero bytes between bytes that repeat nothing.  zlib's Z_RLE strategy (matches of distance one only) finds exactly those
+   runs and skips the hash-chain search that finds nothing else: on index[] it is 5 times faster than the default strategy AND 4 % smaller,
+   on value[] 7.7 times faster and 1 % larger (zlib level 6, one thread: 59 -> 291 and 13 -> 100 MB/s).  Data of another kind (small counts
+   that alternate, text) compresses better the default way, so every member decides for itself on its first 128 KiB: RLE unless that
+   costs more than 5 % of size. */
+static int pgzStrategy (const unsigned char *src, size_t n, int level)
+{
+  const size_t sample = n < ((size_t) 128 << 10) ? n : (size_t) 128 << 10;
+  if (sample < 4096) return Z_DEFAULT_STRATEGY;
+  size_t len[2] = { 0, 0 };
+  for (int which = 0 ; which < 2 ; ++which)
+    { z_stream z; memset (&z, 0, sizeof (z));
+      if (deflateInit2 (&z, level, Z_DEFLATED, -15, 8, which ? Z_RLE : Z_DEFAULT_STRATEGY) != Z_OK) return Z_DEFAULT_STRATEGY;
+      const size_t cap = deflateBound (&z, (uLong) sample) + 64;
+      unsigned char *out = (unsigned char *) malloc (cap);
+      if (!out) { deflateEnd (&z); return Z_DEFAULT_STRATEGY; }
+      z.next_in = (Bytef *) src; z.avail_in = (uInt) sample; z.next_out = out; z.avail_out = (uInt) cap;
+      (void) deflate (&z, Z_FINISH);
+      len[which] = cap - z.avail_out;
+      deflateEnd (&z); free (out);
+    }
+  return len[1] * 100 <= len[0] * 105 ? Z_RLE : Z_DEFAULT_STRATEGY;
+}
+
 /* one member: gzip header (with the sizes) + deflate + crc32 + length, into a malloc ()ed block */
 static unsigned char *pgzMember (const unsigned char *src, size_t n, int level, size_t *outLen)
 {
   z_stream z; memset (&z, 0, sizeof (z));
-  if (deflateInit2 (&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+  if (deflateInit2 (&z, level, Z_DEFLATED, 15 + 16, 8, pgzStrategy (src, n, level)) != Z_OK) return 0;
   unsigned char extra[12] = { 'M', 'G', 8, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   gz_header gh; memset (&gh, 0, sizeof (gh));
   gh.os = 3; gh.extra = extra; gh.extra_len = sizeof (extra);
