@@ -1281,8 +1281,9 @@ def write_mod(cx, ms):
             "read_back": {"entry": "modsetRead through mgGzipOpenRead", "seconds": round(dt_r, 2), "MBps": round(raw_bytes / dt_r / 1e6, 1),
                           "single_stream_MBps": round(sb / dt_r1 / 1e6, 1), "speedup_vs_single_stream": round(raw_bytes / dt_r / (sb / dt_r1), 1),
                           "same_arrays": same},
-            "what": "config 2's set, table bits 30: 104 + 4 * 2^30 + 11 * (max + 1) bytes -> gzip members of 16 MiB deflated in parallel (level 6), "
-                    "written in order into /dev/shm; single_stream: zlib level 6 on one thread over a 256 MiB sample of index[] and value[]"}
+            "what": "config 2's set, table bits 30: 104 + 4 * 2^30 + 11 * (max + 1) bytes -> gzip members of 16 MiB deflated in parallel (level 6; per member Z_RLE where its first 128 KiB "
+                    "say that costs no size: the zero runs of index[] and of the k-mers' high bytes), written in order into /dev/shm; single_stream: zlib level 6, default strategy, "
+                    "on one thread over a 256 MiB sample of index[] and value[] -- what the reference's fzopen + gzwrite does"}
 
 
 def modmap_query_file_long(cx):
