@@ -250,8 +250,10 @@ void    mgModsetWriteText (Modset *ms, FILE *f) ;
 
 /* modmap.c's Reference (modmap.c:35-47) and its three operations, on sequences already in memory
  * (bases 0..3 one byte each, offsets[n+1], names[n]).  The per-k-mer loops run on the GPU
- * (mgInsertReadsDevice / mgQueryReadsDevice); the CSR pack (modmap.c:74-91) and the seed chaining
- * (modmap.c:213-276) are the reference's serial host logic and stay on the host. */
+ * (mgInsertReadsDevice / mgQueryReadsDevice), and so do the per-occurrence bookkeeping, the copy classes and
+ * the CSR pack (modmap.c:106-134,74-91: ordered append, exclusive scan, stable sort by index) and the queries'
+ * tallies and seed chaining (modmap.c:213-276); the arrays below are the caller's, filled from the device when
+ * mgReferenceRead / mgReferenceFastaRead return; the host formats the Q / M lines. */
 typedef struct {
   Modset *ms ;
   U32 size ;                   /* capacity of index/offset/id */

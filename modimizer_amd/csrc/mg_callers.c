@@ -122,6 +122,8 @@ int mgReferenceAddDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
   void *dIx = 0, *dPos = 0, *dRid = 0;
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases) guess = totalBases;
   if (guess < 1) guess = 1;
+  const int timing = mgKnobs ()->seedTiming == 1;          /* dev */
+  struct timespec a0, a1, a2, a3; clock_gettime (CLOCK_MONOTONIC, &a0);
   for (int attempt = 0 ; attempt < 2 ; ++attempt)
     { if (mgDeviceAlloc (&dIx, guess * 4) || mgDeviceAlloc (&dPos, guess * 4) || mgDeviceAlloc (&dRid, guess * 4)) fatal ("device alloc");
       MgStatus s = isAdd ? mgInsertReadsDevice (ms, dPacked, totalBases, dReadOffsets, (U32) nSeq, (U32 *) dIx, (U32 *) dPos, (U32 *) dRid, guess, &n, 0)
@@ -132,13 +134,18 @@ int mgReferenceAddDevice (MgReference *ref, const U32 *dPacked, U64 totalBases, 
       if (s == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }   /* modset.c:58 */
       fatal ("reference scan");
     }
+  clock_gettime (CLOCK_MONOTONIC, &a1);
   /* modmap.c:110-117: the occurrences stay on the device (mg_refpack.hip), appended in order behind those of earlier batches */
   U32 added = 0;
   MgStatus as = mgRefBuildAppend (ref, (const U32 *) dIx, (const U32 *) dPos, (const U32 *) dRid, n, (U32) ref->nSeq, &added);
   if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: reference size overflow\n"); exit (-1); }      /* modmap.c:111 */
   if (as) fatal ("reference append");
   ref->max += added;
+  clock_gettime (CLOCK_MONOTONIC, &a2);
   mgDeviceFree (dIx); mgDeviceFree (dPos); mgDeviceFree (dRid);
+  clock_gettime (CLOCK_MONOTONIC, &a3);
+  if (timing) fprintf (stderr, "mgReferenceAddDevice: %.3f Gbp, %d sequences: allocations + scan + insert %.1f ms, append %.1f ms, frees %.1f ms\n", totalBases / 1e9, nSeq,
+                       (a1.tv_sec - a0.tv_sec) * 1e3 + (a1.tv_nsec - a0.tv_nsec) * 1e-6, (a2.tv_sec - a1.tv_sec) * 1e3 + (a2.tv_nsec - a1.tv_nsec) * 1e-6, (a3.tv_sec - a2.tv_sec) * 1e3 + (a3.tv_nsec - a2.tv_nsec) * 1e-6);
   ref->nSeq += nSeq;
   return 0;
 }

@@ -2,8 +2,9 @@
  * the seed list of every read (scan + lookup, mgQueryReadsDevice) and, new here, the tallies of the
  * "Q" line and the chaining of seeds into "M" blocks (modmap.c:213-276).  The chaining is serial
  * inside a read — every step looks at the block built so far — but reads are independent: one lane
- * per read walks its seeds.  What comes back to the host is a few integers per read and per block;
- * the host only formats the lines.
+ * per read walks its seeds, after a lane per SEED has fetched what the walk needs from the reference
+ * (round 5: see mgChainResolveKernel).  What comes back to the host is a few integers per read and per
+ * block; the host only formats the lines.
  *
  * The reference's rules, kept as they are (they decide what is printed):
  *   - seeds that miss, and copy-M seeds, are skipped; a seed's place in the reference is its FIRST

@@ -14,9 +14,12 @@
  *             the second: modmap.c:219-221,242-254).  Ranks inside a tile come from wave-level matching (8 ballots give every
  *             lane the set of lanes that hold its digit), so a reference that is one k-mer a million times over sorts at the
  *             speed of any other;
- *   mirror    the six arrays go back to the host's Reference in one piece each (mg_xfer.hip), and the device copies of info / loc /
- *             rev / id / offset stay resident: they are what mg_chain.hip's chaining kernel reads -- no re-upload.
- * A Reference whose arrays came from a file (mgReferenceLoad) or were written by the host is uploaded as before.
+ *   mirror    the six arrays go back to the host's Reference in one piece each (mg_xfer.hip); what stays resident is what
+ *             mg_chain.hip's chaining reads, derived from them: li[x] = loc[x] | info[x] << 32 and revid[j] = rev[j] | id[rev[j]] << 32
+ *             (one 8-byte load gives a seed its copy class and CSR offset, one or two adjacent ones its first two occurrences with
+ *             the sequences they lie on) and offset[] -- no re-upload.
+ * A Reference whose arrays came from a file (mgReferenceLoad) or were written by the host is uploaded and the same words derived.
+ * The second half of the file is modasm's read ingest (N3): the same scan and sort make its inverse lists.
  */
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
