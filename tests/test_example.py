@@ -8,9 +8,10 @@ from tests import util
 
 SRC = os.path.join(util.ROOT, "examples", "sketch_file.c")
 SRC_MULTI = os.path.join(util.ROOT, "examples", "multi_gpu.c")
+SRC_MAP = os.path.join(util.ROOT, "examples", "map_file.c")
 
 
-@pytest.mark.parametrize("src", [SRC, SRC_MULTI])
+@pytest.mark.parametrize("src", [SRC, SRC_MULTI, SRC_MAP])
 def test_example_is_plain_c99(src, tmp_path):
     """the header and the examples compile as C99 with warnings on (no C++-isms, no HIP types in the ABI)"""
     r = subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-std=c99", "-I", os.path.join(util.ROOT, "include"),
@@ -53,3 +54,23 @@ def test_example_runs_like_modutils(golden_dir, tmp_path):
     assert r.stdout.splitlines() == util.golden_text("modutils_k21d64.stdout.txt").splitlines()[:9]
     assert open(hist).read() == util.golden_text("modutils_k21d64.hist.txt")
     assert open(dump).read() == util.golden_text("modutils_k21d64.dump.txt")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(util.MODMAP_TAGS))
+@pytest.mark.parametrize("through_files", [False, True])
+def test_map_example_runs_like_modmap(tag, through_files, golden_dir, tmp_path):
+    """examples/map_file.c = `modmap -f ref.fa [-w stem -r stem] -q queries.fa` from plain C: the reference program's output, line for line;
+    with a stem the reference is written (multi-member gzip .mod + .ref), read back (the parallel reader) and queried from the copy"""
+    exe = str(tmp_path / "map_file")
+    libdir = os.path.join(util.ROOT, "modimizer_amd")
+    r = subprocess.run(["gcc", "-O2", "-I", os.path.join(util.ROOT, "include"), SRC_MAP, "-o", exe, "-L", libdir, "-lmodgpu",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    k, w = util.MODMAP_TAGS[tag]
+    args = [exe, "20", str(k), str(w), "17", os.path.join(golden_dir, "ref.fa"), os.path.join(golden_dir, "queries.fa")]
+    if through_files:
+        args.append(str(tmp_path / "stem"))
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert r.stdout.splitlines() == util.golden_text("modmap_%s.stdout.txt" % tag).splitlines()
