@@ -314,6 +314,30 @@ void mgTextCarryKernel (unsigned char *bases, U64 from, U64 count)
     }
 }
 
+/* ... and when the regions do not overlap (the carried record is shorter than what was handed on: always, unless one record is longer than a
+   whole batch) the move is a plain copy by the whole chip -- the one-workgroup form took 6 ms per carry of a 100 Mbp chromosome, a quarter of a
+   reference file's read (tools/longfile_trace.sh) */
+__global__ __launch_bounds__ (256)
+void mgTextCarryWideKernel (unsigned char *bases, U64 from, U64 count)
+{
+  const U64 stride = (U64) gridDim.x * blockDim.x * 4;
+  for (U64 i = ((U64) blockIdx.x * blockDim.x + threadIdx.x) * 4 ; i < count ; i += stride)
+    { if (i + 4 <= count && !((from + i) & 3))
+        *reinterpret_cast<U32 *> (bases + i) = *reinterpret_cast<const U32 *> (bases + from + i);
+      else
+        for (int j = 0 ; j < 4 && i + j < count ; ++j) bases[i + j] = bases[from + i + j];
+    }
+}
+static void txCarry (unsigned char *bases, U64 from, U64 count, hipStream_t st)
+{
+  if (!count) return;
+  if (count <= from)
+    { unsigned grid = (unsigned) ((count / 4 + 255) / 256); if (grid > 8192) grid = 8192; if (!grid) grid = 1;
+      hipLaunchKernelGGL (mgTextCarryWideKernel, dim3 (grid), dim3 (256), 0, st, bases, from, count);
+    }
+  else hipLaunchKernelGGL (mgTextCarryKernel, dim3 (1), dim3 (1024), 0, st, bases, from, count);
+}
+
 /* ======================================================================================== */
 /* FASTQ: four lines a record (seqio.c:325-339).  The line a byte belongs to is the number of newlines before it, a prefix
  * sum; line mod 4 says what the byte is: 0 header ('@' first), 1 sequence (EVERY byte but the newline is a base: A/a C/c G/g
@@ -864,7 +888,7 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
                 /* the open record's bases move to the front; it becomes record 0 of the next batch */
                 const U64 carry = accBases - total;
                 if (!eof)
-                  { if (carry) hipLaunchKernelGGL (mgTextCarryKernel, dim3 (1), dim3 (1024), 0, st, t.dBases, total, carry);
+                  { txCarry (t.dBases, total, carry, st);
                     TxState ns; ns.lastEvent = 0; ns.accBases = carry; ns.accRecs = 1;
                     U64 zero = 0;
                     /* (lastEvent stays what it is on the device: only the two counters change) */
@@ -989,7 +1013,7 @@ static int txParseFastq (int fd, size_t fileSize, TxBufs &t, const TxSink &sink,
             resume = tail[2] + 1;
             if (!eof)
               { const U64 carry = accBases - tail[0];
-                if (carry) hipLaunchKernelGGL (mgTextCarryKernel, dim3 (1), dim3 (1024), 0, st, t.dBases, tail[0], carry);
+                txCarry (t.dBases, tail[0], carry, st);
                 U64 counters[3] = { carry, accQual - tail[1], 0 };               /* accBases, accQual, accRecs */
                 if (hipMemcpyAsync ((char *) t.dTq + offsetof (TqState, accBases), counters, 24, hipMemcpyHostToDevice, st) != hipSuccess
                     || hipStreamSynchronize (st) != hipSuccess) { failed = true; break; }
