@@ -8,10 +8,14 @@
  * destination (memcpy, or a saturating 16-bit add: depth[i] = min (65535, depth[i] + pending[i]), modutils.c:26 applied
  * `pending` times).  Nothing is allocated per call: the blocks, streams and events are made once per device and stay
  * until mgReleaseBuffers ().  Nothing crosses between the threads: no queue, no hand-off, each one's pieces are its own.
+ * There is one such set per DEVICE, with a lock of its own: the host threads of a process that drives several GPUs
+ * (examples/multi_gpu.c, one thread per device) mirror their results side by side, not one after the other.
  */
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -20,9 +24,8 @@
 #include "mg_xfer.h"
 
 #define MG_XFER_MAXT   16
+#define MG_XFER_MAXDEV 16
 #define MG_XFER_PIECE_MAX ((size_t) 16 << 20)
-static size_t gPiece = (size_t) 4 << 20;                 /* bytes per piece: 80 us on the link, long enough to hide a copy call (measured, 4 threads with a stream each: 1 MiB 54 GB/s, 4 MiB 49 - 54, 16 MiB 52; MODGPU_XFER_PIECE_KB: dev) */
-#define MG_XFER_PIECE  gPiece
 
 /* A lane has a copy stream of its own: four queues keep the link at 52 - 54 GB/s, all lanes on the device's default stream reach 46
    (tools/xfer_probe.py) -- and a call that follows such a transfer on the default stream was seen to wait 30 ms for it to drain.
@@ -30,19 +33,15 @@ static size_t gPiece = (size_t) 4 << 20;                 /* bytes per piece: 80 
    made AHEAD of their first use, by a thread started when a Modset gets its device table (mgXferWarm): by the time there is
    something to mirror they exist.  MODGPU_XFER_STREAMS=0 puts the copies on the default stream (dev). */
 struct MgXferLane { hipStream_t st; bool own, made; char *pin[2]; hipEvent_t ev[2]; };
-static struct MgXferCtx { int dev = -1; int T = 0; MgXferLane lane[MG_XFER_MAXT]; std::mutex lock; } gX;
-
-static void mgXferDropLocked (void)
-{
-  for (int t = 0 ; t < gX.T ; ++t)
-    { MgXferLane &l = gX.lane[t];
-      if (l.made) (void) hipStreamSynchronize (l.st);
-      if (l.made && l.own) (void) hipStreamDestroy (l.st);
-      for (int b = 0 ; b < 2 ; ++b) { if (l.pin[b]) (void) hipHostFree (l.pin[b]); if (l.ev[b]) (void) hipEventDestroy (l.ev[b]); }
-      memset (&l, 0, sizeof (l));
-    }
-  gX.T = 0; gX.dev = -1;
-}
+struct MgXferCtx
+{ int T = 0;
+  size_t piece = (size_t) 4 << 20;                         /* bytes per piece: 80 us on the link, long enough to hide a copy call (measured, 4 threads with a stream each: 1 MiB 54 GB/s, 4 MiB 49 - 54, 16 MiB 52; MODGPU_XFER_PIECE_KB: dev) */
+  MgXferLane lane[MG_XFER_MAXT] = {};
+  std::mutex lock;
+  std::mutex warmLock; std::thread warm;                   /* the thread that makes the lanes ahead of their first use: joined before another is started, on release, */
+  ~MgXferCtx () { if (warm.joinable ()) warm.join (); }    /* and when the library's statics go (a std::thread destroyed while it can still be joined ends the process) */
+};
+static MgXferCtx gXs[MG_XFER_MAXDEV];                     /* by device number */
 
 int mgXferThreads (void)
 {
@@ -52,43 +51,68 @@ int mgXferThreads (void)
   if (v < 1) v = 1;
   return (int) v;
 }
-
 extern "C" int mgXferThreadCount (void) { return mgXferThreads (); }
-/* the thread that makes the lanes ahead of their first use; joined before another is started, on release, and when the library's
-   statics are destroyed (a std::thread that is destroyed while it can still be joined ends the process) */
-static std::mutex gWarmLock;
-static struct MgWarmThread { std::thread t; ~MgWarmThread () { if (t.joinable ()) t.join (); } } gWarmHolder;
-#define gWarm gWarmHolder.t
-static void mgXferWarmJoin (void) { std::lock_guard<std::mutex> g (gWarmLock); if (gWarm.joinable ()) gWarm.join (); }
-extern "C" void mgXferReleaseBuffers (void) { mgXferWarmJoin (); std::lock_guard<std::mutex> g (gX.lock); mgXferDropLocked (); }
 
-/* the context for T lanes on the current device (gX.lock held): a lane's stream, blocks and events are made by the thread that runs
-   the lane, on its first piece (sixteen threads page-lock their blocks side by side instead of one after the other) */
-static MgStatus mgXferPrepareLocked (int T)
+/* streams and events belong to a device: made and released with that device current */
+static void mgXferDropLocked (MgXferCtx &X, int dev)
 {
-  int dev = 0; MG_HIP (hipGetDevice (&dev));
+  if (!X.T) return;
+  int before = -1;
+  if (hipGetDevice (&before) != hipSuccess) { (void) hipGetLastError (); before = -1; }
+  if (before != dev) (void) hipSetDevice (dev);
+  for (int t = 0 ; t < X.T ; ++t)
+    { MgXferLane &l = X.lane[t];
+      if (l.made) (void) hipStreamSynchronize (l.st);
+      if (l.own && l.st) (void) hipStreamDestroy (l.st);
+      for (int b = 0 ; b < 2 ; ++b) { if (l.pin[b]) (void) hipHostFree (l.pin[b]); if (l.ev[b]) (void) hipEventDestroy (l.ev[b]); }
+      memset (&l, 0, sizeof (l));
+    }
+  X.T = 0;
+  if (before >= 0 && before != dev) (void) hipSetDevice (before);
+}
+
+extern "C" void mgXferReleaseBuffers (void)
+{
+  for (int dev = 0 ; dev < MG_XFER_MAXDEV ; ++dev)
+    { MgXferCtx &X = gXs[dev];
+      { std::lock_guard<std::mutex> w (X.warmLock); if (X.warm.joinable ()) X.warm.join (); }
+      std::lock_guard<std::mutex> g (X.lock);
+      mgXferDropLocked (X, dev);
+    }
+}
+
+/* the current device's set (0: a device number this file has no room for) */
+static MgXferCtx *mgXferCtxOf (int *devOut)
+{
+  int dev = 0;
+  if (hipGetDevice (&dev) != hipSuccess) { (void) hipGetLastError (); return 0; }
+  if (dev < 0 || dev >= MG_XFER_MAXDEV) return 0;
+  *devOut = dev;
+  return &gXs[dev];
+}
+
+/* room for T lanes (X.lock held): a lane's stream, blocks and events are made by the thread that runs the lane, on its first piece
+   (the threads page-lock their blocks side by side instead of one after the other) */
+static void mgXferPrepareLocked (MgXferCtx &X, int dev, int T)
+{
   const long kb = mgKnobs ()->xferPieceKb;
   size_t piece = (kb != MG_KNOB_UNSET && kb >= 64) ? (size_t) kb << 10 : (size_t) 4 << 20;
   if (piece > MG_XFER_PIECE_MAX) piece = MG_XFER_PIECE_MAX;
-  if ((gX.dev >= 0 && gX.dev != dev) || piece != gPiece) mgXferDropLocked ();      /* streams and events belong to a device; the blocks are a piece long */
-  gPiece = piece;
-  gX.dev = dev;
-  if (T > gX.T) { for (int t = gX.T ; t < T ; ++t) memset (&gX.lane[t], 0, sizeof (MgXferLane)); gX.T = T; }
-  return MG_OK;
+  if (piece != X.piece) { mgXferDropLocked (X, dev); X.piece = piece; }      /* the blocks are a piece long */
+  if (T > X.T) { for (int t = X.T ; t < T ; ++t) memset (&X.lane[t], 0, sizeof (MgXferLane)); X.T = T; }
 }
-static hipError_t mgXferLaneMake (MgXferLane &l)
+static hipError_t mgXferLaneMake (MgXferLane &l, size_t piece)
 {
   if (l.made) return hipSuccess;
   hipError_t e;
   struct timespec a, b1, c; clock_gettime (CLOCK_MONOTONIC, &a);
-  if (mgKnobs ()->xferStreams != 0) { if ((e = hipStreamCreateWithFlags (&l.st, hipStreamNonBlocking)) != hipSuccess) return e; l.own = true; }
-  else { l.st = 0; l.own = false; }                       /* (dev) the device's default stream */
-  l.made = true;
+  if (!l.own && mgKnobs ()->xferStreams != 0) { if ((e = hipStreamCreateWithFlags (&l.st, hipStreamNonBlocking)) != hipSuccess) return e; l.own = true; }      /* (else, dev: the device's default stream, 0) */
   clock_gettime (CLOCK_MONOTONIC, &b1);
   for (int b = 0 ; b < 2 ; ++b)
-    { if (!l.pin[b] && (e = hipHostMalloc ((void **) &l.pin[b], MG_XFER_PIECE, hipHostMallocPortable)) != hipSuccess) return e;
+    { if (!l.pin[b] && (e = hipHostMalloc ((void **) &l.pin[b], piece, hipHostMallocPortable)) != hipSuccess) return e;
       if (!l.ev[b] && (e = hipEventCreateWithFlags (&l.ev[b], hipEventDisableTiming)) != hipSuccess) return e;
     }
+  l.made = true;
   clock_gettime (CLOCK_MONOTONIC, &c);
   if (mgKnobs ()->uploadTiming == 1)
     fprintf (stderr, "mgXferLaneMake: stream %.2f ms, blocks + events %.2f ms\n", (b1.tv_sec - a.tv_sec) * 1e3 + (b1.tv_nsec - a.tv_nsec) * 1e-6, (c.tv_sec - b1.tv_sec) * 1e3 + (c.tv_nsec - b1.tv_nsec) * 1e-6);
@@ -103,15 +127,15 @@ static inline void mgXferApply (char *dst, const char *src, size_t bytes, int op
   for (size_t i = 0 ; i < n ; ++i) { const U32 v = (U32) d[i] + s[i]; d[i] = (U16) (v > 0xffffu ? 0xffffu : v); }   /* (the compiler makes paddusw of it) */
 }
 
-/* thread t of T: pieces t, t + T, t + 2T, ... */
-static hipError_t mgXferLaneRun (int dev, MgXferLane &l, int t, int T, char *dst, const char *src, size_t bytes, int op)
+/* thread t of T, device to host: pieces t, t + T, t + 2T, ... */
+static hipError_t mgXferLaneDown (int dev, MgXferLane &l, size_t piece, int t, int T, char *dst, const char *src, size_t bytes, int op)
 {
   hipError_t e = hipSetDevice (dev);
-  if (e != hipSuccess || (e = mgXferLaneMake (l)) != hipSuccess) return e;
-  const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
+  if (e != hipSuccess || (e = mgXferLaneMake (l, piece)) != hipSuccess) return e;
+  const size_t nPieces = (bytes + piece - 1) / piece;
   size_t p = (size_t) t; int b = 0;
-  auto issue = [&] (size_t piece, int buf) -> hipError_t
-    { const size_t off = piece * MG_XFER_PIECE, len = bytes - off < MG_XFER_PIECE ? bytes - off : MG_XFER_PIECE;
+  auto issue = [&] (size_t pc, int buf) -> hipError_t
+    { const size_t off = pc * piece, len = bytes - off < piece ? bytes - off : piece;
       hipError_t x = hipMemcpyAsync (l.pin[buf], src + off, len, hipMemcpyDeviceToHost, l.st);
       return x != hipSuccess ? x : hipEventRecord (l.ev[buf], l.st);
     };
@@ -120,47 +144,23 @@ static hipError_t mgXferLaneRun (int dev, MgXferLane &l, int t, int T, char *dst
     { const size_t next = p + (size_t) T;
       if (next < nPieces && (e = issue (next, b ^ 1)) != hipSuccess) return e;      /* the other block fills while this one is emptied */
       if ((e = hipEventSynchronize (l.ev[b])) != hipSuccess) return e;
-      const size_t off = p * MG_XFER_PIECE, len = bytes - off < MG_XFER_PIECE ? bytes - off : MG_XFER_PIECE;
+      const size_t off = p * piece, len = bytes - off < piece ? bytes - off : piece;
       mgXferApply (dst + off, l.pin[b], len, op);
     }
   return hipSuccess;
 }
 
-MgStatus mgXferD2H (void *hostDst, const void *devSrc, size_t bytes, int op)
-{
-  if (!bytes) return MG_OK;
-  struct timespec q0; clock_gettime (CLOCK_MONOTONIC, &q0);
-  std::lock_guard<std::mutex> g (gX.lock);
-  const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
-  int T = mgXferThreads ();
-  if ((size_t) T > nPieces) T = (int) nPieces;
-  MgStatus s = mgXferPrepareLocked (T); if (s) return s;
-  const int dev = gX.dev;
-  hipError_t err[MG_XFER_MAXT];
-  for (int t = 0 ; t < T ; ++t) err[t] = hipSuccess;
-  std::vector<std::thread> th;
-  int started = 1;                                             /* lane 0 is the caller's */
-  try { for (int t = 1 ; t < T ; ++t) { th.emplace_back ([&, t] { err[t] = mgXferLaneRun (dev, gX.lane[t], t, T, (char *) hostDst, (const char *) devSrc, bytes, op); }); ++started; } }
-  catch (...) { }                                              /* the system gave fewer threads: the pieces of those that did not start are done below */
-  err[0] = mgXferLaneRun (dev, gX.lane[0], 0, T, (char *) hostDst, (const char *) devSrc, bytes, op);
-  for (auto &x : th) x.join ();
-  for (int t = started ; t < T ; ++t) err[t] = mgXferLaneRun (dev, gX.lane[t], t, T, (char *) hostDst, (const char *) devSrc, bytes, op);
-  for (int t = 0 ; t < T ; ++t) if (err[t] != hipSuccess) return mgHipFail (err[t], "mgXferD2H");
-  if (mgKnobs ()->uploadTiming == 1) { struct timespec q1; clock_gettime (CLOCK_MONOTONIC, &q1); fprintf (stderr, "mgXferD2H: %zu bytes, %d threads, %.2f ms\n", bytes, T, (q1.tv_sec - q0.tv_sec) * 1e3 + (q1.tv_nsec - q0.tv_nsec) * 1e-6); }
-  return MG_OK;
-}
-
 /* The other direction, for the arrays a device table is (re)built from (ms->value, ms->depth): the team fills the
    page-locked blocks from the pageable source and the copy engine drains them. */
-static hipError_t mgXferLaneUp (int dev, MgXferLane &l, int t, int T, char *dDst, const char *hSrc, size_t bytes)
+static hipError_t mgXferLaneUp (int dev, MgXferLane &l, size_t piece, int t, int T, char *dDst, const char *hSrc, size_t bytes)
 {
   hipError_t e = hipSetDevice (dev);
-  if (e != hipSuccess || (e = mgXferLaneMake (l)) != hipSuccess) return e;
-  const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
+  if (e != hipSuccess || (e = mgXferLaneMake (l, piece)) != hipSuccess) return e;
+  const size_t nPieces = (bytes + piece - 1) / piece;
   int b = 0; size_t done = 0;
   for (size_t p = (size_t) t ; p < nPieces ; p += (size_t) T, b ^= 1, ++done)
     { if (done >= 2 && (e = hipEventSynchronize (l.ev[b])) != hipSuccess) return e;      /* the copy that last read this block */
-      const size_t off = p * MG_XFER_PIECE, len = bytes - off < MG_XFER_PIECE ? bytes - off : MG_XFER_PIECE;
+      const size_t off = p * piece, len = bytes - off < piece ? bytes - off : piece;
       memcpy (l.pin[b], hSrc + off, len);
       if ((e = hipMemcpyAsync (dDst + off, l.pin[b], len, hipMemcpyHostToDevice, l.st)) != hipSuccess) return e;
       if ((e = hipEventRecord (l.ev[b], l.st)) != hipSuccess) return e;
@@ -168,27 +168,43 @@ static hipError_t mgXferLaneUp (int dev, MgXferLane &l, int t, int T, char *dDst
   return hipStreamSynchronize (l.st);
 }
 
-MgStatus mgXferH2D (void *devDst, const void *hostSrc, size_t bytes)
+/* op < 0: host to device (a = device destination, b = host source); else device to host with that op (a = host destination, b = device source) */
+static MgStatus mgXferRun (void *a, const void *b, size_t bytes, int op, const char *what)
 {
   if (!bytes) return MG_OK;
-  std::lock_guard<std::mutex> g (gX.lock);
-  const size_t nPieces = (bytes + MG_XFER_PIECE - 1) / MG_XFER_PIECE;
+  struct timespec q0; clock_gettime (CLOCK_MONOTONIC, &q0);
+  int dev = 0;
+  MgXferCtx *Xp = mgXferCtxOf (&dev);
+  if (!Xp)                                                 /* more devices than this file has sets for: the runtime's own copy */
+    { if (op == MG_XFER_SATADD16) { mgSetError ("%s: device number beyond %d", what, MG_XFER_MAXDEV - 1); return MG_ERR_ARG; }
+      MG_HIP (hipMemcpy (a, b, bytes, op < 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+      return MG_OK;
+    }
+  MgXferCtx &X = *Xp;
+  std::lock_guard<std::mutex> g (X.lock);
   int T = mgXferThreads ();
+  mgXferPrepareLocked (X, dev, T);
+  const size_t piece = X.piece, nPieces = (bytes + piece - 1) / piece;
   if ((size_t) T > nPieces) T = (int) nPieces;
-  MgStatus s = mgXferPrepareLocked (T); if (s) return s;
-  const int dev = gX.dev;
   hipError_t err[MG_XFER_MAXT];
   for (int t = 0 ; t < T ; ++t) err[t] = hipSuccess;
+  auto run = [&] (int t)
+    { err[t] = op < 0 ? mgXferLaneUp (dev, X.lane[t], piece, t, T, (char *) a, (const char *) b, bytes)
+                      : mgXferLaneDown (dev, X.lane[t], piece, t, T, (char *) a, (const char *) b, bytes, op); };
   std::vector<std::thread> th;
-  int started = 1;
-  try { for (int t = 1 ; t < T ; ++t) { th.emplace_back ([&, t] { err[t] = mgXferLaneUp (dev, gX.lane[t], t, T, (char *) devDst, (const char *) hostSrc, bytes); }); ++started; } }
-  catch (...) { }
-  err[0] = mgXferLaneUp (dev, gX.lane[0], 0, T, (char *) devDst, (const char *) hostSrc, bytes);
+  int started = 1;                                             /* lane 0 is the caller's */
+  try { for (int t = 1 ; t < T ; ++t) { th.emplace_back (run, t); ++started; } }
+  catch (...) { }                                              /* the system gave fewer threads: the pieces of those that did not start are done below */
+  run (0);
   for (auto &x : th) x.join ();
-  for (int t = started ; t < T ; ++t) err[t] = mgXferLaneUp (dev, gX.lane[t], t, T, (char *) devDst, (const char *) hostSrc, bytes);
-  for (int t = 0 ; t < T ; ++t) if (err[t] != hipSuccess) return mgHipFail (err[t], "mgXferH2D");
+  for (int t = started ; t < T ; ++t) run (t);
+  for (int t = 0 ; t < T ; ++t) if (err[t] != hipSuccess) return mgHipFail (err[t], what);
+  if (mgKnobs ()->uploadTiming == 1) { struct timespec q1; clock_gettime (CLOCK_MONOTONIC, &q1); fprintf (stderr, "%s: %zu bytes, device %d, %d threads, %.2f ms\n", what, bytes, dev, T, (q1.tv_sec - q0.tv_sec) * 1e3 + (q1.tv_nsec - q0.tv_nsec) * 1e-6); }
   return MG_OK;
 }
+
+MgStatus mgXferD2H (void *hostDst, const void *devSrc, size_t bytes, int op) { return mgXferRun (hostDst, devSrc, bytes, op, "mgXferD2H"); }
+MgStatus mgXferH2D (void *devDst, const void *hostSrc, size_t bytes) { return mgXferRun (devDst, hostSrc, bytes, -1, "mgXferH2D"); }
 
 /* public forms (include/modgpu.h) */
 extern "C" MgStatus mgCopyD2HBig (void *hostDst, const void *devSrc, size_t bytes)
@@ -201,8 +217,6 @@ extern "C" MgStatus mgCopyH2DBig (void *devDst, const void *hostSrc, size_t byte
  * fault per 4 KiB instead of a fresh huge page (ms->info of a new Modset, calloc ()ed by modsetCreate: 47 MB came back at 4 GB/s).
  * /proc/self/pagemap says which pages exist (present or swapped); only those are read and sent, the rest of the device array is
  * cleared.  Only for arrays the library allocated itself (anonymous memory); anything odd falls back to the plain copy. */
-#include <fcntl.h>
-#include <unistd.h>
 MgStatus mgXferH2DSparse (void *devDst, const void *hostSrc, size_t bytes)
 {
   if (bytes < ((size_t) 4 << 20)) return mgXferH2D (devDst, hostSrc, bytes);
@@ -236,20 +250,21 @@ MgStatus mgXferH2DSparse (void *devDst, const void *hostSrc, size_t bytes)
 void mgXferWarm (void)
 {
   int dev = 0;
-  if (hipGetDevice (&dev) != hipSuccess) { (void) hipGetLastError (); return; }
+  MgXferCtx *Xp = mgXferCtxOf (&dev);
+  if (!Xp) return;
   const int T = mgXferThreads ();
-  { std::unique_lock<std::mutex> g (gX.lock, std::try_to_lock);
+  { std::unique_lock<std::mutex> g (Xp->lock, std::try_to_lock);
     if (!g.owns_lock ()) return;                          /* a transfer (or a warm-up) is running: the lanes exist or are being made */
-    if (gX.dev == dev && gX.T >= T) { bool all = true; for (int t = 0 ; t < T ; ++t) all = all && gX.lane[t].made; if (all) return; }
+    if (Xp->T >= T) { bool all = true; for (int t = 0 ; t < T ; ++t) all = all && Xp->lane[t].made; if (all) return; }
   }
-  std::lock_guard<std::mutex> w (gWarmLock);
-  if (gWarm.joinable ()) gWarm.join ();
+  std::lock_guard<std::mutex> w (Xp->warmLock);
+  if (Xp->warm.joinable ()) Xp->warm.join ();
   try
-    { gWarm = std::thread ([dev, T]
+    { Xp->warm = std::thread ([dev, T, Xp]
         { if (hipSetDevice (dev) != hipSuccess) return;
-          std::lock_guard<std::mutex> g (gX.lock);          /* a transfer that comes before this is done waits here, and finds the lanes made */
-          if (mgXferPrepareLocked (T)) return;
-          for (int t = 0 ; t < T ; ++t) if (mgXferLaneMake (gX.lane[t]) != hipSuccess) { (void) hipGetLastError (); return; }
+          std::lock_guard<std::mutex> g (Xp->lock);         /* a transfer that comes before this is done waits here, and finds the lanes made */
+          mgXferPrepareLocked (*Xp, dev, T);
+          for (int t = 0 ; t < T ; ++t) if (mgXferLaneMake (Xp->lane[t], Xp->piece) != hipSuccess) { (void) hipGetLastError (); return; }
         });
     }
   catch (...) { }                                          /* no thread to be had: the lanes are made when they are first used */
