@@ -217,6 +217,9 @@ MgStatus mgInsertReadsDevice (Modset *ms, const U32 *dPacked, U64 totalBases,
 /* modsetMerge (modset.c:106-128) with the second set given as bare arrays, entries at [1..n2]: merging
  * per-GPU modsets in rank order reproduces the single-stream build exactly. */
 bool mgModsetMergeArrays (Modset *ms1, U64 *value2, U16 *depth2, U8 *info2, U32 n2) ;
+/* The same with the arrays in DEVICE memory, entry i at [i - 1], and ms1 on the device: nothing of the second set crosses the host
+ * link (what mgModsetMergeRankOrder does with what its peers sent).  false = ms1 has no device table, nothing done. */
+bool mgModsetMergeDeviceArrays (Modset *ms1, const U64 *dValue2, const U16 *dDepth2, const U8 *dInfo2, U32 n2) ;
 
 /* Multi-GPU from C, straight on RCCL (BASELINE config 4).  Reads shard over the GPUs, every GPU builds its own modset, no
  * collective on the data path; these are the exchanges there are.  Communicators as RCCL has them: ONE PROCESS, N DEVICES, a host

@@ -77,7 +77,7 @@ EXPORTS = [
     "mgCommInitAll", "mgCommGetUniqueId", "mgCommInitRank", "mgCommRank", "mgCommSize", "mgCommDestroy", "mgHistogramAllReduce", "mgModsetMergeRankOrder",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
-    "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgFormatF2", "mgModsetMergeArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
+    "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgFormatF2", "mgModsetMergeArrays", "mgModsetMergeDeviceArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
 ]
 
 
@@ -199,6 +199,7 @@ def lib():
     sig("mgHistogramAllReduce", i32, MS, vp, vp); sig("mgModsetMergeRankOrder", i32, MS, vp, i32)
     sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
+    sig("mgModsetMergeDeviceArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetClear", i32, MS, vp); sig("mgModsetDeviceSlots", u64, MS); sig("mgSetVerbose", None, i32)
     sig("mgProfileEnable", None, i32); sig("mgProfileOnly", None, i32); sig("mgProfileReset", None); sig("mgProfileKernels", i32)
     sig("mgProfileGet", i32, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), U64P)

@@ -635,23 +635,18 @@ static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
 
 /* modset.c:106-128 with ms1 on the device.  The caller (mg_host.c) has checked the hashers and
  * regrown ms1's host arrays; ms2's host arrays are current.  Returns 0 on success. */
-extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
+/* ms2's entries 1 .. n2 as device arrays (entry i at [i - 1]) merged into ms1, which is on the device */
+static int mgMergeDeviceCore (Modset *ms1, MgDev *d, const U64 *dV2, const U16 *dD2, const U8 *dI2, U32 n2, hipStream_t st)
 {
-  hipStream_t st = 0;
-  MgDev *d; if (mgDevGet (ms1, &d, st)) return -1;
   MgTable &t = d->t;
-  const U32 n2 = ms2->max, max1 = t.max;
-  if (mgFoldCounts (d, st)) return -1;
-  if (!n2) return 0;
-  U64 *dV2 = 0; U16 *dD2 = 0; U8 *dI2 = 0, *dI1 = 0; U32 *dIdx = 0;
+  const U32 max1 = t.max;
+  U8 *dI1 = 0; U32 *dIdx = 0;
   int rc = -1;
   const size_t cap1 = (size_t) max1 + n2 + 2;
   do {
-    if (hipMalloc ((void **) &dV2, (size_t) n2 * 8) || hipMalloc ((void **) &dD2, (size_t) n2 * 2) || hipMalloc ((void **) &dI2, n2)
-        || hipMalloc ((void **) &dI1, cap1) || hipMalloc ((void **) &dIdx, (size_t) n2 * 4)) break;
+    if (hipMalloc ((void **) &dI1, cap1) || hipMalloc ((void **) &dIdx, (size_t) n2 * 4)) break;
     if (hipMemset (dI1, 0, cap1) || hipDeviceSynchronize ()) break;
-    if (mgXferH2D (dV2, ms2->value + 1, (size_t) n2 * 8) || mgXferH2D (dD2, ms2->depth + 1, (size_t) n2 * 2)
-        || mgXferH2D (dI2, ms2->info + 1, n2) || mgXferH2D (dI1, ms1->info, (size_t) max1 + 1)) break;
+    if (mgXferH2D (dI1, ms1->info, (size_t) max1 + 1)) break;
     /* ms2's values in ms2 index order: existing ones are found, new ones get max1+1, max1+2, ... (modset.c:120) */
     MgStatus as = mgAddBatch (ms1, d, dV2, n2, dIdx, 0, false, st);
     if (as == MG_ERR_CAPACITY) { fprintf (stderr, "FATAL ERROR: %s\n", mgLastError ()); exit (-1); }
@@ -671,8 +666,38 @@ extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
     rc = 0;
   } while (0);
   if (rc && !gErr[0]) mgSetError ("device merge failed");
-  (void) hipFree (dV2); (void) hipFree (dD2); (void) hipFree (dI2); (void) hipFree (dI1); (void) hipFree (dIdx);
+  (void) hipFree (dI1); (void) hipFree (dIdx);
   return rc;
+}
+
+extern "C" int mgHookMergeDevice (Modset *ms1, Modset *ms2)
+{
+  hipStream_t st = 0;
+  MgDev *d; if (mgDevGet (ms1, &d, st)) return -1;
+  const U32 n2 = ms2->max;
+  if (mgFoldCounts (d, st)) return -1;
+  if (!n2) return 0;
+  U64 *dV2 = 0; U16 *dD2 = 0; U8 *dI2 = 0;
+  int rc = -1;
+  do {
+    if (hipMalloc ((void **) &dV2, (size_t) n2 * 8) || hipMalloc ((void **) &dD2, (size_t) n2 * 2) || hipMalloc ((void **) &dI2, n2)) break;
+    if (mgXferH2D (dV2, ms2->value + 1, (size_t) n2 * 8) || mgXferH2D (dD2, ms2->depth + 1, (size_t) n2 * 2) || mgXferH2D (dI2, ms2->info + 1, n2)) break;
+    rc = mgMergeDeviceCore (ms1, d, dV2, dD2, dI2, n2, st);
+  } while (0);
+  if (rc && !gErr[0]) mgSetError ("device merge failed");
+  (void) hipFree (dV2); (void) hipFree (dD2); (void) hipFree (dI2);
+  return rc;
+}
+
+/* the same with the second set's arrays already in device memory (what a rank receives from its peers over xGMI, mg_comm.hip):
+   nothing of the second set crosses the host link */
+extern "C" int mgHookMergeDeviceArrays (Modset *ms1, const U64 *dValue2, const U16 *dDepth2, const U8 *dInfo2, U32 n2)
+{
+  hipStream_t st = 0;
+  MgDev *d; if (mgDevGet (ms1, &d, st)) return -1;
+  if (mgFoldCounts (d, st)) return -1;
+  if (!n2) return 0;
+  return mgMergeDeviceCore (ms1, d, dValue2, dDepth2, dInfo2, n2, st);
 }
 
 /* modset.c:64-77 with ms on the device: survivors keep their order, the table is rebuilt from them */
@@ -874,6 +899,17 @@ extern "C" MgStatus mgModsetAdoptDepthDevice (Modset *ms, const U16 *dDepth16)
   MG_HIP (hipMemcpy (t.baseDepth, dDepth16, ((size_t) t.max + 1) * sizeof (U16), hipMemcpyDeviceToDevice));
   t.baseZero = false; t.liveHistValid = false;
   return MG_OK;
+}
+
+/* ms's entries 1 .. max where the device table keeps them (value, depth with every pending count folded in), for a sender that wants
+   them on the device anyway (mg_comm.hip); -1: no device table */
+extern "C" int mgHookDeviceView (Modset *ms, const U64 **dValue1, const U16 **dDepth1, U32 *max)
+{
+  MgDev *d = mgDevLookup (ms);
+  if (!d || !d->built || d->ticketsOut) return -1;
+  if (hipDeviceSynchronize () != hipSuccess || mgFoldCounts (d, 0)) return -1;
+  *dValue1 = d->t.value + 1; *dDepth1 = d->t.baseDepth + 1; *max = d->t.max;
+  return 0;
 }
 
 extern "C" U64 mgModsetDeviceSlots (Modset *ms) { MgDev *d = mgDevLookup (ms); return d && d->built ? d->t.nSlots : 0; }

@@ -6,7 +6,8 @@
  *   mgModsetMergeRankOrder   the exact global modset: the ranks' (value, depth, info) arrays folded into the root's set in RANK
  *                            order with modsetMerge semantics (modset.c:106-128) -- with contiguous blocks of reads per rank this
  *                            reproduces the single-stream build bit for bit (first-occurrence indices, saturated depths); the
- *                            arrays travel point to point (ncclSend / ncclRecv), one rank at a time.
+ *                            arrays travel point to point (ncclSend / ncclRecv), one rank at a time, from the sender's device
+ *                            table into the root's device merge: value[] and depth[] never touch a host.
  * Two ways to get communicators, as RCCL has them: one process driving N devices with one host thread per device
  * (mgCommInitAll; mgSetDevice is per thread), or one process per device (mgCommGetUniqueId on rank 0, the 128 bytes handed to the
  * others by whatever the caller has -- a file, a socket, MPI --, mgCommInitRank everywhere).
@@ -154,20 +155,26 @@ extern "C" MgStatus mgModsetMergeRankOrder (Modset *ms, MgComm *c, int root)
   U64 *dCount = 0;
   MG_HIP (hipMalloc ((void **) &dCount, 8));
   if (c->rank != root)
-    { /* my arrays, current on the host, staged on the device and sent: count first, then value / depth / info of entries 1 .. max */
-      if ((s = modsetSyncToHost (ms, 0))) { (void) hipFree (dCount); return s; }
-      const U64 n = ms->max;
+    { /* count first, then value / depth / info of entries 1 .. max: value and depth from where the device table keeps them; info lives on
+         the host alone (it is the callers' byte) and is staged.  A set without a device table is staged whole. */
+      const U64 *sV = 0; const U16 *sD = 0; U32 devMax = 0;
+      const bool onDevice = mgHookDeviceView (ms, &sV, &sD, &devMax) == 0;
+      if (!onDevice && (s = modsetSyncToHost (ms, 0))) { (void) hipFree (dCount); return s; }
+      const U64 n = onDevice ? devMax : ms->max;
       U64 *dV = 0; U16 *dD = 0; U8 *dI = 0;
       do {
         s = MG_ERR_HIP;
-        if (hipMalloc ((void **) &dV, (n + 1) * 8) || hipMalloc ((void **) &dD, (n + 1) * 2) || hipMalloc ((void **) &dI, n + 1)) break;
+        if (hipMalloc ((void **) &dI, n + 1)) break;
+        if (!onDevice && (hipMalloc ((void **) &dV, (n + 1) * 8) || hipMalloc ((void **) &dD, (n + 1) * 2))) break;
         if (hipMemcpy (dCount, &n, 8, hipMemcpyHostToDevice) || hipDeviceSynchronize ()) break;
-        if (n && (mgXferH2D (dV, ms->value + 1, n * 8) || mgXferH2D (dD, ms->depth + 1, n * 2) || mgXferH2D (dI, ms->info + 1, n))) break;
+        if (n && mgXferH2D (dI, ms->info + 1, n)) break;
+        if (n && !onDevice && (mgXferH2D (dV, ms->value + 1, n * 8) || mgXferH2D (dD, ms->depth + 1, n * 2))) break;
+        if (!onDevice) { sV = dV; sD = dD; }
         ncclResult_t r = gR.Send (dCount, 1, ncclUint64, root, c->comm, c->st);
         if (r == ncclSuccess && n)
           { gR.GroupStart ();
-            r = gR.Send (dV, n, ncclUint64, root, c->comm, c->st);
-            if (r == ncclSuccess) r = gR.Send (dD, n * 2, ncclUint8, root, c->comm, c->st);
+            r = gR.Send (sV, n, ncclUint64, root, c->comm, c->st);
+            if (r == ncclSuccess) r = gR.Send (sD, n * 2, ncclUint8, root, c->comm, c->st);
             if (r == ncclSuccess) r = gR.Send (dI, n, ncclUint8, root, c->comm, c->st);
             gR.GroupEnd ();
           }
@@ -186,11 +193,10 @@ extern "C" MgStatus mgModsetMergeRankOrder (Modset *ms, MgComm *c, int root)
         if (hipStreamSynchronize (c->st) || hipMemcpy (&n, dCount, 8, hipMemcpyDeviceToHost)) { s = mgHipFail (hipGetLastError (), "merge recv"); break; }
         if (!n) continue;
         U64 *dV = 0; U16 *dD = 0; U8 *dI = 0;
-        U64 *hV = (U64 *) mgAllocBig ((n + 1) * 8); U16 *hD = (U16 *) mgAllocBig ((n + 1) * 2); U8 *hI = (U8 *) mgAllocBig (n + 1);
+        U64 *hV = 0; U16 *hD = 0; U8 *hI = 0;
         do {
           s = MG_ERR_HIP;
-          if (!hV || !hD || !hI) { s = MG_ERR_NOMEM; break; }
-          if (hipMalloc ((void **) &dV, (n + 1) * 8) || hipMalloc ((void **) &dD, (n + 1) * 2) || hipMalloc ((void **) &dI, n + 1)) break;
+          if (hipMalloc ((void **) &dV, n * 8) || hipMalloc ((void **) &dD, n * 2) || hipMalloc ((void **) &dI, n)) break;
           gR.GroupStart ();
           r = gR.Recv (dV, n, ncclUint64, peer, c->comm, c->st);
           if (r == ncclSuccess) r = gR.Recv (dD, n * 2, ncclUint8, peer, c->comm, c->st);
@@ -198,9 +204,13 @@ extern "C" MgStatus mgModsetMergeRankOrder (Modset *ms, MgComm *c, int root)
           gR.GroupEnd ();
           if (r != ncclSuccess) { mgRcclFail (r, "ncclRecv"); break; }
           if (hipStreamSynchronize (c->st)) break;
+          if (mgModsetMergeDeviceArrays (ms, dV, dD, dI, (U32) n)) { s = MG_OK; break; }      /* modset.c:106-128 on the device, from where the arrays arrived */
+          /* the root's set lives on the host alone: the arrays go there and the host merges */
+          hV = (U64 *) mgAllocBig ((n + 1) * 8); hD = (U16 *) mgAllocBig ((n + 1) * 2); hI = (U8 *) mgAllocBig (n + 1);
+          if (!hV || !hD || !hI) { s = MG_ERR_NOMEM; break; }
           if (mgXferD2H (hV + 1, dV, n * 8, MG_XFER_COPY) || mgXferD2H (hD + 1, dD, n * 2, MG_XFER_COPY) || mgXferD2H (hI + 1, dI, n, MG_XFER_COPY)) break;
           (void) hipFree (dV); (void) hipFree (dD); (void) hipFree (dI); dV = 0; dD = 0; dI = 0;
-          if (!mgModsetMergeArrays (ms, hV, hD, hI, (U32) n)) { mgSetError ("mgModsetMergeRankOrder: merge refused"); s = MG_ERR_ARG; break; }      /* modset.c:106-128 */
+          if (!mgModsetMergeArrays (ms, hV, hD, hI, (U32) n)) { mgSetError ("mgModsetMergeRankOrder: merge refused"); s = MG_ERR_ARG; break; }
           s = MG_OK;
         } while (0);
         (void) hipFree (dV); (void) hipFree (dD); (void) hipFree (dI);

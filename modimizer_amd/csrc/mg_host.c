@@ -439,6 +439,20 @@ bool mgModsetMergeArrays (Modset *ms1, U64 *value2, U16 *depth2, U8 *info2, U32 
   return modsetMerge (ms1, &view);
 }
 
+/* the same with the second set's arrays in DEVICE memory (entry i at [i - 1], i = 1..n2) and ms1 on the device: what the root of
+ * mgModsetMergeRankOrder holds after the peers' arrays arrived over xGMI.  false: ms1 has no device table (the caller then
+ * brings the arrays to the host and takes mgModsetMergeArrays). */
+bool mgModsetMergeDeviceArrays (Modset *ms1, const U64 *dValue2, const U16 *dDepth2, const U8 *dInfo2, U32 n2)
+{
+  if (!mgLiveDeviceModsets || !mgHookHasDevice (ms1)) return false;
+  mgHookNeedHostAll (ms1, 0);
+  U64 want = (U64) ms1->max + n2 + 1;
+  if (want >= (ms1->tableSize >> 2)) want = (ms1->tableSize >> 2) - 1;
+  regrow (ms1, (U32) want);
+  if (mgHookMergeDeviceArrays (ms1, dValue2, dDepth2, dInfo2, n2)) die ("modsetMerge on the device failed: %s", mgLastError ());
+  return true;
+}
+
 void modsetSummary (Modset *ms, FILE *f)
 {
   if (mgLiveDeviceModsets) mgHookNeedHostAll (ms, 0);

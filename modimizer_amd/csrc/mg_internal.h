@@ -14,6 +14,8 @@ void mgHookNeedHost (Modset *ms, int wantIndex);   /* make value[] (and index[])
 void mgHookNeedHostAll (Modset *ms, int wantIndex);/* also fold pending device depth counts into depth[] */
 int  mgHookHasDevice (Modset *ms);
 int  mgHookMergeDevice (Modset *ms1, Modset *ms2);   /* modsetMerge with ms1 on the device; 0 = done */
+int  mgHookDeviceView (Modset *ms, const U64 **dValue1, const U16 **dDepth1, U32 *max);      /* entries 1 .. max on the device, counts folded; -1: no device table */
+int  mgHookMergeDeviceArrays (Modset *ms1, const U64 *dValue2, const U16 *dDepth2, const U8 *dInfo2, U32 n2);   /* the second set as device arrays */
 int  mgHookPruneDevice (Modset *ms, int lo, int hi);  /* modsetDepthPrune on the device; 0 = done */
 /* one GPU scan of one read for the iterator facade: *blk = malloc()ed replay block {U64 n; U64 kmer[n]; U32 posF[n]} */
 int  mgIterScan (Seqhash *sh, const char *s, int len, U64 **blk);

@@ -254,11 +254,13 @@ static void *pgzInWorker (void *v)
   for (;;)
     { pthread_mutex_lock (&r->mu);
       const size_t j = r->next++;
+      const int stop = r->failed;
       pthread_mutex_unlock (&r->mu);
-      if (j >= r->n || r->failed) return 0;
+      if (j >= r->n || stop) return 0;
       size_t at = j * r->stride;
       if (!r->stride) for (size_t q = 0 ; q < j ; ++q) at += r->p->mem[r->first + q].usize;
-      if (pgzInflateMember (r->p->fd, &r->p->mem[r->first + j], r->dst + at)) r->failed = 1;
+      if (pgzInflateMember (r->p->fd, &r->p->mem[r->first + j], r->dst + at))
+        { pthread_mutex_lock (&r->mu); r->failed = 1; pthread_mutex_unlock (&r->mu); }
     }
 }
 static int pgzInRun (MgPgzIn *p, size_t first, size_t n, unsigned char *dst, size_t stride)

@@ -591,6 +591,49 @@ def test_merge_and_prune_on_device_vs_golden(golden_dir, tmp_path):
     assert np.array_equal(d_o.to_numpy(np.uint32, len(vals)), np.arange(1, len(vals) + 1, dtype=np.uint32))
 
 
+def test_rank_order_merge_from_device_arrays():
+    """what the root of mgModsetMergeRankOrder does with a peer's arrays (per-GPU sets over contiguous blocks of reads,
+    merged in rank order = the single-stream build): the second block's set handed over as DEVICE arrays (mgModsetMergeDeviceArrays)
+    gives value[] / depth[] / info bits / index[] of the oracle's build over both blocks, and the same as the host-array form."""
+    L = mg.lib()
+    k, w, bits = 21, 64, 22
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b1 = synth_batch(900_000, 60_000, 21)
+    b2 = synth_batch(700_000, 60_000, 21, err=0.05)            # same genome: most k-mers recur, some are new
+    sets = []
+    for form in ("device", "host"):
+        a, b = mg.modsetCreate(sh, bits), mg.modsetCreate(sh, bits)
+        mg.add_sequence_batch(a, *b1); mg.add_sequence_batch(b, *b2)
+        mg.check(L.modsetSyncToHost(b, 0))
+        n2 = b.contents.max
+        bv, bd, bi = mg.modset_arrays(b)
+        bi[1:] = (np.arange(1, n2 + 1) % 4).astype(np.uint8)     # copy bits travel too (modset.c:123-126)
+        mg.check(L.modsetSyncToHost(a, 0))
+        ai = mg.modset_arrays(a)[2]; ai[1:] = ((np.arange(1, a.contents.max + 1) // 3) % 4).astype(np.uint8)
+        if form == "device":
+            dv, dd, di = (mg.DeviceBuffer.from_numpy(x[1:].copy()) for x in (bv, bd, bi))
+            assert L.mgModsetMergeDeviceArrays(a, dv.ptr, dd.ptr, di.ptr, n2)
+        else:
+            assert L.mgModsetMergeArrays(a, bv.ctypes.data, bd.ctypes.data, bi.ctypes.data, n2)
+        mg.check(L.modsetSyncToHost(a, 1))
+        v, d, i = (x.copy() for x in mg.modset_arrays(a))
+        idx = np.ctypeslib.as_array(a.contents.index, (1 << bits,)).copy()
+        sets.append((a.contents.max, v, d, i, idx))
+        if form == "device":
+            oms, _ = oracle_build(oh, bits, [b1, b2])
+            assert_same_modset(a, oms, bits)
+        L.modsetDestroy(a); L.modsetDestroy(b)
+    (m0, v0, d0, i0, x0), (m1, v1, d1, i1, x1) = sets
+    assert m0 == m1 and np.array_equal(v0[1:m0 + 1], v1[1:m0 + 1]) and np.array_equal(d0[:m0 + 1], d1[:m0 + 1])
+    assert np.array_equal(i0[:m0 + 1], i1[:m0 + 1]) and np.array_equal(x0, x1)
+    assert i0[1:m0 + 1].max() == 3 and (i0[1:m0 + 1] & ~np.uint8(3)).max() == 0
+    # a set that lives on the host alone: the device form declines, nothing changes
+    c = mg.modsetCreate(sh, bits)
+    dv = mg.DeviceBuffer.from_numpy(np.arange(4, dtype=np.uint64))
+    assert not L.mgModsetMergeDeviceArrays(c, dv.ptr, dv.ptr, dv.ptr, 2) and c.contents.max == 0
+    L.modsetDestroy(c)
+
+
 @pytest.mark.gpu
 def test_modmap_query_host_chain_path(golden_dir, tmp_path):
     """the path taken when a read has more blocks than the device chaining keeps (seed lists chained on the
