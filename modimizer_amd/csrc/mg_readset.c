@@ -10,8 +10,12 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "modgpu.h"
 #include "mg_internal.h"
+
+static double rsNowMs (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+#define RS_LAP(what) do { if (lapOn) { const double q_ = rsNowMs (); fprintf (stderr, "readset: %s %.2f ms\n", what, q_ - lap); lap = q_; } } while (0)      /* dev: MODGPU_SEED_TIMING=1 */
 
 #define TOPBIT  0x80000000u        /* modasm.c:22: set for forward orientation */
 #define TOPMASK 0x7fffffffu
@@ -73,6 +77,7 @@ static void readsetAddBatchDevice (MgReadset *rs, U32 *dDepth, const void *dPack
 {
   Modset *ms = rs->ms;
   if (nReads <= 0) return;
+  const int lapOn = mgKnobs ()->seedTiming == 1; double lap = lapOn ? rsNowMs () : 0;
   reserveReads (rs, nReads);
   int64_t *offsets = (int64_t *) malloc (((size_t) nReads + 1) * sizeof (int64_t));
   if (mgMemcpyD2H (offsets, dOff, ((size_t) nReads + 1) * 8, 0)) fatal ("D2H");
@@ -82,13 +87,16 @@ static void readsetAddBatchDevice (MgReadset *rs, U32 *dDepth, const void *dPack
   U32 *dHit = 0; U16 *dDx = 0;
   if (mgReadsetSeedsDevice (ms, (const U32 *) dPacked, total, (const U64 *) dOff, (U32) nReads, hStart, hMiss, &dHit, &dDx, dDepth)) fatal ("read scan");
   const U64 n = hStart[nReads];
+  RS_LAP ("batch: scan + lookups + hit lists");
   if (rs->totHit + n + 1 > rs->capHit)
     { rs->capHit = (rs->totHit + n + 1) * 2;
       rs->hit = (U32 *) realloc (rs->hit, rs->capHit * sizeof (U32));
       rs->dx = (U16 *) realloc (rs->dx, rs->capHit * sizeof (U16));
       if (!rs->hit || !rs->dx) { fprintf (stderr, "FATAL ERROR: out of memory\n"); exit (-1); }
+      mgHugeHint (rs->hit, rs->capHit * sizeof (U32)); mgHugeHint (rs->dx, rs->capHit * sizeof (U16));      /* the lists arrive into fresh pages: one fault per 2 MiB, not per 4 KiB */
     }
   if (n && (mgCopyD2HBig (rs->hit + rs->totHit, dHit, (size_t) n * sizeof (U32)) || mgCopyD2HBig (rs->dx + rs->totHit, dDx, (size_t) n * sizeof (U16)))) fatal ("hit lists");
+  RS_LAP ("batch: hit lists to the host");
   mgDeviceFree (dHit); mgDeviceFree (dDx);
   const int first = rs->nReads + 1;                   /* reads are numbered from 1 (modasm.c:95) */
   for (int r = 0 ; r < nReads ; ++r)
@@ -103,15 +111,19 @@ static void readsetAddBatchDevice (MgReadset *rs, U32 *dDepth, const void *dPack
   rs->nReads += nReads;
   rs->hitStart[rs->nReads + 1] = rs->totHit;
   free (hStart); free (hMiss); free (offsets);
+  RS_LAP ("batch: per-read records");
 }
 
 /* ... from host bytes */
 static void readsetAddBatch (MgReadset *rs, U32 *dDepth, const char *bases, const int64_t *offsets, int nReads)
 {
   if (nReads <= 0) return;
+  const int lapOn = mgKnobs ()->seedTiming == 1; double lap = lapOn ? rsNowMs () : 0;
   MgDevBatch b; mgBatchUpload (&b, bases, offsets, nReads);
+  RS_LAP ("pack + upload");
   readsetAddBatchDevice (rs, dDepth, b.dPacked, b.total, b.dOff, nReads);
   mgBatchFree (&b);
+  RS_LAP ("batch in all, + free");
 }
 
 /* invBuild (modasm.c:258-287) and the file's depth[] (modasm.c:174): on the device (mg_refpack.hip: counts saturated, the lists a stable sort
@@ -122,6 +134,7 @@ static void readsetFinish (MgReadset *rs)
   Modset *ms = rs->ms;
   free (rs->invStart); free (rs->invSpace); rs->invSpace = 0;
   rs->invStart = (U64 *) calloc ((size_t) ms->max + 2, sizeof (U64));
+  mgHugeHint (rs->invStart, ((size_t) ms->max + 2) * sizeof (U64));
   if (rs->totHit >= 0xfffffff0ull) { readsetFinishHost (rs); return; }
   if (mgReadsetFinishDevice (rs, ms, ms->max, rs->hit, rs->totHit, rs->hitStart, (U32) rs->nReads, ms->info, ms->depth, rs->invStart, &rs->invSpace, (int *) rs->nCopy))
     fatal ("read set on the device");                  /* (the device table's depth copy was set there too) */
@@ -158,9 +171,13 @@ static void readsetFinishHost (MgReadset *rs)
 
 int mgReadsetRead (MgReadset *rs, const char *bases, const int64_t *offsets, int nReads)
 {
+  const int lapOn = mgKnobs ()->seedTiming == 1; double lap = lapOn ? rsNowMs () : 0;
   U32 *dDepth = readsetBegin (rs);
+  RS_LAP ("begin");
   readsetAddBatch (rs, dDepth, bases, offsets, nReads);
+  lap = lapOn ? rsNowMs () : 0;
   readsetFinish (rs);
+  RS_LAP ("finish");
   return 0;
 }
 

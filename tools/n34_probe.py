@@ -25,7 +25,7 @@ d_bytes = torch.empty(total, dtype=torch.uint8, device=cx.dev)
 mg.check(L.mgUnpackDevice(reads.data_ptr(), total, d_bytes.data_ptr(), cx.stream)); torch.cuda.synchronize()
 h = d_bytes.cpu().numpy(); del d_bytes
 o64 = offs[:n_reads + 1].astype(np.int64)
-for it in range(2):
+for it in range(5):
     rs = L.mgReadsetCreate(ms)
     os.environ["MODGPU_SEED_TIMING"] = "1"; L.mgReloadKnobs()
     t0 = time.perf_counter(); rc = L.mgReadsetRead(rs, h.ctypes.data, o64.ctypes.data, n_reads); dt = time.perf_counter() - t0
