@@ -2,7 +2,10 @@
  * block per GPU; every GPU scans its block and builds its own modset (no collective on the data path); the global depth histogram is
  * one RCCL all-reduce of 65 536 x U64 (mgHistogramAllReduce); and, for the exact global set, the per-GPU modsets are folded into GPU
  * 0's in rank order (mgModsetMergeRankOrder: modsetMerge semantics, modset.c:106-128), which must reproduce -- bit for bit -- the
- * modset ONE stream over all the blocks builds (first-occurrence indices, saturated depths).  One process, one host thread per GPU.
+ * modset ONE stream over all the blocks builds (first-occurrence indices, saturated depths).  Third exchange of SURVEY 8(e): reads COUNTED
+ * against one fixed set that every GPU holds (modasm's ingest, modasm.c:151-191: here the genome's own set, depth zeroed) -- every GPU counts
+ * its block (mgReadsetRead), the counts are summed over the GPUs and clamped (mgDepthAllReduce), and must equal the counts of one stream
+ * over all the blocks.  One process, one host thread per GPU.
  *
  *   gcc -O2 -pthread -I include examples/multi_gpu.c -o multi_gpu -L modimizer_amd -lmodgpu -lm \
  *       -Wl,-rpath,$PWD/modimizer_amd -Wl,-rpath,/opt/rocm/lib
@@ -55,6 +58,7 @@ typedef struct
 { int rank, nGpus; MgComm *comm; U64 blockBases, genomeBases; int check;
   Modset *ms; Seqhash *sh; U64 nHash; U64 hist[65536], local[65536]; double buildMs, reduceMs; int ok;
   void *dReads, *dOff; Plan plan;                 /* kept for the single-stream check on GPU 0 */
+  Modset *fixed;                                  /* the genome's set with this GPU's hit counts, then everybody's */
   pthread_barrier_t *bar;
 } Worker;
 
@@ -75,6 +79,26 @@ static int makeBlock (Worker *w, int rank, void **dReads, void **dOff, Plan *pla
   if (mgSynthReads ((const U32 *) dGenome, w->genomeBases, (const U64 *) dStart, (const U64 *) *dOff, (const U8 *) dStrand, plan->n, plan->total,
                     0.05, 777 + (U64) rank, (U32 *) *dReads, 0) || mgStreamSynchronize (0)) return -1;
   mgDeviceFree (dGenome); mgDeviceFree (dStart); mgDeviceFree (dStrand);
+  return 0;
+}
+
+/* the genome's own modset on the calling thread's device, depth zeroed as modasm does before it counts (modasm.c:158): the same on every GPU */
+static Modset *fixedSet (Worker *w, Seqhash *sh)
+{
+  void *dGenome = 0, *dOff = 0; U64 off[2] = { 0, w->genomeBases }, nh = 0;
+  Modset *ms = modsetCreate (sh, BITS, 0);
+  if (mgDeviceAlloc (&dGenome, mgPackedWords (w->genomeBases) * 4) || mgSynthGenome ((U32 *) dGenome, w->genomeBases, 12345, 0) || mgDeviceAlloc (&dOff, 16)
+      || mgMemcpyH2D (dOff, off, 16, 0) || mgAddReadsDevice (ms, (const U32 *) dGenome, w->genomeBases, (const U64 *) dOff, 1, &nh, 0) || modsetSyncToHost (ms, 0)) return 0;
+  memset (ms->depth, 0, ((size_t) ms->max + 1) * sizeof (U16)); mgModsetHostChanged (ms);
+  mgDeviceFree (dGenome); mgDeviceFree (dOff);
+  return ms;
+}
+/* a block as the host bytes mgReadsetRead takes (one base a byte), appended at bases + at */
+static int blockBytes (const void *dReads, U64 total, char *bases)
+{
+  void *dB = 0;
+  if (mgDeviceAlloc (&dB, total + 16) || mgUnpackDevice ((const U32 *) dReads, total, (U8 *) dB, 0) || mgMemcpyD2H (bases, dB, total, 0)) return -1;
+  mgDeviceFree (dB);
   return 0;
 }
 
@@ -107,6 +131,22 @@ static void *work (void *v)
   pthread_barrier_wait (w->bar);
   all = 1; for (int r = 0 ; r < w->nGpus ; ++r) all = all && w[r - w->rank].ok;
   if (w->check && all) CK (mgModsetMergeRankOrder (w->ms, w->comm, 0));
+  /* reads counted against one fixed set: this GPU's block, then the sum over the GPUs */
+  if (w->check && w->ok)
+    { char *bases = (char *) malloc (w->plan.total + 1); int64_t *off = (int64_t *) malloc (((size_t) w->plan.n + 1) * sizeof (int64_t));
+      for (U32 i = 0 ; i <= w->plan.n ; ++i) off[i] = (int64_t) w->plan.off[i];
+      w->fixed = fixedSet (w, w->sh);
+      if (!w->fixed || !bases || !off || blockBytes (w->dReads, w->plan.total, bases)) { fprintf (stderr, "rank %d: %s\n", w->rank, mgLastError ()); w->ok = 0; }
+      else
+        { MgReadset *rs = mgReadsetCreate (w->fixed);
+          if (mgReadsetRead (rs, bases, off, (int) w->plan.n)) w->ok = 0;
+          mgReadsetDestroy (rs);
+        }
+      free (bases); free (off);
+    }
+  pthread_barrier_wait (w->bar);
+  all = 1; for (int r = 0 ; r < w->nGpus ; ++r) all = all && w[r - w->rank].ok;
+  if (w->check && all) CK (mgDepthAllReduce (w->fixed, w->comm));
   return 0;
 }
 
@@ -164,10 +204,41 @@ int main (int argc, char **argv)
           printf ("merge in rank order: %u entries; identical to the single-stream build over all blocks (value[], depth[]): %s\n", m->max, same ? "yes" : "NO");
           ok = ok && same;
         }
-      modsetDestroy (one); mgSeqhashDestroy (sh);
+      modsetDestroy (one);
+      /* 3. counts against the fixed set, summed over the GPUs == one stream over all the blocks counting into the same set */
+      if (ok)
+        { U64 tot = 0, nr = 0; for (int r = 0 ; r < nGpus ; ++r) { tot += w[r].plan.total; nr += w[r].plan.n; }
+          char *bases = (char *) malloc (tot + 1); int64_t *off = (int64_t *) malloc ((nr + 1) * sizeof (int64_t));
+          U64 at = 0, ri = 0;
+          for (int r = 0 ; r < nGpus && ok ; ++r)
+            { void *dR = w[r].dReads, *dO = w[r].dOff; Plan pl = w[r].plan;
+              if (r) { if (makeBlock (&w[0], r, &dR, &dO, &pl)) { fprintf (stderr, "%s\n", mgLastError ()); ok = 0; break; } }
+              if (blockBytes (dR, pl.total, bases + at)) { fprintf (stderr, "%s\n", mgLastError ()); ok = 0; }
+              for (U32 i = 0 ; i < pl.n ; ++i) off[ri++] = (int64_t) (at + pl.off[i]);
+              at += pl.total;
+              if (r) { mgDeviceFree (dR); mgDeviceFree (dO); free (pl.start); free (pl.off); free (pl.strand); }
+            }
+          off[ri] = (int64_t) at;
+          Modset *whole = ok ? fixedSet (&w[0], sh) : 0;
+          if (ok && whole)
+            { MgReadset *rs = mgReadsetCreate (whole);
+              ok = ok && mgReadsetRead (rs, bases, off, (int) nr) == 0;
+              mgReadsetDestroy (rs);
+              int same = 1; U64 hits = 0;
+              for (int r = 0 ; r < nGpus ; ++r)
+                same = same && w[r].fixed->max == whole->max && !memcmp (w[r].fixed->depth + 1, whole->depth + 1, (size_t) whole->max * 2);
+              for (U32 i = 1 ; i <= whole->max ; ++i) hits += whole->depth[i];
+              printf ("reads counted against the genome's set (%u entries, %llu hits): sum over the GPUs == one stream, on every GPU: %s\n", whole->max, (unsigned long long) hits, same ? "yes" : "NO");
+              ok = ok && same && hits > 0;
+              modsetDestroy (whole);
+            }
+          else ok = 0;
+          free (bases); free (off);
+        }
+      mgSeqhashDestroy (sh);
     }
   for (int r = 0 ; r < nGpus ; ++r)
-    { mgSetDevice (r); modsetDestroy (w[r].ms); mgSeqhashDestroy (w[r].sh); mgDeviceFree (w[r].dReads); mgDeviceFree (w[r].dOff); mgCommDestroy (comms[r]); }
+    { mgSetDevice (r); modsetDestroy (w[r].ms); if (w[r].fixed) modsetDestroy (w[r].fixed); mgSeqhashDestroy (w[r].sh); mgDeviceFree (w[r].dReads); mgDeviceFree (w[r].dOff); mgCommDestroy (comms[r]); }
   if (ok) printf ("MULTI_GPU_OK\n");
   return ok ? 0 : 1;
 }

@@ -236,6 +236,10 @@ void     mgCommDestroy (MgComm *c) ;
 /* config 4's collective: hist65536[d] (host, U64) = over all ranks, the number of modset entries of depth d (modutils.c:53-63 per rank,
  * all-reduced with SUM: 512 KiB a rank over xGMI).  Every rank calls it with its own set and gets the sum. */
 MgStatus mgHistogramAllReduce (Modset *ms, U64 *hist65536, MgComm *c) ;
+/* reads counted against a FIXED set that every rank holds (the same entries everywhere; modasm.c:158-174: depth zeroed, ++depth per hit,
+ * saturating): depth[i] = min (65535, sum over the ranks of their depth[i]) on every rank, in ms->depth and in the device table.  Exact: a
+ * saturating add is associative.  4 bytes per entry per rank through one ncclAllReduce (sum, uint32). */
+MgStatus mgDepthAllReduce (Modset *ms, MgComm *c) ;
 /* the exact global set: on rank `root` ms becomes the merge of every rank's set in RANK order with modsetMerge semantics
  * (modset.c:106-128): with contiguous blocks of reads per rank and root = 0 that is, bit for bit, the set one stream over all the reads
  * builds.  Every rank calls it; the others' sets are sent (point to point, one rank at a time) and left as they are. */

@@ -74,7 +74,7 @@ EXPORTS = [
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
     "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgGzipOpenWrite", "mgGzipOpenRead", "mgReferenceLoad",
-    "mgCommInitAll", "mgCommGetUniqueId", "mgCommInitRank", "mgCommRank", "mgCommSize", "mgCommDestroy", "mgHistogramAllReduce", "mgModsetMergeRankOrder",
+    "mgCommInitAll", "mgCommGetUniqueId", "mgCommInitRank", "mgCommRank", "mgCommSize", "mgCommDestroy", "mgHistogramAllReduce", "mgDepthAllReduce", "mgModsetMergeRankOrder",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
     "mgIterScanHost", "mgIterHostBelow", "mgReloadKnobs", "mgFormatF2", "mgModsetMergeArrays", "mgModsetMergeDeviceArrays", "mgModsetClear", "mgModsetDeviceSlots", "mgSetVerbose", "mgProfileEnable", "mgProfileOnly", "mgProfileReset", "mgProfileKernels", "mgProfileGet",
@@ -196,7 +196,7 @@ def lib():
     sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgGzipOpenWrite", vp, C.c_char_p); sig("mgGzipOpenRead", vp, C.c_char_p);
     sig("mgCommInitAll", i32, C.POINTER(vp), i32, C.POINTER(i32)); sig("mgCommGetUniqueId", i32, vp); sig("mgCommInitRank", i32, C.POINTER(vp), i32, i32, vp, i32)
     sig("mgCommRank", i32, vp); sig("mgCommSize", i32, vp); sig("mgCommDestroy", None, vp)
-    sig("mgHistogramAllReduce", i32, MS, vp, vp); sig("mgModsetMergeRankOrder", i32, MS, vp, i32)
+    sig("mgHistogramAllReduce", i32, MS, vp, vp); sig("mgDepthAllReduce", i32, MS, vp); sig("mgModsetMergeRankOrder", i32, MS, vp, i32)
     sig("mgReferenceLoad", C.POINTER(MgReference), C.c_char_p)
     sig("mgModsetMergeArrays", C.c_bool, MS, vp, vp, vp, u32)
     sig("mgModsetMergeDeviceArrays", C.c_bool, MS, vp, vp, vp, u32)

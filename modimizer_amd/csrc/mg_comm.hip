@@ -3,6 +3,9 @@
  * Reads shard over the GPUs of a node and every GPU builds its own modset: no collective on the data path.  What IS exchanged:
  *   mgHistogramAllReduce     config 4's global depth histogram: all-reduce (sum) of 65 536 x U64 = 512 KiB per rank over xGMI
  *                            (latency-bound; modutils.c:53-63 is what a rank's histogram is);
+ *   mgDepthAllReduce         reads counted against a FIXED modset replicated on every rank (modasm.c:158-174: depth zeroed, then ++depth per
+ *                            hit, saturating): the ranks' 16-bit counts widened, all-reduced (sum, uint32) and clamped to 65 535 -- exact,
+ *                            a saturating add is associative; 4 bytes per entry per rank, a ring bound by its slowest xGMI link;
  *   mgModsetMergeRankOrder   the exact global modset: the ranks' (value, depth, info) arrays folded into the root's set in RANK
  *                            order with modsetMerge semantics (modset.c:106-128) -- with contiguous blocks of reads per rank this
  *                            reproduces the single-stream build bit for bit (first-occurrence indices, saturated depths); the
@@ -142,6 +145,48 @@ extern "C" MgStatus mgHistogramAllReduce (Modset *ms, U64 *hist65536, MgComm *c)
   MG_HIP (hipMemcpyAsync (hist65536, c->dHist, 65536 * sizeof (U64), hipMemcpyDeviceToHost, c->st));
   MG_HIP (hipStreamSynchronize (c->st));
   return MG_OK;
+}
+
+__global__ void mgDepthWidenKernel (const U16 *depth1, U32 n, U32 *wide)
+{ for (U32 i = blockIdx.x * blockDim.x + threadIdx.x ; i < n ; i += gridDim.x * blockDim.x) wide[i] = depth1[i]; }
+__global__ void mgDepthClampKernel (const U32 *wide, U32 n, U16 *depth0)      /* depth0[0] = 0 (entry 0 is nobody's), depth0[i + 1] = min (65535, wide[i]) */
+{ for (U32 i = blockIdx.x * blockDim.x + threadIdx.x ; i <= n ; i += gridDim.x * blockDim.x) depth0[i] = i ? (U16) (wide[i - 1] > 0xffffu ? 0xffffu : wide[i - 1]) : (U16) 0; }
+
+/* ms->depth[i] = min (65535, sum over the ranks of their depth[i]), i = 1 .. max, on every rank: in the host array and in the device table.
+ * The sets must hold the same entries (one set loaded or built identically everywhere, reads counted per rank): max is compared first. */
+extern "C" MgStatus mgDepthAllReduce (Modset *ms, MgComm *c)
+{
+  if (!ms || !c) { mgSetError ("mgDepthAllReduce: null argument"); return MG_ERR_ARG; }
+  MG_HIP (hipSetDevice (c->device));
+  MgStatus s = modsetSyncToHost (ms, 0); if (s) return s;      /* ms->depth is the authority (modutils.c:26: callers bump it themselves): counts pending on the device are folded into it first */
+  const U32 n = ms->max;
+  /* the same set everywhere?  max and its complement, all-reduced with MAX: equal on all ranks iff the two still add up */
+  U64 probe[2] = { n, 0xffffffffull - n };
+  MG_HIP (hipMemcpy (c->dHist, probe, 16, hipMemcpyHostToDevice));
+  MG_NCCL (gR.AllReduce (c->dHist, c->dHist, 2, ncclUint64, ncclMax, c->comm, c->st));
+  MG_HIP (hipMemcpyAsync (probe, c->dHist, 16, hipMemcpyDeviceToHost, c->st));
+  MG_HIP (hipStreamSynchronize (c->st));
+  if (probe[0] + probe[1] != 0xffffffffull) { mgSetError ("mgDepthAllReduce: the ranks' sets differ (this one has %u entries, the largest %llu)", n, (unsigned long long) probe[0]); return MG_ERR_ARG; }
+  if (!n) return MG_OK;
+  U32 *dWide = 0; U16 *dStage = 0, *dOut = 0;
+  s = MG_ERR_HIP;
+  do {
+    if (hipMalloc ((void **) &dWide, (size_t) n * 4) || hipMalloc ((void **) &dOut, ((size_t) n + 1) * 2) || hipMalloc ((void **) &dStage, (size_t) n * 2) || hipDeviceSynchronize ()) break;
+    if ((s = mgXferH2D (dStage, ms->depth + 1, (size_t) n * 2))) break;
+    s = MG_ERR_HIP;
+    const U16 *dD1 = dStage;
+    hipLaunchKernelGGL (mgDepthWidenKernel, dim3 (2048), dim3 (256), 0, c->st, dD1, n, dWide);
+    ncclResult_t r = gR.AllReduce (dWide, dWide, n, ncclUint32, ncclSum, c->comm, c->st);
+    if (r != ncclSuccess) { mgRcclFail (r, "ncclAllReduce"); break; }
+    hipLaunchKernelGGL (mgDepthClampKernel, dim3 (2048), dim3 (256), 0, c->st, dWide, n, dOut);
+    if (hipGetLastError () != hipSuccess || hipStreamSynchronize (c->st)) break;
+    if ((s = mgXferD2H (ms->depth, dOut, ((size_t) n + 1) * 2, MG_XFER_COPY))) break;
+    if ((s = mgModsetAdoptDepthDevice (ms, dOut))) break;      /* the device table's own copy follows (no rebuild from the host on its next use) */
+    s = MG_OK;
+  } while (0);
+  (void) hipFree (dWide); (void) hipFree (dStage); (void) hipFree (dOut);
+  if (s == MG_ERR_HIP && !mgLastError ()[0]) mgHipFail (hipGetLastError (), "mgDepthAllReduce");
+  return s;
 }
 
 /* Every rank calls this.  On `root`, ms afterwards holds the merge of all ranks' sets in rank order (root's own set must be rank

@@ -27,6 +27,20 @@ def allreduce_histogram(hist_tensor):
     return hist_tensor
 
 
+def allreduce_depth(depth_u16):
+    """Reads counted per rank against ONE fixed modset that every rank holds (modasm.c:158-174: depth zeroed, ++depth per hit, saturating):
+    returns min(65535, sum over ranks) per entry as uint16 -- the counts of the single stream over all reads, since a saturating add is
+    associative.  Widened to int32 for the SUM (RCCL on GPU tensors, gloo on CPU).  The C form is mgDepthAllReduce."""
+    import torch
+    import torch.distributed as dist
+    wide = torch.from_numpy(np.ascontiguousarray(depth_u16).astype(np.int32))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            wide = wide.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(wide, op=dist.ReduceOp.SUM)
+    return wide.clamp_(max=65535).cpu().numpy().astype(np.uint16)
+
+
 def merge_modsets_in_rank_order(ms, lib):
     """Exact global modset from per-rank modsets built over CONTIGUOUS blocks of reads: rank by rank, in rank
     order, a rank's (value, depth, info) arrays travel to rank 0 as three tensors (point-to-point send/recv: RCCL

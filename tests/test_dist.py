@@ -146,6 +146,65 @@ def test_rank_order_merge_equals_single_stream_gloo_world2():
     assert np.array_equal(v[1:], oms.values()[1:]) and np.array_equal(dep[1:], oms.depths()[1:])
 
 
+def _count_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    ms, reads = _fixed_set_and_reads(po)
+    lo, hi = mdist.shard_bounds(len(reads), world, rank)
+    q.put((rank, mdist.allreduce_depth(_count_hits(po, ms, reads[lo:hi]))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fixed_set_and_reads(po):
+    """a modset built from a genome, and reads to count against it: among them one short repeat unit a few hundred thousand times over, so
+    that some entries pass 65535 on the single stream and on neither rank alone"""
+    k, d = 15, 4
+    genome = synth.iid_bases(30000, 7)
+    ms = po.Modset(po.Hasher(k, d, 17), 20)
+    ms.add_sequence(genome)
+    unit = genome[1000:1040]
+    tiled = [np.tile(unit, 6000) for _ in range(14)]                    # 84 000 copies of the unit in all: 42 000 in either half of the reads
+    reads = tiled[:7] + [genome[i * 900:i * 900 + 1500] for i in range(30)] + [synth.iid_bases(5000, 99)] + tiled[7:]
+    return ms, reads
+
+
+def _count_hits(po, ms, reads):
+    """modasm.c:161-176 on the oracle: depth[] of a fixed set from these reads alone, saturating"""
+    dep = np.zeros(ms.max + 1, np.uint32)
+    h = po.Hasher(15, 4, 17)
+    for r in reads:
+        for km in h.scan(r)[0]:
+            ix = ms.find(int(km))
+            if ix:
+                dep[ix] += 1
+    return np.minimum(dep, 65535).astype(np.uint16)
+
+
+def test_depth_allreduce_fixed_modset_gloo_world2():
+    """SURVEY 8(e) 'count against a fixed modset': every rank counts its block of reads against the same set; all-reduce (sum, 32-bit) and
+    clamp = the saturated counts of one stream over all the reads, also where the sum passes 65535 and no rank's count does"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_count_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import pyoracle as po
+    ms, reads = _fixed_set_and_reads(po)
+    whole = _count_hits(po, ms, reads)
+    halves = [_count_hits(po, ms, reads[slice(*mdist.shard_bounds(len(reads), world, r))]) for r in range(world)]
+    assert (whole == 65535).any() and not any((h == 65535).any() for h in halves)
+    for _, got in res:
+        assert got.dtype == np.uint16 and np.array_equal(got, whole)
+
+
 def test_bench_gpus_n_starts_n_ranks():
     """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) starts two ranks itself, before anything touches
     a GPU; --dry-launch runs what a rank does around the GPU work on CPU: process group (gloo), a small modset per
@@ -210,6 +269,13 @@ own = d.to_numpy(np.uint64, 65536)
 assert np.array_equal(hist, own) and int(hist.sum()) == ms.contents.max and hist[2] > 0 and int((hist * np.arange(65536, dtype=np.uint64)).sum()) == n
 before = ms.contents.max
 mg.check(L.mgModsetMergeRankOrder(ms, comm, 0)); assert ms.contents.max == before
+mg.check(L.modsetSyncToHost(ms, 0)); dep = mg.modset_arrays(ms)[1].copy()
+mg.check(L.mgDepthAllReduce(ms, comm))                                        # one rank: the sum is its own counts, on the host and in the device table
+assert np.array_equal(mg.modset_arrays(ms)[1], dep)
+d2 = mg.DeviceBuffer(65536 * 8); mg.check(L.mgMemsetD(d2.ptr, 0, 65536 * 8, None)); mg.check(L.modsetDepthHistogramDevice(ms, d2.ptr, None))
+assert np.array_equal(d2.to_numpy(np.uint64, 65536), own)
+n2 = mg.add_sequence_batch(ms, bases[:500_000], np.array([0, 500_000], np.int64))   # and the table still counts on top of it
+mg.check(L.modsetSyncToHost(ms, 0)); assert int(mg.modset_arrays(ms)[1][1:].astype(np.int64).sum()) == n + n2
 L.mgCommDestroy(comm); L.modsetDestroy(ms)
 print("COMM_OK")
 """ % ROOT

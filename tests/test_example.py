@@ -31,13 +31,14 @@ def build_multi_gpu(tmp_path):
 @pytest.mark.gpu
 def test_multi_gpu_example_on_one_gpu(tmp_path):
     """examples/multi_gpu.c = BASELINE config 4 in C (mgCommInitAll on librccl, a host thread per GPU, mgHistogramAllReduce,
-    mgModsetMergeRankOrder) at N = 1: the all-reduced histogram is the GPU's own (modsetDepthHistogramDevice), the merged set is the
+    mgModsetMergeRankOrder, mgDepthAllReduce) at N = 1: the all-reduced histogram is the GPU's own (modsetDepthHistogramDevice), the merged set is the
     single-stream set.  N > 1 runs where the box has more GPUs (tests/test_dist.py::test_bench_on_every_gpu_of_the_box)."""
     exe = build_multi_gpu(tmp_path)
     r = subprocess.run([exe, "1", "60"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
     assert "MULTI_GPU_OK" in r.stdout and "histogram: all-reduced == sum of the ranks' own on every rank: yes" in r.stdout
     assert "identical to the single-stream build over all blocks (value[], depth[]): yes" in r.stdout
+    assert "sum over the GPUs == one stream, on every GPU: yes" in r.stdout          # mgDepthAllReduce (reads counted against a fixed set)
 
 
 @pytest.mark.gpu
