@@ -239,7 +239,8 @@ static U64 mgSurvivorGuess (const Seqhash *sh, U64 totalBases)
 #include <vector>
 #include <unistd.h>
 #define MG_UP_PIECE ((U64) 128 << 20)                 /* bases per piece (a multiple of 16): 32 MiB of packed words */
-static struct MgUpStage { U32 *pin[2] = { 0, 0 }; hipEvent_t done[2]; bool ready = false; int dev = -1; std::mutex lock; } gUp;   /* the events belong to a device: re-made when the caller has moved to another one */
+#define MG_MAXDEV 16
+static struct MgUpStage { U32 *pin[2] = { 0, 0 }; hipEvent_t done[2]; bool ready = false; std::mutex lock; } gUps[MG_MAXDEV];   /* by device (the events belong to one): host threads that drive several GPUs do not take turns on one stage, nor re-make it at every switch */
 
 static int mgHostThreads (void)
 {
@@ -259,18 +260,16 @@ extern "C" MgStatus mgUploadPack (const char *bases, U64 nBases, U32 *dPacked, v
   MgStatus s = mgEnsureDevice (); if (s) return s;
   hipStream_t st = (hipStream_t) stream;
   if (!nBases) { MG_HIP (hipMemsetAsync (dPacked, 0, mgPackedWords (0) * 4, st)); return MG_OK; }
-  std::lock_guard<std::mutex> g (gUp.lock);
   int curDev = 0; MG_HIP (hipGetDevice (&curDev));
-  if (gUp.ready && gUp.dev != curDev)
-    { for (int i = 0 ; i < 2 ; ++i) { (void) hipEventDestroy (gUp.done[i]); (void) hipHostFree (gUp.pin[i]); gUp.pin[i] = 0; }
-      gUp.ready = false;
-    }
+  if (curDev < 0 || curDev >= MG_MAXDEV) { mgSetError ("mgUploadPack: device number beyond %d", MG_MAXDEV - 1); return MG_ERR_ARG; }
+  MgUpStage &gUp = gUps[curDev];
+  std::lock_guard<std::mutex> g (gUp.lock);
   if (!gUp.ready)
     { for (int i = 0 ; i < 2 ; ++i)
-        { MG_HIP (hipHostMalloc ((void **) &gUp.pin[i], (MG_UP_PIECE / 16 + MG_PACK_PAD) * 4, hipHostMallocDefault));
+        { if (!gUp.pin[i]) MG_HIP (hipHostMalloc ((void **) &gUp.pin[i], (MG_UP_PIECE / 16 + MG_PACK_PAD) * 4, hipHostMallocPortable));
           MG_HIP (hipEventCreateWithFlags (&gUp.done[i], hipEventDisableTiming));
         }
-      gUp.ready = true; gUp.dev = curDev;
+      gUp.ready = true;
     }
   const U64 nPieces = (nBases + MG_UP_PIECE - 1) / MG_UP_PIECE;
   int T = mgHostThreads ();
@@ -1178,13 +1177,21 @@ extern "C" MgStatus mgQueryReadsDeviceWait (void *ticket, U64 *nSeeds, void *str
 
 /* grow-only device buffers for the host-buffer entry points (a hipMalloc + hipFree of a gigabyte per call costs
  * milliseconds): the packed reads and their offsets of the batch in flight */
-static struct MgHostBatchBufs { U32 *dP = 0; size_t words = 0; U64 *dOff = 0; size_t offs = 0; int dev = -1; std::mutex lock; } gHb;   /* on device `dev` */
-static void mgHostBatchReleaseLocked (void)              /* gHb.lock is held */
-{ if (gHb.dP) (void) hipFree (gHb.dP);
-  if (gHb.dOff) (void) hipFree (gHb.dOff);
-  gHb.dP = 0; gHb.words = 0; gHb.dOff = 0; gHb.offs = 0; gHb.dev = -1;
+static struct MgHostBatchBufs { U32 *dP = 0; size_t words = 0; U64 *dOff = 0; size_t offs = 0; std::mutex lock; } gHbs[MG_MAXDEV];   /* by device */
+extern "C" void mgHostBatchRelease (void)
+{
+  int before = -1; if (hipGetDevice (&before) != hipSuccess) { (void) hipGetLastError (); before = -1; }
+  for (int dev = 0 ; dev < MG_MAXDEV ; ++dev)
+    { MgHostBatchBufs &b = gHbs[dev];
+      std::lock_guard<std::mutex> g (b.lock);
+      if (!b.dP && !b.dOff) continue;
+      (void) hipSetDevice (dev);
+      if (b.dP) (void) hipFree (b.dP);
+      if (b.dOff) (void) hipFree (b.dOff);
+      b.dP = 0; b.words = 0; b.dOff = 0; b.offs = 0;
+    }
+  if (before >= 0) (void) hipSetDevice (before);
 }
-extern "C" void mgHostBatchRelease (void) { std::lock_guard<std::mutex> g (gHb.lock); mgHostBatchReleaseLocked (); }
 static double mgNowS (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int64_t *readOffsets, int nReads)
@@ -1193,9 +1200,9 @@ extern "C" int64_t mgAddSequenceBatch (Modset *ms, const char *bases, const int6
   if (nReads <= 0) return 0;
   const int timing = mgKnobs ()->uploadTiming == 1;   /* dev */
   int curDev = 0; if (hipGetDevice (&curDev) != hipSuccess) { mgSetError ("mgAddSequenceBatch: no current device"); return -1; }
-  std::lock_guard<std::mutex> g (gHb.lock);            /* ONE lock over the check, the release and the re-key: two host threads on two GPUs cannot interleave them */
-  if (gHb.dev >= 0 && gHb.dev != curDev) mgHostBatchReleaseLocked ();      /* the cached buffers live on the device the previous call ran on */
-  gHb.dev = curDev;
+  if (curDev < 0 || curDev >= MG_MAXDEV) { mgSetError ("mgAddSequenceBatch: device number beyond %d", MG_MAXDEV - 1); return -1; }
+  MgHostBatchBufs &gHb = gHbs[curDev];
+  std::lock_guard<std::mutex> g (gHb.lock);            /* the buffers of this device: one batch at a time through them; a thread on another GPU has that GPU's */
   U64 total = (U64) readOffsets[nReads];
   size_t nw = mgPackedWords (total);
   if (nw > gHb.words)
@@ -1420,11 +1427,16 @@ extern "C" void mgReleaseBuffers (void)
   mgHostBatchRelease ();
   mgIterReleaseBuffers ();
   mgXferReleaseBuffers ();
-  std::lock_guard<std::mutex> g (gUp.lock);
-  if (gUp.ready)
-    { for (int i = 0 ; i < 2 ; ++i) { (void) hipEventDestroy (gUp.done[i]); (void) hipHostFree (gUp.pin[i]); gUp.pin[i] = 0; }
-      gUp.ready = false; gUp.dev = -1;
+  int before = -1; if (hipGetDevice (&before) != hipSuccess) { (void) hipGetLastError (); before = -1; }
+  for (int dev = 0 ; dev < MG_MAXDEV ; ++dev)
+    { MgUpStage &u = gUps[dev];
+      std::lock_guard<std::mutex> g (u.lock);
+      if (!u.ready && !u.pin[0] && !u.pin[1]) continue;
+      (void) hipSetDevice (dev);
+      for (int i = 0 ; i < 2 ; ++i) { if (u.ready) (void) hipEventDestroy (u.done[i]); if (u.pin[i]) (void) hipHostFree (u.pin[i]); u.pin[i] = 0; }
+      u.ready = false;
     }
+  if (before >= 0) (void) hipSetDevice (before);
 }
 
 /* ---------------------------------------------------------------------------------------- */

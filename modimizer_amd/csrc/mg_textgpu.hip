@@ -546,8 +546,17 @@ struct TxBufs {
     tilesCap = basesCap = recCap = packedWords = window = 0; copy = 0; dev = -1;
   }
 };
-static TxBufs gTx;
-extern "C" void mgTextReleaseBuffers (void) { std::lock_guard<std::mutex> g (gTx.lock); if (gTx.dev >= 0) gTx.release (); }
+#define TX_MAXDEV 16
+static TxBufs gTxs[TX_MAXDEV];                       /* by device: a process whose host threads read a file each on a GPU each parses them side by side */
+extern "C" void mgTextReleaseBuffers (void)
+{
+  int before = -1; if (hipGetDevice (&before) != hipSuccess) { (void) hipGetLastError (); before = -1; }
+  for (int dev = 0 ; dev < TX_MAXDEV ; ++dev)
+    { std::lock_guard<std::mutex> g (gTxs[dev].lock);
+      if (gTxs[dev].dev >= 0) { (void) hipSetDevice (gTxs[dev].dev); gTxs[dev].release (); }
+    }
+  if (before >= 0) (void) hipSetDevice (before);
+}
 
 /* text per window: 128 MiB (two pinned and two device buffers of that size are kept between calls; 64 MiB windows: 31.6 Gbp/s on a
    4 Gbp file, 256 MiB: 34.8), less for a file that is smaller */
@@ -800,7 +809,9 @@ static int txParseFile (const char *filename, const TxSink &sink, U64 *nSeqOut, 
       if (tail[i] == '>' && (i > 0 || tn == fileSize)) { close (fd); return -2; }
     }
 
-  TxBufs &t = gTx;
+  int curDev = 0;
+  if (hipGetDevice (&curDev) != hipSuccess || curDev < 0 || curDev >= TX_MAXDEV) { (void) hipGetLastError (); close (fd); return -2; }      /* (no room kept for that device: the host parser) */
+  TxBufs &t = gTxs[curDev];
   std::lock_guard<std::mutex> g (t.lock);
   if (first == '@')
     { const int rq = txParseFastq (fd, fileSize, t, sink, nSeqOut, totLenOut, resumeOff, resumeLine);
