@@ -32,8 +32,14 @@
 #include "mg_xfer.h"
 #include "mg_ref.h"
 
+/* the device side of every Reference, by its address.  The lock guards the MAP (finding, making and dropping an entry); an entry itself belongs
+   to the Reference, which -- like the reference's own struct -- one host thread works on at a time: builds of two References on two GPUs run
+   side by side.  (An unordered_map keeps its elements where they are when it grows: the entry found under the lock stays valid after it.) */
 static std::mutex gRefLock;
 static std::unordered_map<const MgReference *, MgRefDev> gRefDev;
+static std::unordered_map<const MgReference *, std::mutex> gRefOwn;      /* one lock per Reference: two threads that query ONE Reference do not both build its device side */
+static MgRefDev &mgRefEntry (const MgReference *ref) { std::lock_guard<std::mutex> g (gRefLock); return gRefDev[ref]; }
+static std::mutex &mgRefOwnLock (const MgReference *ref) { std::lock_guard<std::mutex> g (gRefLock); return gRefOwn[ref]; }
 
 static void mgRefDevFree (MgRefDev &d)
 { (void) hipFree (d.info); (void) hipFree (d.loc); (void) hipFree (d.rev); (void) hipFree (d.id); (void) hipFree (d.offset);
@@ -65,14 +71,15 @@ extern "C" void mgChainForget (const MgReference *ref)
   std::lock_guard<std::mutex> g (gRefLock);
   auto it = gRefDev.find (ref);
   if (it != gRefDev.end ()) { mgRefDevFree (it->second); gRefDev.erase (it); }
+  gRefOwn.erase (ref);                                 /* (the Reference is going: nobody holds its lock) */
 }
 
 /* device copies of what the chaining reads: the ones the builder left, or uploaded from the host arrays (a Reference read from a
    file, or one whose modset has grown since) */
 MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
 {
-  std::lock_guard<std::mutex> g (gRefLock);
-  MgRefDev &d = gRefDev[ref];
+  std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
+  MgRefDev &d = mgRefEntry (ref);
   const U32 msMax = ref->ms->max, refMax = ref->max;
   if (d.li && d.packed && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
   mgRefDevFree (d);
@@ -350,8 +357,8 @@ static MgStatus mgRefGrow (U32 **p, size_t have, size_t keep, size_t want)      
 extern "C" MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U32 *dPosF, const U32 *dRid, U64 n, U32 idBase, U32 *appended)
 {
   *appended = 0;
-  std::lock_guard<std::mutex> g (gRefLock);
-  MgRefDev &d = gRefDev[ref];
+  std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
+  MgRefDev &d = mgRefEntry (ref);
   if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
   hipStream_t st = 0;
   const size_t msCap = ref->ms->size;
@@ -395,8 +402,8 @@ extern "C" MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U3
    [ref->max], depth / loc [ms->max + 1], info = ms->info; tallies[3] = copy 1, copy 2, multiple. */
 extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffset, U32 *hId, U32 *hDepth, U32 *hRev, U32 *hLoc, U8 *hInfo, U32 tallies[3])
 {
-  std::lock_guard<std::mutex> g (gRefLock);
-  MgRefDev &d = gRefDev[ref];
+  std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
+  MgRefDev &d = mgRefEntry (ref);
   hipStream_t st = 0;
   const U32 msMax = ref->ms->max, n = ref->max;
   const size_t m = (size_t) msMax + 1;
