@@ -7,6 +7,8 @@ homopolymers, tandem repeats, reverse-complement palindromes, reads that end on 
   query     mgQueryReadsDevice on mutated reads, one of the lookup paths: Seed{index, pos}       (modmap.c:197-206)
   minimizer seqhashMinimizerBatch                                                              (seqhash.c:83-152)
   modmap    mgReferenceRead + mgQueryProcess against the oracle's queryProcess, byte for byte   (modmap.c:74-134,188-281)
+  readset   mgReadsetRead / mgReadsetFileRead against the oracle's Readset: hit lists, distances, inverse lists, depth[], RS lines (modasm.c:151-287)
+  pipelined mgQueryReadsDeviceAsync / Wait with two batches in flight == mgQueryReadsDevice batch by batch
 usage: soak.py [seconds (default 300)] [first seed (default: from the clock)]
 Prints one line per trial and, at the end, 'SOAK_OK <trials>' -- or the failing trial's seed (re-run with it as the second argument)."""
 import ctypes as C, os, sys, tempfile, time, traceback
@@ -166,6 +168,81 @@ def trial_modmap(rng, k, w, sd, tmp):
                 raise
 
 
+def trial_readset(rng, k, w, sd, tmp):
+    """modasm's ingest (mgReadsetRead, one call or a FASTA file in small batches) against the oracle's Readset: every array, depth[], the RS lines"""
+    import test_readset as trs
+    if w > 256:
+        w = int(rng.integers(1, 64))
+    h = po.Hasher(k, w, sd); oms = po.Modset(h, 20)
+    g = rng.integers(0, 4, int(rng.integers(5_000, 60_000))).astype(np.uint8)
+    oms.add_sequence(g)
+    if oms.max == 0:
+        oms.close(); return
+    oms.set_copy(1, 2, 3)
+    reads = awkward_reads(rng, k, int(rng.integers(5_000, 150_000)) if w > 2 else int(rng.integers(5_000, 30_000)))
+    reads += [g[a:a + 2500].copy() for a in rng.integers(0, max(1, len(g) - 2500), 5)]
+    ors = po.Readset(oms); ors.read(reads)
+    want = ors.arrays()
+    pmod = str(tmp / "m.mod"); oms.write_mod(pmod)
+    with mg.CFile(pmod, "r") as f:
+        ms = L.modsetRead(f)
+    rs = L.mgReadsetCreate(ms)
+    if rng.random() < 0.5:
+        bases, offs = util.concat_reads(reads)
+        assert L.mgReadsetRead(rs, bases.ctypes.data, offs.ctypes.data, len(reads)) == 0
+    else:
+        fa = str(tmp / "r.fa")
+        with open(fa, "w") as f:
+            for i, r in enumerate(reads):
+                f.write(">r%d\n%s\n" % (i, "".join("ACGT"[b] for b in r)))
+        with mg.knobs(FILE_BATCH_MBP=1, FILE_BATCH_BASES=int(rng.integers(3000, 200_000))):
+            assert L.mgReadsetFileRead(rs, fa.encode()) == 0
+    trs.same(want, trs.lib_arrays(rs))
+    assert np.array_equal(np.ctypeslib.as_array(ms.contents.depth, (ms.contents.max + 1,)), oms.depths()), "depth[] after the ingest"
+    assert trs.rs_lines(trs.stats_text(rs, str(tmp / "s.txt"))) == trs.rs_lines(ors.stats_text(str(tmp / "o.txt"))), "RS lines"
+    L.mgReadsetDestroy(rs); L.modsetDestroy(ms)
+    ors.close(); oms.close()
+
+
+def trial_pipelined(rng, k, w, sd):
+    """mgQueryReadsDeviceAsync / Wait over several batches (two in flight) == mgQueryReadsDevice batch by batch"""
+    path = rng.choice(["direct", "2 levels", ""])
+    with mg.knobs(FIND_PATH=str(path) if path else None):
+        sh = mg.seqhashCreate(k, w, sd)
+        g = rng.integers(0, 4, int(rng.integers(30_000, 150_000))).astype(np.uint8)
+        ms = mg.modsetCreate(sh, 22)
+        mg.add_sequence_batch(ms, g, np.array([0, len(g)], np.int64))
+        batches = []
+        for b in range(int(rng.integers(2, 6))):
+            reads = awkward_reads(rng, k, int(rng.integers(1_000, 150_000)) if w > 2 else 15_000) if rng.random() < 0.85 else [np.zeros(0, np.uint8)]
+            reads += [g[a:a + 2000].copy() for a in rng.integers(0, len(g) - 2000, 3)]
+            bases, offs = util.concat_reads(reads)
+            total = int(offs[-1]); cap = total + 16
+            batches.append(dict(total=total, n=len(reads), cap=cap, p=mg.DeviceBuffer.from_numpy(mg.pack_host(bases)), o=mg.DeviceBuffer.from_numpy(offs.astype(np.uint64)),
+                                ix=[mg.DeviceBuffer(cap * 4) for _ in range(2)], pos=[mg.DeviceBuffer(cap * 4) for _ in range(2)], rid=[mg.DeviceBuffer(cap * 4) for _ in range(2)]))
+        n = C.c_uint64(); counts = []
+        for b in batches:                                           # synchronous: results in slot 0
+            mg.check(L.mgQueryReadsDevice(ms, b["p"].ptr, b["total"], b["o"].ptr, b["n"], b["ix"][0].ptr, b["pos"][0].ptr, b["rid"][0].ptr, b["cap"], C.byref(n), None))
+            counts.append(n.value)
+        tickets = []
+        def wait_one():
+            i, t = tickets.pop(0)
+            mg.check(L.mgQueryReadsDeviceWait(t, C.byref(n), None))
+            assert n.value == counts[i], ("seed count", i, n.value, counts[i])
+        for i, b in enumerate(batches):                             # pipelined: results in slot 1
+            t = C.c_void_p()
+            mg.check(L.mgQueryReadsDeviceAsync(ms, b["p"].ptr, b["total"], b["o"].ptr, b["n"], b["ix"][1].ptr, b["pos"][1].ptr, b["rid"][1].ptr, b["cap"], C.byref(t), None))
+            tickets.append((i, t))
+            if len(tickets) == 2:
+                wait_one()
+        while tickets:
+            wait_one()
+        for i, b in enumerate(batches):
+            for key in ("ix", "pos", "rid"):
+                assert np.array_equal(b[key][0].to_numpy(np.uint32, counts[i]), b[key][1].to_numpy(np.uint32, counts[i])), (key, i)
+        L.modsetDestroy(ms)
+
+
 def main():
     t_end = time.time() + budget
     trials = 0
@@ -177,7 +254,7 @@ def main():
             s = seed0 + trials
             rng = np.random.default_rng(s)
             k, w, sd = draw_params(rng)
-            which = ["scan", "build", "query", "minimizer", "modmap"][trials % 5]
+            which = ["scan", "build", "query", "minimizer", "modmap", "readset", "pipelined"][trials % 7]
             if which == "minimizer" and not have_min:
                 which = "scan"
             t0 = time.time()
@@ -190,9 +267,14 @@ def main():
                     trial_query(rng, k, w, sd)
                 elif which == "minimizer":
                     trial_minimizer(rng, k, w, sd)
+                elif which == "pipelined":
+                    trial_pipelined(rng, k, w, sd)
                 else:
                     sub = tmp / ("t%d" % trials); sub.mkdir()
-                    trial_modmap(rng, k, w, sd, sub)
+                    (trial_modmap if which == "modmap" else trial_readset)(rng, k, w, sd, sub)
+                    for fn in os.listdir(sub):
+                        os.remove(sub / fn)
+                    sub.rmdir()
             except Exception:
                 traceback.print_exc()
                 print("SOAK_FAILED trial %d seed %d: %s k=%d w=%d hasher seed %d" % (trials, s, which, k, w, sd), flush=True)
