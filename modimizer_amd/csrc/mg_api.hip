@@ -239,7 +239,7 @@ static U64 mgSurvivorGuess (const Seqhash *sh, U64 totalBases)
 #include <vector>
 #include <unistd.h>
 #define MG_UP_PIECE ((U64) 128 << 20)                 /* bases per piece (a multiple of 16): 32 MiB of packed words */
-#define MG_MAXDEV 16
+#define MG_MAXDEV 128            /* (an 8-GPU node in its 8-partition mode shows 64 devices) */
 static struct MgUpStage { U32 *pin[2] = { 0, 0 }; hipEvent_t done[2]; bool ready = false; std::mutex lock; } gUps[MG_MAXDEV];   /* by device (the events belong to one): host threads that drive several GPUs do not take turns on one stage, nor re-make it at every switch */
 
 static int mgHostThreads (void)

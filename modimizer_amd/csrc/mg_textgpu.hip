@@ -546,7 +546,7 @@ struct TxBufs {
     tilesCap = basesCap = recCap = packedWords = window = 0; copy = 0; dev = -1;
   }
 };
-#define TX_MAXDEV 16
+#define TX_MAXDEV 128
 static TxBufs gTxs[TX_MAXDEV];                       /* by device: a process whose host threads read a file each on a GPU each parses them side by side */
 extern "C" void mgTextReleaseBuffers (void)
 {

@@ -24,7 +24,7 @@
 #include "mg_xfer.h"
 
 #define MG_XFER_MAXT   16
-#define MG_XFER_MAXDEV 16
+#define MG_XFER_MAXDEV 128        /* (an 8-GPU node in its 8-partition mode shows 64 devices) */
 #define MG_XFER_PIECE_MAX ((size_t) 16 << 20)
 
 /* A lane has a copy stream of its own: four queues keep the link at 52 - 54 GB/s, all lanes on the device's default stream reach 46
