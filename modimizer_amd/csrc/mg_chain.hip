@@ -337,6 +337,9 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
                                      U64 *hHitStart, U32 *hNMiss, U32 **dHitOut, unsigned short **dDxOut, U32 *dDepthAccum)
 {
   *dHitOut = 0; *dDxOut = 0;
+  const bool lapOn = mgKnobs ()->seedTiming == 1;          /* dev */
+  struct timespec lq0; clock_gettime (CLOCK_MONOTONIC, &lq0);
+#define RS_LAP(what) do { if (lapOn) { (void) hipDeviceSynchronize (); struct timespec q_; clock_gettime (CLOCK_MONOTONIC, &q_); fprintf (stderr, "mgReadsetSeedsDevice: %s at %.2f ms\n", what, (q_.tv_sec - lq0.tv_sec) * 1e3 + (q_.tv_nsec - lq0.tv_nsec) * 1e-6); } } while (0)
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
   U32 *dIx = 0, *dPos = 0, *dRid = 0, *dMiss = 0, *dHit = 0; unsigned short *dDx = 0; U64 *dStart = 0, *dHitStart = 0;
   U64 n = 0;
@@ -351,6 +354,7 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
         break;
       }
     if (!dIx) break;
+    RS_LAP ("seeds");
     if (hipMalloc ((void **) &dStart, ((size_t) nReads + 2) * 8) || hipMalloc ((void **) &dHitStart, ((size_t) nReads + 2) * 8)
         || hipMalloc ((void **) &dMiss, ((size_t) nReads + 1) * 4)) break;
     unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
@@ -361,15 +365,19 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
     hipLaunchKernelGGL (mgChainScanKernel, dim3 (1), dim3 (1024), 0, 0, dHitStart, nReads);
     U64 totHit = 0;
     if (hipMemcpy (&totHit, dHitStart + nReads, 8, hipMemcpyDeviceToHost)) break;
+    RS_LAP ("counted");
     if (hipMalloc ((void **) &dHit, (totHit + 1) * 4) || hipMalloc ((void **) &dDx, (totHit + 1) * 2)) break;
     hipLaunchKernelGGL (mgReadsetKernel<true>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss, dHit, dDx, dDepthAccum);
     if (hipGetLastError () != hipSuccess) break;
     if (hipMemcpy (hHitStart, dHitStart, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) || hipMemcpy (hNMiss, dMiss, (size_t) nReads * 4, hipMemcpyDeviceToHost)) break;
     *dHitOut = dHit; *dDxOut = dDx; dHit = 0; dDx = 0;
+    RS_LAP ("written");
     rc = 0;
   } while (0);
   (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dHitStart);
   (void) hipFree (dMiss); (void) hipFree (dHit); (void) hipFree (dDx);
+  RS_LAP ("freed");
+#undef RS_LAP
   if (rc < 0 && !mgLastError ()[0]) mgSetError ("readset seeds on the device failed");
   return rc;
 }

@@ -1,5 +1,5 @@
 """dev: SURVEY §8(f) N3 / N4 timed -- modasm's read ingest (mgReadsetRead: scan + lookup + hit lists + invBuild) from host bytes against a
-modset built from a genome, and the minimizer batch scan (seqhashMinimizerBatchDevice), on ONT-like reads.  usage: n34_probe.py [Gbp] [genome Mbp]"""
+modset built from a genome, and the minimizer batch scan (seqhashMinimizerBatchDevice), on ONT-like reads.  usage: n34_probe.py [Gbp] [genome Mbp] [self]"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -25,6 +25,8 @@ d_bytes = torch.empty(total, dtype=torch.uint8, device=cx.dev)
 mg.check(L.mgUnpackDevice(reads.data_ptr(), total, d_bytes.data_ptr(), cx.stream)); torch.cuda.synchronize()
 h = d_bytes.cpu().numpy(); del d_bytes
 o64 = offs[:n_reads + 1].astype(np.int64)
+if len(sys.argv) > 3 and sys.argv[3] == "self":                    # the modset of the reads themselves: every modimizer is a hit (bench.py's readset_ingest)
+    mg.check(L.mgModsetClear(ms, None)); mg.check(L.mgAddReadsDevice(ms, reads.data_ptr(), total, d_off.data_ptr(), n_reads, C.byref(n), cx.stream))
 for it in range(5):
     rs = L.mgReadsetCreate(ms)
     os.environ["MODGPU_SEED_TIMING"] = "1"; L.mgReloadKnobs()
