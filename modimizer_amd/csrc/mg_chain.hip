@@ -277,35 +277,117 @@ extern "C" int mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
 }
 
 /* ---------------------------------------------------------------------------------------- */
-/* modasm's readsetFileRead (modasm.c:161-188) for a batch of reads: per read the hits (modset index,
- * top bit = forward), the 16-bit distance of each hit to the previous hit of the read, hit / miss counts,
- * and per mod the number of hits.  One lane per read walks its seeds twice (count, then write at the
- * offsets an exclusive scan of the counts gives). */
-
-template <bool WRITE>
+/* modasm's readsetFileRead (modasm.c:161-188) for a batch of reads: per read the hits (modset index, top bit = forward), the 16-bit
+ * distance of each hit to the previous hit of the read, hit / miss counts, and per mod the number of hits.
+ *
+ * A lane per SEED (rounds 1-4: a lane per read walked its seeds twice, the batch waiting for its longest read: 6.5 ms per 4 Gbp).  The
+ * seeds are in read order, so the hits of the batch in seed order ARE the reads' hit lists one after the other: a hit's place is the
+ * number of hits before it (tile counts, their scan, ballots inside a tile); its distance needs the position of the hit before it IN ITS
+ * READ -- the last hit before it in the batch (a running maximum of hit indices, carried through the same tile scan) if that one is not
+ * before the read's first seed, else 0 (modasm.c:172: lastPos starts at 0).  A read's list starts at the hits counted before its first
+ * seed; a read without seeds takes the start of the next read that has some. */
+#define MG_RS_TILE 4096           /* 256 threads x 16 rows; a wave takes 64 consecutive seeds of a row */
 __global__ __launch_bounds__ (256)
-void mgReadsetKernel (const U32 *__restrict__ seedIx, const U32 *__restrict__ seedPosF, const U64 *__restrict__ seedStart, U32 nReads,
-                      U64 *__restrict__ hitStart, U32 *__restrict__ nMiss,
+void mgRsTileCountKernel (const U32 *__restrict__ seedIx, U64 n, U32 *__restrict__ tileCnt, U32 *__restrict__ tileLast)
+{
+  __shared__ U32 sC[4], sL[4];
+  const U64 base = (U64) blockIdx.x * MG_RS_TILE;
+  U32 c = 0, last = 0;                                              /* last: 1 + index (inside the batch) of the tile's last hit, 0: none */
+  for (int j = 0 ; j < 16 ; ++j)
+    { const U64 i = base + (U64) j * 256 + threadIdx.x;
+      if (i < n && seedIx[i]) { ++c; last = (U32) i + 1; }         /* (rows go up: the last assignment is the largest) */
+    }
+  for (int o = 32 ; o ; o >>= 1) { c += __shfl_down (c, o); const U32 l2 = __shfl_down (last, o); last = l2 > last ? l2 : last; }
+  if ((threadIdx.x & 63) == 0) { sC[threadIdx.x >> 6] = c; sL[threadIdx.x >> 6] = last; }
+  __syncthreads ();
+  if (!threadIdx.x)
+    { tileCnt[blockIdx.x] = sC[0] + sC[1] + sC[2] + sC[3];
+      U32 m = sL[0]; for (int q = 1 ; q < 4 ; ++q) m = sL[q] > m ? sL[q] : m;
+      tileLast[blockIdx.x] = m;
+    }
+}
+/* one workgroup: cnt[0 .. nTiles) -> exclusive sums, cnt[nTiles] = total; last[0 .. nTiles) -> the running maximum BEFORE each tile */
+__global__ __launch_bounds__ (1024)
+void mgRsTileScanKernel (U32 *__restrict__ cnt, U32 *__restrict__ last, U32 nTiles)
+{
+  __shared__ U32 sSum[1024], sMax[1024];
+  const int tid = threadIdx.x;
+  const U32 per = (nTiles + 1023) / 1024;
+  U32 sum = 0, mx = 0;
+  for (U32 q = 0 ; q < per ; ++q) { const U32 j = tid * per + q; if (j < nTiles) { sum += cnt[j]; mx = last[j] > mx ? last[j] : mx; } }
+  sSum[tid] = sum; sMax[tid] = mx;
+  __syncthreads ();
+  for (int off = 1 ; off < 1024 ; off <<= 1)
+    { const U32 a = tid >= off ? sSum[tid - off] : 0, b = tid >= off ? sMax[tid - off] : 0;
+      __syncthreads ();
+      sSum[tid] += a; sMax[tid] = b > sMax[tid] ? b : sMax[tid];
+      __syncthreads ();
+    }
+  U32 run = sSum[tid] - sum, rm = tid ? sMax[tid - 1] : 0;
+  for (U32 q = 0 ; q < per ; ++q)
+    { const U32 j = tid * per + q;
+      if (j < nTiles) { const U32 c = cnt[j], l = last[j]; cnt[j] = run; last[j] = rm; run += c; rm = l > rm ? l : rm; }
+    }
+  if (tid == 1023) cnt[nTiles] = sSum[1023];
+}
+__global__ __launch_bounds__ (256)
+void mgRsWriteKernel (const U32 *__restrict__ seedIx, const U32 *__restrict__ seedPosF, const U32 *__restrict__ seedRid, const U64 *__restrict__ seedStart, U64 n,
+                      const U32 *__restrict__ tileBase, const U32 *__restrict__ tilePrev,
+                      U32 *__restrict__ firstHit /* [read]: hits before the read's first seed, for reads that have seeds */,
                       U32 *__restrict__ hit, unsigned short *__restrict__ dx, U32 *__restrict__ depthCount)
 {
-  const U32 r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nReads) return;
-  const U64 s0 = seedStart[r], s1 = seedStart[r + 1];
-  U64 out = WRITE ? hitStart[r] : 0;
-  U32 miss = 0; int lastPos = 0;
-  for (U64 i = s0 ; i < s1 ; ++i)
-    { const U32 x = seedIx[i];
-      if (!x) { ++miss; continue; }
-      if (WRITE)
-        { const U32 pf = seedPosF[i];
-          const int pos = (int) (pf & MG_POS_MASK);
-          hit[out] = (pf & MG_FWD_BIT) ? (x | 0x80000000u) : x;                  /* modasm.c:171 */
-          dx[out] = (unsigned short) (pos - lastPos); lastPos = pos;             /* modasm.c:172 */
-          atomicAdd (&depthCount[x], 1u);                                        /* modasm.c:174, saturated by the caller */
-        }
-      ++out;
+  __shared__ U32 sCnt[64], sLast[64];                                /* per (row, wave), in seed order: hits; 1 + index of the last hit */
+  const U64 base = (U64) blockIdx.x * MG_RS_TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const U64 below = ((U64) 1 << lane) - 1;
+  U32 x[16];
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j)
+    { const U64 i = base + (U64) j * 256 + threadIdx.x;
+      x[j] = i < n ? seedIx[i] : 0u;
+      const U64 b = __ballot (x[j] != 0);
+      if (!lane) { sCnt[j * 4 + w] = (U32) __popcll (b); sLast[j * 4 + w] = b ? (U32) (base + (U64) j * 256 + w * 64) + (63u - (U32) __clzll ((long long) b)) + 1u : 0u; }
     }
-  if (!WRITE) { hitStart[r] = out; nMiss[r] = miss; }
+  __syncthreads ();
+  if (threadIdx.x == 0)
+    { U32 run = tileBase[blockIdx.x], rm = tilePrev[blockIdx.x];
+      for (int q = 0 ; q < 64 ; ++q) { const U32 c = sCnt[q], l = sLast[q]; sCnt[q] = run; sLast[q] = rm; run += c; rm = l > rm ? l : rm; }
+    }
+  __syncthreads ();
+#pragma unroll
+  for (int j = 0 ; j < 16 ; ++j)
+    { const U64 i = base + (U64) j * 256 + threadIdx.x;
+      const U64 b = __ballot (x[j] != 0);
+      if (i >= n) continue;
+      const int g = j * 4 + w;
+      const U32 before = sCnt[g] + (U32) __popcll (b & below);          /* hits of the batch before seed i */
+      const U32 r = seedRid[i];
+      if (i == 0 || seedRid[i - 1] != r) firstHit[r] = before;          /* the read's first seed */
+      if (x[j])
+        { const U64 lower = b & below;
+          const U32 prev = lower ? (U32) (i - lane) + (63u - (U32) __clzll ((long long) lower)) + 1u : sLast[g];      /* 1 + index of the hit before this one in the batch, 0: none */
+          const U32 pf = seedPosF[i];
+          const int pos = (int) (pf & MG_POS_MASK);
+          const int lastPos = (U64) prev > seedStart[r] ? (int) (seedPosF[prev - 1] & MG_POS_MASK) : 0;               /* (prev - 1 >= the read's first seed: a hit of this read) */
+          hit[before] = (pf & MG_FWD_BIT) ? (x[j] | 0x80000000u) : x[j];                                              /* modasm.c:171 */
+          dx[before] = (unsigned short) (pos - lastPos);                                                              /* modasm.c:172 */
+          atomicAdd (&depthCount[x[j]], 1u);                                                                          /* modasm.c:174, saturated by the caller */
+        }
+    }
+}
+/* per read: where its list starts and how many of its seeds missed */
+__global__ void mgRsPerReadKernel (const U64 *__restrict__ seedStart, const U32 *__restrict__ seedRid, const U32 *__restrict__ firstHit, U64 n, U32 totHit, U32 nReads,
+                                   U64 *__restrict__ hitStart, U32 *__restrict__ nMiss)
+{
+  const U32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nReads) return;
+  const U64 s0 = seedStart[r];
+  const U32 h0 = s0 < n ? firstHit[seedRid[s0]] : totHit;             /* (seed s0 is the first seed of the read that owns it: this read, or the next one that has seeds) */
+  hitStart[r] = h0;
+  if (r == nReads) return;
+  const U64 s1 = seedStart[r + 1];
+  const U32 h1 = s1 < n ? firstHit[seedRid[s1]] : totHit;
+  nMiss[r] = (U32) (s1 - s0) - (h1 - h0);
 }
 
 /* exclusive scan of n counts in place, a[n] = total (one workgroup) */
@@ -341,7 +423,7 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
   struct timespec lq0; clock_gettime (CLOCK_MONOTONIC, &lq0);
 #define RS_LAP(what) do { if (lapOn) { (void) hipDeviceSynchronize (); struct timespec q_; clock_gettime (CLOCK_MONOTONIC, &q_); fprintf (stderr, "mgReadsetSeedsDevice: %s at %.2f ms\n", what, (q_.tv_sec - lq0.tv_sec) * 1e3 + (q_.tv_nsec - lq0.tv_nsec) * 1e-6); } } while (0)
   U64 guess = totalBases / (U64) ms->hasher->w; guess += guess / 2 + 65536; if (guess > totalBases + 1) guess = totalBases + 1;
-  U32 *dIx = 0, *dPos = 0, *dRid = 0, *dMiss = 0, *dHit = 0; unsigned short *dDx = 0; U64 *dStart = 0, *dHitStart = 0;
+  U32 *dIx = 0, *dPos = 0, *dRid = 0, *dMiss = 0, *dHit = 0, *dFirst = 0, *dTileCnt = 0, *dTileLast = 0; unsigned short *dDx = 0; U64 *dStart = 0, *dHitStart = 0;
   U64 n = 0;
   int rc = -1;
   do {
@@ -355,19 +437,24 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
       }
     if (!dIx) break;
     RS_LAP ("seeds");
+    if (n >= ((U64) 1 << 32) - 1) { mgSetError ("too many seeds in one batch"); break; }
+    const U32 nTiles = (U32) ((n + MG_RS_TILE - 1) / MG_RS_TILE);
     if (hipMalloc ((void **) &dStart, ((size_t) nReads + 2) * 8) || hipMalloc ((void **) &dHitStart, ((size_t) nReads + 2) * 8)
-        || hipMalloc ((void **) &dMiss, ((size_t) nReads + 1) * 4)) break;
+        || hipMalloc ((void **) &dMiss, ((size_t) nReads + 1) * 4) || hipMalloc ((void **) &dFirst, ((size_t) nReads + 1) * 4)
+        || hipMalloc ((void **) &dTileCnt, ((size_t) nTiles + 2) * 4) || hipMalloc ((void **) &dTileLast, ((size_t) nTiles + 2) * 4)) break;
     unsigned grid = (unsigned) ((n + 1 + 255) / 256); if (grid > 16384) grid = 16384;
-    const unsigned rgrid = (nReads + 255) / 256;
     hipLaunchKernelGGL (mgSeedStartKernel, dim3 (grid), dim3 (256), 0, 0, dRid, n, nReads, dStart);
-    hipLaunchKernelGGL (mgReadsetKernel<false>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss,
-                        (U32 *) 0, (unsigned short *) 0, (U32 *) 0);
-    hipLaunchKernelGGL (mgChainScanKernel, dim3 (1), dim3 (1024), 0, 0, dHitStart, nReads);
-    U64 totHit = 0;
-    if (hipMemcpy (&totHit, dHitStart + nReads, 8, hipMemcpyDeviceToHost)) break;
+    U32 totHit32 = 0;
+    if (nTiles)
+      { hipLaunchKernelGGL (mgRsTileCountKernel, dim3 (nTiles), dim3 (256), 0, 0, dIx, n, dTileCnt, dTileLast);
+        hipLaunchKernelGGL (mgRsTileScanKernel, dim3 (1), dim3 (1024), 0, 0, dTileCnt, dTileLast, nTiles);
+        if (hipMemcpy (&totHit32, dTileCnt + nTiles, 4, hipMemcpyDeviceToHost)) break;
+      }
+    const U64 totHit = totHit32;
     RS_LAP ("counted");
     if (hipMalloc ((void **) &dHit, (totHit + 1) * 4) || hipMalloc ((void **) &dDx, (totHit + 1) * 2)) break;
-    hipLaunchKernelGGL (mgReadsetKernel<true>, dim3 (rgrid), dim3 (256), 0, 0, dIx, dPos, dStart, nReads, dHitStart, dMiss, dHit, dDx, dDepthAccum);
+    if (nTiles) hipLaunchKernelGGL (mgRsWriteKernel, dim3 (nTiles), dim3 (256), 0, 0, dIx, dPos, dRid, dStart, n, dTileCnt, dTileLast, dFirst, dHit, dDx, dDepthAccum);
+    hipLaunchKernelGGL (mgRsPerReadKernel, dim3 (nReads / 256 + 1), dim3 (256), 0, 0, dStart, dRid, dFirst, n, totHit32, nReads, dHitStart, dMiss);
     if (hipGetLastError () != hipSuccess) break;
     if (hipMemcpy (hHitStart, dHitStart, ((size_t) nReads + 1) * 8, hipMemcpyDeviceToHost) || hipMemcpy (hNMiss, dMiss, (size_t) nReads * 4, hipMemcpyDeviceToHost)) break;
     *dHitOut = dHit; *dDxOut = dDx; dHit = 0; dDx = 0;
@@ -375,7 +462,7 @@ extern "C" int mgReadsetSeedsDevice (Modset *ms, const U32 *dPacked, U64 totalBa
     rc = 0;
   } while (0);
   (void) hipFree (dIx); (void) hipFree (dPos); (void) hipFree (dRid); (void) hipFree (dStart); (void) hipFree (dHitStart);
-  (void) hipFree (dMiss); (void) hipFree (dHit); (void) hipFree (dDx);
+  (void) hipFree (dMiss); (void) hipFree (dHit); (void) hipFree (dDx); (void) hipFree (dFirst); (void) hipFree (dTileCnt); (void) hipFree (dTileLast);
   RS_LAP ("freed");
 #undef RS_LAP
   if (rc < 0 && !mgLastError ()[0]) mgSetError ("readset seeds on the device failed");

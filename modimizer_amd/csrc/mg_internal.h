@@ -72,6 +72,7 @@ MG_HIDDEN MgStatus mgReadsetDevBegin (const void *rs, U32 msMax, U32 **dDepth);
 MG_HIDDEN MgStatus mgReadsetFinishDevice (const void *rs, Modset *ms, U32 msMax, const U32 *hHit, U64 totHit, const U64 *hHitStart, U32 nReads, const U8 *hInfo,
                                           U16 *hDepth16, U64 *hInvStart, U32 **hInvSpace, int *hNCopy);
 MG_HIDDEN void mgReadsetDevForget (const void *rs);
+MG_HIDDEN void mgReadsetDevAppendHits (const void *rs, const U32 *dHit, U64 n);      /* a batch's hit list kept on the device for the end of the file */
 MG_HIDDEN MgStatus mgModsetAdoptDepthDevice (Modset *ms, const U16 *dDepth16);      /* the device table's depth copy = dDepth16[0 .. max] (mg_api.hip) */
 /* element count of the reference's Array after appending elements 0..n-1 (array.c:144-170,180-183) */
 MG_HIDDEN int mgRefArrayDim (int first, int size, int n);

@@ -97,6 +97,7 @@ static void readsetAddBatchDevice (MgReadset *rs, U32 *dDepth, const void *dPack
     }
   if (n && (mgCopyD2HBig (rs->hit + rs->totHit, dHit, (size_t) n * sizeof (U32)) || mgCopyD2HBig (rs->dx + rs->totHit, dDx, (size_t) n * sizeof (U16)))) fatal ("hit lists");
   RS_LAP ("batch: hit lists to the host");
+  mgReadsetDevAppendHits (rs, dHit, n);              /* (the inverse lists are made from them on the device when the file is done) */
   mgDeviceFree (dHit); mgDeviceFree (dDx);
   const int first = rs->nReads + 1;                   /* reads are numbered from 1 (modasm.c:95) */
   for (int r = 0 ; r < nReads ; ++r)

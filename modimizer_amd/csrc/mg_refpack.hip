@@ -478,12 +478,12 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
  * (mgRefStableSort: the sort of referencePack), hits on saturated mods keyed past the last mod so that they fall off the end;
  * invStart[] is the exclusive scan of the lists' lengths; a read's copy-class tallies (modasm.c:276-277) are a lane per read. */
 #define MG_RS_TOPMASK 0x7fffffffu
-struct MgReadsetDev { U32 *depth = 0; size_t cap = 0; };
+struct MgReadsetDev { U32 *depth = 0; size_t cap = 0; U32 *hitAll = 0; U64 hitLen = 0, hitCap = 0; bool hitsKept = true; };      /* hitAll: the file's hit lists so far, kept on the device for the inverse lists (given up, and uploaded at the end instead, if the device has no room) */
 static std::mutex gRsLock;
 static std::unordered_map<const void *, MgReadsetDev> gRsDev;
 
 extern "C" void mgReadsetDevForget (const void *rs)
-{ std::lock_guard<std::mutex> g (gRsLock); auto it = gRsDev.find (rs); if (it != gRsDev.end ()) { (void) hipFree (it->second.depth); gRsDev.erase (it); } }
+{ std::lock_guard<std::mutex> g (gRsLock); auto it = gRsDev.find (rs); if (it != gRsDev.end ()) { (void) hipFree (it->second.depth); (void) hipFree (it->second.hitAll); gRsDev.erase (it); } }
 
 /* the per-mod hit counts of the file that follows: device U32[msMax + 2], zero (modasm.c:158) */
 extern "C" MgStatus mgReadsetDevBegin (const void *rs, U32 msMax, U32 **dDepth)
@@ -493,8 +493,27 @@ extern "C" MgStatus mgReadsetDevBegin (const void *rs, U32 msMax, U32 **dDepth)
   const size_t want = (size_t) msMax + 2;
   if (d.cap < want) { (void) hipFree (d.depth); d.depth = 0; d.cap = 0; MG_HIP (hipMalloc ((void **) &d.depth, want * 4)); d.cap = want; }
   MG_HIP (hipMemset (d.depth, 0, want * 4));
+  d.hitLen = 0; d.hitsKept = true;
   *dDepth = d.depth;
   return MG_OK;
+}
+
+/* a batch's hit list (device, n words) behind the file's so far */
+extern "C" void mgReadsetDevAppendHits (const void *rs, const U32 *dHit, U64 n)
+{
+  std::lock_guard<std::mutex> g (gRsLock);
+  auto it = gRsDev.find (rs); if (it == gRsDev.end ()) return;
+  MgReadsetDev &d = it->second;
+  if (!d.hitsKept || !n) return;
+  if (d.hitLen + n > d.hitCap)
+    { const U64 cap = (d.hitLen + n) + (d.hitLen ? (d.hitLen + n) / 2 : 0) + 1024;      /* (a file that is one batch gets what it needs; one of many batches grows by halves) */
+      U32 *q = 0;
+      if (hipMalloc ((void **) &q, cap * 4) != hipSuccess || (d.hitLen && hipMemcpy (q, d.hitAll, d.hitLen * 4, hipMemcpyDeviceToDevice) != hipSuccess))
+        { (void) hipGetLastError (); (void) hipFree (q); (void) hipFree (d.hitAll); d.hitAll = 0; d.hitCap = d.hitLen = 0; d.hitsKept = false; return; }
+      (void) hipFree (d.hitAll); d.hitAll = q; d.hitCap = cap;
+    }
+  if (hipMemcpy (d.hitAll + d.hitLen, dHit, n * 4, hipMemcpyDeviceToDevice) != hipSuccess) { (void) hipGetLastError (); d.hitsKept = false; return; }
+  d.hitLen += n;
 }
 
 __global__ void mgRsCountKernel (const U32 *__restrict__ depth32, U32 msMax, U32 *__restrict__ cnt, unsigned short *__restrict__ depth16)
@@ -543,18 +562,24 @@ extern "C" MgStatus mgReadsetFinishDevice (const void *rs, Modset *ms, U32 msMax
 {
   *hInvSpace = 0;
   MgReadsetDev d;
-  { std::lock_guard<std::mutex> g (gRsLock); auto it = gRsDev.find (rs); if (it == gRsDev.end ()) { mgSetError ("mgReadsetFinishDevice: no read set in progress"); return MG_ERR_ARG; } d = it->second; }
+  bool kept = false;
+  { std::lock_guard<std::mutex> g (gRsLock); auto it = gRsDev.find (rs); if (it == gRsDev.end ()) { mgSetError ("mgReadsetFinishDevice: no read set in progress"); return MG_ERR_ARG; }
+    d = it->second;
+    kept = d.hitsKept && d.hitAll && d.hitLen == totHit && totHit;      /* the lists are on the device already: no upload */
+    if (kept) { it->second.hitAll = 0; it->second.hitCap = it->second.hitLen = 0; }      /* (this call owns them now, and frees them) */
+    else { (void) hipFree (it->second.hitAll); it->second.hitAll = 0; it->second.hitCap = it->second.hitLen = 0; }
+  }
   hipStream_t st = 0;
   const size_t m = (size_t) msMax + 1;
-  U32 *dHit = 0, *dCnt = 0, *dKey = 0, *dVal = 0, *dSorted = 0, *tiles = 0; U64 *dStart = 0, *dInv64 = 0; U8 *dInfo = 0; unsigned short *dD16 = 0; int4 *dNc = 0;
+  U32 *dHit = kept ? d.hitAll : 0, *dCnt = 0, *dKey = 0, *dVal = 0, *dSorted = 0, *tiles = 0; U64 *dStart = 0, *dInv64 = 0; U8 *dInfo = 0; unsigned short *dD16 = 0; int4 *dNc = 0;
   MgStatus s = MG_ERR_HIP;
   do {
     const size_t histWords = (size_t) 256 * ((totHit + MG_RSORT_TILE - 1) / MG_RSORT_TILE + 1);
     const size_t scanTiles = ((m + 2) > histWords ? (m + 2) : histWords) / MG_SCAN_TILE + 4;
     if (hipMalloc ((void **) &tiles, scanTiles * 4) || hipMalloc ((void **) &dCnt, (m + 2) * 4) || hipMalloc ((void **) &dD16, (m + 1) * 2) || hipMalloc ((void **) &dInv64, (m + 2) * 8)
         || hipMalloc ((void **) &dInfo, m) || hipMalloc ((void **) &dStart, ((size_t) nReads + 3) * 8) || hipMalloc ((void **) &dNc, ((size_t) nReads + 2) * sizeof (int4))
-        || hipMalloc ((void **) &dHit, (totHit + 1) * 4) || hipMalloc ((void **) &dKey, (totHit + 1) * 4) || hipMalloc ((void **) &dVal, (totHit + 1) * 4) || hipDeviceSynchronize ()) break;
-    if ((s = mgXferH2DSparse (dInfo, hInfo, m)) || (s = mgXferH2D (dStart, hHitStart, ((size_t) nReads + 2) * 8)) || (totHit && (s = mgXferH2D (dHit, hHit, totHit * 4)))) break;
+        || (!kept && hipMalloc ((void **) &dHit, (totHit + 1) * 4)) || hipMalloc ((void **) &dKey, (totHit + 1) * 4) || hipMalloc ((void **) &dVal, (totHit + 1) * 4) || hipDeviceSynchronize ()) break;
+    if ((s = mgXferH2DSparse (dInfo, hInfo, m)) || (s = mgXferH2D (dStart, hHitStart, ((size_t) nReads + 2) * 8)) || (totHit && !kept && (s = mgXferH2D (dHit, hHit, totHit * 4)))) break;
     s = MG_ERR_HIP;
     hipLaunchKernelGGL (mgRsCountKernel, dim3 (2048), dim3 (256), 0, st, d.depth, msMax, dCnt, dD16);
     if ((s = mgRefExclusiveScan (dCnt, dCnt, m + 1, tiles, st))) break;      /* dCnt[i] = first place of mod i's list; [msMax + 1] = the lists' total */
