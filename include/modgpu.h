@@ -295,6 +295,9 @@ FILE *mgGzipOpenWrite (const char *name) ;
  * from its first byte to its last (any other gzip file, a plain file): the caller then takes the reference's fzopen / gzopen, as
  * mgReferenceLoad and mgReadsetLoad do by themselves. */
 FILE *mgGzipOpenRead (const char *name) ;
+/* the reference's fzopen (utils.c:107-127) on top of the two: "w" = mgGzipOpenWrite; "r" = mgGzipOpenRead, and for any other gzip file
+ * or a plain file zlib's gzopen behind a FILE * (what modsetRead / modsetWrite, seqhashRead / seqhashWrite take). */
+FILE *mgFzOpen (const char *name, const char *mode) ;
 MgReference *mgReferenceLoad (const char *root) ;
 /* modmap.c:188-281: "Q" line and "M" lines for every read. */
 int  mgQueryProcess (MgReference *ref, const char *bases, const int64_t *offsets, int nReads,

@@ -73,7 +73,7 @@ EXPORTS = [
     "mgModsetHostChanged", "modsetDepthHistogramDevice", "mgAddReadsDevice", "mgQueryReadsDevice", "mgQueryReadsDeviceAsync", "mgQueryReadsDeviceWait",
     "mgAddSequenceBatch", "mgDepthHistogram", "mgSynthGenome", "mgSynthReads",
     "mgInsertReadsDevice", "mgAddSequences", "mgModsetWriteText", "mgReferenceCreate", "mgReferenceDestroy",
-    "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgGzipOpenWrite", "mgGzipOpenRead", "mgReferenceLoad",
+    "mgReferenceRead", "mgQueryProcess", "mgReferenceWrite", "mgGzipOpenWrite", "mgFzOpen", "mgGzipOpenRead", "mgReferenceLoad",
     "mgCommInitAll", "mgCommGetUniqueId", "mgCommInitRank", "mgCommRank", "mgCommSize", "mgCommDestroy", "mgHistogramAllReduce", "mgDepthAllReduce", "mgModsetMergeRankOrder",
     "mgReadsetCreate", "mgReadsetDestroy", "mgReadsetRead", "mgReadsetFileRead", "mgReadsetStats", "mgReadsetWrite", "mgReadsetLoad",
     "mgSeqOpen", "mgSeqNextBatch", "mgSeqBatchFree", "mgSeqClose", "mgSeqReleaseBuffers", "mgReleaseBuffers", "mgTextParseFileDevice", "mgAddSequenceFile", "mgReferenceFastaRead", "mgQueryFile",
@@ -193,7 +193,7 @@ def lib():
     sig("mgTextParseFileDevice", i32, C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64))
     sig("mgAddSequenceFile", i32, MS, C.c_char_p, vp); sig("mgReferenceFastaRead", i32, vp, C.c_char_p, C.c_bool, vp)
     sig("mgQueryFile", i32, vp, C.c_char_p, vp)
-    sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgGzipOpenWrite", vp, C.c_char_p); sig("mgGzipOpenRead", vp, C.c_char_p);
+    sig("mgReferenceWrite", None, vp, C.c_char_p); sig("mgGzipOpenWrite", vp, C.c_char_p); sig("mgGzipOpenRead", vp, C.c_char_p); sig("mgFzOpen", vp, C.c_char_p, C.c_char_p);
     sig("mgCommInitAll", i32, C.POINTER(vp), i32, C.POINTER(i32)); sig("mgCommGetUniqueId", i32, vp); sig("mgCommInitRank", i32, C.POINTER(vp), i32, i32, vp, i32)
     sig("mgCommRank", i32, vp); sig("mgCommSize", i32, vp); sig("mgCommDestroy", None, vp)
     sig("mgHistogramAllReduce", i32, MS, vp, vp); sig("mgDepthAllReduce", i32, MS, vp); sig("mgModsetMergeRankOrder", i32, MS, vp, i32)

@@ -208,21 +208,27 @@ static ssize_t gzCookieRead (void *c, char *buf, size_t n)        /* (gzread tak
 { if (n > ((size_t) 1 << 30)) n = (size_t) 1 << 30; int r = gzread ((gzFile) c, buf, (unsigned) n); return r < 0 ? -1 : r; }
 static int gzCookieClose (void *c) { return gzclose ((gzFile) c) == Z_OK ? 0 : -1; }
 
+/* the reference's fzopen (utils.c:107-127): "w" a gzip file, "r" a gzip file or a plain one */
+FILE *mgFzOpen (const char *name, const char *mode)
+{
+  FILE *f = 0;
+  if (mode[0] == 'w') return mgGzipOpenWrite (name);                /* a gzip file of independent members, deflated by a team of threads (mg_pgzip.c) */
+  if ((f = mgGzipOpenRead (name))) return f;                        /* a file of this library's members: they are found by their size fields and inflated in parallel */
+  gzFile z = gzopen (name, mode);
+  if (z)
+    { (void) gzbuffer (z, 1 << 20);
+      cookie_io_functions_t io = { gzCookieRead, 0, 0, gzCookieClose };
+      f = fopencookie (z, mode, io);
+      if (!f) gzclose (z);
+    }
+  return f;
+}
+
 FILE *mgTagOpen (const char *root, const char *tag, const char *mode)      /* utils.c:129-139 */
 {
   char *name = (char *) malloc (strlen (root) + strlen (tag) + 2);
   sprintf (name, "%s.%s", root, tag);
-  FILE *f = 0;
-  if (mode[0] == 'w') f = mgGzipOpenWrite (name);                  /* a gzip file of independent members, deflated by a team of threads (mg_pgzip.c) */
-  else if (!(f = mgGzipOpenRead (name)))                            /* a file of this library's members: they are found by their size fields and inflated in parallel */
-    { gzFile z = gzopen (name, mode);
-      if (z)
-        { (void) gzbuffer (z, 1 << 20);
-          cookie_io_functions_t io = { gzCookieRead, 0, 0, gzCookieClose };
-          f = fopencookie (z, mode, io);
-          if (!f) gzclose (z);
-        }
-    }
+  FILE *f = mgFzOpen (name, mode);
   free (name);
   return f;
 }

@@ -42,6 +42,27 @@ def test_multi_gpu_example_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["k21d16", "k17d31"])
+def test_ingest_example_runs_like_modasm(tag, golden_dir, tmp_path):
+    """examples/ingest_file.c = `modasm -m src.mod -f reads2.fa -S -w stem` on the library: the reference program's own stdout
+    (tests/golden/asm_*.stdout.txt) and, but for the addresses a file holds, its .mod and .readset bytes"""
+    import gzip
+    from tests import test_readset as trs
+    exe = str(tmp_path / "ingest_file")
+    libdir = os.path.join(util.ROOT, "modimizer_amd")
+    r = subprocess.run(["gcc", "-O2", "-I", os.path.join(util.ROOT, "include"), os.path.join(util.ROOT, "examples", "ingest_file.c"), "-o", exe,
+                        "-L", libdir, "-lmodgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    stem = os.path.join(golden_dir, "asm_%s" % tag)
+    out = str(tmp_path / "out")
+    r = subprocess.run([exe, stem + "_src.mod", os.path.join(golden_dir, "reads2.fa"), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert r.stdout.splitlines() == util.golden_text("asm_%s.stdout.txt" % tag).splitlines()[:len(r.stdout.splitlines())] and r.stdout.count("RS ") == 6
+    assert trs.mod_mask(gzip.open(out + ".mod").read()) == trs.mod_mask(gzip.open(stem + ".mod").read())
+    assert trs.readset_mask(gzip.open(out + ".readset").read()) == trs.readset_mask(gzip.open(stem + ".readset").read())
+
+
+@pytest.mark.gpu
 def test_example_runs_like_modutils(golden_dir, tmp_path):
     exe = str(tmp_path / "sketch_file")
     libdir = os.path.join(util.ROOT, "modimizer_amd")
