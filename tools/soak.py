@@ -25,6 +25,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xffffff
 L = mg.lib(); mg.check(L.mgSetDevice(0))
 TILE = tscan.TILE
+LARGE = os.environ.get("SOAK_LARGE") == "1"        # build trials only, at sizes where every stage of the bucketed build has many workgroups
 
 
 def draw_params(rng):
@@ -96,6 +97,9 @@ def _trial_build(rng, k, w, sd):
     if rng.random() < 0.15:                                        # now and then a batch large enough for the bucketed build by itself (>= 1.5e6 modimizers is its rule)
         tot = int(min(12_000_000, max(tot, 2_000_000 * min(w, 8))))
         bits = 24
+    if LARGE:                                                      # SOAK_LARGE=1: batches of 30 - 300 Mbp (3e6 .. 1e8 modimizers), table bits to match
+        tot = int(rng.integers(30_000_000, 300_000_000)) if w >= 16 else int(rng.integers(10_000_000, 60_000_000))
+        bits = 28
     reads = awkward_reads(rng, k, tot)
     cuts = sorted(set([0, len(reads)] + [int(x) for x in rng.integers(0, len(reads) + 1, int(rng.integers(0, 3)))]))
     ms = mg.modsetCreate(sh, bits); oms = po.Modset(oh, bits)
@@ -255,6 +259,10 @@ def main():
             rng = np.random.default_rng(s)
             k, w, sd = draw_params(rng)
             which = ["scan", "build", "query", "minimizer", "modmap", "readset", "pipelined"][trials % 7]
+            if LARGE:
+                which = "build"
+                if k < 12:
+                    k = int(rng.choice([15, 17, 19, 21, 25, 31]))      # (short k-mers: a handful of distinct values, nothing for the table to do)
             if which == "minimizer" and not have_min:
                 which = "scan"
             t0 = time.time()
