@@ -1110,9 +1110,7 @@ extern "C" MgStatus mgQueryReadsDeviceAsync (Modset *ms, const U32 *dPacked, U64
   if (!d->side)
     { /* lowest priority: the lookups are a chain of short kernels that should not queue behind the scan's workgroups; the scan fills what they leave */
       int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange (&lo, &hi);
-      const long pk = mgKnobs ()->sidePriority;           /* dev: 0 = default priority */
-      if (pk == 0) MG_HIP (hipStreamCreateWithFlags (&d->side, hipStreamNonBlocking));
-      else MG_HIP (hipStreamCreateWithPriority (&d->side, hipStreamNonBlocking, lo));
+      MG_HIP (hipStreamCreateWithPriority (&d->side, hipStreamNonBlocking, lo));      /* (default priority instead: no difference measured, DESIGN_EXPERIMENTS §J) */
       for (int i = 0 ; i < 2 ; ++i) MG_HIP (hipEventCreateWithFlags (&d->scanned[i], hipEventDisableTiming));
       MG_HIP (hipEventCreateWithFlags (&d->inputReady, hipEventDisableTiming));
     }

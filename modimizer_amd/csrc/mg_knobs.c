@@ -41,12 +41,11 @@ static void readAll (void)
   k.iterHostBelow = num ("MODGPU_ITER_HOST_BELOW");
   k.segSlack = num ("MODGPU_SEG_SLACK");
   k.partDigits = num ("MODGPU_PART_DIGITS");
-  k.findBits = num ("MODGPU_FIND_BITS"); k.findSubpass = num ("MODGPU_FIND_WGS");
+  k.findBits = num ("MODGPU_FIND_BITS");
   k.scatterGrid = num ("MODGPU_SCATTER_GRID");     k.tableLoad = num ("MODGPU_TABLE_LOAD");
   k.packThreads = num ("MODGPU_PACK_THREADS");     k.parseThreads = num ("MODGPU_PARSE_THREADS");
   k.xferThreads = num ("MODGPU_XFER_THREADS");       k.gzipThreads = num ("MODGPU_GZIP_THREADS");
   k.xferPieceKb = num ("MODGPU_XFER_PIECE_KB");      k.xferStreams = num ("MODGPU_XFER_STREAMS");
-  k.sidePriority = num ("MODGPU_SIDE_PRIORITY");
   k.seedTiming = num ("MODGPU_SEED_TIMING");       k.uploadTiming = num ("MODGPU_UPLOAD_TIMING");
   k.textTiming = num ("MODGPU_TEXT_TIMING");       k.parseTiming = getenv ("MODGPU_PARSE_TIMING") ? 1 : MG_KNOB_UNSET;
   k.scanDebug = num ("MODGPU_SCAN_DEBUG");         k.bucketDebug = num ("MODGPU_BUCKET_DEBUG");

@@ -41,7 +41,6 @@ typedef struct {
   /* development knobs */
   long scatterGrid;        /* MODGPU_SCATTER_GRID */
   long segSlack;           /* MODGPU_SEG_SLACK: the scan's segment room as a multiple of the fair share (1..8, default 3) */
-  long findSubpass;        /* MODGPU_FIND_WGS: dev, workgroups per XCD of the partitioned lookup */
   long partDigits;         /* MODGPU_PART_DIGITS: 0 = the second partition pass counts its digits from the elements (8 bytes each) instead of from the digit bytes the first pass leaves beside them */
   long findBits;           /* MODGPU_FIND_BITS: bits of the partitioned lookup's digit (3..9) */
   long tableLoad;          /* MODGPU_TABLE_LOAD: per cent */
@@ -49,8 +48,7 @@ typedef struct {
   long parseThreads;       /* MODGPU_PARSE_THREADS */
   long gzipThreads;        /* MODGPU_GZIP_THREADS: threads that deflate the members of a .mod / .ref / .readset file (mg_pgzip.c) */
   long xferPieceKb;        /* MODGPU_XFER_PIECE_KB: dev, bytes per piece of the array transfers (default 4096) */
-  long xferStreams;        /* MODGPU_XFER_STREAMS: dev, 1 = a copy stream per transfer thread instead of the device's default stream */
-  long sidePriority;       /* MODGPU_SIDE_PRIORITY: dev, 0 = the pipelined query's scan stream at default priority (else lowest) */
+  long xferStreams;        /* MODGPU_XFER_STREAMS: dev, 0 = the array transfers' copies on the device's default stream instead of a stream per transfer thread */
   long xferThreads;        /* MODGPU_XFER_THREADS: host threads of the array transfers (mg_xfer.hip) */
   long seedTiming, uploadTiming, textTiming, parseTiming;   /* MODGPU_*_TIMING prints */
   long scanDebug, bucketDebug;                               /* only read by -DMG_ABLATE builds */

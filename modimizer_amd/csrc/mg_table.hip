@@ -2076,7 +2076,6 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
   MgStatus s = mgPartPass (t, MG_EL_SEG, true, f, (const U64 *) 0, 0, n, whole, 1, loB, nBins, el, (U32 *) 0, binStart, cursor, binCount, chunkBase, st,
                            counted->binCount, &segSrc, subSeg, runTab, &subElems, 0, 0, digits, 0, (U32) 1 << loB);
   if (s) return s;
-  const long wk = mgKnobs ()->findSubpass;                    /* (dev: MODGPU_FIND_WGS, workgroups per XCD) */
   if (twoLevels)      /* ---- two levels: the lookups bucket by bucket out of LDS (a table of few buckets has no fine digit: one level) ---- */
     { char *w2 = (char *) scratch2;
       const U64 NB = (U64) 1 << t->log2NB;
@@ -2108,7 +2107,7 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
       MG_HIP (hipGetLastError ());
       return MG_OK;
     }
-  const U32 wgPerXcd = wk != MG_KNOB_UNSET && wk > 0 ? (U32) wk : 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
+  const U32 wgPerXcd = 256;                                  /* 2048 workgroups of 256: eight waves per SIMD */
   MG_LAUNCH (MG_K_BUCKET_FIND, st, mgBinFindKernel, dim3 (8 * wgPerXcd), dim3 (256), 0, st, t->slots, mgGeomOf (t), f, el, binStart, nBins, wgPerXcd);
   const U64 nSub = (n + subElems - 1) / subElems;
   const unsigned ug = (unsigned) (nSub < 2048 ? nSub : 2048);
