@@ -481,6 +481,14 @@ struct MgDev {
                               goes through the runtime's staging path, whose wake-up was seen to take 10 - 25 ms now and then */
   U32 hostIndexMax;        /* entries 1..hostIndexMax are present in the host index[] table */
   bool built;
+  int device = -1;         /* the GPU the table lives on: the one that was current when it was built */
+};
+/* the calling thread on a modset's own GPU for the length of a scope (the scalar API's hooks and the mirror may be reached from a thread
+   that has since moved to another GPU with mgSetDevice) */
+struct MgOnDevice
+{ int before = -1; bool moved = false;
+  explicit MgOnDevice (int dev) { if (dev >= 0 && hipGetDevice (&before) == hipSuccess && before != dev) moved = hipSetDevice (dev) == hipSuccess; }
+  ~MgOnDevice () { if (moved) (void) hipSetDevice (before); }
 };
 
 static std::mutex gRegLock;
@@ -493,6 +501,7 @@ static MgDev *mgDevLookup (const Modset *ms)
 static void mgDevFree (MgDev *d)
 {
   if (!d) return;
+  MgOnDevice here (d->device);
   if (d->hPin) (void) hipHostFree (d->hPin);
   if (d->built)
     { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
@@ -548,12 +557,18 @@ static MgStatus mgDevGet (Modset *ms, MgDev **out, hipStream_t st)
   MgDev *d = mgDevLookup (ms);
   if (!d)
     { d = new MgDev (); d->built = false; d->hostIndexMax = 0; d->hPin = 0;
+      if (hipGetDevice (&d->device) != hipSuccess) { delete d; return mgHipFail (hipGetLastError (), "hipGetDevice"); }
       if (hipHostMalloc ((void **) &d->hPin, 256, hipHostMallocDefault) != hipSuccess) { delete d; return mgHipFail (hipGetLastError (), "hipHostMalloc"); }
       if ((s = mgDevBuild (ms, d, st))) { mgDevFree (d); return s; }
       mgXferWarm ();                                       /* what is built on the device comes back through mg_xfer.hip: its streams are made meanwhile */
       std::lock_guard<std::mutex> g (gRegLock); gReg[ms] = d; mgLiveDeviceModsets = (int) gReg.size ();
     }
-  else if (ms->max > d->t.max)
+  else
+    { int cur = -1;
+      if (hipGetDevice (&cur) != hipSuccess || cur != d->device)
+        { mgSetError ("this Modset's table lives on GPU %d, the calling thread is on GPU %d (mgSetDevice)", d->device, cur); return MG_ERR_ARG; }
+    }
+  if (d->built && ms->max > d->t.max)
     { /* the host appended entries through the scalar API (modsetIndexFind isAdd): mirror them */
       U32 first = d->t.max + 1, last = ms->max;
       if (last >= (ms->tableSize >> 2)) { mgSetError ("modset max %u beyond table capacity", last); return MG_ERR_CAPACITY; }
@@ -592,6 +607,11 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
 {
   hipStream_t st = (hipStream_t) stream;
   MgDev *d = mgDevLookup (ms);
+  if (d)
+    { int cur = -1;
+      if (hipGetDevice (&cur) != hipSuccess || cur != d->device)
+        { mgSetError ("this Modset's table lives on GPU %d, the calling thread is on GPU %d (mgSetDevice)", d->device, cur); return MG_ERR_ARG; }
+    }
   /* Host arrays only hold what the host was given: with a device table, entries beyond
      syncedMax exist on the device alone and index[] is populated up to hostIndexMax. */
   U32 hostIndexed = d ? d->hostIndexMax : ms->max;
@@ -853,6 +873,7 @@ extern "C" MgStatus modsetSyncToHost (Modset *ms, int wantIndex)
 {
   MgDev *d = mgDevLookup (ms);
   if (!d) return MG_OK;
+  MgOnDevice here (d->device);
   MgTable &t = d->t;
   hipStream_t st = 0;
   MgStatus s;
@@ -906,6 +927,7 @@ extern "C" int mgHookDeviceView (Modset *ms, const U64 **dValue1, const U16 **dD
 {
   MgDev *d = mgDevLookup (ms);
   if (!d || !d->built || d->ticketsOut) return -1;
+  { int cur = -1; if (hipGetDevice (&cur) != hipSuccess || cur != d->device) return -1; }      /* (a sender stages from the host then) */
   if (hipDeviceSynchronize () != hipSuccess || mgFoldCounts (d, 0)) return -1;
   *dValue1 = d->t.value + 1; *dDepth1 = d->t.baseDepth + 1; *max = d->t.max;
   return 0;
