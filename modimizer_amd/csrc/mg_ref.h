@@ -14,6 +14,7 @@ struct MgRefDev {
   U8 *info = 0; U32 *loc = 0, *rev = 0, *id = 0;
   U32 *index = 0, *depth = 0;        /* per occurrence: modset index; per modset index: occurrences */
   size_t capOcc = 0, capMs = 0;
+  int device = -1;                   /* the GPU all of this lives on */
 };
 MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out);
 #endif

@@ -81,8 +81,10 @@ MgStatus mgRefDevGet (const MgReference *ref, MgRefDev *out)
   std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
   MgRefDev &d = mgRefEntry (ref);
   const U32 msMax = ref->ms->max, refMax = ref->max;
-  if (d.li && d.packed && d.msMax == msMax && d.refMax == refMax) { *out = d; return MG_OK; }
-  mgRefDevFree (d);
+  int cur = 0; MG_HIP (hipGetDevice (&cur));
+  if (d.li && d.packed && d.msMax == msMax && d.refMax == refMax && d.device == cur) { *out = d; return MG_OK; }
+  mgRefDevFree (d);                                    /* (also: made on another GPU than the one the calling thread is on now -- uploaded again, here) */
+  d.device = cur;
   const size_t m = (size_t) msMax + 1, n = refMax ? refMax : 1;
   MG_HIP (hipMalloc ((void **) &d.info, m));
   MG_HIP (hipMalloc ((void **) &d.loc, m * 4));
@@ -360,6 +362,10 @@ extern "C" MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U3
   std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
   MgRefDev &d = mgRefEntry (ref);
   if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
+  { int cur = 0; MG_HIP (hipGetDevice (&cur));
+    if (d.device >= 0 && d.device != cur && d.depth) { mgSetError ("this Reference is being built on GPU %d, the calling thread is on GPU %d", d.device, cur); return MG_ERR_ARG; }
+    d.device = cur;
+  }
   hipStream_t st = 0;
   const size_t msCap = ref->ms->size;
   if (!d.depth)
@@ -412,6 +418,10 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
   const bool lapOn = mgKnobs ()->seedTiming == 1;
 #define MG_LAP(what) do { if (lapOn) { (void) hipStreamSynchronize (st); struct timespec q_; clock_gettime (CLOCK_MONOTONIC, &q_); fprintf (stderr, "mgRefBuildFinish: %s at %.1f ms\n", what, (q_.tv_sec - tq0.tv_sec) * 1e3 + (q_.tv_nsec - tq0.tv_nsec) * 1e-6); } } while (0)
   if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
+  { int cur = 0; MG_HIP (hipGetDevice (&cur));
+    if (d.device >= 0 && d.device != cur && d.depth) { mgSetError ("this Reference is being built on GPU %d, the calling thread is on GPU %d", d.device, cur); return MG_ERR_ARG; }
+    d.device = cur;
+  }
   if (!d.depth)                                                      /* no batch ever came: an empty reference */
     { MG_HIP (hipMalloc ((void **) &d.depth, (m + 1) * 4)); MG_HIP (hipMemsetAsync (d.depth, 0, (m + 1) * 4, st)); d.capMs = m; }
   if (m > d.capMs + 1) { mgSetError ("modset grew beyond its size"); return MG_ERR_CAPACITY; }
