@@ -9,7 +9,7 @@ cat > $D/stubs.c <<'EOS'
 #include "mg_internal.h"
 volatile int mgLiveDeviceModsets = 0;
 void mgHookDestroy (Modset *ms) {} void mgHookHostRewrote (Modset *ms) {} void mgHookNeedHost (Modset *ms, int w) {} void mgHookNeedHostAll (Modset *ms, int w) {}
-int mgHookHasDevice (Modset *ms) { return 0; } int mgHookMergeDevice (Modset *a, Modset *b) { return -1; } int mgHookPruneDevice (Modset *m, int a, int b) { return -1; }
+int mgHookHasDevice (Modset *ms) { return 0; } int mgHookMergeDevice (Modset *a, Modset *b) { return -1; } int mgHookMergeDeviceArrays (Modset *a, const U64 *v, const U16 *d, const U8 *i, U32 n) { return -1; } int mgHookPruneDevice (Modset *m, int a, int b) { return -1; }
 int mgIterScan (Seqhash *sh, const char *s, int len, U64 **blk) { return -1; } int mgIterRequireDevice (void) { return 0; } void mgIterReleaseBuffers (void) {}
 int mgIterMinScan (Seqhash *sh, const char *s, int len, U64 **rec, U64 *n) { return -1; } const char *mgLastError (void) { return "stub"; }
 EOS

@@ -13,7 +13,7 @@ int64_t mgAddSequenceBatch (Modset *ms, const char *b, const int64_t *o, int n) 
 int mgReferenceRead (MgReference *r, const char *b, const int64_t *o, int n, const char **nm, bool a, FILE *f) { (void) r; (void) b; (void) o; (void) n; (void) nm; (void) a; (void) f; return 0; }
 int mgQueryProcess (MgReference *r, const char *b, const int64_t *o, int n, const char **nm, FILE *f) { (void) r; (void) b; (void) o; (void) n; (void) nm; (void) f; return 0; }
 #include "mg_internal.h"
-int mgTextForEachBatchDevice (const char *fn, MgTextBatchFn f, void *c, U64 bb, U64 *a, U64 *b, U64 *d, U64 *e) { (void) fn; (void) f; (void) c; (void) bb; (void) a; (void) b; (void) d; (void) e; return -2; }
+int mgTextForEachBatchDevice (const char *fn, MgTextBatchFn f, void *c, U64 bb, U64 br, U64 *a, U64 *b, U64 *d, U64 *e) { (void) fn; (void) f; (void) c; (void) bb; (void) br; (void) a; (void) b; (void) d; (void) e; return -2; }
 int mgQueryProcessDevice (MgReference *r, const U32 *p, U64 t, const U64 *o, int n, const char **nm, FILE *f) { (void) r; (void) p; (void) t; (void) o; (void) n; (void) nm; (void) f; return 0; }
 MgQueryPipe *mgQueryPipeOpen (MgReference *r, FILE *f) { (void) r; (void) f; return 0; }
 int mgQueryPipePush (MgQueryPipe *p, const U32 *d, U64 t, const U64 *o, int n, const char *ib, const U64 *io) { (void) p; (void) d; (void) t; (void) o; (void) n; (void) ib; (void) io; return 0; }
