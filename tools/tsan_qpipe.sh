@@ -45,6 +45,8 @@ size_t mgPackedWords (U64 n) { (void) n; abort (); }
 MgStatus mgUploadPack (const char *b, U64 n, U32 *d, void *s) { (void) b; (void) n; (void) d; (void) s; abort (); }
 bool modsetPack (Modset *ms) { (void) ms; abort (); } Modset *modsetRead (FILE *f) { (void) f; abort (); } void modsetWrite (Modset *ms, FILE *f) { (void) ms; (void) f; abort (); }
 char *seqString (U64 k, int len) { (void) k; (void) len; abort (); }
+MgStatus mgRefBuildAppend (MgReference *ref, const U32 *a, const U32 *b, const U32 *c, U64 n, U32 idBase, U32 *appended) { (void) ref; (void) a; (void) b; (void) c; (void) n; (void) idBase; (void) appended; abort (); }
+MgStatus mgRefBuildFinish (MgReference *ref, U32 *a, U32 *b, U32 *c, U32 *d, U32 *e, U32 *f, U8 *g, U32 t[3]) { (void) ref; (void) a; (void) b; (void) c; (void) d; (void) e; (void) f; (void) g; (void) t; abort (); }
 EOS
 cat > $D/main.c <<'EOS'
 #include <stdio.h>
@@ -91,7 +93,7 @@ int main (int argc, char **argv)
 EOS
 for san in thread address,undefined; do
   gcc -g -O1 -fsanitize=$san -fno-sanitize-recover=all -std=gnu11 -I$R/include -I$R/modimizer_amd/csrc -o $D/t $D/main.c $D/stubs.c \
-      $R/modimizer_amd/csrc/mg_callers.c $R/modimizer_amd/csrc/mg_knobs.c -lpthread -lm -lz
+      $R/modimizer_amd/csrc/mg_callers.c $R/modimizer_amd/csrc/mg_pgzip.c $R/modimizer_amd/csrc/mg_knobs.c -lpthread -lm -lz
   $D/t $D/out.txt $D/want.txt
   cmp $D/out.txt $D/want.txt && echo "  -fsanitize=$san: output identical ($(wc -l < $D/out.txt) lines)"
 done
