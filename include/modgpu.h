@@ -66,7 +66,8 @@ typedef enum {
 const char *mgLastError (void) ;
 int  mgDeviceCount (void) ;                 /* 0 when no device; never initialises a context */
 MgStatus mgSetDevice (int device) ;         /* device used by subsequent calls of this thread */
-const char *mgVersion (void) ;
+const char *mgVersion (void) ;                 /* "modgpu <version> (gfx950) src=<hash>" */
+const char *mgSourceHash (void) ;             /* 16 hex digits: hash of the sources this binary was compiled from (csrc/mg_version.c) */
 
 /* The per-read facade's latency switch (seqhash.c:154-196 behind modRCiterator).  A synchronous per-read call cannot
  * hide a kernel launch (13-15 us launch + poll whatever the length), so modRCiterator scans reads shorter than

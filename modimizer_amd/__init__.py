@@ -65,7 +65,7 @@ EXPORTS = [
     "minimizerRCiterator", "minimizerRCnext", "seqString", "mgSeqhashDestroy", "mgSeqhashRCiteratorDestroy",
     "modsetCreate", "modsetDestroy", "modsetWrite", "modsetRead", "modsetIndexFind", "modsetSummary",
     "modsetPack", "modsetDepthPrune", "modsetMerge",
-    "mgLastError", "mgDeviceCount", "mgSetDevice", "mgVersion", "mgDeviceAlloc", "mgDeviceFree",
+    "mgLastError", "mgDeviceCount", "mgSetDevice", "mgVersion", "mgSourceHash", "mgDeviceAlloc", "mgDeviceFree",
     "mgMemcpyH2D", "mgMemcpyD2H", "mgMemsetD", "mgStreamSynchronize",
     "mgPackedWords", "mgPackHost", "mgPackDevice", "mgUnpackDevice", "mgUploadPack",
     "mgScanWorkBytes", "seqhashScanBatchDevice", "seqhashScanBatch", "seqhashMinimizerBatchDevice", "seqhashMinimizerBatch",
@@ -105,15 +105,38 @@ def knobs(**kv):
         lib().mgReloadKnobs()
 
 
+def source_hash():
+    """the hash csrc/Makefile bakes into the library (mg_version.c): sha256 over the `sha256sum` listing of every source, 16 hex digits"""
+    import hashlib
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".c", ".h"))) + ["Makefile", "../../include/modgpu.h", "../../include/modgpu_compat.h"]
+    inc = os.path.join(_HERE, "..", "include")
+    path = lambda n: os.path.join(inc, os.path.basename(n)) if n.startswith("../") else os.path.join(CSRC, n)
+    listing = "".join("%s  %s\n" % (hashlib.sha256(open(path(n), "rb").read()).hexdigest(), n) for n in names)
+    return hashlib.sha256(listing.encode()).hexdigest()[:16]
+
+
+def binary_hash(path=None):
+    """the source hash a built libmodgpu.so carries, read out of the file (no dlopen); None if there is no such file or marker"""
+    import re
+    try:
+        m = re.search(rb"MODGPU_SRC_HASH=([0-9a-f]{16})", open(path or LIB_PATH, "rb").read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def build(force=False):
-    """Compile libmodgpu.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".c", ".h"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "modgpu.h")); srcs.append(os.path.join(_HERE, "..", "include", "modgpu_compat.h"))
-    stale = force or not os.path.exists(LIB_PATH) or \
-        any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if stale:
-        cmd = ["make", "-C", CSRC, "-j4", "-s"] + (["-B"] if force else [])
-        subprocess.check_call(cmd)
+    """Compile libmodgpu.so for gfx950 in-tree (hipcc cross-compiles without a GPU) whenever the binary is not the one these sources
+    make: the hash baked into it differs from the tree's (a stale .so that rode along cannot be used), or it does not exist."""
+    import fcntl
+    if os.environ.get("MODGPU_LIB"):                    # a variant build under tools/: the caller's business
+        return LIB_PATH
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lk:     # tests start many processes: one make at a time
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if force or binary_hash() != source_hash():
+            subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"] + (["-B"] if force else []))
+            if binary_hash() != source_hash():
+                raise RuntimeError("libmodgpu.so does not carry the hash of its sources after make: %s != %s" % (binary_hash(), source_hash()))
     return LIB_PATH
 
 
@@ -121,7 +144,7 @@ _lib = None
 
 
 def lib():
-    """Load libmodgpu.so (building it first if the sources are newer). Raises if unavailable."""
+    """Load libmodgpu.so, building it first if it is not the build of the sources in the tree. Raises if unavailable."""
     global _lib
     if _lib is not None:
         return _lib
@@ -131,9 +154,12 @@ def lib():
             import torch  # noqa: F401
         except Exception:
             pass
-    if not os.path.exists(LIB_PATH):
-        build()
+    build()
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    if not os.environ.get("MODGPU_LIB"):
+        L.mgSourceHash.restype = C.c_char_p
+        if L.mgSourceHash().decode() != source_hash():
+            raise RuntimeError("the loaded libmodgpu.so was not built from the sources in this tree")
     vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int64
     SH, MS, IT = C.POINTER(Seqhash), C.POINTER(Modset), C.POINTER(SeqhashRCiterator)
 
@@ -158,6 +184,7 @@ def lib():
     sig("modsetMerge", C.c_bool, MS, MS)
     sig("mgLastError", C.c_char_p); sig("mgDeviceCount", i32); sig("mgSetDevice", i32, i32)
     sig("mgVersion", C.c_char_p)
+    sig("mgSourceHash", C.c_char_p)
     sig("mgDeviceAlloc", i32, C.POINTER(vp), C.c_size_t); sig("mgDeviceFree", i32, vp)
     sig("mgMemcpyH2D", i32, vp, vp, C.c_size_t, vp); sig("mgMemcpyD2H", i32, vp, vp, C.c_size_t, vp)
     sig("mgMemsetD", i32, vp, i32, C.c_size_t, vp); sig("mgStreamSynchronize", i32, vp)

@@ -21,7 +21,6 @@ void mgSetError (const char *fmt, ...)
 { va_list ap; va_start (ap, fmt); vsnprintf (gErr, sizeof (gErr), fmt, ap); va_end (ap); }
 
 extern "C" const char *mgLastError (void) { return gErr; }
-extern "C" const char *mgVersion (void) { return "modgpu 0.1 (gfx950)"; }
 
 MgStatus mgHipFail (hipError_t e, const char *what)
 { mgSetError ("HIP error %d (%s) in %s", (int) e, hipGetErrorString (e), what); return MG_ERR_HIP; }

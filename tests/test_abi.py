@@ -87,3 +87,29 @@ def test_iterator_dies_without_device(n):
     env = dict(os.environ, MODGPU_NO_TORCH="1", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "FATAL ERROR" in r.stderr and "modRCiterator" in r.stderr and "no HIP device" in r.stderr
+
+
+def test_binary_carries_the_hash_of_its_sources(tmp_path, monkeypatch):
+    """libmodgpu.so is git-ignored yet rides along to the GPU box, so the binary says what it was built from --
+    csrc/Makefile bakes a hash of every source into it (mg_version.c), the binding recomputes it from the tree, and a library whose
+    hash differs is rebuilt before it is loaded (modimizer_amd.build); smoke() asserts equality."""
+    import shutil
+    L = mg.lib()
+    h = mg.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h)
+    assert L.mgSourceHash().decode() == h == mg.binary_hash()
+    assert L.mgVersion().decode().endswith("src=" + h)
+    # any change to any source changes the tree's hash: the unchanged binary is then seen as stale
+    csrc = tmp_path / "csrc"
+    shutil.copytree(mg.CSRC, csrc, ignore=shutil.ignore_patterns("*.o"))
+    monkeypatch.setattr(mg, "CSRC", str(csrc))
+    assert mg.source_hash() == h
+    for name in ("mg_scan.hip", "mg_host.c", "mg_common.h", "Makefile"):
+        p = os.path.join(str(csrc), name)
+        old = open(p, "rb").read()
+        open(p, "ab").write(b"\n")
+        assert mg.source_hash() != h, name
+        open(p, "wb").write(old)
+        assert mg.source_hash() == h
+    # a library file without the marker (or none at all) has no hash
+    assert mg.binary_hash(str(tmp_path / "nothing.so")) is None

@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 
 from modimizer_amd import dist as mdist   # noqa: E402
 from modimizer_amd import synth           # noqa: E402
+from tests.util import bench_lines        # noqa: E402
 
 
 def test_shard_bounds_cover_and_are_contiguous():
@@ -205,20 +206,38 @@ def test_depth_allreduce_fixed_modset_gloo_world2():
         assert got.dtype == np.uint16 and np.array_equal(got, whole)
 
 
-def test_bench_gpus_n_starts_n_ranks():
-    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) starts two ranks itself, before anything touches
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_gpus_n_starts_n_ranks(n):
+    """`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N ranks itself, before anything touches
     a GPU; --dry-launch runs what a rank does around the GPU work on CPU: process group (gloo), a small modset per
-    rank through the scalar host API, the histogram all-reduce, MAX-over-ranks timing, one JSON line from rank 0"""
+    rank through the scalar host API, the histogram all-reduce, MAX-over-ranks timing, one JSON line from rank 0.
+    N = 8 is the shape of the driver's scaling run (it must not be the first time that launch executes)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(line) == 1                                  # one line, from rank 0 only
+    assert len(line) == 1 and r.stdout.rstrip().splitlines()[-1] == line[0]      # one line, from rank 0 only, and it is the last
+    assert len(line[0]) < 8192
     j = json.loads(line[0])
-    assert j["n_gpus"] == 2 and j["dry_launch"] is True and j["steps"] == 3
-    assert j["kmers_all_ranks"] == 3000 + 3100             # both ranks' blocks took part
-    assert j["histogram_entries"] == j["entries_all_ranks"] == 1000 + 1010   # the all-reduced histogram holds every entry of every rank
+    assert j["n_gpus"] == n and j["dry_launch"] is True and j["steps"] == 3
+    assert j["kmers_all_ranks"] == sum(3000 + 100 * r_ for r_ in range(n))       # every rank's block took part
+    assert j["histogram_entries"] == j["entries_all_ranks"] == sum(1000 + 10 * r_ for r_ in range(n))   # the all-reduced histogram holds every entry of every rank
+
+
+def test_bench_under_the_drivers_launcher_world8():
+    """the driver's own command for N = 8 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` -- where bench.py is a RANK (WORLD_SIZE set), not the launcher; dry: gloo, no GPU"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 8 and j["histogram_entries"] == j["entries_all_ranks"] == sum(1000 + 10 * r_ for r_ in range(8))
 
 
 @pytest.mark.gpu
@@ -232,17 +251,19 @@ def test_bench_multi_rank_path_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    j, full, compact = bench_lines(r.stdout)
+    assert len(compact) == 1 and len(compact[0]) < 8192 and r.stdout.rstrip().splitlines()[-1] == compact[0]
     assert j["n_gpus"] == 1 and "config 4" in j["config"]["workload"]
     c = j["collective"]
     assert c["matches_local_sums"] is True and c["histogram_entries"] == j["config"]["modset_entries"] > 0
-    assert j["roofline"]["kernel"] and j["roofline"]["alu"]["floor_ms"] > 0
+    assert j["roofline"]["kernel"] and j["roofline"]["frac"] > 0 and full["roofline"]["alu"]["floor_ms"] > 0
     # every rank's block checked on its own GPU (prefix property), the single-GPU figure of the same workload, and the
     # query sharding (north_star: reads shard, modset replicated) at this world size
-    assert j["per_rank_parity"] is True and j["per_rank_parity_rank0"]["prefix_entries"] > 0
+    assert j["per_rank_parity"] is True and full["per_rank_parity_rank0"]["prefix_entries"] > 0
     assert j["single_gpu_block_gbps"] > 0
-    c3 = j["other_configs"]["c3_sharded"]
+    c3 = full["other_configs"]["c3_sharded"]
     assert "error" not in c3 and c3["n_gpus"] == 1 and c3["value"] > 0 and 0.25 < c3["seed_hit_fraction"] < 0.45
+    assert j["other_configs"]["c3_sharded"]["value"] == c3["value"]
 
 
 @pytest.mark.gpu
@@ -339,15 +360,39 @@ def test_bench_world2_code_path_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                 # rank 0 only
-    j = json.loads(lines[0])
+    j, full, lines = bench_lines(r.stdout)
+    assert len(lines) == 1 and len(lines[0]) < 8192        # rank 0 only, and under the size the driver can read
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]  # ... as the LAST line of stdout
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "block r on rank r" in j["config"]["workload"]
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
+        assert key in j, key
+    r_ = j["roofline"]                                     # the N > 1 line carries the roofline object too
+    assert r_["bound"] == "hbm" and r_["kernel"] and r_["frac"] > 0 and r_["peak"] == 8000.0 and r_["avg_launch_ms"] > 0
     c = j["collective"]
     assert c["matches_local_sums"] is True and c["histogram_entries"] == c["entries_all_ranks"] > j["config"]["modset_entries"]
     assert j["per_rank_parity"] is True and j["single_gpu_block_gbps"] > 0
-    c3 = j["other_configs"]["c3_sharded"]
+    c3 = full["other_configs"]["c3_sharded"]
     assert "error" not in c3 and c3["n_gpus"] == 2 and c3["value"] > 0 and 0.25 < c3["seed_hit_fraction"] < 0.45
+    assert j["other_configs"]["c3_sharded"]["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_forced_dist_agrees_with_plain_single_gpu():
+    """N = 1 through the N > 1 code path (MODGPU_BENCH_FORCE_DIST=1: process group on RCCL, histogram + all-reduce in the step) against the
+    same block through the plain N = 1 code (`--only c4_block`: scan + build + histogram, no collective): the all-reduce of 512 KiB and
+    the barriers must not cost more than 3 % of a step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MODGPU_BENCH_GBP="6", MASTER_PORT=str(_free_port()))
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu", "--no-other"],
+                       capture_output=True, text=True, timeout=900, env=dict(env, MODGPU_BENCH_FORCE_DIST="1"), cwd=ROOT)
+    assert a.returncode == 0, a.stderr[-2000:]
+    ja, _, _ = bench_lines(a.stdout)
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--only", "c4_block"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert b.returncode == 0, b.stderr[-2000:]
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])["result"]
+    assert ja["collective"]["matches_local_sums"] is True and ja["config"]["modset_entries"] == jb["modset_entries"]
+    assert abs(ja["value"] / jb["value"] - 1) < 0.03, (ja["value"], jb["value"], ja["single_gpu_block_gbps"])
 
 
 def _gpu_count():
@@ -371,11 +416,12 @@ def test_bench_on_every_gpu_of_the_box(n):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    j, full, lines = bench_lines(r.stdout)
+    assert len(lines[-1]) < 8192 and j["roofline"]["frac"] > 0
     assert j["n_gpus"] == n and j["scaling"] == "weak"
     assert j["collective"]["matches_local_sums"] is True and j["per_rank_parity"] is True
     assert j["value"] >= 0.8 * n * j["single_gpu_block_gbps"], (j["value"], j["single_gpu_block_gbps"])
-    c3 = j["other_configs"]["c3_sharded"]
+    c3 = full["other_configs"]["c3_sharded"]
     assert "error" not in c3 and c3["n_gpus"] == n and c3["value"] > 0
     # the same from C: examples/multi_gpu.c (one process, a host thread per GPU, mgCommInitAll / mgHistogramAllReduce /
     # mgModsetMergeRankOrder on librccl): the all-reduced histogram is the sum of the GPUs' own, and the per-GPU sets merged in rank

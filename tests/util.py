@@ -77,3 +77,12 @@ def oracle_scan_batch(hasher, bases, offs):
 
 MODUTILS_TAGS = {"k21d64": (20, 21, 64, 17), "k31d4": (22, 31, 4, 17), "k19d31": (20, 19, 31, 17)}
 MODMAP_TAGS = {"k21d64": (21, 64), "k15d8": (15, 8), "k19d31": (19, 31)}
+
+
+def bench_lines(stdout):
+    """bench.py's stdout -> (the driver's line, the whole result): the LAST line is the compact one the driver parses,
+    an earlier `BENCH_DETAIL {...}` line carries everything"""
+    lines = stdout.splitlines()
+    compact = [l for l in lines if l.startswith("{")]
+    detail = [l for l in lines if l.startswith("BENCH_DETAIL ")]
+    return (json.loads(compact[-1]) if compact else None, json.loads(detail[-1][len("BENCH_DETAIL "):]) if detail else None, compact)
