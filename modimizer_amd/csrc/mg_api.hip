@@ -637,8 +637,11 @@ extern "C" MgStatus mgModsetClear (Modset *ms, void *stream)
 static MgStatus mgAddBatch (Modset *ms, MgDev *d, const U64 *dKmer, U64 n, U32 *dIndexOut, int withDepth,
                             bool arenaLive, hipStream_t st, const MgHistReq *counted = 0, const MgSegSrc *segSrc = 0);
 
-/* fold the pending device counts into baseDepth (afterwards baseDepth[i] IS depth[i]) */
-static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
+/* fold the pending device counts into baseDepth (afterwards baseDepth[i] IS depth[i]).  The callers that go on to REWRITE the host's depth[]
+   wholesale from baseDepth (merge, prune) pass no `host`; one that leaves the host arrays alone (mgHookDeviceView) passes the Modset, and
+   the pending counts reach its depth[] as modsetSyncToHost would have brought them -- the fold clears pendingDepth, so no later sync would
+   (a sender of a rank-order merge was left with stale host depths) */
+static MgStatus mgFoldCounts (MgDev *d, hipStream_t st, Modset *host = 0)
 {
   MgTable &t = d->t;
   if (!t.max) return MG_OK;
@@ -648,6 +651,7 @@ static MgStatus mgFoldCounts (MgDev *d, hipStream_t st)
   U16 *dDelta = (U16 *) d->arena.take ((size_t) t.max * sizeof (U16));
   s = mgTableExportDepth (&t, dDelta, st);
   MG_HIP (hipStreamSynchronize (st));
+  if (!s && host) s = mgXferD2H (host->depth + 1, dDelta, (size_t) t.max * sizeof (U16), MG_XFER_SATADD16);      /* modutils.c:26, `pending` times */
   return s;
 }
 
@@ -927,7 +931,7 @@ extern "C" int mgHookDeviceView (Modset *ms, const U64 **dValue1, const U16 **dD
   MgDev *d = mgDevLookup (ms);
   if (!d || !d->built || d->ticketsOut) return -1;
   { int cur = -1; if (hipGetDevice (&cur) != hipSuccess || cur != d->device) return -1; }      /* (a sender stages from the host then) */
-  if (hipDeviceSynchronize () != hipSuccess || mgFoldCounts (d, 0)) return -1;
+  if (hipDeviceSynchronize () != hipSuccess || mgFoldCounts (d, 0, ms)) return -1;
   *dValue1 = d->t.value + 1; *dDepth1 = d->t.baseDepth + 1; *max = d->t.max;
   return 0;
 }

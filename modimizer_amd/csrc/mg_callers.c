@@ -159,6 +159,13 @@ void mgReferenceFinish (MgReference *ref, U64 totLen, bool isAdd, FILE *out)
   fprintf (out, "  %d hashes from %d reference sequences, total length %lld\n", ref->max, ref->nSeq, (long long) totLen);
   const int timing = mgKnobs ()->seedTiming == 1;          /* dev */
   struct timespec f0, f1, f2, f3; clock_gettime (CLOCK_MONOTONIC, &f0);
+  { U32 again[3];
+    if (mgRefPackedTallies (ref, again))                  /* a further file that added nothing to a packed Reference (one that adds died in the append, modmap.c:111): */
+      { fprintf (out, "  %d copy 1, %d copy 2, %d multiple\n", again[0], again[1], again[2]);      /* the classes and the packed arrays are what they were */
+        if (isAdd) modsetPack (ms);
+        return;
+      }
+  }
   if (modsetSyncToHost (ms, 0)) fatal ("modsetSyncToHost");       /* value[] of the new entries */
   clock_gettime (CLOCK_MONOTONIC, &f1);
   const U32 n = ref->max ? ref->max : 1, m = ms->max + 1;

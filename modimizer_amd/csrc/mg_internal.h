@@ -57,6 +57,7 @@ MG_HIDDEN int  mgChainQueryDevice (const MgReference *ref, const U32 *dPacked, U
 MG_HIDDEN void mgChainForget (const MgReference *ref);
 /* the Reference built on the device (mg_refpack.hip): a batch's seeds appended (modmap.c:110-117), then copy classes + referencePack (modmap.c:125-129,74-91) into the caller's arrays */
 MG_HIDDEN MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U32 *dPosF, const U32 *dRid, U64 n, U32 idBase, U32 *appended);
+MG_HIDDEN int mgRefPackedTallies (MgReference *ref, U32 tallies[3]);      /* 1: packed on the device, nothing added since */
 MG_HIDDEN MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffset, U32 *hId, U32 *hDepth, U32 *hRev, U32 *hLoc, U8 *hInfo, U32 tallies[3]);
 MG_HIDDEN void *mgPinnedAlloc (size_t bytes);          /* page-locked host memory (0: none to be had) */
 MG_HIDDEN void mgPinnedFree (void *p);

@@ -120,7 +120,11 @@ __device__ __forceinline__ void mgMinStageTile (const MgMinLds &L, const U32 *__
   const U64 g0 = readStart + t0;
   const U64 w0 = g0 >> 4; const U32 odd = (U32) (g0 & 15);
   const U32 nW = (odd + span + (U32) p.k - 1 + 15) / 16 + 2;
-  for (U32 i = (U32) lane ; i < nW ; i += 64) L.words[i] = packed[w0 + i];      /* (the stream has MG_PACK_PAD words of slack behind it) */
+  /* ... but never past the read: the tile's span may reach up to TB bases beyond its last k-mer (all of them masked below), and the stream has
+     only MG_PACK_PAD words of slack behind its last base -- the two words a k-mer's extraction reads past its own are covered by that
+     (the unclamped load ran ~35 words past the end of the last read of a batch) */
+  const U64 wLast = ((readStart + nk + (U32) p.k - 2) >> 4) + 2;
+  for (U32 i = (U32) lane ; i < nW ; i += 64) L.words[i] = w0 + i <= wLast ? packed[w0 + i] : 0u;
   MG_MIN_WAVE_SYNC ();
   for (U32 i = (U32) lane ; i < span ; i += 64)
     { const U32 q = t0 + i;

@@ -130,13 +130,16 @@ static void readsetAddBatch (MgReadset *rs, U32 *dDepth, const char *bases, cons
 /* invBuild (modasm.c:258-287) and the file's depth[] (modasm.c:174): on the device (mg_refpack.hip: counts saturated, the lists a stable sort
    of the hits' read numbers by mod, a read's copy-class tallies a lane per read); a set of 2^32 hits or more takes the loops below */
 static void readsetFinishHost (MgReadset *rs);
-static void readsetFinish (MgReadset *rs)
+/* hitsBefore: rs->totHit when this file began.  A further file into a read set that holds hits already (modasm.c:158 zeroes depth[] per file
+   and invBuild then walks ALL hits with the last file's depths: undefined in the reference): the device counted this file's hits alone, so
+   depth[] and the lists are made from all the hits by the host loops, which agree with one another */
+static void readsetFinish (MgReadset *rs, U64 hitsBefore)
 {
   Modset *ms = rs->ms;
   free (rs->invStart); free (rs->invSpace); rs->invSpace = 0;
   rs->invStart = (U64 *) calloc ((size_t) ms->max + 2, sizeof (U64));
   mgHugeHint (rs->invStart, ((size_t) ms->max + 2) * sizeof (U64));
-  if (rs->totHit >= 0xfffffff0ull) { readsetFinishHost (rs); return; }
+  if (rs->totHit >= 0xfffffff0ull || hitsBefore) { mgReadsetDevForget (rs); readsetFinishHost (rs); return; }
   if (mgReadsetFinishDevice (rs, ms, ms->max, rs->hit, rs->totHit, rs->hitStart, (U32) rs->nReads, ms->info, ms->depth, rs->invStart, &rs->invSpace, (int *) rs->nCopy))
     fatal ("read set on the device");                  /* (the device table's depth copy was set there too) */
 }
@@ -173,11 +176,12 @@ static void readsetFinishHost (MgReadset *rs)
 int mgReadsetRead (MgReadset *rs, const char *bases, const int64_t *offsets, int nReads)
 {
   const int lapOn = mgKnobs ()->seedTiming == 1; double lap = lapOn ? rsNowMs () : 0;
+  const U64 hitsBefore = rs->totHit;
   U32 *dDepth = readsetBegin (rs);
   RS_LAP ("begin");
   readsetAddBatch (rs, dDepth, bases, offsets, nReads);
   lap = lapOn ? rsNowMs () : 0;
-  readsetFinish (rs);
+  readsetFinish (rs, hitsBefore);
   RS_LAP ("finish");
   return 0;
 }
@@ -191,6 +195,7 @@ static int rsHostBatch (MgSeqBatch *b, void *v)
 int mgReadsetFileRead (MgReadset *rs, const char *filename)       /* modasm.c:151-191 */
 {
   { FILE *f = fopen (filename, "rb"); if (!f) return -1; fclose (f); }
+  const U64 hitsBefore = rs->totHit;
   RsFileCtx c; c.rs = rs; c.dDepth = readsetBegin (rs);
   /* plain FASTA / FASTQ text: parsed on the device (mg_textgpu.hip), the batches never exist as host bytes; gzip, a last line without
      its newline, FASTQ that breaks a rule: the host parser, from the first record the device parser has not handed on */
@@ -198,12 +203,12 @@ int mgReadsetFileRead (MgReadset *rs, const char *filename)       /* modasm.c:15
   U64 nSeq = 0, totLen = 0, resumeOff = 0, resumeLine = 1;
   U64 batch = (U64) (kn->fileBatchMbp != MG_KNOB_UNSET && kn->fileBatchMbp > 0 ? kn->fileBatchMbp : 512) * 1000000;
   int rc = mgTextForEachBatchDevice (filename, rsDeviceBatch, &c, batch, 0, &nSeq, &totLen, &resumeOff, &resumeLine);
-  if (rc == -1) return -1;
   if (rc == -2) rc = mgSeqForEachBatchFrom (filename, 0, 1, 0, rsHostBatch, &c);
   else if (rc == -3) rc = mgSeqForEachBatchFrom (filename, (size_t) resumeOff, resumeLine, nSeq, rsHostBatch, &c);
-  if (rc) return rc;
-  readsetFinish (rs);
-  return 0;
+  /* a parser error after batches were appended: the reads that came are in rs (nReads, hit[] moved on), so depth[] / the inverse lists /
+     nCopy[] are still made for them and the file's device buffers released -- rs is never left half built; the error goes back */
+  readsetFinish (rs, hitsBefore);
+  return rc;
 }
 
 void mgReadsetStats (MgReadset *rs, FILE *out)                     /* modasm.c:193-253 */

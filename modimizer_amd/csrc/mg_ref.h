@@ -10,6 +10,7 @@ struct MgRefDev {
   U32 msMax = 0, refMax = 0;         /* what the arrays above were made for */
   int nSeq = 0;
   bool packed = false;               /* they are valid */
+  U32 tallies[3] = {0, 0, 0};        /* copy 1 / copy 2 / multiple of the packed reference (modmap.c:125-130): the report of a further file that adds nothing */
   /* while the reference is being read and packed (mg_refpack.hip): */
   U8 *info = 0; U32 *loc = 0, *rev = 0, *id = 0;
   U32 *index = 0, *depth = 0;        /* per occurrence: modset index; per modset index: occurrences */

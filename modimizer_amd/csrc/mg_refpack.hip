@@ -361,12 +361,26 @@ extern "C" MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U3
   *appended = 0;
   std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
   MgRefDev &d = mgRefEntry (ref);
-  if (d.packed) { mgSetError ("the reference is packed already"); return MG_ERR_ARG; }
+  hipStream_t st = 0;
+  if (d.packed)
+    { /* a further file read into a packed Reference: referencePack left size == max (modmap.c:80), so the reference dies on the FIRST seed
+         that has an index (modmap.c:111) and otherwise goes on, adds nothing and reports again */
+      if (!n) return MG_OK;
+      const U32 nT = (U32) ((n + MG_SCAN_TILE - 1) / MG_SCAN_TILE);
+      U32 *tl = 0, cnt = 0;
+      MG_HIP (hipMalloc ((void **) &tl, ((size_t) nT + 2) * 4));
+      hipLaunchKernelGGL (mgRefCountHitsKernel, dim3 (nT), dim3 (256), 0, st, dIx, n, tl);
+      hipLaunchKernelGGL (mgRefScanSmallKernel, dim3 (1), dim3 (1024), 0, st, tl, nT);
+      const bool bad = hipMemcpyAsync (&cnt, tl + nT, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize (st) != hipSuccess;
+      (void) hipFree (tl);
+      if (bad) return mgHipFail (hipGetLastError (), "reference append");
+      if (cnt) { mgSetError ("reference size overflow"); return MG_ERR_CAPACITY; }
+      return MG_OK;
+    }
   { int cur = 0; MG_HIP (hipGetDevice (&cur));
     if (d.device >= 0 && d.device != cur && d.depth) { mgSetError ("this Reference is being built on GPU %d, the calling thread is on GPU %d", d.device, cur); return MG_ERR_ARG; }
     d.device = cur;
   }
-  hipStream_t st = 0;
   const size_t msCap = ref->ms->size;
   if (!d.depth)
     { MG_HIP (hipMalloc ((void **) &d.depth, (msCap + 1) * 4));
@@ -402,6 +416,16 @@ extern "C" MgStatus mgRefBuildAppend (MgReference *ref, const U32 *dIx, const U3
   } while (0);
   (void) hipFree (tiles);
   return s;
+}
+
+/* 1 (and the tallies of its copy classes) if ref is packed on the device and nothing came since: what a further mgReferenceFinish reports again */
+extern "C" int mgRefPackedTallies (MgReference *ref, U32 tallies[3])
+{
+  std::lock_guard<std::mutex> own (mgRefOwnLock (ref));
+  MgRefDev &d = mgRefEntry (ref);
+  if (!d.packed || d.refMax != ref->max || d.msMax != ref->ms->max) return 0;
+  tallies[0] = d.tallies[0]; tallies[1] = d.tallies[1]; tallies[2] = d.tallies[2];
+  return 1;
 }
 
 /* modmap.c:125-129 + 74-91.  The host arrays are the caller's, sized as referencePack sizes them: index / offset / id / rev
@@ -470,6 +494,7 @@ extern "C" MgStatus mgRefBuildFinish (MgReference *ref, U32 *hIndex, U32 *hOffse
     if ((s = mgRefDerive (d, msMax, n, st))) break;
     MG_LAP ("derive");
     d.msMax = msMax; d.refMax = n; d.packed = true;
+    d.tallies[0] = tallies[0]; d.tallies[1] = tallies[1]; d.tallies[2] = tallies[2];
     s = MG_OK;
   } while (0);
   (void) hipFree (tiles); (void) hipFree (dTal);

@@ -216,10 +216,33 @@ extern "C" MgStatus mgCopyH2DBig (void *devDst, const void *hostSrc, size_t byte
  * zero, and READING them maps the shared zero page -- after which the first write to each (the mirror coming back) is a copy-on-write
  * fault per 4 KiB instead of a fresh huge page (ms->info of a new Modset, calloc ()ed by modsetCreate: 47 MB came back at 4 GB/s).
  * /proc/self/pagemap says which pages exist (present or swapped); only those are read and sent, the rest of the device array is
- * cleared.  Only for arrays the library allocated itself (anonymous memory); anything odd falls back to the plain copy. */
+ * cleared.  Only for private anonymous memory (checked: mgRangeIsPrivateAnon); anything else takes the plain copy. */
+/* [a, a + bytes) lies entirely in private anonymous mappings (/proc/self/maps: perms "..p", inode 0) -- what malloc () / calloc () hand out.
+   Only there does "neither present nor swapped" mean "never written, reads as zero": a file-backed or shared mapping a caller put in the
+   place of a transparent struct's array (ms->info is the caller's to replace, modset.h:17-28) has non-resident pages with contents */
+static bool mgRangeIsPrivateAnon (size_t a, size_t bytes)
+{
+  FILE *f = fopen ("/proc/self/maps", "r");
+  if (!f) return false;
+  char line[512];
+  size_t at = a; const size_t end = a + bytes;
+  bool ok = true;
+  while (ok && at < end && fgets (line, sizeof line, f))
+    { unsigned long lo, hi, off, ino; char perms[8]; unsigned maj, mnr;
+      if (sscanf (line, "%lx-%lx %7s %lx %x:%x %lu", &lo, &hi, perms, &off, &maj, &mnr, &ino) != 7) continue;
+      if (hi <= at) continue;
+      if (lo > at) { ok = false; break; }                  /* a hole (the list is sorted by address) */
+      if (perms[3] != 'p' || ino != 0) { ok = false; break; }
+      at = hi;
+    }
+  fclose (f);
+  return ok && at >= end;
+}
+
 MgStatus mgXferH2DSparse (void *devDst, const void *hostSrc, size_t bytes)
 {
   if (bytes < ((size_t) 4 << 20)) return mgXferH2D (devDst, hostSrc, bytes);
+  if (!mgRangeIsPrivateAnon ((size_t) hostSrc, bytes)) return mgXferH2D (devDst, hostSrc, bytes);
   const size_t pg = (size_t) sysconf (_SC_PAGESIZE);
   const size_t a0 = (size_t) hostSrc, firstPage = a0 / pg, lastPage = (a0 + bytes - 1) / pg, nPages = lastPage - firstPage + 1;
   U64 *ent = (U64 *) malloc (nPages * 8);

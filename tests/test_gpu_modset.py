@@ -635,6 +635,33 @@ def test_rank_order_merge_from_device_arrays():
 
 
 @pytest.mark.gpu
+def test_sender_of_a_rank_order_merge_keeps_its_host_depths():
+    """what a non-root rank of mgModsetMergeRankOrder does to its own set (mg_comm.hip -> mgHookDeviceView: the pending device
+    counts folded so that value[] / depth[] can leave from the device table) must leave the caller's depth[] what a sync would have made
+    it -- "the other ranks' sets are left as they are" -- although the fold clears the pending flag.  Counts added afterwards still land."""
+    L = mg.lib()
+    k, w, bits = 21, 64, 22
+    sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
+    b1 = synth_batch(900_000, 60_000, 21)
+    b2 = synth_batch(300_000, 60_000, 21, err=0.05)
+    ms = mg.modsetCreate(sh, bits)
+    mg.add_sequence_batch(ms, *b1)                                # counted on the device, never synced: the usual state before a merge
+    dv, dd, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+    assert L.mgHookDeviceView(ms, C.byref(dv), C.byref(dd), C.byref(n)) == 0 and n.value == ms.contents.max
+    oms, _ = oracle_build(oh, bits, [b1])
+    dev_depth = np.empty(n.value, np.uint16)
+    mg.check(L.mgMemcpyD2H(dev_depth.ctypes.data, dd, dev_depth.nbytes, None))
+    assert np.array_equal(dev_depth, oms.depths()[1:])           # what the sender ships
+    mg.check(L.modsetSyncToHost(ms, 1))
+    assert_same_modset(ms, oms, bits)                             # ... and what it keeps
+    mg.add_sequence_batch(ms, *b2)
+    oms2, _ = oracle_build(oh, bits, [b1, b2])
+    mg.check(L.modsetSyncToHost(ms, 1))
+    assert_same_modset(ms, oms2, bits)
+    L.modsetDestroy(ms)
+
+
+@pytest.mark.gpu
 def test_modmap_query_host_chain_path(golden_dir, tmp_path):
     """the path taken when a read has more blocks than the device chaining keeps (seed lists chained on the
     host): same lines.  Forced through MODGPU_QUERY_HOST_CHAIN=1 in a fresh process."""
