@@ -524,6 +524,7 @@ static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
   t.wantR = 4096;                                      /* 64 KiB of LDS per bucket, 1024-thread workgroups (measured best) */
   { const long r = mgKnobs ()->bucketR; if (r != MG_KNOB_UNSET && r >= 256) t.wantR = (U32) r; }     /* test knob */
   t.size = ms->size;
+  t.pin = d->hPin + 24;                                /* (hPin: 32 words; 0-1 the add's counters, 8-23 the scans' counts) */
   U64 cap = (ms->tableSize >> 2);                      /* device arrays cover the largest legal size */
   MG_HIP (hipMalloc ((void **) &t.value, cap * sizeof (U64)));
   MG_HIP (hipMalloc ((void **) &t.baseDepth, cap * sizeof (U16)));

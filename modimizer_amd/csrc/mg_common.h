@@ -105,7 +105,9 @@ __device__ __forceinline__ U32 mgWaveInclusiveSum (U32 v)
  * the table stores the mixed value itself (+1) as the key: being a bijection it identifies the k-mer, and a k-mer's
  * bucket digits are a prefix of its key -- which lets the partition passes drop the digits a bin already implies and
  * carry the first-occurrence ordinal in the freed bits of one 8-byte element (see mg_table.hip). */
-struct MgGeom { U32 R, rMask; int log2NB; int kbits; };      /* kbits = 2k */
+struct MgGeom { U32 R; int log2NB; int kbits; };      /* kbits = 2k.  NB = 2^log2NB is a power of two (the partition passes and the scan's digit
+                                                          counts read the bucket id's top bits); R, the slots of a bucket, is ANY number (a multiple
+                                                          of 64): the table is sized by its entries, not to the next power of two (round 6) */
 __device__ __forceinline__ U64 mgMixBits (U64 x, int b)        /* murmur-style bijection of b-bit values */
 {
   if (b <= 32)                                                  /* the same function in 32-bit arithmetic: modulo 2^b only the multipliers' low words count */
@@ -157,9 +159,14 @@ __device__ __forceinline__ U32 mgBucketOfM (U64 m, const MgGeom &g)
    differ there) */
 __device__ __forceinline__ U32 mgHomeOfM (U64 m, const MgGeom &g)
 {
-  if (g.kbits < 24) return (U32) m & g.rMask;
-  return ((U32) m ^ ((U32) (m >> (g.kbits - MG_MIX_TOP)) * 0x9E5u)) & g.rMask;
+  /* R is no power of two: the home is the high part of hash x R (a multiply-high instead of a mask), so the hash's TOP bits count --
+     one more multiply spreads the low word's bits there (a bucket's k-mers share the bits of the bucket id that fall into that word) */
+  U32 x = (U32) m;
+  if (g.kbits >= 24) x ^= (U32) (m >> (g.kbits - MG_MIX_TOP)) * 0x9E5u;
+  return __umulhi (x * 0x85EBCA6Bu, g.R);
 }
+/* the next slot of a probe sequence: linear, wrapping inside the bucket */
+__device__ __forceinline__ U32 mgNextSlot (U32 at, U32 R) { return at + 1 == R ? 0u : at + 1; }
 #endif /* __HIPCC__ */
 
 /* The bucket id (log2NB bits) is split into a coarse digit (high bits, first partition pass) and a fine one. */
@@ -211,7 +218,9 @@ MgStatus mgLaunchMinimizers (const MgHashParams &p, U32 w, const U32 *dPacked, c
 /* device modset table: NB = 2^log2NB buckets of R slots; see mg_table.hip */
 struct MgSlot { U64 key; U32 ord; U32 cnt; };      /* 16 bytes; key = kmer+1, 0 = empty */
 struct MgTable {
-  MgSlot *slots; U64 nSlots;
+  MgSlot *slots; U64 nSlots;      /* nSlots = NB x R: what the table USES of its allocation */
+  U64 capSlots;        /* slots allocated (grow-only: the geometry changes inside it without a hipMalloc) */
+  U32 capNB;           /* entries of occ[] allocated */
   U32 R; int log2NB;
   int kbits;           /* 2k: width of the k-mers this table holds (and of its hash) */
   U32 *occ;            /* [NB] non-zero when the bucket may hold entries */
@@ -226,15 +235,19 @@ struct MgTable {
   U64 *counters;       /* device U64[8]: 0 = new entries of the last add, 1 = bucket overflow */
   bool pendingDepth;   /* an add with depth counting ran since the counts were last folded into baseDepth / the host's depth[] */
   bool dirty;          /* buckets with occ == 0 hold undefined bytes (never zeroed): see mgTableClean */
+  bool empty;          /* nothing has been put into the table since it was made or forgotten (every occ[] is zero): its geometry is free to change */
+  U64 *pin;            /* four page-locked host words for small read-backs in the middle of an add (mgDevBuild) */
   int newPct;          /* new entries per 100 modimizers in the last bucketed add (a hint for the next one: mg_table.hip, markDup) */
   int loadPct;         /* slots are provided for entries * 100 / loadPct (0: 60).  A set that is only being built and counted
                           (mgAddReadsDevice) takes 75: its size is set from the OCCURRENCES of a batch, an upper bound of
                           the new entries, and the bucket images are the largest stream of the build; before lookups the
                           table is brought back to 60 (a probe that misses walks to the next empty slot) */
   int  maxLog2Slots;   /* tableBits - 1: the size at which load <= 0.5 for the largest legal set */
-  U32  wantR;          /* preferred slots per bucket */
+  U32  wantR;          /* most slots per bucket (4096: 64 KiB of LDS); a table's R lies between half of it and it */
+  int  tightPct;       /* a set built by ONE bucketed add into an empty table is brought to this load once the dedup kernel has counted its
+                          entries (mgTableAdd; 0: MG_TIGHT_PCT_DEFAULT): the bucket images the merge kernel streams back hold entries, not air */
 };
-MgStatus mgTableAlloc (MgTable *t, int log2Slots, hipStream_t st);       /* (re)allocate slots/occ, empty table */
+MgStatus mgTableAlloc (MgTable *t, U64 slotsWanted, hipStream_t st);     /* geometry for that many slots (or a few more), empty table; allocates only when the capacity is short */
 MgStatus mgTableEnsure (MgTable *t, U64 nIncoming, hipStream_t st);      /* grow (rehash) so that max+nIncoming fits at load <= 0.6 */
 MgStatus mgTableClean (MgTable *t, hipStream_t st);                      /* zero the never-written buckets; dirty = false */
 void     mgTableForget (MgTable *t, hipStream_t st);                     /* all buckets empty again (no memset of the slots) */

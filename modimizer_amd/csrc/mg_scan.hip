@@ -711,7 +711,7 @@ void mgSegCompactKernel (const U64 *__restrict__ segKmer, const U32 *__restrict_
               if (outPosF) outPosF[dst + i] = pf[j];
               if (outRead) outRead[dst + i] = rd[j];
               if (histBins)
-                { MgGeom hg; hg.R = 0; hg.rMask = 0; hg.log2NB = histLog2NB; hg.kbits = histKbits;
+                { MgGeom hg; hg.R = 0; hg.log2NB = histLog2NB; hg.kbits = histKbits;
                   const U32 bucket = mgBucketOfM (mgMixK (km[j], histKbits), hg);
                   atomicAdd (&sH[(bucket >> histShift) & (histBins - 1)], 1u);
                 }

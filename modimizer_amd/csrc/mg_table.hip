@@ -41,6 +41,7 @@
 #include <type_traits>
 
 #define MG_ASSIGNED 0x80000000u
+#define MG_R_QUANTUM 64u              /* slots per bucket come in multiples of this (a bucket starts on a 1 KiB boundary) */
 /* -DMG_BUILD_PRIO: the build's kernels raise their waves' issue priority (s_setprio 3).  An experiment of round 3 for running
  * them beside the instruction-bound scan of the next batch on a second stream ("scan || build"): with it the
  * co-run gains 9 % over no priority, but it still takes 93 % of the sum of the two (the build's kernels need the wave slots the
@@ -82,7 +83,7 @@ __global__ void mgTableInsertKernel (MgSlot *__restrict__ slots, MgGeom g, const
               if (cur == 0) cur = key;
             }
           if (cur == key) { ok = true; break; }
-          at = (at + 1) & g.rMask;
+          at = mgNextSlot (at, g.R);
         }
       if (!ok) { counters[1] = 1; slotId[o] = 0xffffffffu; continue; }
       const U64 s = base + at;
@@ -339,7 +340,7 @@ void mgTableFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict_
           for (U32 probes = 1 ; live[j] && cur != 0 ; ++probes)
             { if (cur == key[j]) { res[j] = mgIsAssigned (ord) ? (ord & ~MG_ASSIGNED) : 0; break; }
               if (probes >= g.R) break;
-              at[j] = (at[j] + 1) & g.rMask;
+              at[j] = mgNextSlot (at[j], g.R);
               const uint4 w = *reinterpret_cast<const uint4 *> (&slots[base[j] + at[j]]);
               cur = ((U64) w.y << 32) | w.x; ord = w.z;
             }
@@ -376,7 +377,7 @@ void mgTableFindSegKernel (const MgSlot *__restrict__ slots, MgGeom g, const MgS
           const U64 cur64 = ((U64) w.y << 32) | w.x;
           if (cur64 == key) { res = mgIsAssigned (w.z) ? (w.z & ~MG_ASSIGNED) : 0; break; }
           if (cur64 == 0) break;
-          slot = (slot + 1) & g.rMask;
+          slot = mgNextSlot (slot, g.R);
         }
       __builtin_nontemporal_store (res, &out[o]);
     }
@@ -401,7 +402,7 @@ __global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, MgGeom g, const U
               if (cur == 0) { placed = true; break; }
             }
           if (cur == key) { dup = true; break; }     /* duplicate value in the host arrays: keep the first */
-          at = (at + 1) & g.rMask;
+          at = mgNextSlot (at, g.R);
         }
       if (placed) { slots[base + at].ord = (U32) i | MG_ASSIGNED; atomicAdd (&occ[b], 1u); }
       else if (!dup) counters[1] = 1;
@@ -411,30 +412,32 @@ __global__ void mgTableLoadKernel (MgSlot *__restrict__ slots, MgGeom g, const U
 /* ======================================================================================== */
 /* whole-table streaming passes (export / histogram)                                          */
 
-/* pending depth counts -> delta16[idx-1], folded into baseDepth, cnt zeroed */
-__global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, U64 nSlots, const U32 *__restrict__ occ, int log2R,
+/* pending depth counts -> delta16[idx-1], folded into baseDepth, cnt zeroed.  A workgroup takes whole buckets (R is no power of two:
+   one occupancy test per bucket instead of a division per slot) */
+__global__ void mgTableExportDepthKernel (MgSlot *__restrict__ slots, U32 nBuckets, const U32 *__restrict__ occ, U32 R,
                                           U16 *__restrict__ baseDepth, U16 *__restrict__ delta, U32 max)
 {
-  U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
-  const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; s < nSlots ; s += stride)
-    { if (!occ[s >> log2R]) continue;
-      uint4 v = *reinterpret_cast<const uint4 *> (&slots[s]);
-      if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
-      U32 idx = v.z & ~MG_ASSIGNED, c = v.w;
-      if (idx > max) continue;
-      U32 cl = c > 0xffffu ? 0xffffu : c;
-      delta[idx - 1] = (U16) cl;
-      U32 b = (U32) baseDepth[idx] + cl;
-      baseDepth[idx] = (U16) (b > 0xffffu ? 0xffffu : b);
-      if (c) slots[s].cnt = 0;
+  for (U32 bk = blockIdx.x ; bk < nBuckets ; bk += gridDim.x)
+    { if (!occ[bk]) continue;
+      MgSlot *base = slots + (U64) bk * R;
+      for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
+        { uint4 v = *reinterpret_cast<const uint4 *> (&base[i]);
+          if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
+          U32 idx = v.z & ~MG_ASSIGNED, c = v.w;
+          if (idx > max) continue;
+          U32 cl = c > 0xffffu ? 0xffffu : c;
+          delta[idx - 1] = (U16) cl;
+          U32 b = (U32) baseDepth[idx] + cl;
+          baseDepth[idx] = (U16) (b > 0xffffu ? 0xffffu : b);
+          if (c) base[i].cnt = 0;
+        }
     }
 }
 
 /* K5: histogram of min(65535, baseDepth + pending) over all entries (modutils.c:53-63) */
 #define MG_HIST_LDS_BINS 8192
 __global__ __launch_bounds__ (256)
-void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U32 *__restrict__ occ, int log2R,
+void mgTableHistKernel (const MgSlot *__restrict__ slots, U32 nBuckets, const U32 *__restrict__ occ, U32 R,
                         const U16 *__restrict__ baseDepth, unsigned long long *__restrict__ hist)
 {
   __shared__ U32 sBins[MG_HIST_LDS_BINS];
@@ -443,12 +446,11 @@ void mgTableHistKernel (const MgSlot *__restrict__ slots, U64 nSlots, const U32 
   /* a workgroup takes whole buckets (one occupancy test per bucket) and keeps four 16-byte loads per lane in
      flight; whole waves run every step, so the two commonest bins (depth 1 and 2: sequencing errors) are counted
      per wave with ballots instead of 64 colliding LDS atomics */
-  const U32 R = 1u << log2R, nBuckets = (U32) (nSlots >> log2R);
   const int lane = threadIdx.x & 63;
   U32 n1 = 0, n2 = 0;
   for (U32 bk = blockIdx.x ; bk < nBuckets ; bk += gridDim.x)
     { if (!occ[bk]) continue;
-      const MgSlot *base = slots + ((U64) bk << log2R);
+      const MgSlot *base = slots + (U64) bk * R;
       for (U32 i0 = 0 ; i0 < R ; i0 += 4 * blockDim.x)
         { uint4 v[4];
 #pragma unroll
@@ -906,7 +908,7 @@ struct MgBucketArgs {
 extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
 
 /* find-or-claim the LDS slot of key; returns R on overflow */
-__device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 rMask, U32 home, unsigned long long key)
+__device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 home, unsigned long long key)
 {
   U32 at = home;
   for (U32 probes = 0 ; probes < R ; ++probes)
@@ -916,7 +918,7 @@ __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 
           if (cur == 0) cur = key;
         }
       if (cur == key) return at;
-      at = (at + 1) & rMask;
+      at = mgNextSlot (at, R);
     }
   return R;
 }
@@ -1030,7 +1032,7 @@ __device__ __forceinline__ void mgDedupRun (const MgBucketArgs &a, U32 b, unsign
       bool done = false;
       if (first && __ballot (!same) == 0 MG_ABLATE_AND (!(a.debug & 6)))                     /* (uniform) */
         { U64 m; U32 o0; mgOccurrence<PACKED> (a, b, x0, tx0, &m, &o0);
-          const U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);          /* (every lane claims the same slot with the same key) */
+          const U32 at = mgLdsClaim (sKey, R, mgHomeOfM (m, a.g), m + 1);          /* (every lane claims the same slot with the same key) */
           if (at < R)
             { U32 tok[MG_HOT_DEPTH], tmax = 0, cnt = 0;
 #pragma unroll
@@ -1065,7 +1067,7 @@ __device__ __forceinline__ void mgDedupRun (const MgBucketArgs &a, U32 b, unsign
 #ifdef MG_ABLATE
                   if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
 #endif
-                  at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+                  at = mgLdsClaim (sKey, R, mgHomeOfM (m, a.g), m + 1);
                   if (at == R) a.counters[1] = 1;
                 }
 #ifdef MG_ABLATE
@@ -1161,7 +1163,7 @@ __device__ __forceinline__ void mgDedupHotBucket (const MgBucketArgs &a, U32 b, 
           if (live)
             { U64 m; U32 ord;
               mgOccurrence<PACKED> (a, b, a.pK[i], PACKED ? 0u : a.pT[i], &m, &ord);
-              const U32 at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+              const U32 at = mgLdsClaim (sKey, R, mgHomeOfM (m, a.g), m + 1);
               if (at == R) a.counters[1] = 1;
               else
                 { const U32 tok = mgToken (ord);
@@ -1246,7 +1248,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #ifdef MG_ABLATE
                 if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
 #endif
-                at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (m, a.g), m + 1);
+                at = mgLdsClaim (sKey, R, mgHomeOfM (m, a.g), m + 1);
                 if (at == R) a.counters[1] = 1;
 #ifdef MG_ABLATE
                 else if (a.debug & 2) { sOrd[at] = mgToken (ord); sCnt[at] = 1; }
@@ -1380,7 +1382,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #ifdef MG_ABLATE
               if (a.debug & 32) { at = mgHomeOfM (km, a.g); sKey[at] = km + 1; } else
 #endif
-              at = mgLdsClaim (sKey, R, a.g.rMask, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
+              at = mgLdsClaim (sKey, R, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
               if (at == R) { a.counters[1] = 1; continue; }
               if (i < nNew) { sOrd[at] = ord; sCnt[at] = c; }
               else if (c) atomicAdd (&sCnt[at], c);
@@ -1508,7 +1510,7 @@ void mgBinFindKernel (const MgSlot *__restrict__ slots, MgGeom g, MgPartFmt f, U
               const U64 cur64 = ((U64) w.y << 32) | w.x;
               if (cur64 == key) { res = mgIsAssigned (w.z) ? (w.z & ~MG_ASSIGNED) : 0; break; }
               if (cur64 == 0) break;
-              slot = (slot + 1) & g.rMask;
+              slot = mgNextSlot (slot, g.R);
             }
           __builtin_nontemporal_store (((x & ordMask) << 32) | res, &el[i]);
         }
@@ -1577,7 +1579,7 @@ void mgBucketFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict
                 { const unsigned long long cur = sKey[slot];
                   if (cur == key) { res = sIdx[slot]; break; }
                   if (cur == 0) break;
-                  slot = (slot + 1) & g.rMask;
+                  slot = mgNextSlot (slot, g.R);
                 }
             }
           __builtin_nontemporal_store (((x & posMask) << 32) | res, &el[i]);
@@ -1653,7 +1655,7 @@ static inline unsigned mgGrid (U64 n, unsigned per = 256, unsigned cap = 16384)
 { U64 b = (n + per - 1) / per; if (b > cap) b = cap; if (b < 1) b = 1; return (unsigned) b; }
 static inline size_t mgAl (size_t n) { return (n + 255) & ~(size_t) 255; }
 static inline int mgLog2 (U64 x) { int l = 0; while (((U64) 1 << l) < x) ++l; return l; }
-static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.rMask = t->R - 1; g.log2NB = t->log2NB; g.kbits = t->kbits; return g; }
+static inline MgGeom mgGeomOf (const MgTable *t) { MgGeom g; g.R = t->R; g.log2NB = t->log2NB; g.kbits = t->kbits; return g; }
 
 #define MG_RANK_UNITS 8192           /* waves that share the ordered flag count */
 static inline U64 mgRankRowsPerUnit (U64 n, U32 *nBlocks)
@@ -1779,6 +1781,22 @@ static MgStatus mgPartPass (const MgTable *t, int inMode, bool packed, const MgP
   return MG_OK;
 }
 
+/* the dedup kernel's per-bucket counts of distinct k-mers: out[0] = their sum, out[1] = the largest (out[] zeroed by the launcher) */
+__global__ __launch_bounds__ (256)
+void mgUniqStatsKernel (const U32 *__restrict__ uniqCount, U32 nBuckets, unsigned long long *__restrict__ out)
+{
+  unsigned long long sum = 0; U32 mx = 0;
+  for (U32 b = blockIdx.x * 256 + threadIdx.x ; b < nBuckets ; b += gridDim.x * 256) { const U32 c = uniqCount[b]; sum += c; mx = c > mx ? c : mx; }
+  for (int off = 32 ; off ; off >>= 1)
+    { sum += ((unsigned long long) (U32) __shfl_xor ((int) (U32) (sum >> 32), off) << 32) | (U32) __shfl_xor ((int) (U32) sum, off);
+      const U32 o = (U32) __shfl_xor ((int) mx, off); mx = o > mx ? o : mx;
+    }
+  if ((threadIdx.x & 63) == 0) { if (sum) atomicAdd (&out[0], sum); if (mx) atomicMax (&out[1], (unsigned long long) mx); }
+}
+
+#define MG_TIGHT_PCT_DEFAULT 60      /* see MgTable.tightPct */
+#define MG_TIGHT_MIN_R 1024u         /* a bucket keeps room for the spread of a later add's share around its mean (mgTableEnsure sizes by the mean) */
+
 /* insert a batch (ordinal order = array order); counters[0] = number of new entries afterwards */
 MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *scratch, hipStream_t st,
                      const MgHistReq *counted, const MgSegSrc *segSrc)
@@ -1788,6 +1806,8 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   MgSegSrc noSrc; noSrc.segKmer = 0; noSrc.segCount = 0; noSrc.segStart = 0; noSrc.segCap = 0; noSrc.nSegs = 0;
   t->liveHistValid = false;                          /* set again below if this add is the set's only one */
   if (withDepth) t->pendingDepth = true;
+  const bool wasEmpty = t->empty && t->max == 0;
+  t->empty = false;
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
@@ -1876,6 +1896,15 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
     const bool dense = ((U64) t->max + expectNew) * 2 > t->nSlots;
     a.slotShift = (t->kbits <= MG_SLOT_SHIFT && (slotEnv >= 0 ? slotEnv != 0 : dense)) ? MG_SLOT_SHIFT : 0;
   }
+  /* An add into an EMPTY table (a set built from one batch: every step of the benchmarks, the first file of a run) does not know its
+     entries until the dedup kernel has counted them -- the table was sized from the batch's occurrences, an upper bound (1.5 x the entries
+     at config 2) -- and nothing is in the table yet, so its geometry is still free: after the dedup kernel R is brought down to what
+     the entries need at the tight load, and the merge kernel streams back that much less (round 6; before: 2^28 slots of 16 bytes at load
+     0.38 rewritten every step).  The dedup kernel's image is then not the merge kernel's: no slots carried over. */
+  int tightPct = t->tightPct ? t->tightPct : MG_TIGHT_PCT_DEFAULT;
+  { const long tk = mgKnobs ()->tightLoad; if (tk != MG_KNOB_UNSET && tk >= 0 && tk <= 95) tightPct = (int) tk; }
+  const bool tighten = wasEmpty && tightPct > 0 && t->log2NB > 0;
+  if (tighten) a.slotShift = 0;
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;
   a.grp = grp; a.baseMax = t->max; a.size = t->size; a.withDepth = withDepth;
@@ -1944,6 +1973,24 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   if (bigR) MG_DEDUP_PICK (MG_DEDUP_PER_BIG); else MG_DEDUP_PICK (MG_DEDUP_PER);
 #undef MG_DEDUP_PICK
 #undef MG_DEDUP_LAUNCH
+  if (tighten)
+    { unsigned long long *st2 = (unsigned long long *) (t->counters + 2);
+      MG_HIP (hipMemsetAsync (st2, 0, 16, st));
+      MG_LAUNCH (MG_K_RANK_SCAN, st, mgUniqStatsKernel, dim3 ((unsigned) (NB / 256 < 256 ? (NB + 255) / 256 : 256)), dim3 (256), 0, st, uniqCount, (U32) NB, st2);
+      MG_HIP (hipMemcpyAsync (t->pin, t->counters + 1, 24, hipMemcpyDeviceToHost, st));      /* overflow flag, entries, the fullest bucket's */
+      MG_HIP (hipStreamSynchronize (st));
+      const U64 over = t->pin[0], U = t->pin[1], M = t->pin[2];
+      if (!over)
+        { U64 Rn = (U * 100 / ((U64) NB * (U64) tightPct) + 1 + MG_R_QUANTUM - 1) / MG_R_QUANTUM * MG_R_QUANTUM;
+          const U64 Rfit = (M + M / 8 + 16 + MG_R_QUANTUM - 1) / MG_R_QUANTUM * MG_R_QUANTUM;      /* the fullest bucket at load 0.89 at most */
+          if (Rn < Rfit) Rn = Rfit;
+          if (Rn < MG_TIGHT_MIN_R) Rn = MG_TIGHT_MIN_R;
+          if (Rn < t->R)
+            { t->R = (U32) Rn; t->nSlots = (U64) NB * Rn; a.g = mgGeomOf (t);
+              lds = (size_t) t->R * 16 + 16 + MG_LIVE_BINS * 4;
+            }
+        }
+    }
   MG_LAUNCH (MG_K_RANK_COUNT, st, mgRankCountKernel, dim3 (nRankBlocks), dim3 (256), 0, st, flags, n, rankTiles, blockCount);
   MG_LAUNCH (MG_K_RANK_SCAN, st, mgRankScanKernel, dim3 (1), dim3 (1024), 0, st, blockCount, nRankBlocks * 4, blockBase, t->counters);
   if (segSrc)
@@ -2120,7 +2167,7 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st)
 {
   if (last < first) return MG_OK;
-  t->liveHistValid = false;
+  t->liveHistValid = false; t->empty = false;
   { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
   MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
              t->slots, mgGeomOf (t), dValue, first, last, t->occ, t->counters);
@@ -2135,8 +2182,10 @@ MgStatus mgTableExportDepth (MgTable *t, U16 *dDelta, hipStream_t st)
   t->baseZero = false;                                   /* the fold below writes baseDepth */
   t->pendingDepth = false;
   t->liveHistValid = false;
-  MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (mgGrid (t->nSlots, 256, 8192)), dim3 (256), 0, st,
-             t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseDepth, dDelta, t->max);
+  { const U32 NB = (U32) 1 << t->log2NB;
+    MG_LAUNCH (MG_K_TABLE_EXPORT, st, mgTableExportDepthKernel, dim3 (NB < 8192 ? NB : 8192), dim3 (256), 0, st,
+               t->slots, NB, t->occ, t->R, t->baseDepth, dDelta, t->max);
+  }
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -2153,8 +2202,10 @@ MgStatus mgTableHistogram (MgTable *t, U64 *dHist, hipStream_t st)
       MG_HIP (hipGetLastError ());
       return MG_OK;
     }
-  MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (mgGrid (t->nSlots, 256, 2048)), dim3 (256), 0, st,
-             t->slots, t->nSlots, t->occ, mgLog2 (t->R), t->baseZero ? (const U16 *) 0 : t->baseDepth, (unsigned long long *) dHist);
+  { const U32 NB = (U32) 1 << t->log2NB;
+    MG_LAUNCH (MG_K_TABLE_HIST, st, mgTableHistKernel, dim3 (NB < 2048 ? NB : 2048), dim3 (256), 0, st,
+               t->slots, NB, t->occ, t->R, t->baseZero ? (const U16 *) 0 : t->baseDepth, (unsigned long long *) dHist);
+  }
   MG_HIP (hipGetLastError ());
   return MG_OK;
 }
@@ -2187,50 +2238,64 @@ void mgCleanEmptyBucketsKernel (MgSlot *__restrict__ slots, MgGeom g, const U32 
     }
 }
 
-/* old table -> new (larger) table: every assigned entry is re-inserted with its index and count */
-__global__ void mgRehashKernel (const MgSlot *__restrict__ oldSlots, U64 oldN, const U32 *__restrict__ oldOcc, int oldLog2R,
+/* old table -> new table (another geometry): every assigned entry is re-inserted with its index and count */
+__global__ void mgRehashKernel (const MgSlot *__restrict__ oldSlots, U32 oldNB, const U32 *__restrict__ oldOcc, U32 oldR,
                                 MgSlot *__restrict__ slots, MgGeom g, U32 *__restrict__ occ, U64 *counters)
 {
-  U64 s = (U64) blockIdx.x * blockDim.x + threadIdx.x;
-  const U64 stride = (U64) gridDim.x * blockDim.x;
-  for ( ; s < oldN ; s += stride)
-    { if (!oldOcc[s >> oldLog2R]) continue;
-      uint4 v = *reinterpret_cast<const uint4 *> (&oldSlots[s]);
-      if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
-      const unsigned long long key = ((unsigned long long) v.y << 32) | v.x;
-      const U64 m = key - 1;                                  /* the key IS the mixed k-mer: no re-hash needed to re-place it */
-      const U32 b = mgBucketOfM (m, g);
-      const U64 base = (U64) b * g.R;
-      U32 at = mgHomeOfM (m, g);
-      bool placed = false;
-      for (U32 probes = 0 ; probes < g.R ; ++probes)
-        { if (slots[base + at].key == 0 && atomicCAS ((unsigned long long *) &slots[base + at].key, 0ull, key) == 0) { placed = true; break; }
-          at = (at + 1) & g.rMask;
+  for (U32 bk = blockIdx.x ; bk < oldNB ; bk += gridDim.x)
+    { if (!oldOcc[bk]) continue;
+      const MgSlot *from = oldSlots + (U64) bk * oldR;
+      for (U32 i = threadIdx.x ; i < oldR ; i += blockDim.x)
+        { uint4 v = *reinterpret_cast<const uint4 *> (&from[i]);
+          if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
+          const unsigned long long key = ((unsigned long long) v.y << 32) | v.x;
+          const U64 m = key - 1;                                  /* the key IS the mixed k-mer: no re-hash needed to re-place it */
+          const U32 b = mgBucketOfM (m, g);
+          const U64 base = (U64) b * g.R;
+          U32 at = mgHomeOfM (m, g);
+          bool placed = false;
+          for (U32 probes = 0 ; probes < g.R ; ++probes)
+            { if (slots[base + at].key == 0 && atomicCAS ((unsigned long long *) &slots[base + at].key, 0ull, key) == 0) { placed = true; break; }
+              at = mgNextSlot (at, g.R);
+            }
+          if (!placed) { counters[1] = 1; continue; }
+          slots[base + at].ord = v.z; slots[base + at].cnt = v.w;
+          if (!occ[b]) occ[b] = 1;
         }
-      if (!placed) { counters[1] = 1; continue; }
-      slots[base + at].ord = v.z; slots[base + at].cnt = v.w;
-      if (!occ[b]) occ[b] = 1;
     }
 }
 
-static void mgSetGeometry (MgTable *t, int log2Slots)
+/* Geometry for `want` slots: NB a power of two, R = want / NB rounded up to a multiple of 64, between half of wantR and wantR where the size
+   allows (R = 4096: a bucket's image is 64 KiB of LDS); at most 2^18 buckets (two 9-bit partition passes), R up to 8192 beyond that. */
+static void mgSetGeometry (MgTable *t, U64 want)
 {
-  t->nSlots = (U64) 1 << log2Slots;
-  U32 R = t->wantR ? t->wantR : 4096;
-  if (R > 8192) R = 8192;                        /* the dedup kernel's threads hold MG_DEDUP_PER (R <= 4096) or MG_DEDUP_PER_BIG slots each */
-  int lgR = mgLog2 (R); R = (U32) 1 << lgR;
-  if (lgR > log2Slots) { lgR = log2Slots; R = (U32) 1 << lgR; }
-  int lgNB = log2Slots - lgR;
-  while (lgNB > 18) { ++lgR; R <<= 1; --lgNB; }      /* at most 2^18 buckets (two 9-bit partition passes): R = 8192 for the 2^31 slots of table bits 32 */
-  t->R = R; t->log2NB = lgNB;
+  U32 Rmax = t->wantR ? t->wantR : 4096;
+  if (Rmax > 8192) Rmax = 8192;                   /* the dedup kernel's threads hold MG_DEDUP_PER (R <= 4096) or MG_DEDUP_PER_BIG slots each */
+  if (Rmax < MG_R_QUANTUM) Rmax = MG_R_QUANTUM;
+  if (want < MG_R_QUANTUM) want = MG_R_QUANTUM;
+  int lgNB = 0;
+  while (lgNB < 18 && (want + ((U64) 1 << lgNB) - 1) / ((U64) 1 << lgNB) > Rmax) ++lgNB;
+  U64 R = (want + ((U64) 1 << lgNB) - 1) >> lgNB;
+  R = (R + MG_R_QUANTUM - 1) / MG_R_QUANTUM * MG_R_QUANTUM;
+  if (R > 8192) R = 8192;
+  t->R = (U32) R; t->log2NB = lgNB; t->nSlots = R << lgNB;
 }
 
-MgStatus mgTableAlloc (MgTable *t, int log2Slots, hipStream_t st)
+/* an empty table of (at least) `want` slots; memory is only allocated when the capacity is short */
+MgStatus mgTableAlloc (MgTable *t, U64 want, hipStream_t st)
 {
-  if (t->slots) { MG_HIP (hipStreamSynchronize (st)); MG_HIP (hipFree (t->slots)); MG_HIP (hipFree (t->occ)); t->slots = 0; t->occ = 0; }
-  mgSetGeometry (t, log2Slots);
-  MG_HIP (hipMalloc ((void **) &t->slots, t->nSlots * sizeof (MgSlot)));
-  MG_HIP (hipMalloc ((void **) &t->occ, ((size_t) 1 << t->log2NB) * sizeof (U32)));
+  mgSetGeometry (t, want);
+  const U32 NB = (U32) 1 << t->log2NB;
+  if (!t->slots || t->nSlots > t->capSlots)
+    { if (t->slots) { MG_HIP (hipStreamSynchronize (st)); MG_HIP (hipFree (t->slots)); t->slots = 0; t->capSlots = 0; }
+      MG_HIP (hipMalloc ((void **) &t->slots, t->nSlots * sizeof (MgSlot)));
+      t->capSlots = t->nSlots;
+    }
+  if (!t->occ || NB > t->capNB)
+    { if (t->occ) { MG_HIP (hipStreamSynchronize (st)); MG_HIP (hipFree (t->occ)); t->occ = 0; t->capNB = 0; }
+      MG_HIP (hipMalloc ((void **) &t->occ, (size_t) NB * sizeof (U32)));
+      t->capNB = NB;
+    }
   mgTableForget (t, st);
   return MG_OK;
 }
@@ -2240,6 +2305,7 @@ void mgTableForget (MgTable *t, hipStream_t st)
   (void) hipMemsetAsync (t->occ, 0, ((size_t) 1 << t->log2NB) * sizeof (U32), st);
   t->dirty = true;               /* no memset of the slots: a bucket is defined once something wrote all of it */
   t->liveHistValid = false;
+  t->empty = true;
 }
 
 MgStatus mgTableClean (MgTable *t, hipStream_t st)
@@ -2252,35 +2318,44 @@ MgStatus mgTableClean (MgTable *t, hipStream_t st)
   return MG_OK;
 }
 
-/* slots needed so that `entries` fit at load <= 0.6 */
-static int mgLog2SlotsFor (const MgTable *t, U64 entries)
+/* slots needed so that `entries` fit at the table's load (0.6 unless the caller set loadPct); at most 2^maxLog2Slots */
+static U64 mgSlotsFor (const MgTable *t, U64 entries)
 {
   const long lk = mgKnobs ()->tableLoad;
   const int envPct = lk != MG_KNOB_UNSET && lk >= 10 && lk <= 150 ? (int) lk : 0;   /* dev knob (above 100: experiments only) */
   const int loadPct = envPct ? envPct : (t->loadPct ? t->loadPct : 60);
   U64 need = entries * 100 / (U64) loadPct + 1;      /* entries / 0.6 by default */
-  int lg = mgLog2 (need);
-  if (lg < 16) lg = 16;
-  if (lg > t->maxLog2Slots) lg = t->maxLog2Slots;
-  return lg;
+  if (need < ((U64) 1 << 16)) need = (U64) 1 << 16;
+  if (need > ((U64) 1 << t->maxLog2Slots)) need = (U64) 1 << t->maxLog2Slots;
+  return need;
+}
+
+/* the table in another geometry: the assigned entries re-placed (their keys are their hashes) */
+static MgStatus mgTableRehashTo (MgTable *t, U64 want, hipStream_t st)
+{
+  MgSlot *oldSlots = t->slots; U32 *oldOcc = t->occ; const U32 oldNB = (U32) 1 << t->log2NB, oldR = t->R;
+  t->slots = 0; t->occ = 0; t->capSlots = 0; t->capNB = 0;
+  MgStatus s = mgTableAlloc (t, want, st); if (s) return s;
+  if ((s = mgTableClean (t, st))) return s;
+  MG_LAUNCH (MG_K_TABLE_LOAD, st, mgRehashKernel, dim3 (oldNB < 8192 ? oldNB : 8192), dim3 (256), 0, st,
+             oldSlots, oldNB, oldOcc, oldR, t->slots, mgGeomOf (t), t->occ, t->counters);
+  MG_HIP (hipGetLastError ());
+  MG_HIP (hipStreamSynchronize (st));
+  MG_HIP (hipFree (oldSlots)); MG_HIP (hipFree (oldOcc));
+  t->empty = false;
+  return MG_OK;
 }
 
 MgStatus mgTableEnsure (MgTable *t, U64 nIncoming, hipStream_t st)
 {
-  int want = mgLog2SlotsFor (t, (U64) t->max + nIncoming);
-  if (t->slots && ((U64) 1 << want) <= t->nSlots) return MG_OK;
+  U64 want = mgSlotsFor (t, (U64) t->max + nIncoming);
+  if (t->slots && want <= t->nSlots) return MG_OK;
   if (!t->slots || !t->max) return mgTableAlloc (t, want, st);
-  /* grow: rehash the assigned entries into a fresh, zeroed table */
-  MgSlot *oldSlots = t->slots; U32 *oldOcc = t->occ; const U64 oldN = t->nSlots; const int oldLog2R = mgLog2 (t->R);
-  t->slots = 0; t->occ = 0;
-  MgStatus s = mgTableAlloc (t, want, st); if (s) return s;
-  if ((s = mgTableClean (t, st))) return s;
-  MG_LAUNCH (MG_K_TABLE_LOAD, st, mgRehashKernel, dim3 (mgGrid (oldN, 256, 8192)), dim3 (256), 0, st,
-             oldSlots, oldN, oldOcc, oldLog2R, t->slots, mgGeomOf (t), t->occ, t->counters);
-  MG_HIP (hipGetLastError ());
-  MG_HIP (hipStreamSynchronize (st));
-  MG_HIP (hipFree (oldSlots)); MG_HIP (hipFree (oldOcc));
-  return MG_OK;
+  /* grow: a table that takes adds grows by half at least (sized to the entry, every add would re-place everything) */
+  if (nIncoming && want < t->nSlots + t->nSlots / 2) want = t->nSlots + t->nSlots / 2;
+  if (want > ((U64) 1 << t->maxLog2Slots)) want = (U64) 1 << t->maxLog2Slots;
+  if (want <= t->nSlots) return MG_OK;
+  return mgTableRehashTo (t, want, st);
 }
 
 /* ======================================================================================== */
