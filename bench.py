@@ -655,6 +655,12 @@ def emit(out):
             json.dump(out, f, indent=1)
     except OSError:
         detail = None
+    if os.path.isdir(os.path.join(HERE, "gpurun_out")):      # (a gpurun call brings only gpurun_out/ back)
+        try:
+            with open(os.path.join(HERE, "gpurun_out", "bench_detail_last.json"), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
     print("BENCH_DETAIL " + json.dumps(out), flush=True)
     print(compact_line(out, detail), flush=True)
 

@@ -513,6 +513,10 @@ static void mgDevFree (MgDev *d)
   delete d;
 }
 
+/* the load a table is brought to before lookups (a probe that misses walks to the next empty slot, and a workgroup of the partitioned
+   lookups waits for its longest walk).  Rounds 1-5 asked for 60 and got 35-60: the slot count was rounded up to a power of two (config 3:
+   0.35).  With the slot count free the figure is the load: 60 cost config 3's bucket lookups 0.99 -> 1.41 ms; 40 is what they had. */
+#define MG_LOOKUP_LOAD_PCT 40
 static MgStatus mgDevBuild (Modset *ms, MgDev *d, hipStream_t st)
 {
   MgTable &t = d->t;
@@ -861,7 +865,7 @@ extern "C" MgStatus modsetFindBatchDevice (Modset *ms, const U64 *dKmer, U64 n, 
 {
   hipStream_t st = (hipStream_t) stream;
   MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
-  d->t.loadPct = 60;
+  d->t.loadPct = MG_LOOKUP_LOAD_PCT;
   if (d->t.slots && (s = mgTableEnsure (&d->t, 0, st))) return s;
   return mgTableFind (&d->t, dKmer, n, dIndexOut, st);
 }
@@ -1074,7 +1078,7 @@ static MgStatus mgSeedReads (Modset *ms, int mode, const U32 *dPacked, U64 total
   if (nSeeds) *nSeeds = 0;
   if (!totalBases || !nReads) return MG_OK;
   MgScanBufs b; U64 n = 0;
-  d->t.loadPct = 60;                                   /* lookups follow (or are this call): see MgTable.loadPct */
+  d->t.loadPct = MG_LOOKUP_LOAD_PCT;                                   /* lookups follow (or are this call): see MgTable.loadPct */
   if (mode == 0 && d->t.slots && (s = mgTableEnsure (&d->t, 0, st))) return s;
   const int timing = mgKnobs ()->seedTiming == 1;   /* dev */
   struct timespec q0, q1, q2; if (timing) clock_gettime (CLOCK_MONOTONIC, &q0);
@@ -1131,7 +1135,7 @@ extern "C" MgStatus mgQueryReadsDeviceAsync (Modset *ms, const U32 *dPacked, U64
   *ticket = 0;
   MgDev *d; MgStatus s = mgDevGet (ms, &d, st); if (s) return s;
   if (d->ticketsOut >= 2) { mgSetError ("two query batches are in flight already"); return MG_ERR_ARG; }
-  d->t.loadPct = 60;
+  d->t.loadPct = MG_LOOKUP_LOAD_PCT;
   if (d->t.slots && !d->ticketsOut && (s = mgTableEnsure (&d->t, 0, st))) return s;      /* (with a batch in flight the table has its lookup shape already) */
   if (!d->side)
     { /* lowest priority: the lookups are a chain of short kernels that should not queue behind the scan's workgroups; the scan fills what they leave */

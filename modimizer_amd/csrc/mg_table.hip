@@ -907,17 +907,30 @@ struct MgBucketArgs {
 
 extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
 
-/* find-or-claim the LDS slot of key; returns R on overflow */
+/* find-or-claim the LDS slot of key; returns R on overflow.  Linear probing: the slot is the first one of home, home + 1, ... (wrapping
+ * inside the bucket) that holds the key or is empty.  This loop is what both bucket kernels spend their time in -- a workgroup waits at
+ * its barrier for its LONGEST chain (8 links at load 0.38, 30 at 0.6, 80 at 0.75), every link a dependent LDS round trip -- and its code
+ * shape counts: the same loop written for several slots per step (profiles/r06_ab_table_geometry.txt) cost the dedup kernel 0.25 ms.
+ * MG_CLAIM_CAS_FIRST: the compare-and-swap IS the probe (one round trip where the slot is empty, not a read and then the swap). */
+#ifndef MG_CLAIM_CAS_FIRST
+#define MG_CLAIM_CAS_FIRST 1
+#endif
 __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 home, unsigned long long key)
 {
   U32 at = home;
   for (U32 probes = 0 ; probes < R ; ++probes)
-    { unsigned long long cur = sKey[at];
+    {
+#if MG_CLAIM_CAS_FIRST
+      const unsigned long long cur = atomicCAS (&sKey[at], 0ull, key);
+      if (cur == 0 || cur == key) return at;
+#else
+      unsigned long long cur = sKey[at];
       if (cur == 0)
         { cur = atomicCAS (&sKey[at], 0ull, key);
           if (cur == 0) cur = key;
         }
       if (cur == key) return at;
+#endif
       at = mgNextSlot (at, R);
     }
   return R;
@@ -1794,7 +1807,7 @@ void mgUniqStatsKernel (const U32 *__restrict__ uniqCount, U32 nBuckets, unsigne
   if ((threadIdx.x & 63) == 0) { if (sum) atomicAdd (&out[0], sum); if (mx) atomicMax (&out[1], (unsigned long long) mx); }
 }
 
-#define MG_TIGHT_PCT_DEFAULT 60      /* see MgTable.tightPct */
+#define MG_TIGHT_PCT_DEFAULT 50      /* see MgTable.tightPct */
 #define MG_TIGHT_MIN_R 1024u         /* a bucket keeps room for the spread of a later add's share around its mean (mgTableEnsure sizes by the mean) */
 
 /* insert a batch (ordinal order = array order); counters[0] = number of new entries afterwards */
@@ -1897,13 +1910,21 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
     a.slotShift = (t->kbits <= MG_SLOT_SHIFT && (slotEnv >= 0 ? slotEnv != 0 : dense)) ? MG_SLOT_SHIFT : 0;
   }
   /* An add into an EMPTY table (a set built from one batch: every step of the benchmarks, the first file of a run) does not know its
-     entries until the dedup kernel has counted them -- the table was sized from the batch's occurrences, an upper bound (1.5 x the entries
-     at config 2) -- and nothing is in the table yet, so its geometry is still free: after the dedup kernel R is brought down to what
-     the entries need at the tight load, and the merge kernel streams back that much less (round 6; before: 2^28 slots of 16 bytes at load
-     0.38 rewritten every step).  The dedup kernel's image is then not the merge kernel's: no slots carried over. */
+     entries until the dedup kernel has counted them -- the table was sized from the batch's occurrences, an upper bound -- and nothing is
+     in the table yet, so its geometry is still free: after the dedup kernel R can be brought down to what the entries need at the tight
+     load, and the merge kernel streams back that much less.  The price: the dedup kernel's image is then not the merge kernel's, so no
+     slots are carried over and the merge kernel claims its own -- and a workgroup waits for its LONGEST probe chain (8 links at load 0.38,
+     30 at 0.6, 80 at 0.75; profiles/r06_ab_table_geometry.txt: the merge kernel 1.07 / 1.20 / 1.44 / 2.5 ms at tight loads 50 / 60 / 70 / 80
+     per cent on config 2, against 0.65 ms with carried slots at load 0.77).  So the table is only tightened where that pays: when the share
+     of new k-mers the previous add saw (newPct; unknown: all new) says the entries will leave a quarter of the slots and more unused even at
+     the tight load -- reads of deep coverage with few errors (config 5: a sixth of the modimizers are new; 4.3 -> 1.07 GB of bucket images). */
   int tightPct = t->tightPct ? t->tightPct : MG_TIGHT_PCT_DEFAULT;
   { const long tk = mgKnobs ()->tightLoad; if (tk != MG_KNOB_UNSET && tk >= 0 && tk <= 95) tightPct = (int) tk; }
-  const bool tighten = wasEmpty && tightPct > 0 && t->log2NB > 0;
+  bool tighten = wasEmpty && tightPct > 0 && t->log2NB > 0;
+  if (tighten && mgKnobs ()->tightLoad == MG_KNOB_UNSET)          /* (the knob forces it: tests, sweeps) */
+    { const U64 expectNew = t->newPct > 0 ? n * (U64) t->newPct / 100 : n;
+      tighten = expectNew * 100 / (U64) tightPct < t->nSlots - t->nSlots / 4;
+    }
   if (tighten) a.slotShift = 0;
   a.slots = t->slots; a.g = g; a.nBuckets = (U32) NB; a.bucketStart = bucketStart;
   a.pK = kB; a.pT = tB; a.pC = cB; a.uniqCount = uniqCount; a.occ = t->occ; a.flags = flags;

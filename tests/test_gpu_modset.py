@@ -461,8 +461,8 @@ print("chunked ok", n)
 
 def test_table_regrown_before_lookups():
     """mgAddReadsDevice sizes the device table for occurrences / 0.75 (a set being built and counted); a lookup batch first
-    brings it to entries / 0.6 (rehash on the device).  Since round 6 the slot count is NB x R with R any multiple of 64, not the
-    next power of two: 90 000 distinct k-mers take 120 832 slots after the build (load 0.74), 151 552 after the first lookup;
+    brings it to entries / 0.4 (rehash on the device).  Since round 6 the slot count is NB x R with R any multiple of 64, not the
+    next power of two: 90 000 distinct k-mers take 120 832 slots after the build (load 0.74), 225 000 or so after the first lookup;
     indices, values and depths unchanged, found and absent k-mers answered as before"""
     L = mg.lib()
     k, w, bits = 21, 4, 22
@@ -483,7 +483,7 @@ def test_table_regrown_before_lookups():
     want = np.array([oms.find(int(x)) for x in q], np.uint32)
     assert np.array_equal(got, want)
     slots1 = L.mgModsetDeviceSlots(ms)
-    assert oms.max / 0.6 <= slots1 < oms.max / 0.6 * 1.04 and slots1 > slots0, (slots1, oms.max)
+    assert oms.max / 0.4 <= slots1 < oms.max / 0.4 * 1.04 and slots1 > slots0, (slots1, oms.max)
     b2 = rng.integers(0, 4, 50_000).astype(np.uint8)
     assert mg.add_sequence_batch(ms, b2, np.array([0, len(b2)], np.int64)) == oms.add_sequence(b2)
     assert_same_modset(ms, oms, bits)
