@@ -1466,8 +1466,9 @@ void mgRankLookupKernel (const MgBucketArgs a, U32 groupsPerSlice)
       return idx < a.size ? ((U32) idx | MG_ASSIGNED) : 0;
     };
   /* MG_LOOKUP_UNROLL lists per round, all their loads in flight together.  (Fetching the next round's ordinals under
-     this round's gathers, or 8 lists per round, changes nothing: the kernel runs at the rate the CU's address unit
-     takes scattered lanes, tools/ubench_rand.) */
+     this round's gathers, or 8 lists per round, changes nothing; nor does using every lane of every gather -- round 6: a wave's 64
+     lists flattened, 64 items per instruction instead of a list's 42, 0.935 against 0.897 ms, DESIGN_EXPERIMENTS.md §K: what counts is
+     the number of scattered LANES the memory path takes, 115 G/s here, not the number of instructions.) */
   for (int j = 0 ; j < 64 ; j += MG_LOOKUP_UNROLL)
     { U64 l[MG_LOOKUP_UNROLL]; U32 m[MG_LOOKUP_UNROLL], tok[MG_LOOKUP_UNROLL]; uint4 r[MG_LOOKUP_UNROLL];
 #pragma unroll
