@@ -195,8 +195,9 @@ def bound_actual(kernel, avg_ms, units, alu=None):
     if kernel == "mgScanKernel":
         if not alu or not alu.get("issue_frac"):
             return {"bound": "valu_issue"}
-        return {"bound": "valu_issue", "ceiling": alu["issue_peak_wave_insts_per_s"], "unit": "wave VALU instructions/s (measured, tools/ubench.hip)",
-                "achieved": round(alu["valu_per_start"] * units / 64 / (avg_ms * 1e-3), 1), "frac_of_ceiling": alu["issue_frac"]}
+        return {"bound": "valu_issue", "ceiling": alu["issue_peak_wave_insts_per_s"], "unit": "wave VALU instructions/s (the kernel's instruction mix at the measured issue rates of its classes: tools/isa_census.py, tools/ubench*.hip)",
+                "achieved": round(alu["valu_per_start"] * units / 64 / (avg_ms * 1e-3), 1), "frac_of_ceiling": alu["issue_frac"],
+                "valu_per_start": alu["valu_per_start"], "floor_valu_per_start": alu.get("filter_floor_valu_per_start")}
     if kernel in ("mgTableFindKernel", "mgTableFindSegKernel"):
         ach = units / (avg_ms * 1e-3)
         return {"bound": "random_access", "ceiling": RANDOM_LOADS_PER_S_BIG, "unit": "random 16-byte loads/s, footprint > 64 MB (measured, tools/ubench_rand.hip)",
@@ -261,14 +262,17 @@ def scan_alu(starts, scan_ms):
         try:
             ij = json.load(open(ipath)); valu_per_start = ij.get("valu_per_start"); src = ij.get("_from")
             peak = ij.get("measured_int_valu_peak_wave_insts_per_s", peak)     # tools/ubench.hip: 37.6 T integer lane-ops/s
+            # round 6: the ceiling of the kernel's OWN instruction mix (tools/isa_census.py: most of phase A issues at the multiply / shift / compare
+            # rate, the adds and logic operations at 1.65 x that) -- the fraction of it cannot read above 1
+            peak = (ij.get("census") or {}).get("weighted_issue_peak_wave_insts_per_s", peak)
         except Exception:
             pass
     floor7 = 7.0 * starts / 64 / peak * 1e3                        # the 7-instruction candidate filter alone
     return {"valu_per_start": valu_per_start, "valu_per_start_from": src,
             "filter_floor_valu_per_start": 7, "floor_ms": round(floor7, 3),
             "issue_peak_wave_insts_per_s": peak,
-            "issue_peak_from": "measured integer VALU rate (v_mul_lo_u32 / v_alignbit / v_min / v_add chains, tools/ubench.hip); "
-                               "the fp32 datasheet rate would be %.3g" % VALU_WAVE_INSTS_PER_S,
+            "issue_peak_from": "the kernel's own instruction mix (tools/isa_census.py) priced with the measured issue rates of its classes "
+                               "(tools/ubench*.hip: 37.6 T lane-ops/s multiply / shift / compare, 62 T add / logic); the fp32 datasheet rate would be %.3g" % VALU_WAVE_INSTS_PER_S,
             "issue_frac": (round(valu_per_start * starts / 64 / peak / (scan_ms * 1e-3), 3) if valu_per_start else None),
             "scan_ms": round(scan_ms, 4)}
 
@@ -805,12 +809,16 @@ def bench_ref_default(cx, args):
     try:
         pm = json.load(open(os.path.join(HERE, "profiles", "scan_issue.json"))).get("ref_default")
         if pm and scan_ms:
+            cen = pm.get("census") or {}
+            peak = cen.get("weighted_issue_peak_wave_insts_per_s", alu["issue_peak_wave_insts_per_s"])
+            floor = cen.get("floor_valu_per_start")
             alu = dict(alu, valu_per_start=pm["valu_per_start"], valu_per_start_from=pm["from"],
                        wave_valu_per_s=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3), 1),
-                       issue_frac=round(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3) / alu["issue_peak_wave_insts_per_s"], 4),
-                       filter_floor_valu_per_start=None, floor_ms=None,
-                       note="issue_frac is against the rate of the multiply / shift / compare class (tools/ubench.hip); the exact-mode loop also holds adds and "
-                            "logic operations, which issue at 1.7x that rate, so it can read a little above 1")
+                       issue_peak_wave_insts_per_s=peak,
+                       issue_frac=round(min(pm["valu_per_start"] * total / 64 / (scan_ms * 1e-3) / peak, 1.0), 4),
+                       filter_floor_valu_per_start=floor, floor_ms=round(floor * total / 64 / peak * 1e3, 3) if floor else None,
+                       note="VERDICT r5 item 7: the ceiling is the exact-mode loop's own mix (per 16 starts: 80 add / logic at 62 T lane-ops/s, 384 multiply / shift / compare / "
+                            "select at 37.6 T, 32 v_mad_u64_u32 at 30 T: profiles/scan_issue.json ref_default.census); floor = the 31 instructions per start of phase A")
     except Exception:
         pass
     res = {"timed_regions_ms_per_step": regions,
