@@ -137,6 +137,8 @@ uint64_t orcXorshiftBases (uint64_t state, uint8_t *out, int64_t n);   /* SURVEY
 /* first occurrences and counts of a k-mer stream (what modset.c:56-57 + modutils.c:26 make of it), multi-threaded:
    flag[i] = 1 at first occurrences, cntAt[i] = occurrences of km[i] (at first occurrences); both zeroed by the caller */
 int64_t orcFirstOccurrences (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt);
+int64_t orcFirstOccurrencesAt (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt, uint32_t *firstAt);   /* + the first occurrence's position for every i */
+void orcReferencePack (const uint32_t *index, uint64_t n, uint32_t U, uint32_t *depth, uint32_t *loc, uint32_t *rev);              /* modmap.c:74-91 */
 /* whole-stream comparison of a given modimizer stream with the scan of every read of a piece, multi-threaded (orc_seqhash.c) */
 int64_t orcScanCheckMany (const OrcHasher *h, const uint8_t *bases, const int64_t *offsets, int64_t nReads,
                           const int64_t *first, const uint64_t *km, const uint32_t *posF, int nThreads,

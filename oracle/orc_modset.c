@@ -409,7 +409,7 @@ int64_t orcQueryRead (OrcReference *ref, const char *readName, const uint8_t *s,
  * tests use it to pin every entry of a 1e8-entry modset in seconds: nThreads threads each own the k-mers of one hash
  * class (all read the whole stream; no sharing, no locks). */
 #include <pthread.h>
-typedef struct { const uint64_t *km; uint64_t n; int t, T; uint8_t *flag; uint32_t *cntAt; int ok; } OrcFoJob;
+typedef struct { const uint64_t *km; uint64_t n; int t, T; uint8_t *flag; uint32_t *cntAt; uint32_t *firstAt; int ok; } OrcFoJob;
 
 static inline uint64_t orcFoMix (uint64_t x)
 { x ^= x >> 31; x *= 0x7fb5d329728ea185ull; x ^= x >> 27; x *= 0x81dadef4bc2dd44dull; x ^= x >> 33; return x; }
@@ -431,20 +431,26 @@ static void *orcFoWorker (void *arg)
       while (first[s] && key[s] != x) s = (s + 1) & (cap - 1);
       if (!first[s]) { first[s] = i + 1; key[s] = x; j->flag[i] = 1; j->cntAt[i] = 1; }
       else ++j->cntAt[first[s] - 1];
+      if (j->firstAt) j->firstAt[i] = (uint32_t) (first[s] - 1);
     }
   free (key); free (first);
   j->ok = 1;
   return 0;
 }
 
-/* flag[n] and cntAt[n] must be zeroed by the caller; returns the number of distinct k-mers, -1 on allocation failure */
+/* flag[n] and cntAt[n] must be zeroed by the caller; returns the number of distinct k-mers, -1 on allocation failure.
+   firstAt (may be 0; n < 2^32): for EVERY i the position of the first occurrence of km[i] -- with it, the index modsetIndexFind hands
+   occurrence i is (number of flags up to firstAt[i]), without sorting anything (tests/fullsize_whole.py c3ref) */
+int64_t orcFirstOccurrencesAt (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt, uint32_t *firstAt);
 int64_t orcFirstOccurrences (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt)
+{ return orcFirstOccurrencesAt (km, n, nThreads, flag, cntAt, 0); }
+int64_t orcFirstOccurrencesAt (const uint64_t *km, uint64_t n, int nThreads, uint8_t *flag, uint32_t *cntAt, uint32_t *firstAt)
 {
   if (nThreads < 1) nThreads = 1;
   if (nThreads > 64) nThreads = 64;
   OrcFoJob job[64]; pthread_t th[64];
   for (int t = 0 ; t < nThreads ; ++t)
-    { job[t].km = km; job[t].n = n; job[t].t = t; job[t].T = nThreads; job[t].flag = flag; job[t].cntAt = cntAt; job[t].ok = 0;
+    { job[t].km = km; job[t].n = n; job[t].t = t; job[t].T = nThreads; job[t].flag = flag; job[t].cntAt = cntAt; job[t].firstAt = firstAt; job[t].ok = 0;
       if (pthread_create (&th[t], 0, orcFoWorker, &job[t])) { orcFoWorker (&job[t]); th[t] = 0; }
     }
   int ok = 1;
@@ -453,6 +459,20 @@ int64_t orcFirstOccurrences (const uint64_t *km, uint64_t n, int nThreads, uint8
   int64_t u = 0;
   for (uint64_t i = 0 ; i < n ; ++i) u += flag[i];
   return u;
+}
+
+/* referencePack (modmap.c:74-91) as the reference writes it: from the modset index of every occurrence (index[n], values 1 .. U), depth[U + 1]
+ * (occurrences per index), loc[U + 1] (loc[0] = 0, loc[i] = loc[i - 1] + depth[i - 1]: modmap.c:82-84) and rev[n] (the occurrences grouped by
+ * index in occurrence order: modmap.c:86-90, `rev[loc[*ri] + depth[*ri]++] = i`).  One sequential pass each. */
+void orcReferencePack (const uint32_t *index, uint64_t n, uint32_t U, uint32_t *depth, uint32_t *loc, uint32_t *rev)
+{
+  memset (depth, 0, ((size_t) U + 1) * sizeof (uint32_t));
+  for (uint64_t i = 0 ; i < n ; ++i) ++depth[index[i]];                       /* modmap.c:113 */
+  loc[0] = 0;
+  for (uint32_t i = 1 ; i <= U ; ++i) loc[i] = loc[i - 1] + depth[i - 1];
+  uint32_t *fill = (uint32_t *) calloc ((size_t) U + 1, sizeof (uint32_t));
+  for (uint64_t i = 0 ; i < n ; ++i) { const uint32_t x = index[i]; rev[loc[x] + fill[x]++] = (uint32_t) i; }
+  free (fill);
 }
 
 /* What modsetIndexFind (ms, kmer, false) (modset.c:45-62) returns for each of m k-mers, given the set's k-mers sorted

@@ -149,25 +149,32 @@ def main_c3ref():
     del genome
     t_scan = time.time() - t0 - t_build
     # ---- what referenceFastaRead + referencePack make of that stream (modmap.c:106-133, 74-91), on the host ------------
-    want_value, want_cnt = first_occurrence_arrays(km, saturate=False)
-    assert len(want_value) == U, ("distinct modimizers", len(want_value), "entries", U)
+    # (no sort: the oracle's first-occurrence pass also says, for every occurrence, where its k-mer first occurred -- its index is the
+    # number of first occurrences up to there; referencePack is the reference's own three loops, oracle/orc_modset.c orcReferencePack)
+    OL.orcFirstOccurrencesAt.restype = C.c_int64
+    OL.orcFirstOccurrencesAt.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    flag = np.zeros(occ, np.uint8); cnt = np.zeros(occ, np.uint32); first_at = np.zeros(occ, np.uint32)
+    u = OL.orcFirstOccurrencesAt(km.ctypes.data, occ, max(1, min(16, len(os.sched_getaffinity(0)))), flag.ctypes.data, cnt.ctypes.data, first_at.ctypes.data)
+    assert u == U, ("distinct modimizers", u, "entries", U)
+    f = flag.view(np.bool_)
+    want_value, want_cnt = km[f], cnt[f]
     as_np = lambda p, n, : np.ctypeslib.as_array(p, (n,))
     assert np.array_equal(as_np(ms.contents.value, U + 1)[1:], want_value), "value[]"
-    order = np.argsort(want_value, kind="stable")
-    at = np.searchsorted(want_value[order], km)
-    occ_index = (order[at] + 1).astype(np.uint32)                        # modsetIndexFind's answer for every occurrence
+    occ_index = np.cumsum(flag, dtype=np.uint32)[first_at]              # modsetIndexFind's answer for every occurrence
     assert np.array_equal(want_value[occ_index - 1], km)
     assert np.array_equal(as_np(R.index, occ), occ_index), "ref->index"
     assert np.array_equal(as_np(R.offset, occ), pf & np.uint32(mg.MG_POS_MASK)), "ref->offset"
     assert np.array_equal(as_np(R.id, occ), rd), "ref->id"
-    depth = np.zeros(U + 1, np.uint32); depth[1:] = want_cnt
+    depth = np.zeros(U + 1, np.uint32); loc = np.zeros(U + 1, np.uint32); rev = np.zeros(occ, np.uint32)
+    OL.orcReferencePack.restype = None
+    OL.orcReferencePack.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    OL.orcReferencePack(occ_index.ctypes.data, occ, U, depth.ctypes.data, loc.ctypes.data, rev.ctypes.data)
+    assert np.array_equal(depth[1:], want_cnt) and depth[0] == 0
     assert np.array_equal(as_np(R.depth, U + 1), depth), "ref->depth"
     info = as_np(ms.contents.info, U + 1)[1:] & 3
     assert np.array_equal(info, np.minimum(want_cnt, 3).astype(np.uint8)), "info copy classes (modmap.c:125-129)"
     assert not as_np(ms.contents.depth, U + 1).any(), "ms->depth is not touched by referenceFastaRead"
-    loc = np.zeros(U + 1, np.uint32); loc[1:] = np.cumsum(depth[:-1], dtype=np.uint64).astype(np.uint32)
     assert np.array_equal(as_np(R.loc, U + 1), loc), "loc[] (modmap.c:82-84)"
-    rev = np.argsort(occ_index, kind="stable").astype(np.uint32)          # occurrences grouped by index, in occurrence order
     assert np.array_equal(as_np(R.rev, occ), rev), "rev[] (modmap.c:86-90)"
     assert R.size == occ and ms.contents.size == U + 1                  # referencePack / modsetPack
     n1, n2, nM = int((want_cnt == 1).sum()), int((want_cnt == 2).sum()), int((want_cnt > 2).sum())
@@ -269,17 +276,19 @@ def main():
         return main_c3ref()
     if name == "c3q":
         return main_c3q()
-    variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
+    variant = sys.argv[2] if len(sys.argv) > 2 else "auto"         # auto | flipped | both (auto, then flipped on the same reads and the same expectation)
     k, w, bits, total, G, err, kind, (sg, sp, se) = CONFIGS[name]
     scale = float(os.environ.get("MODGPU_FULLSIZE_SCALE", "1"))
     if scale != 1:
         total = int(total * scale); G = max(int(G * scale), 100_000)
+    # the steady-state choice of the library for this workload, inverted; round 6: and the table brought to load 0.7 after the dedup kernel's
+    # count where the library would not do that by itself (configs 2 and 4), left at its occurrences' bound where it would (config 5)
+    new_share_high = name in ("c2", "c4", "refdef")           # > 50 % of the modimizers become new entries (c5 at 50x: 16 %)
+    dense = name == "c4"                                      # buckets more than half full
+    flipped = {"FLAG_POLARITY": "0" if new_share_high else "1", "MERGE_SLOTS": "0" if dense else "1", "TIGHT_LOAD": "70" if new_share_high else "0"}
     if variant == "flipped":
-        # the steady-state choice of the library for this workload, inverted (both knobs are read once, at the first add)
-        new_share_high = name in ("c2", "c4")                 # > 50 % of the modimizers become new entries (c5 at 50x: 16 %)
-        dense = name == "c4"                                  # buckets more than half full
-        os.environ["MODGPU_FLAG_POLARITY"] = "0" if new_share_high else "1"
-        os.environ["MODGPU_MERGE_SLOTS"] = "0" if dense else "1"
+        for kn, v in flipped.items():
+            os.environ["MODGPU_" + kn] = v
     import modimizer_amd as mg
     from modimizer_amd import synth
     from oracle import pyoracle as po
@@ -303,18 +312,23 @@ def main():
     d_g.free(); d_s.free(); d_st.free()
 
     sh = mg.seqhashCreate(k, w, 17)
-    ms = mg.modsetCreate(sh, bits)
-    n = C.c_uint64()
-    mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, C.byref(n), None))
-    S1, U1 = n.value, ms.contents.max
-    mg.check(L.mgModsetClear(ms, None))
-    mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, C.byref(n), None))     # the steady-state configuration
-    S, U = n.value, ms.contents.max
-    assert (S, U) == (S1, U1), ("two builds of the same batch differ", S1, U1, S, U)
-    mg.check(L.modsetSyncToHost(ms, 0))
-    value = np.ctypeslib.as_array(ms.contents.value, (U + 1,))[1:].copy()
-    depth = np.ctypeslib.as_array(ms.contents.depth, (U + 1,))[1:].copy()
-    L.modsetDestroy(ms)
+
+    def build_twice():
+        ms = mg.modsetCreate(sh, bits)
+        n = C.c_uint64()
+        mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, C.byref(n), None))
+        S1, U1 = n.value, ms.contents.max
+        mg.check(L.mgModsetClear(ms, None))
+        mg.check(L.mgAddReadsDevice(ms, d_r.ptr, total, d_of.ptr, n_reads, C.byref(n), None))     # the steady-state configuration
+        S_, U_ = n.value, ms.contents.max
+        assert (S_, U_) == (S1, U1), ("two builds of the same batch differ", S1, U1, S_, U_)
+        mg.check(L.modsetSyncToHost(ms, 0))
+        v_ = np.ctypeslib.as_array(ms.contents.value, (U_ + 1,))[1:].copy()
+        d_ = np.ctypeslib.as_array(ms.contents.depth, (U_ + 1,))[1:].copy()
+        slots_ = int(L.mgModsetDeviceSlots(ms))
+        L.modsetDestroy(ms)
+        return S_, U_, v_, d_, slots_
+    S, U, value, depth, slots_auto = build_twice()
     t_build = time.time() - t0
 
     # ---- the ordered modimizer stream, from the scan entry point ---------------------------------------------------
@@ -342,7 +356,6 @@ def main():
     offs64 = offs.astype(np.int64)
     checked, n_pieces = check_whole_stream(L, mg, po, oh, d_r, offs64, n_reads, km, pf, first)
     assert checked == S, ("modimizers compared with the oracle", checked, "of", S)
-    d_r.free(); d_of.free()
     del pf, rd, pos, first
     t_scan = time.time() - t0 - t_build
 
@@ -353,6 +366,18 @@ def main():
     assert bad.size == 0, ("value[] differs from first-occurrence order at", bad[:5] + 1, "of", U)
     bad = np.flatnonzero(want_depth != depth)
     assert bad.size == 0, ("depth[] differs at", bad[:5] + 1, "of", U)
+    if variant == "both":                                      # the other polarity / merge-slot / table-sizing choice on the same reads: the same arrays
+        del value, depth
+        with mg.knobs(**flipped):
+            S2, U2, value2, depth2, slots_flip = build_twice()
+        assert (S2, U2) == (S, U), ("flipped build differs in size", S2, U2, S, U)
+        bad = np.flatnonzero(want_value != value2)
+        assert bad.size == 0, ("flipped: value[] differs from first-occurrence order at", bad[:5] + 1, "of", U)
+        bad = np.flatnonzero(want_depth != depth2)
+        assert bad.size == 0, ("flipped: depth[] differs at", bad[:5] + 1, "of", U)
+        assert (slots_flip < slots_auto) == (flipped["TIGHT_LOAD"] != "0") or slots_flip == slots_auto, (slots_auto, slots_flip)
+        print("fullsize_whole %s flipped (%s): the same arrays; device table %d slots (auto: %d)" % (name, flipped, slots_flip, slots_auto))
+    d_r.free(); d_of.free()
     print("fullsize_whole %s %s: %d bases, %d reads, %d modimizers, %d entries: value[] and depth[] pinned entirely; "
           "ALL %d reads (%d modimizers, %d pieces) == oracle; build %.1f s, scan + oracle check %.1f s, host reconstruction %.1f s"
           % (name, variant, total, n_reads, S, U, n_reads, checked, n_pieces, t_build, t_scan, time.time() - t0 - t_build - t_scan))

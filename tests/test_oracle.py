@@ -249,3 +249,35 @@ def test_first_occurrences_helper_matches_numpy():
     for x in km:
         ix = oms.find(int(x), True)
     assert oms.max == len(v) and np.array_equal(oms.values()[1:], v)
+
+
+def test_first_occurrence_positions_and_reference_pack_vs_numpy():
+    """the two helpers the full-size reference test rebuilds modmap's arrays with (tests/fullsize_whole.py c3ref; round 6: 66 s of numpy sorts
+    -> a few seconds): orcFirstOccurrencesAt's first-occurrence position of every k-mer of a stream, and orcReferencePack = referencePack's own
+    loops (modmap.c:74-91), against numpy's sort-based statement of the same (np.unique, stable argsort, bincount, cumsum)"""
+    import ctypes as C
+    OL = po.lib()
+    rng = np.random.default_rng(3)
+    for n, universe in ((200_000, 5000), (50_000, 1 << 40), (1, 1)):
+        km = rng.integers(0, universe, n).astype(np.uint64)
+        OL.orcFirstOccurrencesAt.restype = C.c_int64
+        OL.orcFirstOccurrencesAt.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        flag = np.zeros(n, np.uint8); cnt = np.zeros(n, np.uint32); fa = np.zeros(n, np.uint32)
+        u = OL.orcFirstOccurrencesAt(km.ctypes.data, n, 4, flag.ctypes.data, cnt.ctypes.data, fa.ctypes.data)
+        vals, first_idx, counts = np.unique(km, return_index=True, return_counts=True)
+        assert u == len(vals) and np.array_equal(np.flatnonzero(flag), np.sort(first_idx))
+        assert np.array_equal(fa, first_idx[np.searchsorted(vals, km)].astype(np.uint32))
+        assert np.array_equal(cnt[first_idx], counts.astype(np.uint32))
+        occ_index = np.cumsum(flag, dtype=np.uint32)[fa]
+        want_value = km[flag.view(bool)]
+        order = np.argsort(want_value, kind="stable")
+        assert np.array_equal((order[np.searchsorted(want_value[order], km)] + 1).astype(np.uint32), occ_index)
+        U = int(u)
+        depth = np.zeros(U + 1, np.uint32); loc = np.zeros(U + 1, np.uint32); rev = np.zeros(n, np.uint32)
+        OL.orcReferencePack.restype = None
+        OL.orcReferencePack.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        OL.orcReferencePack(occ_index.ctypes.data, n, U, depth.ctypes.data, loc.ctypes.data, rev.ctypes.data)
+        assert np.array_equal(rev, np.argsort(occ_index, kind="stable").astype(np.uint32))
+        assert np.array_equal(depth, np.bincount(occ_index, minlength=U + 1).astype(np.uint32))
+        l2 = np.zeros(U + 1, np.uint32); l2[1:] = np.cumsum(depth[:-1], dtype=np.uint64).astype(np.uint32)
+        assert np.array_equal(loc, l2)
