@@ -82,7 +82,10 @@ BUILD_KNOBS = [{}, {}, {"TABLE_PATH": "bucket"}, {"TABLE_PATH": "direct"}, {"TAB
                {"TABLE_PATH": "bucket", "PART_PACKED": 0, "FLAG_POLARITY": 1}, {"TABLE_PATH": "bucket", "BUCKET_R": 1024, "BUCKET_T": 256},
                {"TABLE_PATH": "bucket", "HOT_SPLIT": "200,64"}, {"TABLE_PATH": "bucket", "HOT_SPLIT": "200,64", "FLAG_POLARITY": 0},
                {"TABLE_PATH": "bucket", "PART_BIG": 0}, {"TABLE_PATH": "bucket", "PART_DIGITS": 0}, {"TABLE_PATH": "bucket", "MERGE_SLOTS": 0},
-               {"TABLE_PATH": "bucket", "MERGE_SLOTS": 1}, {"ADD_CHUNK": 100000}, {"SCAN_GENERIC": 1}, {"SCAN_GRID": 64}]
+               {"TABLE_PATH": "bucket", "MERGE_SLOTS": 1}, {"ADD_CHUNK": 100000}, {"SCAN_GENERIC": 1}, {"SCAN_GRID": 64},
+               # round 6: the table brought to a tight load after the dedup kernel's count (forced, with the slack a bucket keeps cut to nothing at 95), or never
+               {"TABLE_PATH": "bucket", "TIGHT_LOAD": 70}, {"TABLE_PATH": "bucket", "TIGHT_LOAD": 95, "FLAG_POLARITY": 1}, {"TABLE_PATH": "bucket", "TIGHT_LOAD": 0},
+               {"TABLE_PATH": "bucket", "TIGHT_LOAD": 50, "BUCKET_R": 2048, "BUCKET_T": 512}, {"TABLE_LOAD": 95}, {"TABLE_PATH": "bucket", "TABLE_LOAD": 30}]
 
 
 def trial_build(rng, k, w, sd):
