@@ -1822,6 +1822,14 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   if (withDepth) t->pendingDepth = true;
   const bool wasEmpty = t->empty && t->max == 0;
   t->empty = false;
+  { /* EXPERIMENT (MODGPU_PREDICT_LOAD): R from the previous add's share of new k-mers BEFORE the dedup kernel, so that its image is the merge kernel's */
+    const long pk = mgKnobs ()->predictLoad;
+    if (wasEmpty && pk != MG_KNOB_UNSET && pk > 0 && t->newPct > 0 && t->log2NB > 0 && mgTableUseBuckets (t, n))
+      { const U64 NBp = (U64) 1 << t->log2NB, expectU = n * (U64) t->newPct / 100;
+        const U64 Rn = (expectU * 100 / (NBp * (U64) pk) + 1 + MG_R_QUANTUM - 1) / MG_R_QUANTUM * MG_R_QUANTUM;
+        if (Rn < t->R && Rn >= 1024) { t->R = (U32) Rn; t->nSlots = NBp * Rn; }
+      }
+  }
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
