@@ -1260,7 +1260,6 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 U32 at;
 #ifdef MG_ABLATE
                 if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
-#endif
                 at = mgLdsClaim (sKey, R, mgHomeOfM (m, a.g), m + 1);
                 if (at == R) a.counters[1] = 1;
 #ifdef MG_ABLATE
@@ -1268,6 +1267,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #endif
                 else { mgDedupCount (a, sOrd, sCnt, at, ord); }
               }
+#endif
           /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies) */
           mgDedupRun<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo + (U64) MG_BUCKET_PREFETCH * T, hi);
           }
@@ -1822,14 +1822,6 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   if (withDepth) t->pendingDepth = true;
   const bool wasEmpty = t->empty && t->max == 0;
   t->empty = false;
-  { /* EXPERIMENT (MODGPU_PREDICT_LOAD): R from the previous add's share of new k-mers BEFORE the dedup kernel, so that its image is the merge kernel's */
-    const long pk = mgKnobs ()->predictLoad;
-    if (wasEmpty && pk != MG_KNOB_UNSET && pk > 0 && t->newPct > 0 && t->log2NB > 0 && mgTableUseBuckets (t, n))
-      { const U64 NBp = (U64) 1 << t->log2NB, expectU = n * (U64) t->newPct / 100;
-        const U64 Rn = (expectU * 100 / (NBp * (U64) pk) + 1 + MG_R_QUANTUM - 1) / MG_R_QUANTUM * MG_R_QUANTUM;
-        if (Rn < t->R && Rn >= 1024) { t->R = (U32) Rn; t->nSlots = NBp * Rn; }
-      }
-  }
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
