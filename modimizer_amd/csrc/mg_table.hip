@@ -1260,6 +1260,7 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 U32 at;
 #ifdef MG_ABLATE
                 if (a.debug & 4) { at = mgHomeOfM (m, a.g); sKey[at] = m + 1; } else
+#endif
                 at = mgLdsClaim (sKey, R, mgHomeOfM (m, a.g), m + 1);
                 if (at == R) a.counters[1] = 1;
 #ifdef MG_ABLATE
@@ -1267,7 +1268,6 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #endif
                 else { mgDedupCount (a, sOrd, sCnt, at, ord); }
               }
-#endif
           /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies) */
           mgDedupRun<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo + (U64) MG_BUCKET_PREFETCH * T, hi);
           }
