@@ -2373,8 +2373,9 @@ MgStatus mgTableEnsure (MgTable *t, U64 nIncoming, hipStream_t st)
   U64 want = mgSlotsFor (t, (U64) t->max + nIncoming);
   if (t->slots && want <= t->nSlots) return MG_OK;
   if (!t->slots || !t->max) return mgTableAlloc (t, want, st);
-  /* grow: a table that takes adds grows by half at least (sized to the entry, every add would re-place everything) */
-  if (nIncoming && want < t->nSlots + t->nSlots / 2) want = t->nSlots + t->nSlots / 2;
+  /* grow: a table that takes adds doubles at least (sized to the entry, every add would re-place everything; doubling re-places every
+     entry twice over a set's life, growing by half three times: tools/incremental_probe.py, ten 1 Gbp batches into one set, 34.9 against 30 ms) */
+  if (nIncoming && want < 2 * t->nSlots) want = 2 * t->nSlots;
   if (want > ((U64) 1 << t->maxLog2Slots)) want = (U64) 1 << t->maxLog2Slots;
   if (want <= t->nSlots) return MG_OK;
   return mgTableRehashTo (t, want, st);
