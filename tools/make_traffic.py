@@ -5,7 +5,7 @@ usage: tools/make_traffic.py r03"""
 import json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-tags = {"c2": "10", "c3": "c3", "c5": "c5", "c4": "12.5"}           # the keys bench.py's roofline_of() looks a kernel's traffic up under
+tags = {"c2": "10", "c3": "c3", "c5": "c5", "c4": "12.5", "odd": "ref_default"}           # ("odd": tools/prof_pmc.sh <tag>_odd --only ref_default)           # the keys bench.py's roofline_of() looks a kernel's traffic up under
 out = {"_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units) of bench.py: key '10' = the headline "
                 "workload (config 2, 10 Gbp), 'c3' / 'c5' / '12.5' = bench.py --only c3 / c5 / c4_block.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 counts wide "
                 "coalesced streaming reads at half) ONLY for the kernels whose reads are such streams ('x2'); for gather-dominated kernels (random rank "
@@ -48,6 +48,15 @@ for cfg, key in tags.items():
         hist["round %d" % int(tag.lstrip("r"))] = si["valu_per_start"]
         si["history"] = hist
         if "ref_default" in old: si["ref_default"] = old["ref_default"]      # the exact-mode scan's own pass (tools/prof_pmc.sh --only ref_default)
+        if "census" in old: si["census"] = old["census"]                     # tools/isa_census.py's class mix and the ceiling it prices (round 6)
         json.dump(si, open(os.path.join(R, "profiles", "scan_issue.json"), "w"), indent=1)
+# the exact-mode scan's counters (bench.py --only ref_default): VALU per start into scan_issue.json's ref_default entry
+d = os.path.join(R, "gpurun_out", "prof_%s_odd" % tag, "summary.json")
+if os.path.exists(d):
+    j = json.load(open(d)); sip = os.path.join(R, "profiles", "scan_issue.json"); si = json.load(open(sip))
+    s = j["mgScanKernel"]; rd = si.setdefault("ref_default", {})
+    rd.update({"from": "profiles/%s_odd_pmc_summary.txt (rocprofv3 --pmc SQ_INSTS_VALU ... on bench.py --only ref_default, 10 Gbp)" % tag,
+               "SQ_INSTS_VALU": s["SQ_INSTS_VALU"], "SQ_INSTS_SALU": s.get("SQ_INSTS_SALU"), "valu_per_start": round(s["SQ_INSTS_VALU"] * 64 / 1e10, 2), "avg_ms_under_trace": s.get("avg_ms")})
+    json.dump(si, open(sip, "w"), indent=1)
 json.dump(out, open(os.path.join(R, "profiles", "traffic.json"), "w"), indent=1)
 print("wrote profiles/traffic.json, profiles/scan_issue.json;", {k: v for k, v in out.items() if k in ("mgScanKernel", "mgTableFindSegKernel", "mgPartScatterKernel")})
