@@ -305,6 +305,14 @@ def roofline_of(kern, table, alg_bytes, tag, extra=None, units=None):
                 tfrom = "profiles/traffic.json (%s; separate rocprofv3 --pmc passes of an earlier run of this command, not this run)" % tj.get("_from", "round profile")
         except Exception:
             traffic = None
+    step_traffic = None
+    if os.path.exists(tpath):                         # the step's HBM bytes by the counters: every kernel's per-launch figure x its launches in a step
+        try:
+            tj = json.load(open(tpath))
+            parts = [tj[kn][tag] * max(v[1], 1) for kn, v in table.items() if isinstance(tj.get(kn), dict) and tj[kn].get(tag)]
+            step_traffic = round(sum(parts)) if parts else None
+        except Exception:
+            step_traffic = None
     r = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": tfrom,
          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": ab,
@@ -314,6 +322,9 @@ def roofline_of(kern, table, alg_bytes, tag, extra=None, units=None):
          "kernels_ms_per_step_from": "one extra step after the timed region, every launch bracketed"}
     if extra:
         r.update(extra)
+    if step_traffic and isinstance(r.get("whole_step"), dict):
+        r["whole_step"] = dict(r["whole_step"], counter_bytes_per_step=step_traffic,
+                               counter_bytes_from="profiles/traffic.json: every kernel's PMC bytes per launch x its launches in a step (an earlier run of this command)")
     ba = bound_actual(dom, avg_ms, (units or {}).get(dom, 0), (extra or {}).get("alu"))
     if ba:
         r["bound_actual"] = ba
@@ -421,7 +432,7 @@ def gpu_rank(args):
                             "read_only_0.25B_per_base": 0.25 * total,
                             "scan_GBps_this_path": round(alg["mgScanKernel"] / (scan_ms * 1e-3) / 1e9, 1) if scan_ms else None,
                             "scan_read_only_frac": round(0.25 * total / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if scan_ms else None},
-             "whole_step": {"bytes_per_base": 0.25 + 28.0 / d,
+             "whole_step": {"bytes_per_base": 0.25 + 28.0 / d, "algorithmic_bytes_per_step": (0.25 + 28.0 / d) * total,
                             "GBps": round((0.25 + 28.0 / d) * total * args.steps / dt / 1e9, 1),
                             "frac": round((0.25 + 28.0 / d) * total * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)}}
     roofline = roofline_of(kern, table, alg, "%g" % gbp, extra, units={"mgScanKernel": starts, "mgRankLookupKernel": float(entries)})
