@@ -309,8 +309,7 @@ def roofline_of(kern, table, alg_bytes, tag, extra=None, units=None):
     if os.path.exists(tpath):                         # the step's HBM bytes by the counters: every kernel's per-launch figure x its launches in a step
         try:
             tj = json.load(open(tpath))
-            parts = [tj[kn][tag] * max(v[1], 1) for kn, v in table.items() if isinstance(tj.get(kn), dict) and tj[kn].get(tag)]
-            step_traffic = round(sum(parts)) if parts else None
+            step_traffic = (tj.get("_step_bytes") or {}).get(tag)      # every launch of every kernel of a step, summed by tools/make_traffic.py
         except Exception:
             step_traffic = None
     r = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -324,7 +323,7 @@ def roofline_of(kern, table, alg_bytes, tag, extra=None, units=None):
         r.update(extra)
     if step_traffic and isinstance(r.get("whole_step"), dict):
         r["whole_step"] = dict(r["whole_step"], counter_bytes_per_step=step_traffic,
-                               counter_bytes_from="profiles/traffic.json: every kernel's PMC bytes per launch x its launches in a step (an earlier run of this command)")
+                               counter_bytes_from="profiles/traffic.json _step_bytes: the PMC bytes of every launch of a step of an earlier run of this command")
     ba = bound_actual(dom, avg_ms, (units or {}).get(dom, 0), (extra or {}).get("alu"))
     if ba:
         r["bound_actual"] = ba

@@ -10,7 +10,7 @@ out = {"_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (FETC
                 "workload (config 2, 10 Gbp), 'c3' / 'c5' / '12.5' = bench.py --only c3 / c5 / c4_block.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 counts wide "
                 "coalesced streaming reads at half) ONLY for the kernels whose reads are such streams ('x2'); for gather-dominated kernels (random rank "
                 "records, random flag bytes, bucket probes) the raw counter is used ('raw').  Values are PER-LAUNCH averages: mgPartScatterKernel runs "
-                "twice per step (both passes together: twice its value).",
+                "twice per step (both passes together: twice its value).  _step_bytes: all the library's kernels of a step (config 3: of a query batch), every launch counted.",
        "_from": "profiles/%s_{c2,c3,c5}_pmc_summary.txt" % tag}
 for cfg, key in tags.items():
     d = os.path.join(R, "gpurun_out", "prof_%s_%s" % (tag, cfg))
@@ -20,6 +20,8 @@ for cfg, key in tags.items():
     shutil.copy(os.path.join(d, "summary.txt"), os.path.join(R, "profiles", "%s_%s_pmc_summary.txt" % (tag, cfg)))
     if os.path.exists(os.path.join(d, "kernel_stats.csv")):
         shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(R, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
+    steps = max(j.get("mgScanKernel", {}).get("calls", 1), 1) / (9.0 if cfg == "c3" else 1.0)      # launches of the scan = steps profiled (config 3: nine batches a "step")
+    out.setdefault("_step_bytes", {})[key] = round(sum(v["hbm_bytes"] * v["calls"] for k, v in j.items() if k.startswith("mg") and "Synth" not in k and "hbm_bytes" in v) / steps / (9.0 if cfg == "c3" else 1.0))
     for k, v in j.items():
         if "hbm_bytes" in v:
             if k == "mgPartHistBytesKernel":                # the library's profile slot (and bench.py's table) calls the second pass's counts mgPartHistKernel whichever kernel made them
