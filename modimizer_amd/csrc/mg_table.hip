@@ -2287,6 +2287,54 @@ __global__ void mgRehashKernel (const MgSlot *__restrict__ oldSlots, U32 oldNB, 
     }
 }
 
+/* The same bucket by bucket (round 6): a bucket is a self-contained table and its id a prefix of its keys, so when NB stays or grows a NEW bucket's
+   entries all come from ONE old bucket (its id's leading bits).  A workgroup per new bucket reads the parent's slots as a stream, claims the entries
+   that are its own in an LDS image of the new geometry and streams the image out: no global atomic, every byte read and written once or twice
+   (tools/incremental_probe.py: 4.4 -> 1.3 ms for 9.3e7 entries). */
+__global__ __launch_bounds__ (1024)
+void mgRehashBucketKernel (const MgSlot *__restrict__ oldSlots, int oldLog2NB, const U32 *__restrict__ oldOcc, U32 oldR,
+                           MgSlot *__restrict__ slots, MgGeom g, U32 *__restrict__ occ, U64 *counters)
+{
+  unsigned long long *sKey = reinterpret_cast<unsigned long long *> (mgDynLds);
+  U32 *sOrd = reinterpret_cast<U32 *> (mgDynLds + (size_t) g.R * 8);
+  U32 *sCnt = sOrd + g.R;
+  U32 *sN = sCnt + g.R;
+  const U32 T = blockDim.x, tid = threadIdx.x, NB = 1u << g.log2NB;
+  const int up = g.log2NB - oldLog2NB;                                /* >= 0 */
+  for (U32 b = blockIdx.x ; b < NB ; b += gridDim.x)
+    { const U32 parent = b >> up;
+      if (!oldOcc[parent]) continue;                                  /* (uniform) nothing there: the new bucket stays unwritten, occ 0 */
+      for (U32 i = tid ; i < g.R ; i += T) { sKey[i] = 0; sOrd[i] = 0; sCnt[i] = 0; }
+      if (tid == 0) sN[0] = 0;
+      __syncthreads ();
+      const MgSlot *from = oldSlots + (U64) parent * oldR;
+      U32 mine = 0;
+      for (U32 i = tid ; i < oldR ; i += T)
+        { const uint4 v = *reinterpret_cast<const uint4 *> (&from[i]);
+          if (!(v.x | v.y) || !mgIsAssigned (v.z)) continue;
+          const unsigned long long key = ((unsigned long long) v.y << 32) | v.x;
+          const U64 m = key - 1;
+          if (mgBucketOfM (m, g) != b) continue;
+          const U32 at = mgLdsClaim (sKey, g.R, mgHomeOfM (m, g), key);
+          if (at == g.R) { counters[1] = 1; continue; }
+          sOrd[at] = v.z; sCnt[at] = v.w; ++mine;
+        }
+      if (mine) atomicAdd (&sN[0], mine);
+      __syncthreads ();
+      const U32 n = sN[0];
+      if (n)                                                          /* (uniform) */
+        { for (U32 i = tid ; i < g.R ; i += T)
+            { const unsigned long long k = sKey[i];
+              typedef unsigned v4u __attribute__ ((ext_vector_type (4)));
+              v4u vv = { (U32) k, (U32) (k >> 32), sOrd[i], sCnt[i] };
+              __builtin_nontemporal_store (vv, reinterpret_cast<v4u *> (&slots[(U64) b * g.R + i]));
+            }
+          if (tid == 0) occ[b] = n;
+        }
+      __syncthreads ();
+    }
+}
+
 /* Geometry for `want` slots: NB a power of two, R = want / NB rounded up to a multiple of 64, between half of wantR and wantR where the size
    allows (R = 4096: a bucket's image is 64 KiB of LDS); at most 2^18 buckets (two 9-bit partition passes), R up to 8192 beyond that. */
 static void mgSetGeometry (MgTable *t, U64 want)
@@ -2358,9 +2406,21 @@ static MgStatus mgTableRehashTo (MgTable *t, U64 want, hipStream_t st)
   MgSlot *oldSlots = t->slots; U32 *oldOcc = t->occ; const U32 oldNB = (U32) 1 << t->log2NB, oldR = t->R;
   t->slots = 0; t->occ = 0; t->capSlots = 0; t->capNB = 0;
   MgStatus s = mgTableAlloc (t, want, st); if (s) return s;
-  if ((s = mgTableClean (t, st))) return s;
-  MG_LAUNCH (MG_K_TABLE_LOAD, st, mgRehashKernel, dim3 (oldNB < 8192 ? oldNB : 8192), dim3 (256), 0, st,
-             oldSlots, oldNB, oldOcc, oldR, t->slots, mgGeomOf (t), t->occ, t->counters);
+  int oldLog2NB = 0; while (((U32) 1 << oldLog2NB) < oldNB) ++oldLog2NB;
+  if (t->log2NB >= oldLog2NB && mgKnobs ()->tablePath != 'd')             /* bucket by bucket, out of LDS (the new buckets nothing goes into stay unwritten: dirty again) */
+    { const U32 NB = (U32) 1 << t->log2NB;
+      const size_t lds = (size_t) t->R * 16 + 16;
+      if (lds > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgRehashBucketKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      MG_HIP (hipMemsetAsync (t->occ, 0, (size_t) NB * sizeof (U32), st));
+      MG_LAUNCH (MG_K_TABLE_LOAD, st, mgRehashBucketKernel, dim3 (NB < 2048 ? NB : 2048), dim3 (1024), lds, st,
+                 oldSlots, oldLog2NB, oldOcc, oldR, t->slots, mgGeomOf (t), t->occ, t->counters);
+      t->dirty = true;
+    }
+  else
+    { if ((s = mgTableClean (t, st))) return s;                          /* (the atomic path claims slots in a zeroed table) */
+      MG_LAUNCH (MG_K_TABLE_LOAD, st, mgRehashKernel, dim3 (oldNB < 8192 ? oldNB : 8192), dim3 (256), 0, st,
+                 oldSlots, oldNB, oldOcc, oldR, t->slots, mgGeomOf (t), t->occ, t->counters);
+    }
   MG_HIP (hipGetLastError ());
   MG_HIP (hipStreamSynchronize (st));
   MG_HIP (hipFree (oldSlots)); MG_HIP (hipFree (oldOcc));
