@@ -131,12 +131,19 @@ def build(force=False):
     import fcntl
     if os.environ.get("MODGPU_LIB"):                    # a variant build under tools/: the caller's business
         return LIB_PATH
-    with open(os.path.join(CSRC, ".build.lock"), "w") as lk:     # tests start many processes: one make at a time
-        fcntl.flock(lk, fcntl.LOCK_EX)
+    def make_if_stale():
         if force or binary_hash() != source_hash():
             subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"] + (["-B"] if force else []))
             if binary_hash() != source_hash():
                 raise RuntimeError("libmodgpu.so does not carry the hash of its sources after make: %s != %s" % (binary_hash(), source_hash()))
+    try:
+        lk = open(os.path.join(CSRC, ".build.lock"), "w")     # tests start many processes: one make at a time
+    except OSError:                                            # (a read-only tree: nothing to serialise, and nothing to build unless the binary is stale)
+        make_if_stale()
+        return LIB_PATH
+    with lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        make_if_stale()
     return LIB_PATH
 
 

@@ -1921,7 +1921,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
      the tight load -- reads of deep coverage with few errors (config 5: a sixth of the modimizers are new; 4.3 -> 1.07 GB of bucket images). */
   int tightPct = t->tightPct ? t->tightPct : MG_TIGHT_PCT_DEFAULT;
   { const long tk = mgKnobs ()->tightLoad; if (tk != MG_KNOB_UNSET && tk >= 0 && tk <= 95) tightPct = (int) tk; }
-  bool tighten = wasEmpty && tightPct > 0 && t->log2NB > 0;
+  bool tighten = wasEmpty && tightPct > 0 && t->log2NB > 0 && t->pin;
   if (tighten && mgKnobs ()->tightLoad == MG_KNOB_UNSET)          /* (the knob forces it: tests, sweeps) */
     { const U64 expectNew = t->newPct > 0 ? n * (U64) t->newPct / 100 : n;
       tighten = expectNew * 100 / (U64) tightPct < t->nSlots - t->nSlots / 4;
