@@ -36,3 +36,9 @@ echo "== MODGPU_PART_DIGITS=0 (the second partition pass counts its digits from 
 MODGPU_PART_DIGITS=0 MODGPU_TABLE_PATH=bucket python -m pytest tests/test_gpu_modset.py -q -x 2>&1 | tail -2
 MODGPU_PART_DIGITS=0 MODGPU_FIND_PATH=2 python -m pytest tests/test_gpu_modset.py tests/test_dropin.py -q -x -m gpu 2>&1 | tail -2
 MODGPU_PART_DIGITS=0 MODGPU_TABLE_PATH=bucket python tests/fuzz_gpu.py 29 150 2>&1 | tail -2
+echo "== round 6: the table tightened after the dedup kernel's count at every bucketed add into an empty table (70 %, and 95 %: no slack but the fullest bucket's), never, and a table sized at 30 / 95 % of the default"
+for kn in "MODGPU_TIGHT_LOAD=70" "MODGPU_TIGHT_LOAD=95" "MODGPU_TIGHT_LOAD=0" "MODGPU_TABLE_LOAD=30" "MODGPU_TABLE_LOAD=95" "MODGPU_BUCKET_R=2048 MODGPU_BUCKET_T=512"; do
+  echo "-- $kn"
+  env $kn MODGPU_TABLE_PATH=bucket python -m pytest tests/test_gpu_modset.py tests/test_readset.py tests/test_dropin.py -q -x -m gpu 2>&1 | tail -2
+  env $kn MODGPU_TABLE_PATH=bucket python tests/fuzz_gpu.py 23 150 2>&1 | tail -2
+done
