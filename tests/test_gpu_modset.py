@@ -464,6 +464,11 @@ def test_table_regrown_before_lookups():
     brings it to entries / 0.4 (rehash on the device).  Since round 6 the slot count is NB x R with R any multiple of 64, not the
     next power of two: 90 000 distinct k-mers take 120 832 slots after the build (load 0.74), 225 000 or so after the first lookup;
     indices, values and depths unchanged, found and absent k-mers answered as before"""
+    with mg.knobs(TABLE_LOAD=None, TIGHT_LOAD=None, TABLE_PATH=None, BUCKET_R=None):      # (the slot counts asserted are the defaults': tools/test_paths.sh runs the suite under sizing knobs)
+        _table_regrown_before_lookups()
+
+
+def _table_regrown_before_lookups():
     L = mg.lib()
     k, w, bits = 21, 4, 22
     sh = mg.seqhashCreate(k, w, 17); oh = po.Hasher(k, w, 17)
