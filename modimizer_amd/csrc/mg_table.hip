@@ -915,9 +915,6 @@ extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
 #ifndef MG_CLAIM_CAS_FIRST
 #define MG_CLAIM_CAS_FIRST 1
 #endif
-#ifndef MG_DEDUP_ILP
-#define MG_DEDUP_ILP 1
-#endif
 __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 home, unsigned long long key)
 {
   U32 at = home;
@@ -1256,25 +1253,6 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
           if (HOT) mgDedupHotBucket<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo, hi);   /* reduced to weighted entries by mgHotReduceKernel */
           else
           {
-#if MG_DEDUP_ILP
-          /* the first probes of the thread's occurrences go out together: most claims end with the first */
-          { U64 mm[MG_BUCKET_PREFETCH]; U32 oo[MG_BUCKET_PREFETCH], hh[MG_BUCKET_PREFETCH]; unsigned long long cu[MG_BUCKET_PREFETCH]; bool lv[MG_BUCKET_PREFETCH];
-#pragma unroll
-            for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-              { lv[j] = lo + (U64) j * T + tid < hi; mm[j] = 0; oo[j] = 0; hh[j] = 0;
-                if (lv[j]) { mgOccurrence<PACKED> (a, b, ck[j], ct[j], &mm[j], &oo[j]); hh[j] = mgHomeOfM (mm[j], a.g); }
-              }
-#pragma unroll
-            for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j) cu[j] = lv[j] ? atomicCAS (&sKey[hh[j]], 0ull, (unsigned long long) mm[j] + 1) : 1ull;
-#pragma unroll
-            for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
-              if (lv[j])
-                { const U32 at = (cu[j] == 0 || cu[j] == (unsigned long long) mm[j] + 1) ? hh[j] : mgLdsClaim (sKey, R, mgNextSlot (hh[j], R), mm[j] + 1);
-                  if (at == R) a.counters[1] = 1;
-                  else mgDedupCount (a, sOrd, sCnt, at, oo[j]);
-                }
-          }
-#else
 #pragma unroll
           for (int j = 0 ; j < MG_BUCKET_PREFETCH ; ++j)
             if (lo + (U64) j * T + tid < hi)
@@ -1290,7 +1268,6 @@ void mgBucketDedupKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #endif
                 else { mgDedupCount (a, sOrd, sCnt, at, ord); }
               }
-#endif
           /* the occurrences beyond the ones fetched ahead (a bucket with a k-mer of very many copies) */
           mgDedupRun<PACKED> (a, b, sKey, sOrd, sCnt, R, T, tid, lo + (U64) MG_BUCKET_PREFETCH * T, hi);
           }
@@ -1398,23 +1375,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
                 }
               __syncthreads ();
             }
-          /* the rank lookup kernel has turned the new uniques' ordinals into indices: place and count.  The first probes of the uniques fetched
-             ahead go out together (round 6): a claim is a dependent LDS round trip, and most end with the first */
-          U32 pre[MG_MERGE_PREFETCH], preHome[MG_MERGE_PREFETCH];
-#pragma unroll
-          for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j) { pre[j] = 0xffffffffu; preHome[j] = 0; }
-          if (!a.slotShift MG_ABLATE_AND (!(a.debug & 32)))
-            { unsigned long long cur[MG_MERGE_PREFETCH];
-#pragma unroll
-              for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j)
-                { const bool live = (U32) j * T + tid < nu;
-                  preHome[j] = live ? mgHomeOfM (ck[j], a.g) : 0u;
-                  cur[j] = live ? atomicCAS (&sKey[preHome[j]], 0ull, (unsigned long long) ck[j] + 1) : 1ull;
-                }
-#pragma unroll
-              for (int j = 0 ; j < MG_MERGE_PREFETCH ; ++j)
-                if ((U32) j * T + tid < nu && (cur[j] == 0 || cur[j] == (unsigned long long) ck[j] + 1)) pre[j] = preHome[j];
-            }
+          /* the rank lookup kernel has turned the new uniques' ordinals into indices: place and count */
           for (U32 i = tid, jj = 0 ; i < nu ; i += T, ++jj)
             { U64 km; U32 ord, c;
               if (jj < MG_MERGE_PREFETCH)
@@ -1434,15 +1395,7 @@ void mgBucketMergeKernel (const MgBucketArgs a, U32 bucketsPerBlock)
 #ifdef MG_ABLATE
               if (a.debug & 32) { at = mgHomeOfM (km, a.g); sKey[at] = km + 1; } else
 #endif
-              { U32 first = 0xffffffffu, home = 0; bool probed = false;
-                if (jj < MG_MERGE_PREFETCH MG_ABLATE_AND (!(a.debug & 32)))
-                  { first = pre[0]; home = preHome[0]; probed = true;
-#pragma unroll
-                    for (int j = 1 ; j < MG_MERGE_PREFETCH ; ++j) if (jj == (U32) j) { first = pre[j]; home = preHome[j]; }
-                  }
-                if (first != 0xffffffffu) at = first;
-                else at = mgLdsClaim (sKey, R, probed ? mgNextSlot (home, R) : mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
-              }
+              at = mgLdsClaim (sKey, R, mgHomeOfM (km, a.g), km + 1);      /* km: the mixed k-mer the dedup kernel left */
               if (at == R) { a.counters[1] = 1; continue; }
               if (i < nNew) { sOrd[at] = ord; sCnt[at] = c; }
               else if (c) atomicAdd (&sCnt[at], c);
