@@ -503,7 +503,7 @@ static void mgDevFree (MgDev *d)
   MgOnDevice here (d->device);
   if (d->hPin) (void) hipHostFree (d->hPin);
   if (d->built)
-    { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ);
+    { (void) hipFree (d->t.slots); (void) hipFree (d->t.value); (void) hipFree (d->t.occ); (void) hipFree (d->t.find8);
       (void) hipFree (d->t.baseDepth); (void) hipFree (d->t.counters); (void) hipFree (d->t.liveHist);
     }
   if (d->side) { (void) hipStreamSynchronize (d->side); (void) hipStreamDestroy (d->side); }      /* (a scan started by mgQueryReadsDeviceAsync and never waited for still writes into an arena) */

@@ -235,6 +235,10 @@ struct MgTable {
   U64 *counters;       /* device U64[8]: 0 = new entries of the last add, 1 = bucket overflow */
   bool pendingDepth;   /* an add with depth counting ran since the counts were last folded into baseDepth / the host's depth[] */
   bool dirty;          /* buckets with occ == 0 hold undefined bytes (never zeroed): see mgTableClean */
+  U64 *find8;          /* the partitioned lookups' copy of the table, 8 bytes a slot: (key's bits below the bucket id + 1) << 31 | index, 0 = empty (mg_table.hip
+                          mgTableFind8); made when a lookup batch finds it missing or stale, the table itself being 16 bytes a slot with the counts */
+  U64 find8Cap;        /* slots allocated for it */
+  U64 find8Version, version;      /* version: bumped by whatever changes a slot's key or index (add, load, rehash, clear); find8 is the copy of find8Version */
   bool empty;          /* nothing has been put into the table since it was made or forgotten (every occ[] is zero): its geometry is free to change */
   U64 *pin;            /* four page-locked host words for small read-backs in the middle of an add (mgDevBuild) */
   int newPct;          /* new entries per 100 modimizers in the last bucketed add (a hint for the next one: mg_table.hip, markDup) */

@@ -43,7 +43,7 @@ static void readAll (void)
   k.partDigits = num ("MODGPU_PART_DIGITS");
   k.findBits = num ("MODGPU_FIND_BITS");
   k.scatterGrid = num ("MODGPU_SCATTER_GRID");     k.tableLoad = num ("MODGPU_TABLE_LOAD");
-  k.tightLoad = num ("MODGPU_TIGHT_LOAD");
+  k.tightLoad = num ("MODGPU_TIGHT_LOAD");         k.find8 = num ("MODGPU_FIND8");
   k.packThreads = num ("MODGPU_PACK_THREADS");     k.parseThreads = num ("MODGPU_PARSE_THREADS");
   k.xferThreads = num ("MODGPU_XFER_THREADS");       k.gzipThreads = num ("MODGPU_GZIP_THREADS");
   k.xferPieceKb = num ("MODGPU_XFER_PIECE_KB");      k.xferStreams = num ("MODGPU_XFER_STREAMS");

@@ -44,6 +44,7 @@ typedef struct {
   long partDigits;         /* MODGPU_PART_DIGITS: 0 = the second partition pass counts its digits from the elements (8 bytes each) instead of from the digit bytes the first pass leaves beside them */
   long findBits;           /* MODGPU_FIND_BITS: bits of the partitioned lookup's digit (3..9) */
   long tableLoad;          /* MODGPU_TABLE_LOAD: per cent */
+  long find8;              /* MODGPU_FIND8: 0 = the two-level lookups stream the 16-byte table itself, not its 8-byte copy */
   long tightLoad;          /* MODGPU_TIGHT_LOAD: per cent; the load a set built by one add into an empty table is brought to after the dedup kernel
                               has counted its entries (0: off, the table keeps the size its occurrences' bound gave it) */
   long packThreads;        /* MODGPU_PACK_THREADS */

@@ -1602,6 +1602,62 @@ void mgBucketFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict
     }
 }
 
+/* The same out of an 8-byte-per-slot copy of the table (round 6).  The two-level lookups STREAM the table once per batch -- 16 bytes a slot of which
+ * a lookup needs the key and the index; a bucket implies the key's leading bits, so where (2k - log2 NB) + 31 <= 64 both fit one word:
+ * (key's bits below the bucket id + 1) << 31 | index, 0 = empty.  The copy (MgTable.find8) is made by mgTablePack8Kernel when a lookup batch finds
+ * it missing or older than the table (one streaming pass), and a batch then reads half the bytes: config 3's table 1.9 -> 0.95 GB per batch. */
+__global__ __launch_bounds__ (256)
+void mgTablePack8Kernel (const MgSlot *__restrict__ slots, const U32 *__restrict__ occ, U32 nBuckets, U32 R, int remB, U64 *__restrict__ out)
+{
+  const U64 remMask = ((U64) 1 << remB) - 1;
+  for (U32 b = blockIdx.x ; b < nBuckets ; b += gridDim.x)
+    { if (!occ[b]) continue;                                /* (never read: the lookups ask occ[] first) */
+      for (U32 i = threadIdx.x ; i < R ; i += blockDim.x)
+        { const uint4 v = *reinterpret_cast<const uint4 *> (&slots[(U64) b * R + i]);
+          const U64 key = ((U64) v.y << 32) | v.x;
+          U64 w = 0;
+          if (key && mgIsAssigned (v.z)) w = ((((key - 1) & remMask) + 1) << 31) | (U64) (v.z & ~MG_ASSIGNED);
+          __builtin_nontemporal_store (w, &out[(U64) b * R + i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__ (1024)
+void mgBucketFind8Kernel (const U64 *__restrict__ find8, const U32 *__restrict__ occ, MgGeom g, MgPartFmt f, U32 nBuckets, int remB,
+                          const U64 *__restrict__ bucketStart, U64 *__restrict__ el, U32 bucketsPerBlock)
+{
+  const U32 R = g.R, T = blockDim.x, tid = threadIdx.x;
+  unsigned long long *sW = reinterpret_cast<unsigned long long *> (mgDynLds);
+  const U64 posMask = ((U64) 1 << f.ordBits) - 1, remMask = ((U64) 1 << remB) - 1;
+  U32 b = blockIdx.x * bucketsPerBlock, bEnd = b + bucketsPerBlock;
+  if (bEnd > nBuckets) bEnd = nBuckets;
+  for ( ; b < bEnd ; ++b)
+    { const U64 lo = bucketStart[b], hi = bucketStart[b + 1];
+      if (hi == lo) continue;                                /* (uniform) */
+      const bool any = occ[b] != 0;
+      if (any)
+        { for (U32 i = tid ; i < R ; i += T) sW[i] = __builtin_nontemporal_load (&find8[(U64) b * R + i]);
+          __syncthreads ();
+        }
+      for (U64 i = lo + tid ; i < hi ; i += T)
+        { const U64 x = __builtin_nontemporal_load (&el[i]);
+          U32 res = 0;
+          if (any)
+            { const U64 m = ((U64) (b >> f.loB) << f.remBits) | (x >> f.ordBits), want = (m & remMask) + 1;
+              U32 slot = mgHomeOfM (m, g);
+              for (U32 probes = 0 ; probes < R ; ++probes)
+                { const unsigned long long cur = sW[slot];
+                  if ((cur >> 31) == want) { res = (U32) cur & 0x7fffffffu; break; }
+                  if (cur == 0) break;
+                  slot = mgNextSlot (slot, g.R);
+                }
+            }
+          __builtin_nontemporal_store (((x & posMask) << 32) | res, &el[i]);
+        }
+      __syncthreads ();                                      /* the image is loaded again for the next bucket */
+    }
+}
+
 /* the second level's results back into the order of the first pass's output: a workgroup per (chunk, half) of that output */
 template <int SUB>
 __global__ __launch_bounds__ (1024)
@@ -1821,7 +1877,7 @@ MgStatus mgTableAdd (MgTable *t, const U64 *dKmer, U64 n, int withDepth, void *s
   t->liveHistValid = false;                          /* set again below if this add is the set's only one */
   if (withDepth) t->pendingDepth = true;
   const bool wasEmpty = t->empty && t->max == 0;
-  t->empty = false;
+  t->empty = false; ++t->version;
   MgGeom g = mgGeomOf (t);
   char *wb = (char *) scratch;
   unsigned char *flags = (unsigned char *) wb;       wb += mgAl (n);
@@ -2160,12 +2216,29 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
       s = mgPartPass (t, MG_EL_PACKED, true, f, el, (const U32 *) 0, n, binStart, nBins, 0, nBins2, el2, (U32 *) 0, fineStart, fineCursor, fineCount, chunkBase2, st,
                       (const U32 *) 0, (const MgSegSrc *) 0, (MgSubSeg *) 0, runTab2, &sub2, 1, &maxChunks2, 0, 0, 0, digits);
       if (s) return s;
-      const size_t lds = (size_t) t->R * 12 + 16;
-      if (lds > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgBucketFindKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       unsigned bGrid = (unsigned) (NB < 4096 ? NB : 4096);
       const U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
       bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
-      MG_LAUNCH (MG_K_BUCKET_FIND, st, mgBucketFindKernel, dim3 (bGrid), dim3 (1024), lds, st, t->slots, t->occ, mgGeomOf (t), f, (U32) NB, fineStart, el2, perBlock);
+      const int remB = t->kbits - t->log2NB;
+      if (remB >= 1 && remB + 31 <= 64 && mgKnobs ()->find8 != 0)       /* (test knob MODGPU_FIND8=0: the 16-byte table itself) */
+        { if (!t->find8 || t->find8Version != t->version || t->find8Cap < t->nSlots)
+            { if (t->find8Cap < t->nSlots)
+                { if (t->find8) { MG_HIP (hipStreamSynchronize (st)); MG_HIP (hipFree (t->find8)); t->find8 = 0; t->find8Cap = 0; }
+                  MG_HIP (hipMalloc ((void **) &t->find8, t->nSlots * sizeof (U64)));
+                  t->find8Cap = t->nSlots;
+                }
+              MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTablePack8Kernel, dim3 ((unsigned) (NB < 8192 ? NB : 8192)), dim3 (256), 0, st, t->slots, t->occ, (U32) NB, t->R, remB, t->find8);
+              t->find8Version = t->version;
+            }
+          const size_t lds8 = (size_t) t->R * 8 + 16;
+          if (lds8 > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgBucketFind8Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds8));
+          MG_LAUNCH (MG_K_BUCKET_FIND, st, mgBucketFind8Kernel, dim3 (bGrid), dim3 (1024), lds8, st, t->find8, t->occ, mgGeomOf (t), f, (U32) NB, remB, fineStart, el2, perBlock);
+        }
+      else
+        { const size_t lds = (size_t) t->R * 12 + 16;
+          if (lds > 48 * 1024) MG_HIP (hipFuncSetAttribute ((const void *) mgBucketFindKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+          MG_LAUNCH (MG_K_BUCKET_FIND, st, mgBucketFindKernel, dim3 (bGrid), dim3 (1024), lds, st, t->slots, t->occ, mgGeomOf (t), f, (U32) NB, fineStart, el2, perBlock);
+        }
       const unsigned g2 = 2 * maxChunks2 < 2048 ? 2 * maxChunks2 : 2048;
       if (sub2 == MG_PART_SUB_BIG) MG_LAUNCH (MG_K_UNPART, st, mgUnpartPosKernel<MG_PART_SUB_BIG>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
       else                         MG_LAUNCH (MG_K_UNPART, st, mgUnpartPosKernel<MG_PART_SUB>, dim3 (g2), dim3 (1024), 0, st, el2, runTab2, nBins2, binStart, chunkBase2, nBins, 2 * sub2, idxA);
@@ -2189,7 +2262,7 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
 MgStatus mgTableLoadHost (MgTable *t, const U64 *dValue, U32 first, U32 last, hipStream_t st)
 {
   if (last < first) return MG_OK;
-  t->liveHistValid = false; t->empty = false;
+  t->liveHistValid = false; t->empty = false; ++t->version;
   { MgStatus cs = mgTableClean (t, st); if (cs) return cs; }
   MG_LAUNCH (MG_K_TABLE_LOAD, st, mgTableLoadKernel, dim3 (mgGrid ((U64) last - first + 1)), dim3 (256), 0, st,
              t->slots, mgGeomOf (t), dValue, first, last, t->occ, t->counters);
@@ -2375,7 +2448,7 @@ void mgTableForget (MgTable *t, hipStream_t st)
   (void) hipMemsetAsync (t->occ, 0, ((size_t) 1 << t->log2NB) * sizeof (U32), st);
   t->dirty = true;               /* no memset of the slots: a bucket is defined once something wrote all of it */
   t->liveHistValid = false;
-  t->empty = true;
+  t->empty = true; ++t->version;
 }
 
 MgStatus mgTableClean (MgTable *t, hipStream_t st)
@@ -2424,7 +2497,7 @@ static MgStatus mgTableRehashTo (MgTable *t, U64 want, hipStream_t st)
   MG_HIP (hipGetLastError ());
   MG_HIP (hipStreamSynchronize (st));
   MG_HIP (hipFree (oldSlots)); MG_HIP (hipFree (oldOcc));
-  t->empty = false;
+  t->empty = false; ++t->version;
   return MG_OK;
 }
 
