@@ -1603,7 +1603,7 @@ void mgBucketFindKernel (const MgSlot *__restrict__ slots, const U32 *__restrict
 }
 
 /* The same out of an 8-byte-per-slot copy of the table (round 6).  The two-level lookups STREAM the table once per batch -- 16 bytes a slot of which
- * a lookup needs the key and the index; a bucket implies the key's leading bits, so where (2k - log2 NB) + 31 <= 64 both fit one word:
+ * a lookup needs the key and the index; a bucket implies the key's leading bits, so where 2k - log2 NB <= 32 both fit one word:
  * (key's bits below the bucket id + 1) << 31 | index, 0 = empty.  The copy (MgTable.find8) is made by mgTablePack8Kernel when a lookup batch finds
  * it missing or older than the table (one streaming pass), and a batch then reads half the bytes: config 3's table 1.9 -> 0.95 GB per batch. */
 __global__ __launch_bounds__ (256)
@@ -2220,7 +2220,7 @@ MgStatus mgTableFindPartitioned (MgTable *t, const MgSegSrc &segSrc, U64 n, cons
       const U32 perBlock = (U32) ((NB + bGrid - 1) / bGrid);
       bGrid = (unsigned) ((NB + perBlock - 1) / perBlock);
       const int remB = t->kbits - t->log2NB;
-      if (remB >= 1 && remB + 31 <= 64 && mgKnobs ()->find8 != 0)       /* (test knob MODGPU_FIND8=0: the 16-byte table itself) */
+      if (remB >= 1 && remB <= 32 && mgKnobs ()->find8 != 0)          /* (rem + 1 <= 2^32 above a 31-bit index: one word) */       /* (test knob MODGPU_FIND8=0: the 16-byte table itself) */
         { if (!t->find8 || t->find8Version != t->version || t->find8Cap < t->nSlots)
             { if (t->find8Cap < t->nSlots)
                 { if (t->find8) { MG_HIP (hipStreamSynchronize (st)); MG_HIP (hipFree (t->find8)); t->find8 = 0; t->find8Cap = 0; }
