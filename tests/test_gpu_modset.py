@@ -243,7 +243,9 @@ def test_golden_modmap_flow(tag, golden_dir, tmp_path):
 
 @pytest.mark.parametrize("k,w,bits,path", [(21, 32, 22, "direct"), (21, 32, 22, "part"), (19, 31, 23, "part"), (15, 8, 24, "part"),
                                             (27, 4, 22, "part"), (31, 4, 22, "part"),
-                                            (21, 32, 22, "2 levels"), (19, 31, 23, "2 levels"), (15, 8, 24, "2 levels"), (27, 4, 22, "2 levels"), (21, 64, 28, "2 levels")])
+                                            (21, 32, 22, "2 levels"), (19, 31, 23, "2 levels"), (15, 8, 24, "2 levels"), (27, 4, 22, "2 levels"), (21, 64, 28, "2 levels"),
+                                            # round 6: the two-level lookups read an 8-byte copy of the table where 2k - log2 NB <= 32 (16 buckets here: k <= 18): the widest key that fits, and one more bit
+                                            (18, 8, 22, "2 levels"), (17, 4, 22, "2 levels"), (16, 8, 22, "2 levels")])
 def test_seed_lists_vs_oracle(k, w, bits, path):
     """mgQueryReadsDevice: Seed{index,pos} per read incl. misses (modmap.c:197-206) -- by direct probes in ordinal order and by
     the partitioned lookup (mgTableFindPartitioned: first partition pass of the build on the query's modimizers, lookups bin by
