@@ -910,27 +910,15 @@ extern __shared__ __attribute__ ((aligned (16))) unsigned char mgDynLds[];
 /* find-or-claim the LDS slot of key; returns R on overflow.  Linear probing: the slot is the first one of home, home + 1, ... (wrapping
  * inside the bucket) that holds the key or is empty.  This loop is what both bucket kernels spend their time in -- a workgroup waits at
  * its barrier for its LONGEST chain (8 links at load 0.38, 30 at 0.6, 80 at 0.75), every link a dependent LDS round trip -- and its code
- * shape counts: the same loop written for several slots per step (profiles/r06_ab_table_geometry.txt) cost the dedup kernel 0.25 ms.
- * MG_CLAIM_CAS_FIRST: the compare-and-swap IS the probe (one round trip where the slot is empty, not a read and then the swap). */
-#ifndef MG_CLAIM_CAS_FIRST
-#define MG_CLAIM_CAS_FIRST 1
-#endif
+ * shape counts (DESIGN_EXPERIMENTS.md section K: four slots a step, lanes walking independently, first probes issued together all made the
+ * kernels slower).  The compare-and-swap IS the probe: one round trip where the slot is empty, not a read and then the swap (round 6:
+ * dedup 1.32 -> 1.25 ms, merge 1.18 -> 1.07). */
 __device__ __forceinline__ U32 mgLdsClaim (unsigned long long *sKey, U32 R, U32 home, unsigned long long key)
 {
   U32 at = home;
   for (U32 probes = 0 ; probes < R ; ++probes)
-    {
-#if MG_CLAIM_CAS_FIRST
-      const unsigned long long cur = atomicCAS (&sKey[at], 0ull, key);
+    { const unsigned long long cur = atomicCAS (&sKey[at], 0ull, key);
       if (cur == 0 || cur == key) return at;
-#else
-      unsigned long long cur = sKey[at];
-      if (cur == 0)
-        { cur = atomicCAS (&sKey[at], 0ull, key);
-          if (cur == 0) cur = key;
-        }
-      if (cur == key) return at;
-#endif
       at = mgNextSlot (at, R);
     }
   return R;
